@@ -1,0 +1,257 @@
+/*
+ * td_hotpath.h -- C-ABI of the MI355X-native linear auditory-attention-decoding
+ * hot path (ridge TRF fit, CCA moments/transform, windowed correlation,
+ * attended-speaker decision).
+ *
+ * The reference (google/telluride_decoding v2.1.6) is pure Python and has no
+ * FFI of its own: the boundary is the Python call
+ * surface of the functions cited next to each entry point below.  This header
+ * is what a ctypes (or cgo / JNI) binding of that surface binds; see
+ * INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every function returns TD_OK (0) or a negative td_status; the message is
+ *     available from td_last_error().  No exceptions cross the ABI.
+ *   - Pointers named *_dev are DEVICE addresses (hipMalloc / td_malloc / a
+ *     torch tensor's data_ptr()).  Pointers named *_host are host addresses.
+ *   - All matrices are row-major, time x feature ("num_frames x num_channels",
+ *     reference result_store.py:43-44, infer_decoder.py:296-297); `ld*` is the
+ *     row stride in ELEMENTS.
+ *   - Several recordings ("files", "trials") are passed concatenated along
+ *     time with a host array file_offsets[F+1] of row offsets; temporal
+ *     context never crosses a file boundary (reference brain_data.py:722-724).
+ *   - All work is stream-ordered on the handle's stream (td_set_stream adopts an
+ *     external hipStream_t, e.g. torch's current stream).  One handle per host
+ *     thread and GPU; handles are not thread-safe (the reference objects are
+ *     not either: SURVEY.md 8b "Threading").
+ */
+#ifndef TD_HOTPATH_H_
+#define TD_HOTPATH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum td_status {
+  TD_OK = 0,
+  TD_ERR_INVALID = -1,   /* bad argument (Python side raises ValueError/TypeError) */
+  TD_ERR_HIP = -2,       /* a HIP runtime call failed */
+  TD_ERR_SINGULAR = -3,  /* matrix not positive definite (numpy: LinAlgError)  */
+  TD_ERR_NOMEM = -4,
+  TD_ERR_STATE = -5      /* call sequence error (e.g. solve before accumulate)  */
+} td_status;
+
+typedef struct td_handle td_handle; /* owns stream, workspace, error string */
+typedef struct td_stats td_stats;   /* device-resident sufficient statistics */
+
+/* ------------------------------------------------------------------ lifecycle */
+int td_version(void);
+int td_device_count(int* count);
+int td_create(int device_id, td_handle** out);
+int td_destroy(td_handle* h);
+const char* td_last_error(const td_handle* h); /* h may be NULL: last global */
+/* A new handle queues work on a private non-blocking stream.  td_set_stream adopts
+ * an external hipStream_t instead (NULL = HIP's default stream, which is what
+ * torch.cuda.current_stream().cuda_stream is unless the caller changed it);
+ * td_use_own_stream goes back to the private one. */
+int td_set_stream(td_handle* h, void* hip_stream);
+int td_use_own_stream(td_handle* h);
+int td_synchronize(td_handle* h);
+
+/* Device memory helpers for callers that do not bring their own allocator. */
+int td_malloc(td_handle* h, size_t bytes, void** dev_ptr);
+int td_free(td_handle* h, void* dev_ptr);
+int td_memcpy_h2d(td_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+int td_memcpy_d2h(td_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+int td_memset(td_handle* h, void* dst_dev, int value, size_t bytes);
+
+/* hipEvent timing on the handle's stream (bench.py's roofline leg). */
+int td_timer_start(td_handle* h);
+int td_timer_stop(td_handle* h, float* elapsed_ms); /* synchronises the stop event */
+
+/* ------------------------------------------------------------------ A1 + A2
+ * Sufficient statistics of lagged regression / CCA inputs WITHOUT building the
+ * lag matrix.  Replaces, per file, the context builder
+ *   brain_data.BrainData.add_temporal_context (brain_data.py:425-483)
+ * and the accumulate loops of
+ *   brain_model.calculate_linear_regressor_parameters_from_dataset
+ *       (brain_model.py:422-446: sum_xtx, sum_x, sum_xty, num_samples) and
+ *   cca.calculate_cca_parameters_from_dataset (cca.py:304-332: cov_xx, cov_yy,
+ *       cov_xy, sum_x, sum_y, total_frames).
+ *
+ * Feature layout (the numerical contract): lagged column l*C + c of input_1
+ * holds x~[t + l - pre, c], x~ zero outside the file (brain_data.py:448-454).
+ *
+ *   c1,pre1,post1 : input_1 ("x", EEG) channels and context
+ *   c2,pre2,post2 : input_2 (CCA second view); c2 = 0 when unused
+ *   d             : width of the regression target y; d = 0 when unused
+ */
+int td_stats_create(td_handle* h, int c1, int pre1, int post1, int c2, int pre2,
+                    int post2, int d, td_stats** out);
+int td_stats_destroy(td_handle* h, td_stats* s);
+int td_stats_reset(td_handle* h, td_stats* s);
+
+/* Adds F files.  x_dev[rows, c1] (ld ldx), x2_dev[rows, c2] or NULL,
+ * y_dev[rows, d] or NULL; rows = file_offsets_host[F].
+ * input_offset > 0 drops that many leading rows of x, < 0 of x2 and y
+ * (brain_data.py:466-475).  rows_used_host[F] (may be NULL = all) gives, per
+ * file, how many rows of the zipped streams enter the sums: the caller uses it
+ * to reproduce batch(drop_remainder=True) (brain_data.py:369-370), which drops
+ * the tail of the LAST file only. */
+int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
+                        const float* x2_dev, int64_t ldx2, const float* y_dev,
+                        int64_t ldy, const int64_t* file_offsets_host, int num_files,
+                        int input_offset, const int64_t* rows_used_host);
+
+/* Frames summed so far (num_samples / total_frames) and number of files. */
+int td_stats_counts(td_handle* h, const td_stats* s, int64_t* frames, int64_t* files);
+
+/* Additive algebra for sharding and leave-one-out sweeps
+ * (regression.py:151-242): dst = sum_i srcs[i].  All must share one layout. */
+int td_stats_combine(td_handle* h, td_stats* dst, td_stats* const* srcs, int n);
+
+/* Packed form for ONE all-reduce(sum) over ranks: doubles.  Every rank packs
+ * its own statistics; file-boundary samples go to the slot range
+ * [file_slot, file_slot + own files) of total_file_slots so that the sum over
+ * ranks is the concatenation. */
+int td_stats_packed_len(td_handle* h, const td_stats* s, int64_t total_file_slots,
+                        int64_t* num_doubles);
+int td_stats_pack(td_handle* h, const td_stats* s, double* buf_dev,
+                  int64_t total_file_slots, int64_t file_slot);
+int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev,
+                    int64_t total_file_slots);
+
+/* Dense moment matrices (float64, device), expanded from the compact lag
+ * statistics with exact file-edge corrections.  k1 = c1*(pre1+1+post1),
+ * k2 = c2*(pre2+1+post2).
+ *   xtx_dev [(k1+1) x (k1+1)] : sum_xtx incl. the trailing ones column
+ *                               (brain_model.py:434-437)
+ *   xty_dev [(k1+1) x d]      : sum_xty (brain_model.py:439)
+ *   x2tx2_dev [k2 x k2], xtx2_dev [k1 x k2], sum_x2_dev [k2] : cca.py:325-329
+ * Any output pointer may be NULL. */
+int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev,
+                     double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev);
+
+/* ------------------------------------------------------------------ A3
+ * Ridge solve for a batch of lambdas: cov_x = XtX/n + lambda*I over ALL k1+1
+ * diagonal entries incl. the bias (brain_model.py:447-455), then
+ * solve(cov_x, cov_xy) (:477).  Float64 Cholesky on the device.
+ *   w_dev [n_lambda, k1, d] float32, b_dev [n_lambda, d] float32.
+ * TD_ERR_SINGULAR when cov_x is not positive definite. */
+int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
+                   float* w_dev, float* b_dev);
+
+/* Generic SPD solve used by the above and by the shrinkage branch
+ * (brain_model.py:456-477): a_dev [batch, n, n] float64 (destroyed),
+ * rhs_dev [batch, n, nrhs] float64 (overwritten with the solution). */
+int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, int batch);
+
+/* ------------------------------------------------------------------ A3' / A4 forward
+ * Linear model forward X.W + b on the lagged view of x, never materialised
+ * (Keras Dense in brain_model.py:335-341, 376).  out_dev [rows, d] float32. */
+int td_predict_fir(td_handle* h, const float* x_dev, int64_t ldx,
+                   const int64_t* file_offsets_host, int num_files, int c, int pre,
+                   int post, const float* w_dev, const float* b_dev, int d,
+                   float* out_dev, int64_t ldout);
+
+/* CCA transform [(x - mean1).rot1 | (x2 - mean2).rot2] on lagged views
+ * (cca.BrainCcaLayer.call, cca.py:150-161).  out_dev [rows, 2*dims]. */
+int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int pre1,
+                     int post1, const float* x2_dev, int64_t ldx2, int c2, int pre2,
+                     int post2, const int64_t* file_offsets_host, int num_files,
+                     const float* mean1_dev, const float* rot1_dev,
+                     const float* mean2_dev, const float* rot2_dev, int dims,
+                     float* out_dev, int64_t ldout);
+
+/* ------------------------------------------------------------------ A5 / A6 / A7
+ * Five running sums per window and column, in float64:
+ *   out_dev[w][col] = {sum a, sum b, sum a^2, sum b^2, sum a*b}
+ * over frames [k*hop, k*hop + width) of each trial, full windows only
+ * (result_store.py:253-271; step = width//2 in infer_decoder.py:498-499).
+ * Both correlation flavours derive from them: per-window Pearson
+ * (brain_model.pearson_correlation, brain_model.py:34-79) and the
+ * global-statistics score of Decoder.compute_correlation
+ * (infer_decoder.py:312-328) averaged per window (infer.py:263-265).
+ * window_offsets_host[T+1] (output) receives the first window index of each
+ * trial; the caller sizes out_dev with td_window_count. */
+int td_window_count(const int64_t* trial_offsets_host, int num_trials, int width, int hop,
+                    int64_t* window_offsets_host, int64_t* total_windows);
+int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev,
+                   int64_t ldb, int cols, const int64_t* trial_offsets_host,
+                   int num_trials, int width, int hop, double* out_dev);
+
+/* Per-window scores from the five sums.
+ *   mode 0: global-statistics correlation mean over the window of
+ *           (a-mean_a)(b-mean_b)/power (infer_decoder.py:327-328), then the
+ *           column reduction `reduction` (0 first, 1 second, 2 mean) of
+ *           infer_decoder.py:441-446.  (mean-squared / lda need per-frame values: use
+ *           td_frame_scores.)
+ *   mode 1: per-window Pearson r (brain_model.py:62-79), incl. the
+ *           "any constant column zeroes every column" rule.
+ * scores_dev [total_windows] (mode 0) or [total_windows, cols] (mode 1). */
+int td_window_scores(td_handle* h, const double* sums_dev, int64_t total_windows,
+                     int cols, int width, int mode, int reduction,
+                     const double* mean_a_host, const double* mean_b_host,
+                     const double* power_host, double* scores_dev);
+
+/* Per-frame reduced correlation score (Decoder.infer_one, infer_decoder.py:439-455)
+ * for reductions that are not linear in the window sums.
+ *   reduction: 0 first, 1 second, 2 mean, 3 mean-squared, 4 lda (affine map
+ *   lda_w_host[cols], slope, intercept of scaled_lda.py:344-355).
+ * out_dev [rows] float64. */
+int td_frame_scores(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev,
+                    int64_t ldb, int cols, int64_t rows, int reduction,
+                    const double* mean_a_host, const double* mean_b_host,
+                    const double* power_host, const double* lda_w_host, double lda_slope,
+                    double lda_intercept, double* out_dev);
+
+/* Window means of a float64 per-frame signal (infer.regress_and_correlate,
+ * infer.py:261-266; infer_decoder.average_data :748-783 when hop == width). */
+int td_window_means(td_handle* h, const double* v_dev, const int64_t* trial_offsets_host,
+                    int num_trials, int width, int hop, double* out_dev);
+
+/* ------------------------------------------------------------------ A8 / A9
+ * Winner-take-all: out[i] = s1[i] > s2[i] (strict; ties -> speaker 2)
+ * (attention_decoder.AttentionDecoder.attention, attention_decoder.py:128-134). */
+int td_decide_wta(td_handle* h, const double* s1_dev, const double* s2_dev, int64_t n,
+                  uint8_t* out_dev);
+/* Stepped decoder with hysteresis, one state per trial starting at 0.5
+ * (attention_decoder.StepAttentionDecoder, attention_decoder.py:141-173).
+ * state_inout_host[T] may be NULL (fresh 0.5). */
+int td_decide_step(td_handle* h, const double* s1_dev, const double* s2_dev,
+                   const int64_t* window_offsets_host, int num_trials, uint8_t* out_dev,
+                   double* state_inout_host);
+
+/* State-space decoder, batched over independent trials
+ * (attention_decoder.StateSpaceAttentionDecoder.attention,
+ * attention_decoder.py:329-451).  params_host[8] =
+ * {outer_iter, inner_iter, newton_iter, forward_lag, backward_lag, offset,
+ *  tuned(0/1), reserved}; prior_host[4] = {rho_att, rho_unatt, mu_att, mu_unatt}
+ * (tune_log_normal_priors, :277-327) used when tuned = 1.
+ * out_dev [total_windows, 3] = (p, lower, upper). */
+int td_decode_ssd(td_handle* h, const double* s1_dev, const double* s2_dev,
+                  const int64_t* window_offsets_host, int num_trials,
+                  const double* params_host, const double* prior_host, double* out_dev);
+
+/* ------------------------------------------------------------------ fused decode
+ * Raw EEG -> decisions in one pass: FIR predict, global-statistics correlation
+ * against two candidate envelopes, window means, winner-take-all.  Equivalent to
+ * infer.run_reduction_test's inner loop (infer.py:376-407) with reduction
+ * 'first' and decoder 'wta'.  env_dev [rows, 2].  corr_host[6] =
+ * {mean_truth, mean_pred, power} for speaker 1 then speaker 2.
+ * scores_dev [total_windows, 2] float64, decisions_dev [total_windows] u8. */
+int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int pre,
+                    int post, const float* w_dev, const float* b_dev,
+                    const float* env_dev, int64_t ldenv,
+                    const int64_t* trial_offsets_host, int num_trials, int width,
+                    int hop, const double* corr_host, double* scores_dev,
+                    uint8_t* decisions_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TD_HOTPATH_H_ */

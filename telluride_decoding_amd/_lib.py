@@ -1,0 +1,139 @@
+"""ctypes binding of libtd_hotpath.so (the C-ABI in include/td_hotpath.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no
+MI355X is visible, every entry point raises `HotPathUnavailable`.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, 'libtd_hotpath.so')
+HEADER = os.path.join(os.path.dirname(PKG), 'include', 'td_hotpath.h')
+
+TD_OK = 0
+TD_ERR_INVALID = -1
+TD_ERR_HIP = -2
+TD_ERR_SINGULAR = -3
+TD_ERR_NOMEM = -4
+TD_ERR_STATE = -5
+
+
+class HotPathUnavailable(RuntimeError):
+  """The HIP extension (or a GPU) is missing; there is no CPU fallback."""
+
+
+class HotPathError(RuntimeError):
+  pass
+
+
+_c = ctypes
+_vp, _i, _i64, _f, _d, _sz = (_c.c_void_p, _c.c_int, _c.c_int64, _c.c_float,
+                              _c.c_double, _c.c_size_t)
+_pi64 = _c.POINTER(_c.c_int64)
+_pd = _c.POINTER(_c.c_double)
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    'td_version': [],
+    'td_device_count': [_c.POINTER(_i)],
+    'td_create': [_i, _c.POINTER(_vp)],
+    'td_destroy': [_vp],
+    'td_last_error': [_vp],
+    'td_set_stream': [_vp, _vp],
+    'td_use_own_stream': [_vp],
+    'td_synchronize': [_vp],
+    'td_malloc': [_vp, _sz, _c.POINTER(_vp)],
+    'td_free': [_vp, _vp],
+    'td_memcpy_h2d': [_vp, _vp, _vp, _sz],
+    'td_memcpy_d2h': [_vp, _vp, _vp, _sz],
+    'td_memset': [_vp, _vp, _i, _sz],
+    'td_timer_start': [_vp],
+    'td_timer_stop': [_vp, _c.POINTER(_f)],
+    'td_stats_create': [_vp, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)],
+    'td_stats_destroy': [_vp, _vp],
+    'td_stats_reset': [_vp, _vp],
+    'td_stats_accumulate': [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _pi64, _i, _i,
+                            _pi64],
+    'td_stats_counts': [_vp, _vp, _pi64, _pi64],
+    'td_stats_combine': [_vp, _vp, _c.POINTER(_vp), _i],
+    'td_stats_packed_len': [_vp, _vp, _i64, _pi64],
+    'td_stats_pack': [_vp, _vp, _vp, _i64, _i64],
+    'td_stats_unpack': [_vp, _vp, _vp, _i64],
+    'td_stats_moments': [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'td_ridge_solve': [_vp, _vp, _pd, _i, _vp, _vp],
+    'td_spd_solve': [_vp, _vp, _vp, _i, _i, _i],
+    'td_predict_fir': [_vp, _vp, _i64, _pi64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64],
+    'td_cca_transform': [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i, _i, _pi64, _i,
+                         _vp, _vp, _vp, _vp, _i, _vp, _i64],
+    'td_window_count': [_pi64, _i, _i, _i, _pi64, _pi64],
+    'td_window_sums': [_vp, _vp, _i64, _vp, _i64, _i, _pi64, _i, _i, _i, _vp],
+    'td_window_scores': [_vp, _vp, _i64, _i, _i, _i, _i, _pd, _pd, _pd, _vp],
+    'td_frame_scores': [_vp, _vp, _i64, _vp, _i64, _i, _i64, _i, _pd, _pd, _pd, _pd, _d,
+                        _d, _vp],
+    'td_window_means': [_vp, _vp, _pi64, _i, _i, _i, _vp],
+    'td_decide_wta': [_vp, _vp, _vp, _i64, _vp],
+    'td_decide_step': [_vp, _vp, _vp, _pi64, _i, _vp, _pd],
+    'td_decode_ssd': [_vp, _vp, _vp, _pi64, _i, _pd, _pd, _vp],
+    'td_decode_fused': [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i64, _pi64, _i, _i,
+                        _i, _pd, _vp, _vp],
+}
+_RESTYPE = {'td_last_error': _c.c_char_p}
+
+_lib = None
+
+
+def header_symbols():
+  """Every function name the C header declares."""
+  with open(HEADER) as f:
+    text = f.read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(td_[a-z0-9_]+)\s*\(', text)))
+
+
+def load():
+  """Loads the shared library (no GPU needed) and sets the prototypes."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise HotPathUnavailable(
+        'HIP extension %s is missing: build it with '
+        '`python -m telluride_decoding_amd.build` (hipcc, gfx950). '
+        'There is no CPU fallback for the hot path.' % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, args in SIGNATURES.items():
+    fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+    fn.argtypes = args
+    fn.restype = _RESTYPE.get(name, _i)
+  _lib = lib
+  return lib
+
+
+def check(handle_ptr, status):
+  if status == TD_OK:
+    return
+  lib = load()
+  msg = lib.td_last_error(handle_ptr)
+  msg = msg.decode() if msg else 'status %d' % status
+  if status == TD_ERR_INVALID:
+    raise ValueError(msg)
+  if status == TD_ERR_SINGULAR:
+    raise np.linalg.LinAlgError(msg)
+  if status == TD_ERR_NOMEM:
+    raise MemoryError(msg)
+  if status == TD_ERR_HIP and handle_ptr is None:
+    raise HotPathUnavailable(msg)
+  raise HotPathError(msg)
+
+
+def i64_array(values):
+  arr = np.ascontiguousarray(values, dtype=np.int64)
+  return arr, arr.ctypes.data_as(_pi64)
+
+
+def f64_array(values):
+  arr = np.ascontiguousarray(values, dtype=np.float64)
+  return arr, arr.ctypes.data_as(_pd)

@@ -1,0 +1,194 @@
+// Handle lifecycle, error reporting, memory and timing helpers of the C-ABI.
+#include "td_common.h"
+
+thread_local std::string td_global_error;
+
+int td_fail(td_handle* h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  td_global_error = buf;
+  if (h) h->error = buf;
+  return code;
+}
+
+int td_scratch(td_handle* h, size_t bytes, void** out) {
+  if (bytes > h->scratch_bytes) {
+    if (h->scratch) {
+      TD_HIP(h, hipStreamSynchronize(h->stream));
+      TD_HIP(h, hipFree(h->scratch));
+      h->scratch = nullptr;
+      h->scratch_bytes = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&h->scratch, want);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipMalloc(&h->scratch, want);
+    }
+    if (e != hipSuccess)
+      return td_fail(h, TD_ERR_NOMEM, "scratch allocation of %zu bytes failed: %s", bytes,
+                     hipGetErrorString(e));
+    h->scratch_bytes = want;
+  }
+  *out = h->scratch;
+  return TD_OK;
+}
+
+int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst) {
+  if (bytes == 0) return TD_OK;
+  td_handle::PinSlot& slot = h->pin[h->pin_next];
+  h->pin_next = (h->pin_next + 1) % td_handle::kPinSlots;
+  if (!slot.ev) TD_HIP(h, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+  if (slot.used) TD_HIP(h, hipEventSynchronize(slot.ev));
+  if (bytes > slot.bytes) {
+    if (slot.p) TD_HIP(h, hipHostFree(slot.p));
+    slot.p = nullptr;
+    slot.bytes = 0;
+    const size_t want = bytes * 2 < 16384 ? 16384 : bytes * 2;
+    TD_HIP(h, hipHostMalloc(&slot.p, want, hipHostMallocDefault));
+    slot.bytes = want;
+  }
+  memcpy(slot.p, host, bytes);
+  TD_HIP(h, hipMemcpyAsync(dev_dst, slot.p, bytes, hipMemcpyHostToDevice, h->stream));
+  TD_HIP(h, hipEventRecord(slot.ev, h->stream));
+  slot.used = true;
+  return TD_OK;
+}
+
+extern "C" {
+
+int td_version(void) { return 1; }
+
+int td_device_count(int* count) {
+  if (!count) return td_fail(nullptr, TD_ERR_INVALID, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return td_fail(nullptr, TD_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  return TD_OK;
+}
+
+int td_create(int device_id, td_handle** out) {
+  if (!out) return td_fail(nullptr, TD_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return td_fail(nullptr, TD_ERR_HIP,
+                   "no HIP device available (%s): the MI355X hot path cannot run on CPU",
+                   e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device_id < 0 || device_id >= n)
+    return td_fail(nullptr, TD_ERR_INVALID, "device_id %d out of range [0, %d)", device_id, n);
+  td_handle* h = new td_handle();
+  h->device = device_id;
+  TD_HIP(h, hipSetDevice(device_id));
+  TD_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  TD_HIP(h, hipEventCreate(&h->ev_start));
+  TD_HIP(h, hipEventCreate(&h->ev_stop));
+  TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flag), sizeof(int) * 64));
+  TD_HIP(h, hipMemset(h->dev_flag, 0, sizeof(int) * 64));
+  *out = h;
+  return TD_OK;
+}
+
+int td_destroy(td_handle* h) {
+  if (!h) return TD_OK;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  if (h->scratch) hipFree(h->scratch);
+  for (auto& slot : h->pin) {
+    if (slot.p) hipHostFree(slot.p);
+    if (slot.ev) hipEventDestroy(slot.ev);
+  }
+  if (h->dev_flag) hipFree(h->dev_flag);
+  if (h->ev_start) hipEventDestroy(h->ev_start);
+  if (h->ev_stop) hipEventDestroy(h->ev_stop);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  delete h;
+  return TD_OK;
+}
+
+const char* td_last_error(const td_handle* h) {
+  return h ? h->error.c_str() : td_global_error.c_str();
+}
+
+int td_set_stream(td_handle* h, void* hip_stream) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL is HIP's default stream
+  return TD_OK;
+}
+
+int td_use_own_stream(td_handle* h) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  h->stream = h->own_stream;
+  return TD_OK;
+}
+
+int td_synchronize(td_handle* h) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  return TD_OK;
+}
+
+int td_malloc(td_handle* h, size_t bytes, void** dev_ptr) {
+  if (!h || !dev_ptr) return td_fail(h, TD_ERR_INVALID, "td_malloc: NULL argument");
+  *dev_ptr = nullptr;
+  if (bytes == 0) return TD_OK;
+  hipError_t e = hipMalloc(dev_ptr, bytes);
+  if (e != hipSuccess)
+    return td_fail(h, TD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return TD_OK;
+}
+
+int td_free(td_handle* h, void* dev_ptr) {
+  if (!dev_ptr) return TD_OK;
+  if (h) TD_HIP(h, hipStreamSynchronize(h->stream));
+  TD_HIP(h, hipFree(dev_ptr));
+  return TD_OK;
+}
+
+int td_memcpy_h2d(td_handle* h, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  if (bytes == 0) return TD_OK;
+  TD_HIP(h, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->stream));
+  TD_HIP(h, hipStreamSynchronize(h->stream));  // host buffer is the caller's: do not outlive the call
+  return TD_OK;
+}
+
+int td_memcpy_d2h(td_handle* h, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  if (bytes == 0) return TD_OK;
+  TD_HIP(h, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  return TD_OK;
+}
+
+int td_memset(td_handle* h, void* dst_dev, int value, size_t bytes) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  if (bytes == 0) return TD_OK;
+  TD_HIP(h, hipMemsetAsync(dst_dev, value, bytes, h->stream));
+  return TD_OK;
+}
+
+int td_timer_start(td_handle* h) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  TD_HIP(h, hipEventRecord(h->ev_start, h->stream));
+  return TD_OK;
+}
+
+int td_timer_stop(td_handle* h, float* elapsed_ms) {
+  if (!h || !elapsed_ms) return td_fail(h, TD_ERR_INVALID, "td_timer_stop: NULL argument");
+  TD_HIP(h, hipEventRecord(h->ev_stop, h->stream));
+  TD_HIP(h, hipEventSynchronize(h->ev_stop));
+  TD_HIP(h, hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
+  return TD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,711 @@
+// Decode side of the hot path (SURVEY.md 8a rows A3'/A4 forward, A5-A9):
+// FIR prediction on the never-materialised lag view, windowed correlation sums,
+// per-window scores and the attended-speaker decision.
+#include "td_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------- FIR predict
+// out[t][q] = b[q] + sum_{l,c} x~[t + l - pre][c] * W[(l*C + c)][q]
+// (Keras Dense on the lag matrix: brain_model.py:335-341; lag layout
+// brain_data.py:448-454).  One workgroup = 256 consecutive frames of one file;
+// the x rows it needs are staged in LDS once (row stride padded by one float so
+// that 64 lanes reading 64 consecutive rows hit 64 different banks), weights
+// are LDS broadcasts.  Lags are processed in chunks of 32, channels of 64.
+struct FirTile {
+  long long row0;     // global first row of the file
+  long long nrows;    // rows in the file
+  long long t0;       // first output frame (file relative) of this tile
+};
+
+constexpr int kFirLagChunk = 32;
+constexpr int kFirChChunk = 64;
+constexpr int kFirMaxD = 16;
+
+template <int DB>   // outputs handled per pass
+__global__ __launch_bounds__(kThreads) void predict_fir_kernel(
+    const float* __restrict__ x, long long ldx, const FirTile* __restrict__ tiles, int c, int pre,
+    int post, const float* __restrict__ w, const float* __restrict__ bias, int d, int q0,
+    float* __restrict__ out, long long ldout) {
+  __shared__ float xs[(kThreads + kFirLagChunk) * (kFirChChunk + 1)];
+  __shared__ float ws[kFirLagChunk * kFirChChunk * DB];
+  const FirTile tile = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int nl = pre + 1 + post;
+  float acc[DB];
+#pragma unroll
+  for (int q = 0; q < DB; ++q) acc[q] = 0.f;
+
+  for (int l0 = 0; l0 < nl; l0 += kFirLagChunk) {
+    const int lc = (nl - l0 < kFirLagChunk) ? nl - l0 : kFirLagChunk;
+    for (int c0 = 0; c0 < c; c0 += kFirChChunk) {
+      const int cc = (c - c0 < kFirChChunk) ? c - c0 : kFirChChunk;
+      __syncthreads();
+      // stage x rows [t0 + l0 - pre, + 256 + lc - 1) x channels [c0, c0+cc)
+      const int nrows = kThreads + lc - 1;
+      for (int idx = tid; idx < nrows * kFirChChunk; idx += kThreads) {
+        const int r = idx / kFirChChunk, col = idx % kFirChChunk;
+        const long long u = tile.t0 + l0 - pre + r;
+        float v = 0.f;
+        if (col < cc && u >= 0 && u < tile.nrows) v = x[(tile.row0 + u) * ldx + c0 + col];
+        xs[r * (kFirChChunk + 1) + col] = v;
+      }
+      for (int idx = tid; idx < lc * kFirChChunk * DB; idx += kThreads) {
+        const int q = idx % DB;
+        const int col = (idx / DB) % kFirChChunk;
+        const int l = idx / (DB * kFirChChunk);
+        float v = 0.f;
+        if (col < cc && q0 + q < d) v = w[((long long)(l0 + l) * c + c0 + col) * d + q0 + q];
+        ws[idx] = v;
+      }
+      __syncthreads();
+      for (int l = 0; l < lc; ++l) {
+        const float* xr = xs + (tid + l) * (kFirChChunk + 1);
+        const float* wr = ws + l * kFirChChunk * DB;
+#pragma unroll 8
+        for (int col = 0; col < kFirChChunk; ++col) {
+          const float xv = xr[col];
+#pragma unroll
+          for (int q = 0; q < DB; ++q) acc[q] = fmaf(xv, wr[col * DB + q], acc[q]);
+        }
+      }
+    }
+  }
+  const long long t = tile.t0 + tid;
+  if (t < tile.nrows) {
+#pragma unroll
+    for (int q = 0; q < DB; ++q)
+      if (q0 + q < d)
+        out[(tile.row0 + t) * ldout + q0 + q] = acc[q] + (bias ? bias[q0 + q] : 0.f);
+  }
+}
+
+// bias[k] = -sum_f mean[f] * rot[f][k]   (CCA centring folded into the FIR bias)
+__global__ void neg_mean_rot_kernel(const float* __restrict__ mean, const float* __restrict__ rot,
+                                    int k, int dims, float* __restrict__ bias) {
+  const int q = blockIdx.x;
+  __shared__ double red[kThreads];
+  double s = 0.0;
+  for (int f = threadIdx.x; f < k; f += kThreads) s += (double)mean[f] * (double)rot[(long long)f * dims + q];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = kThreads / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bias[q] = (float)(-red[0]);
+}
+
+// ---------------------------------------------------------------- window sums
+struct WinDesc {
+  long long row0;   // global first row of the window
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// One workgroup per window; 5 float64 sums per column, fixed reduction tree
+// (bitwise reproducible).
+__global__ __launch_bounds__(kThreads) void window_sums_kernel(
+    const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
+    int cols, const long long* __restrict__ win_row0, int width, double* __restrict__ out) {
+  __shared__ double red[4][5];
+  const long long r0 = win_row0[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int col = 0; col < cols; ++col) {
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int r = tid; r < width; r += kThreads) {
+      const double av = (double)a[(r0 + r) * lda + col];
+      const double bv = (double)b[(r0 + r) * ldb + col];
+      s[0] += av; s[1] += bv; s[2] += av * av; s[3] += bv * bv; s[4] += av * bv;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double v = wave_sum(s[k]);
+      if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < 5)
+      out[((long long)blockIdx.x * cols + col) * 5 + tid] =
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void window_means_kernel(
+    const double* __restrict__ v, const long long* __restrict__ win_row0, int width,
+    double* __restrict__ out) {
+  __shared__ double red[4];
+  const long long r0 = win_row0[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  for (int r = tid; r < width; r += kThreads) s += v[r0 + r];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) out[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)width;
+}
+
+struct ScoreParams {
+  double mean_a[16], mean_b[16], power[16], lda_w[16];
+  double lda_slope, lda_intercept;
+};
+
+// mode 0: mean over the window of (a-ma)(b-mb)/power per column, reduced across
+// columns; mode 1: per-window Pearson per column with the reference's "any
+// constant column zeroes everything" rule (brain_model.py:72-79).
+__global__ void window_scores_kernel(const double* __restrict__ sums, long long n_win, int cols,
+                                     int width, int mode, int reduction, ScoreParams sp,
+                                     double* __restrict__ scores) {
+  const long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (w >= n_win) return;
+  const double* s = sums + w * cols * 5;
+  const double n = (double)width;
+  if (mode == 0) {
+    double acc = 0.0;
+    const int c_lo = reduction == 1 ? 1 : 0;
+    const int c_hi = reduction == 2 ? cols : c_lo + 1;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const double sa = s[c * 5 + 0], sb = s[c * 5 + 1], sab = s[c * 5 + 4];
+      // sum (a-ma)(b-mb) = sab - ma*sb - mb*sa + n*ma*mb
+      const double num = sab - sp.mean_a[c] * sb - sp.mean_b[c] * sa + n * sp.mean_a[c] * sp.mean_b[c];
+      acc += num / (sp.power[c] * n);
+    }
+    scores[w] = acc / (double)(c_hi - c_lo);
+  } else {
+    double prod_a = 1.0, prod_b = 1.0;
+    for (int c = 0; c < cols; ++c) {
+      const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
+      prod_a *= s[c * 5 + 2] - sa * sa / n;
+      prod_b *= s[c * 5 + 3] - sb * sb / n;
+    }
+    const bool zero = (prod_a <= 0.0) || (prod_b <= 0.0);
+    for (int c = 0; c < cols; ++c) {
+      const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
+      const double va = s[c * 5 + 2] - sa * sa / n, vb = s[c * 5 + 3] - sb * sb / n;
+      const double cov = s[c * 5 + 4] - sa * sb / n;
+      scores[w * cols + c] = zero ? 0.0 : cov / (sqrt(va) * sqrt(vb));
+    }
+  }
+}
+
+// Per-frame reduced score (Decoder.infer_one, infer_decoder.py:439-455), formed
+// in float64 from the float32 inputs (the reference rounds each step to float32;
+// this is the same value to ~1e-7 relative).
+__global__ void frame_scores_kernel(const float* __restrict__ a, long long lda,
+                                    const float* __restrict__ b, long long ldb, int cols,
+                                    long long rows, int reduction, ScoreParams sp,
+                                    double* __restrict__ out) {
+  for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < rows;
+       r += (long long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    if (reduction == 0 || reduction == 1) {
+      const int c = reduction;
+      acc = ((double)a[r * lda + c] - sp.mean_a[c]) * ((double)b[r * ldb + c] - sp.mean_b[c]) /
+            sp.power[c];
+    } else {
+      for (int c = 0; c < cols; ++c) {
+        const double v = ((double)a[r * lda + c] - sp.mean_a[c]) *
+                         ((double)b[r * ldb + c] - sp.mean_b[c]) / sp.power[c];
+        if (reduction == 2) acc += v;
+        else if (reduction == 3) acc += (v > 0.0 ? v * v : (v < 0.0 ? -v * v : 0.0));
+        else acc += v * sp.lda_w[c];
+      }
+      if (reduction == 2 || reduction == 3) acc /= (double)cols;
+      else acc = sp.lda_slope * acc + sp.lda_intercept;
+    }
+    out[r] = acc;
+  }
+}
+
+// ---------------------------------------------------------------- decisions
+__global__ void decide_wta_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
+                                  long long n, unsigned char* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = s1[i] > s2[i] ? 1 : 0;
+}
+
+// One lane per trial: a sequential +-0.1 scan clipped to [0.1, 0.9]
+// (attention_decoder.py:169-173), float64 like the Python floats there.
+__global__ void decide_step_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
+                                   const long long* __restrict__ win_off, int n_trials,
+                                   unsigned char* __restrict__ out, double* __restrict__ state) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_trials) return;
+  double st = state[t];
+  for (long long i = win_off[t]; i < win_off[t + 1]; ++i) {
+    if (s1[i] > s2[i]) st = fmin(0.9, st + 0.1);
+    else st = fmax(0.1, st - 0.1);
+    out[i] = st > 0.5 ? 1 : 0;
+  }
+  state[t] = st;
+}
+
+// ---------------------------------------------------------------- state-space decoder
+// attention_decoder.StateSpaceAttentionDecoder.attention (attention_decoder.py:
+// 329-451), one lane per trial, sequential over the trial's windows.
+constexpr int kMaxKw = 32;
+
+struct SsdParams {
+  int outer_iter, inner_iter, newton_iter, k_f, k_b;
+  double offset;
+  int tuned;
+  double rho_d[2], mu_d[2];
+};
+
+// np.sum order for a short vector: NumPy's pairwise routine keeps 8 running
+// sums for n >= 8, combines them as a balanced tree and then adds the tail.
+__device__ double np_sum(const double* a, int n) {
+  if (n < 8) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += a[i];
+    return s;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+
+__global__ void ssd_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
+                           const long long* __restrict__ win_off, int n_trials, SsdParams sp,
+                           double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_trials) return;
+  const int kw = sp.k_f + sp.k_b + 1;
+  const double c0 = 1.96;
+  const double mean_p = 0.2, var_p = 5.0;
+  const double a_0 = 2 + mean_p * mean_p / var_p;
+  const double b_0 = mean_p * (a_0 - 1);
+  const double alpha_0[2] = {6.4113e+02, 4.0434e+03};
+  const double beta_0[2] = {3.7581e+02, 6.2791e+03};
+  double mu_0[2] = {-0.3994, -1.5103};
+  double rho_d[2] = {1.7060, 0.64395};
+  double mu_d[2] = {-0.3994, -1.5103};
+  if (sp.tuned) {
+    rho_d[0] = sp.rho_d[0]; rho_d[1] = sp.rho_d[1];
+    mu_d[0] = sp.mu_d[0]; mu_d[1] = sp.mu_d[1];
+    mu_0[0] = sp.mu_d[0]; mu_0[1] = sp.mu_d[1];
+  }
+  const double lam = 1.0;
+  double r1h[kMaxKw], r2h[kMaxKw];           // last kw |r + offset|
+  double z_last[kMaxKw], eta_last[kMaxKw];   // z_smoothed[-kw:], eta_smoothed[-kw:]
+  double z_kk[kMaxKw + 1], s_kk[kMaxKw + 1], z_pred[kMaxKw + 1], s_pred[kMaxKw + 1];
+  double z_cap[kMaxKw + 1], s_cap[kMaxKw + 1], sm[kMaxKw];
+  double l1[kMaxKw], l2[kMaxKw], ep[kMaxKw], tmp[kMaxKw], eta[kMaxKw];
+  for (int i = 0; i < kw; ++i) { z_last[i] = 0.0; eta_last[i] = 0.3; r1h[i] = r2h[i] = 0.0; }
+  for (int i = 0; i <= kw; ++i) z_kk[i] = s_kk[i] = z_pred[i] = s_pred[i] = z_cap[i] = s_cap[i] = 0.0;
+  for (int i = 0; i < kw; ++i) sm[i] = 0.0;
+  int calls = 0;
+  for (long long w = win_off[t]; w < win_off[t + 1]; ++w) {
+    ++calls;
+    for (int i = 0; i + 1 < kw; ++i) { r1h[i] = r1h[i + 1]; r2h[i] = r2h[i + 1]; }
+    r1h[kw - 1] = fabs(s1[w] + sp.offset);
+    r2h[kw - 1] = fabs(s2[w] + sp.offset);
+    if (calls < kw) {
+      out[w * 3 + 0] = 0.5; out[w * 3 + 1] = 0.5; out[w * 3 + 2] = 0.5;
+      continue;
+    }
+    for (int i = 0; i < kw; ++i) { l1[i] = log(r1h[i]); l2[i] = log(r2h[i]); eta[i] = eta_last[i]; }
+    const double* z = z_last;   // first outer iteration; afterwards z_cap + 1
+    for (int it = 0; it < sp.outer_iter; ++it) {
+      for (int i = 0; i < kw; ++i) {
+        const double d10 = l1[i] - mu_d[0], d11 = l1[i] - mu_d[1];
+        const double d21 = l2[i] - mu_d[1], d20 = l2[i] - mu_d[0];
+        const double p11 = (1.0 / r1h[i]) * sqrt(rho_d[0]) * exp(-0.5 * rho_d[0] * (d10 * d10));
+        const double p12 = (1.0 / r1h[i]) * sqrt(rho_d[1]) * exp(-0.5 * rho_d[1] * (d11 * d11));
+        const double p21 = (1.0 / r2h[i]) * sqrt(rho_d[1]) * exp(-0.5 * rho_d[1] * (d21 * d21));
+        const double p22 = (1.0 / r2h[i]) * sqrt(rho_d[0]) * exp(-0.5 * rho_d[0] * (d20 * d20));
+        const double p = 1.0 / (1.0 + exp(-z[i]));
+        ep[i] = (p * p11 * p21) / (p * p11 * p21 + (1.0 - p) * p12 * p22);
+      }
+      for (int i = 0; i < kw; ++i) tmp[i] = ep[i] * l1[i] + (1.0 - ep[i]) * l2[i];
+      mu_d[0] = (np_sum(tmp, kw) + kw * mu_0[0]) / (2.0 * kw);
+      for (int i = 0; i < kw; ++i) tmp[i] = ep[i] * l2[i] + (1.0 - ep[i]) * l1[i];
+      mu_d[1] = (np_sum(tmp, kw) + kw * mu_0[1]) / (2.0 * kw);
+      for (int i = 0; i < kw; ++i) {
+        const double u = l1[i] - mu_d[0], v = l2[i] - mu_d[0];
+        tmp[i] = ep[i] * (u * u) + (1.0 - ep[i]) * (v * v);
+      }
+      {
+        const double dm = mu_d[0] - mu_0[0];
+        rho_d[0] = (2.0 * kw * alpha_0[0]) / (np_sum(tmp, kw) + kw * (2.0 * beta_0[0] + dm * dm));
+      }
+      for (int i = 0; i < kw; ++i) {
+        const double u = l2[i] - mu_d[1], v = l1[i] - mu_d[1];
+        tmp[i] = ep[i] * (u * u) + (1.0 - ep[i]) * (v * v);
+      }
+      {
+        const double dm = mu_d[1] - mu_0[1];
+        rho_d[1] = (2.0 * kw * alpha_0[1]) / (np_sum(tmp, kw) + kw * (2.0 * beta_0[1] + dm * dm));
+      }
+      for (int in = 0; in < sp.inner_iter; ++in) {
+        for (int k = 1; k <= kw; ++k) {
+          z_pred[k] = lam * z_kk[k - 1];
+          s_pred[k] = lam * lam * s_kk[k - 1] + eta[k - 1];
+          for (int nt = 0; nt < sp.newton_iter; ++nt) {
+            const double ez = exp(z_kk[k]);
+            z_kk[k] = z_kk[k] - (z_kk[k] - z_pred[k] - s_pred[k] * (ep[k - 1] - ez / (1 + ez))) /
+                                    (1 + s_pred[k] * ez / ((1 + ez) * (1 + ez)));
+          }
+          const double ez = exp(z_kk[k]);
+          s_kk[k] = 1.0 / (1.0 / s_pred[k] + ez / ((1 + ez) * (1 + ez)));
+        }
+        z_cap[kw] = z_kk[kw];
+        s_cap[kw] = s_kk[kw];
+        for (int k = 0; k < kw; ++k) {   // ascending, as in the reference (:423-430)
+          sm[k] = s_kk[k] * lam / s_pred[k + 1];
+          z_cap[k] = z_kk[k] + sm[k] * (z_cap[k + 1] - z_pred[k + 1]);
+          s_cap[k] = s_kk[k] + sm[k] * sm[k] * (s_cap[k + 1] - s_pred[k + 1]);
+        }
+        z_kk[0] = z_cap[0];
+        s_kk[0] = s_cap[0];
+        for (int i = 0; i < kw; ++i) {
+          const double dz = z_cap[i + 1] - z_cap[i];
+          eta[i] = (dz * dz + s_cap[i + 1] + s_cap[i] - 2.0 * s_cap[i + 1] * sm[i] + 2 * b_0) /
+                   (1 + 2 * (a_0 + 1));
+        }
+      }
+      z = z_cap + 1;
+    }
+    for (int i = 0; i < kw; ++i) { z_last[i] = z_cap[i + 1]; eta_last[i] = eta[i]; }
+    z_kk[0] = z_cap[1];
+    const double zd = z_last[kw - 1 - sp.k_f], ed = eta_last[kw - 1 - sp.k_f];
+    out[w * 3 + 0] = 1.0 / (1 + exp(-zd));
+    out[w * 3 + 1] = 1.0 / (1 + exp(-zd - c0 * sqrt(ed)));
+    out[w * 3 + 2] = 1.0 / (1 + exp(-zd + c0 * sqrt(ed)));
+  }
+}
+
+// ---------------------------------------------------------------- helpers
+int build_windows(const int64_t* trial_offsets, int num_trials, int width, int hop,
+                  std::vector<long long>* row0, std::vector<int64_t>* win_off) {
+  win_off->assign(num_trials + 1, 0);
+  row0->clear();
+  for (int t = 0; t < num_trials; ++t) {
+    const int64_t n = trial_offsets[t + 1] - trial_offsets[t];
+    (*win_off)[t] = (int64_t)row0->size();
+    if (n >= width)
+      for (int64_t s = 0; s + width <= n; s += hop) row0->push_back(trial_offsets[t] + s);
+  }
+  (*win_off)[num_trials] = (int64_t)row0->size();
+  return TD_OK;
+}
+
+int fill_score_params(td_handle* h, ScoreParams* sp, int cols, const double* mean_a,
+                      const double* mean_b, const double* power, const double* lda_w,
+                      double slope, double intercept) {
+  TD_REQUIRE(h, cols >= 1 && cols <= 16, "cols must be in [1, 16], not %d", cols);
+  memset(sp, 0, sizeof(*sp));
+  for (int c = 0; c < cols; ++c) {
+    sp->mean_a[c] = mean_a ? mean_a[c] : 0.0;
+    sp->mean_b[c] = mean_b ? mean_b[c] : 0.0;
+    sp->power[c] = power ? power[c] : 1.0;
+    sp->lda_w[c] = lda_w ? lda_w[c] : 0.0;
+  }
+  sp->lda_slope = slope;
+  sp->lda_intercept = intercept;
+  return TD_OK;
+}
+
+int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
+               int c, int pre, int post, const float* w, const float* bias, int d, float* out,
+               int64_t ldout) {
+  std::vector<FirTile> tiles;
+  for (int f = 0; f < num_files; ++f) {
+    const int64_t n = offs[f + 1] - offs[f];
+    for (int64_t t0 = 0; t0 < n; t0 += kThreads) {
+      FirTile t;
+      t.row0 = offs[f]; t.nrows = n; t.t0 = t0;
+      tiles.push_back(t);
+    }
+  }
+  if (tiles.empty()) return TD_OK;
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, tiles.size() * sizeof(FirTile), &scratch));
+  TD_TRY(td_upload_async(h, tiles.data(), tiles.size() * sizeof(FirTile), scratch));
+  const FirTile* dt = reinterpret_cast<const FirTile*>(scratch);
+  for (int q0 = 0; q0 < d;) {
+    const int left = d - q0;
+    if (left >= 4) {
+      hipLaunchKernelGGL(predict_fir_kernel<4>, dim3((unsigned)tiles.size()), dim3(kThreads), 0,
+                         h->stream, x, (long long)ldx, dt, c, pre, post, w, bias, d, q0, out,
+                         (long long)ldout);
+      q0 += 4;
+    } else if (left >= 2) {
+      hipLaunchKernelGGL(predict_fir_kernel<2>, dim3((unsigned)tiles.size()), dim3(kThreads), 0,
+                         h->stream, x, (long long)ldx, dt, c, pre, post, w, bias, d, q0, out,
+                         (long long)ldout);
+      q0 += 2;
+    } else {
+      hipLaunchKernelGGL(predict_fir_kernel<1>, dim3((unsigned)tiles.size()), dim3(kThreads), 0,
+                         h->stream, x, (long long)ldx, dt, c, pre, post, w, bias, d, q0, out,
+                         (long long)ldout);
+      q0 += 1;
+    }
+  }
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int td_predict_fir(td_handle* h, const float* x_dev, int64_t ldx,
+                   const int64_t* file_offsets_host, int num_files, int c, int pre, int post,
+                   const float* w_dev, const float* b_dev, int d, float* out_dev, int64_t ldout) {
+  if (!h || !x_dev || !file_offsets_host || !w_dev || !out_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_predict_fir: NULL argument");
+  TD_REQUIRE(h, c > 0 && pre >= 0 && post >= 0 && d > 0, "td_predict_fir: bad sizes");
+  TD_REQUIRE(h, ldx >= c && ldout >= d, "td_predict_fir: leading dimension too small");
+  return launch_fir(h, x_dev, ldx, file_offsets_host, num_files, c, pre, post, w_dev, b_dev, d,
+                    out_dev, ldout);
+}
+
+int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int pre1, int post1,
+                     const float* x2_dev, int64_t ldx2, int c2, int pre2, int post2,
+                     const int64_t* file_offsets_host, int num_files, const float* mean1_dev,
+                     const float* rot1_dev, const float* mean2_dev, const float* rot2_dev,
+                     int dims, float* out_dev, int64_t ldout) {
+  if (!h || !x_dev || !x2_dev || !file_offsets_host || !mean1_dev || !rot1_dev || !mean2_dev ||
+      !rot2_dev || !out_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_cca_transform: NULL argument");
+  TD_REQUIRE(h, dims > 0 && dims <= kFirMaxD, "td_cca_transform: dims must be in [1, %d]", kFirMaxD);
+  TD_REQUIRE(h, ldout >= 2 * dims, "td_cca_transform: ldout too small");
+  const int k1 = c1 * (pre1 + 1 + post1), k2 = c2 * (pre2 + 1 + post2);
+  float* bias = nullptr;
+  TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&bias), sizeof(float) * 2 * dims));
+  hipLaunchKernelGGL(neg_mean_rot_kernel, dim3((unsigned)dims), dim3(kThreads), 0, h->stream,
+                     mean1_dev, rot1_dev, k1, dims, bias);
+  hipLaunchKernelGGL(neg_mean_rot_kernel, dim3((unsigned)dims), dim3(kThreads), 0, h->stream,
+                     mean2_dev, rot2_dev, k2, dims, bias + dims);
+  int rc = launch_fir(h, x_dev, ldx, file_offsets_host, num_files, c1, pre1, post1, rot1_dev, bias,
+                      dims, out_dev, ldout);
+  if (rc == TD_OK)
+    rc = launch_fir(h, x2_dev, ldx2, file_offsets_host, num_files, c2, pre2, post2, rot2_dev,
+                    bias + dims, dims, out_dev + dims, ldout);
+  hipStreamSynchronize(h->stream);
+  hipFree(bias);
+  return rc;
+}
+
+int td_window_count(const int64_t* trial_offsets_host, int num_trials, int width, int hop,
+                    int64_t* window_offsets_host, int64_t* total_windows) {
+  if (!trial_offsets_host || num_trials < 0 || width <= 0 || hop <= 0)
+    return td_fail(nullptr, TD_ERR_INVALID, "td_window_count: bad argument");
+  std::vector<long long> row0;
+  std::vector<int64_t> off;
+  build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
+  if (window_offsets_host)
+    for (int t = 0; t <= num_trials; ++t) window_offsets_host[t] = off[t];
+  if (total_windows) *total_windows = (int64_t)row0.size();
+  return TD_OK;
+}
+
+int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev, int64_t ldb,
+                   int cols, const int64_t* trial_offsets_host, int num_trials, int width, int hop,
+                   double* out_dev) {
+  if (!h || !a_dev || !b_dev || !trial_offsets_host || !out_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_window_sums: NULL argument");
+  TD_REQUIRE(h, cols > 0 && width > 0 && hop > 0, "td_window_sums: bad sizes");
+  std::vector<long long> row0;
+  std::vector<int64_t> off;
+  build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
+  if (row0.empty()) return TD_OK;
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, row0.size() * sizeof(long long), &scratch));
+  TD_TRY(td_upload_async(h, row0.data(), row0.size() * sizeof(long long), scratch));
+  hipLaunchKernelGGL(window_sums_kernel, dim3((unsigned)row0.size()), dim3(kThreads), 0, h->stream,
+                     a_dev, (long long)lda, b_dev, (long long)ldb, cols,
+                     reinterpret_cast<const long long*>(scratch), width, out_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_window_means(td_handle* h, const double* v_dev, const int64_t* trial_offsets_host,
+                    int num_trials, int width, int hop, double* out_dev) {
+  if (!h || !v_dev || !trial_offsets_host || !out_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_window_means: NULL argument");
+  TD_REQUIRE(h, width > 0 && hop > 0, "td_window_means: bad sizes");
+  std::vector<long long> row0;
+  std::vector<int64_t> off;
+  build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
+  if (row0.empty()) return TD_OK;
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, row0.size() * sizeof(long long), &scratch));
+  TD_TRY(td_upload_async(h, row0.data(), row0.size() * sizeof(long long), scratch));
+  hipLaunchKernelGGL(window_means_kernel, dim3((unsigned)row0.size()), dim3(kThreads), 0,
+                     h->stream, v_dev, reinterpret_cast<const long long*>(scratch), width, out_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_window_scores(td_handle* h, const double* sums_dev, int64_t total_windows, int cols,
+                     int width, int mode, int reduction, const double* mean_a_host,
+                     const double* mean_b_host, const double* power_host, double* scores_dev) {
+  if (!h || !sums_dev || !scores_dev) return td_fail(h, TD_ERR_INVALID, "td_window_scores: NULL");
+  TD_REQUIRE(h, mode == 0 || mode == 1, "td_window_scores: mode must be 0 or 1");
+  TD_REQUIRE(h, mode == 1 || (reduction >= 0 && reduction <= 2),
+             "Unknown reduction technique: %d", reduction);
+  TD_REQUIRE(h, mode == 1 || reduction != 1 || cols >= 2, "reduction 'second' needs >= 2 columns");
+  ScoreParams sp;
+  TD_TRY(fill_score_params(h, &sp, cols, mean_a_host, mean_b_host, power_host, nullptr, 1.0, 0.0));
+  if (total_windows <= 0) return TD_OK;
+  hipLaunchKernelGGL(window_scores_kernel, dim3((unsigned)td_ceil_div(total_windows, 256)),
+                     dim3(256), 0, h->stream, sums_dev, (long long)total_windows, cols, width, mode,
+                     reduction, sp, scores_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_frame_scores(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev, int64_t ldb,
+                    int cols, int64_t rows, int reduction, const double* mean_a_host,
+                    const double* mean_b_host, const double* power_host,
+                    const double* lda_w_host, double lda_slope, double lda_intercept,
+                    double* out_dev) {
+  if (!h || !a_dev || !b_dev || !out_dev) return td_fail(h, TD_ERR_INVALID, "td_frame_scores: NULL");
+  TD_REQUIRE(h, reduction >= 0 && reduction <= 4, "Unknown reduction technique: %d", reduction);
+  TD_REQUIRE(h, reduction != 1 || cols >= 2, "reduction 'second' needs >= 2 columns");
+  TD_REQUIRE(h, reduction != 4 || lda_w_host, "lda reduction needs its weights");
+  ScoreParams sp;
+  TD_TRY(fill_score_params(h, &sp, cols, mean_a_host, mean_b_host, power_host, lda_w_host,
+                           lda_slope, lda_intercept));
+  if (rows <= 0) return TD_OK;
+  long long blocks = td_ceil_div(rows, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(frame_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, a_dev,
+                     (long long)lda, b_dev, (long long)ldb, cols, (long long)rows, reduction, sp,
+                     out_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_decide_wta(td_handle* h, const double* s1_dev, const double* s2_dev, int64_t n,
+                  uint8_t* out_dev) {
+  if (!h || !s1_dev || !s2_dev || !out_dev) return td_fail(h, TD_ERR_INVALID, "td_decide_wta: NULL");
+  if (n <= 0) return TD_OK;
+  long long blocks = td_ceil_div(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(decide_wta_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, s1_dev,
+                     s2_dev, (long long)n, out_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_decide_step(td_handle* h, const double* s1_dev, const double* s2_dev,
+                   const int64_t* window_offsets_host, int num_trials, uint8_t* out_dev,
+                   double* state_inout_host) {
+  if (!h || !s1_dev || !s2_dev || !window_offsets_host || !out_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_decide_step: NULL");
+  if (num_trials <= 0) return TD_OK;
+  const size_t off_bytes = td_round_up(sizeof(long long) * (num_trials + 1), 256);
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, off_bytes + sizeof(double) * num_trials, &scratch));
+  std::vector<long long> off(window_offsets_host, window_offsets_host + num_trials + 1);
+  std::vector<double> st(num_trials, 0.5);
+  if (state_inout_host) st.assign(state_inout_host, state_inout_host + num_trials);
+  double* dstate = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + off_bytes);
+  TD_TRY(td_upload_async(h, off.data(), sizeof(long long) * off.size(), scratch));
+  TD_TRY(td_upload_async(h, st.data(), sizeof(double) * st.size(), dstate));
+  hipLaunchKernelGGL(decide_step_kernel, dim3((unsigned)td_ceil_div(num_trials, 64)), dim3(64), 0,
+                     h->stream, s1_dev, s2_dev, reinterpret_cast<const long long*>(scratch),
+                     num_trials, out_dev, dstate);
+  TD_HIP(h, hipGetLastError());
+  if (state_inout_host) {
+    TD_HIP(h, hipMemcpyAsync(state_inout_host, dstate, sizeof(double) * num_trials,
+                             hipMemcpyDeviceToHost, h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  return TD_OK;
+}
+
+int td_decode_ssd(td_handle* h, const double* s1_dev, const double* s2_dev,
+                  const int64_t* window_offsets_host, int num_trials, const double* params_host,
+                  const double* prior_host, double* out_dev) {
+  if (!h || !s1_dev || !s2_dev || !window_offsets_host || !params_host || !out_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_decode_ssd: NULL");
+  SsdParams sp;
+  sp.outer_iter = (int)params_host[0];
+  sp.inner_iter = (int)params_host[1];
+  sp.newton_iter = (int)params_host[2];
+  sp.k_f = (int)params_host[3];
+  sp.k_b = (int)params_host[4];
+  sp.offset = params_host[5];
+  sp.tuned = params_host[6] != 0.0 ? 1 : 0;
+  TD_REQUIRE(h, sp.k_f >= 0 && sp.k_b >= 0 && sp.k_f + sp.k_b + 1 <= kMaxKw,
+             "state-space window k_f + k_b + 1 must be <= %d", kMaxKw);
+  TD_REQUIRE(h, !sp.tuned || prior_host, "tuned priors requested but not given");
+  for (int i = 0; i < 2; ++i) {
+    sp.rho_d[i] = sp.tuned ? prior_host[i] : 0.0;
+    sp.mu_d[i] = sp.tuned ? prior_host[2 + i] : 0.0;
+  }
+  if (num_trials <= 0) return TD_OK;
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, sizeof(long long) * (num_trials + 1), &scratch));
+  std::vector<long long> off(window_offsets_host, window_offsets_host + num_trials + 1);
+  TD_TRY(td_upload_async(h, off.data(), sizeof(long long) * off.size(), scratch));
+  hipLaunchKernelGGL(ssd_kernel, dim3((unsigned)td_ceil_div(num_trials, 64)), dim3(64), 0,
+                     h->stream, s1_dev, s2_dev, reinterpret_cast<const long long*>(scratch),
+                     num_trials, sp, out_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int pre, int post,
+                    const float* w_dev, const float* b_dev, const float* env_dev, int64_t ldenv,
+                    const int64_t* trial_offsets_host, int num_trials, int width, int hop,
+                    const double* corr_host, double* scores_dev, uint8_t* decisions_dev) {
+  if (!h || !eeg_dev || !w_dev || !env_dev || !trial_offsets_host || !corr_host || !scores_dev ||
+      !decisions_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_decode_fused: NULL argument");
+  TD_REQUIRE(h, num_trials > 0 && width > 0 && hop > 0, "td_decode_fused: bad sizes");
+  const int64_t rows = trial_offsets_host[num_trials];
+  std::vector<long long> row0;
+  std::vector<int64_t> off;
+  build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
+  const int64_t nwin = (int64_t)row0.size();
+  // workspace: pred [rows] f32, sums [nwin][2][5] f64, s1/s2 [nwin] f64
+  float* pred = nullptr;
+  const size_t bytes = td_round_up(sizeof(float) * rows, 256) +
+                       sizeof(double) * (size_t)nwin * (10 + 2) + 256;
+  TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&pred), bytes));
+  double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(pred) +
+                                           td_round_up(sizeof(float) * rows, 256));
+  double* s1 = sums + (size_t)nwin * 10;
+  double* s2 = s1 + nwin;
+  int rc = launch_fir(h, eeg_dev, ldx, trial_offsets_host, num_trials, c, pre, post, w_dev, b_dev,
+                      1, pred, 1);
+  for (int spk = 0; spk < 2 && rc == TD_OK && nwin > 0; ++spk) {
+    // a = envelope of speaker spk (the "truth" stream), b = prediction
+    rc = td_window_sums(h, env_dev + spk, ldenv, pred, 1, 1, trial_offsets_host, num_trials, width,
+                        hop, sums + (size_t)spk * nwin * 5);
+    if (rc == TD_OK)
+      rc = td_window_scores(h, sums + (size_t)spk * nwin * 5, nwin, 1, width, 0, 0,
+                            corr_host + 3 * spk, corr_host + 3 * spk + 1, corr_host + 3 * spk + 2,
+                            spk == 0 ? s1 : s2);
+  }
+  if (rc == TD_OK && nwin > 0) {
+    rc = td_decide_wta(h, s1, s2, nwin, decisions_dev);
+    // interleave scores [nwin][2]
+    hipMemcpy2DAsync(scores_dev, 2 * sizeof(double), s1, sizeof(double), sizeof(double), nwin,
+                     hipMemcpyDeviceToDevice, h->stream);
+    hipMemcpy2DAsync(scores_dev + 1, 2 * sizeof(double), s2, sizeof(double), sizeof(double), nwin,
+                     hipMemcpyDeviceToDevice, h->stream);
+  }
+  hipStreamSynchronize(h->stream);
+  hipFree(pred);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,455 @@
+// Lagged cross-covariance accumulate -- the dominant kernel of the TRF / CCA fit.
+//
+//   G[e][i][j] (+)= sum_segments sum_{u=u_begin}^{u_end-1} A~[u][i] * B~[u+e][j]
+//
+// It replaces BOTH the reference's lag-matrix builder (brain_data.py:425-457:
+// zero-pad, tf.signal.frame, reshape -- a 32x blow-up at 32 lags) and the dense
+// per-minibatch `sum_xtx += x.T @ x` (brain_model.py:437, cca.py:325-327): the
+// C x (C*L) lagged cross-covariance carries the same information as the
+// (C*L)^2 matrix (block-Toeplitz up to file edges, fixed up exactly in
+// stats.hip) at 1/L of the flops, and the lag matrix only ever exists as
+// shifted views of an LDS tile.
+//
+// MI355X mapping (gfx950, wave64):
+//   * one workgroup = 256 threads = 4 waves, one per SIMD; it owns a time slab of
+//     one file, 64 A-channels, 64 B-channels and 8 consecutive lags
+//     -> a 64 x 512 f32 accumulator = 128 VGPR/lane, 2 workgroups per CU;
+//   * each wave owns 2 lags: 2(M) x 2(N) tiles of v_mfma_f32_32x32x2_f32 per lag
+//     (exact f32 FMA chains; gfx950 has no xf32/TF32);
+//   * the time x channel matrix is read with coalesced 16-byte loads -- one
+//     64-channel row is one 256-byte line -- into an LDS tile of T (+7 lag halo)
+//     rows; MFMA operands are conflict-free ds_read_b32 of that tile (lanes 0-31
+//     walk one row, lanes 32-63 the next: the two k-slices of 32x32x2);
+//   * every workgroup writes ONE f32 partial slab at the end; a second kernel
+//     sums the slabs in float64 (bitwise reproducible -- no float atomics);
+//   * blockIdx is remapped so the workgroups that share a time slab (the lag
+//     groups) land on one XCD and hit its L2.
+#include "td_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kTile = 128;     // time samples per LDS tile
+constexpr int kLagsPerWg = 8;  // lags per workgroup (2 per wave)
+constexpr int kHalo = 8;       // extra B rows (7 needed)
+
+struct LagWork {
+  long long a_row0, a_valid, b_row0, b_valid, u_begin, u_end;
+};
+
+struct LagParams {
+  const float* a;
+  const float* b;
+  long long lda, ldb;
+  int ca, cb;        // real channel counts
+  int a_ones;        // append a ones column to A at index ca
+  const LagWork* works;
+  int n_work, n_groups, n_cat, n_cbt;
+  int e_min, e_count;
+  float* partial;    // [n_work][e_pad][ca_pad][cb_pad]
+  int e_pad, ca_pad, cb_pad;
+};
+
+// Bijective XCD-aware remap: physical block b runs on XCD b % 8 (observed
+// round-robin dispatch; speed only).  Give each XCD a contiguous range of
+// logical ids so that neighbours in logical order share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, within = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + within;
+}
+
+// ---- tile staging: global -> LDS, zero-filled outside the segment ----------
+// rows [row_lo, row_lo + nrows) of the segment-relative stream; valid rows are
+// [0, valid) AND (for A) < u_limit.  64 channels starting at c0; channels >= c
+// are zero.  `ones_col` (>= 0) is filled with 1.0 on valid-or-not rows inside
+// [ones_lo, ones_hi).
+template <bool kAligned>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ g,
+                                           long long ld, long long row0_global,
+                                           long long row_lo, int nrows, long long valid,
+                                           long long row_limit, int c0, int c, int tid) {
+  // 16 threads cover one 64-channel row with float4; 16 rows per pass.
+  const int c4 = (tid & 15) * 4;
+  for (int r = tid >> 4; r < nrows; r += kThreads / 16) {
+    const long long u = row_lo + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u >= 0 && u < valid && u < row_limit) {
+      const float* p = g + (row0_global + u) * ld + c0 + c4;
+      if (kAligned) {
+        if (c0 + c4 + 3 < c) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (c0 + c4 + 0 < c) v.x = p[0];
+          if (c0 + c4 + 1 < c) v.y = p[1];
+          if (c0 + c4 + 2 < c) v.z = p[2];
+        }
+      } else {
+        if (c0 + c4 + 0 < c) v.x = p[0];
+        if (c0 + c4 + 1 < c) v.y = p[1];
+        if (c0 + c4 + 2 < c) v.z = p[2];
+        if (c0 + c4 + 3 < c) v.w = p[3];
+      }
+    }
+    *reinterpret_cast<float4*>(lds + r * 64 + c4) = v;
+  }
+}
+
+template <bool kM2, bool kN2>
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ as,
+                                          const float* __restrict__ bs, int wave, int lane,
+                                          f32x16 (&acc)[2][2][2]) {
+  const int lr = lane & 31, lk = lane >> 5;
+  const float* ap = as + lk * 64 + lr;
+  const float* bp = bs + (lk + 2 * wave) * 64 + lr;
+#pragma unroll 4
+  for (int kk = 0; kk < kTile / 2; ++kk) {
+    const float a0 = ap[kk * 128];
+    const float a1 = kM2 ? ap[kk * 128 + 32] : 0.f;
+#pragma unroll
+    for (int le = 0; le < 2; ++le) {
+      const float b0 = bp[kk * 128 + le * 64];
+      acc[le][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[le][0][0], 0, 0, 0);
+      if (kM2) acc[le][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[le][1][0], 0, 0, 0);
+      if (kN2) {
+        const float b1 = bp[kk * 128 + le * 64 + 32];
+        acc[le][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[le][0][1], 0, 0, 0);
+        if (kM2) acc[le][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[le][1][1], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <bool kAligned>
+__global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[(kTile + kTile + kHalo) * 64];
+  float* as = lds;
+  float* bs = lds + kTile * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int group = id % p.n_groups; id /= p.n_groups;
+  const int cbt = id % p.n_cbt; id /= p.n_cbt;
+  const int cat = id % p.n_cat; id /= p.n_cat;
+  const LagWork w = p.works[id];
+  const int e0 = p.e_min + group * kLagsPerWg;
+
+  const int ca_eff = p.ca + p.a_ones;
+  const bool m2 = ca_eff - cat * 64 > 32;
+  const bool n2 = p.cb - cbt * 64 > 32;
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.f;
+
+  const int ones_col = p.a_ones ? p.ca - cat * 64 : -1;  // local column or out of tile
+
+  for (long long ut = w.u_begin; ut < w.u_end; ut += kTile) {
+    stage_tile<kAligned>(as, p.a, p.lda, w.a_row0, ut, kTile, w.a_valid, w.u_end, cat * 64, p.ca,
+                         tid);
+    stage_tile<kAligned>(bs, p.b, p.ldb, w.b_row0, ut + e0, kTile + kHalo, w.b_valid,
+                         0x7fffffffffffffffLL, cbt * 64, p.cb, tid);
+    if (ones_col >= 0 && ones_col < 64) {
+      __syncthreads();
+      for (int r = tid; r < kTile; r += kThreads) {
+        const long long u = ut + r;
+        as[r * 64 + ones_col] = (u >= w.u_begin && u < w.u_end) ? 1.f : 0.f;
+      }
+    }
+    __syncthreads();
+    if (m2) {
+      if (n2) mfma_tile<true, true>(as, bs, wave, lane, acc);
+      else    mfma_tile<true, false>(as, bs, wave, lane, acc);
+    } else {
+      if (n2) mfma_tile<false, true>(as, bs, wave, lane, acc);
+      else    mfma_tile<false, false>(as, bs, wave, lane, acc);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue: one partial slab per workgroup.  32x32 C/D map: col = lane & 31,
+  // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  const int lr = lane & 31, lk = lane >> 5;
+  float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
+#pragma unroll
+  for (int le = 0; le < 2; ++le) {
+    const int e_idx = group * kLagsPerWg + 2 * wave + le;
+    float* pe = slab + (size_t)e_idx * p.ca_pad * p.cb_pad;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = cat * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int j = cbt * 64 + n * 32 + lr;
+          pe[(size_t)i * p.cb_pad + j] = acc[le][m][n][r];
+        }
+  }
+}
+
+// ---- skinny-A variant (ca_eff <= 8: regression targets [y | 1]) -------------
+// VALU kernel: thread = (B channel j, lag phase q); 8 lags x NI A-columns of f32
+// accumulators per thread; A rows are LDS broadcasts.
+constexpr int kSmallLags = 32;  // lags per workgroup
+
+template <int NI, bool kAligned>
+__global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
+  __shared__ __attribute__((aligned(16))) float as[kTile * 8];
+  __shared__ __attribute__((aligned(16))) float bs[(kTile + kSmallLags) * 64];
+  const int tid = threadIdx.x;
+  const int j = tid & 63, q = tid >> 6;
+
+  int id = blockIdx.x;
+  const int group = id % p.n_groups; id /= p.n_groups;
+  const int cbt = id % p.n_cbt; id /= p.n_cbt;
+  const LagWork w = p.works[id];
+  const int e0 = p.e_min + group * kSmallLags;
+
+  float acc[8][NI];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[m][i] = 0.f;
+
+  for (long long ut = w.u_begin; ut < w.u_end; ut += kTile) {
+    // A tile: [kTile][8]
+    for (int idx = tid; idx < kTile * 8; idx += kThreads) {
+      const int r = idx >> 3, i = idx & 7;
+      const long long u = ut + r;
+      float v = 0.f;
+      if (u >= w.u_begin && u < w.u_end && u >= 0) {
+        if (i < p.ca) {
+          if (u < w.a_valid) v = p.a[(w.a_row0 + u) * p.lda + i];
+        } else if (i == p.ca && p.a_ones) {
+          v = 1.f;
+        }
+      }
+      as[idx] = v;
+    }
+    stage_tile<kAligned>(bs, p.b, p.ldb, w.b_row0, ut + e0, kTile + kSmallLags, w.b_valid,
+                         0x7fffffffffffffffLL, cbt * 64, p.cb, tid);
+    __syncthreads();
+#pragma unroll 2
+    for (int r = 0; r < kTile; ++r) {
+      float a[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = as[r * 8 + i];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float b = bs[(r + q + 4 * m) * 64 + j];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[m][i] = fmaf(a[i], b, acc[m][i]);
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int e_idx = group * kSmallLags + q + 4 * m;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      slab[((size_t)e_idx * p.ca_pad + i) * p.cb_pad + cbt * 64 + j] = acc[m][i];
+  }
+}
+
+// ---- slab reduction in float64 ----------------------------------------------
+__global__ void lagcov_reduce_kernel(const float* __restrict__ partial, int n_work, int e_pad,
+                                     int ca_pad, int cb_pad, int e_count, int ca_eff, int cb,
+                                     double* __restrict__ g, int accumulate) {
+  const long long total = (long long)e_count * ca_eff * cb;
+  const size_t slab = (size_t)e_pad * ca_pad * cb_pad;
+  for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total;
+       o += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(o % cb);
+    const int i = (int)((o / cb) % ca_eff);
+    const int e = (int)(o / ((long long)cb * ca_eff));
+    const float* src = partial + ((size_t)e * ca_pad + i) * cb_pad + j;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int w = 0;
+    for (; w + 3 < n_work; w += 4) {
+      s0 += (double)src[(size_t)(w + 0) * slab];
+      s1 += (double)src[(size_t)(w + 1) * slab];
+      s2 += (double)src[(size_t)(w + 2) * slab];
+      s3 += (double)src[(size_t)(w + 3) * slab];
+    }
+    for (; w < n_work; ++w) s0 += (double)src[(size_t)w * slab];
+    const double s = (s0 + s1) + (s2 + s3);
+    g[o] = accumulate ? g[o] + s : s;
+  }
+}
+
+// ---- float64 column sums (sum of y over the rows that enter the fit) --------
+__global__ void colsum_kernel(const float* __restrict__ a, long long lda, int ca,
+                              const LagWork* __restrict__ works, int n_work,
+                              double* __restrict__ partial) {
+  // block b handles work item b; thread t handles column t % ca over rows t / ca + k*stride
+  __shared__ double red[kThreads];
+  const LagWork w = works[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int c = 0; c < ca; ++c) {
+    double s = 0.0;
+    for (long long u = w.u_begin + tid; u < w.u_end; u += kThreads)
+      if (u >= 0 && u < w.a_valid) s += (double)a[(w.a_row0 + u) * lda + c];
+    red[tid] = s;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) partial[(size_t)blockIdx.x * ca + c] = red[0];
+    __syncthreads();
+  }
+}
+
+__global__ void colsum_reduce_kernel(const double* __restrict__ partial, int n_work, int ca,
+                                     double* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ca) return;
+  double s = 0.0;
+  for (int w = 0; w < n_work; ++w) s += partial[(size_t)w * ca + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// Splits segments into slabs of at most `slab` samples (a multiple of kTile).
+std::vector<LagWork> split_work(const std::vector<LagSeg>& segs, long long slab) {
+  std::vector<LagWork> works;
+  for (const LagSeg& s : segs) {
+    for (long long u = s.u_begin; u < s.u_end; u += slab) {
+      LagWork w;
+      w.a_row0 = s.a_row0; w.a_valid = s.a_valid;
+      w.b_row0 = s.b_row0; w.b_valid = s.b_valid;
+      w.u_begin = u;
+      w.u_end = (u + slab < s.u_end) ? u + slab : s.u_end;
+      works.push_back(w);
+    }
+  }
+  return works;
+}
+
+}  // namespace
+
+int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
+              int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+              double* g_dev, bool accumulate) {
+  const int ca_eff = ca + (a_ones ? 1 : 0);
+  TD_REQUIRE(h, ca_eff > 0 && cb > 0 && e_count > 0, "lagcov: empty problem");
+  long long total = 0;
+  for (const LagSeg& s : segs) total += (s.u_end > s.u_begin) ? s.u_end - s.u_begin : 0;
+  if (total == 0) {
+    if (!accumulate)
+      TD_HIP(h, hipMemsetAsync(g_dev, 0, sizeof(double) * e_count * ca_eff * cb, h->stream));
+    return TD_OK;
+  }
+  const bool small = ca_eff <= 8;
+  const int lags_per_wg = small ? kSmallLags : kLagsPerWg;
+  LagParams p;
+  p.a = a; p.b = b; p.lda = lda; p.ldb = ldb; p.ca = ca; p.cb = cb; p.a_ones = a_ones ? 1 : 0;
+  p.e_min = e_min; p.e_count = e_count;
+  p.n_groups = (int)td_ceil_div(e_count, lags_per_wg);
+  p.n_cat = small ? 1 : (int)td_ceil_div(ca_eff, 64);
+  p.n_cbt = (int)td_ceil_div(cb, 64);
+  p.e_pad = p.n_groups * lags_per_wg;
+  p.ca_pad = small ? 8 : p.n_cat * 64;
+  p.cb_pad = p.n_cbt * 64;
+
+  // Slab length: aim at ~1024 workgroups (2 resident per CU x 256 CUs x 2
+  // rounds), never shorter than 4 tiles, never longer than 16384 samples (bounds
+  // the length of one f32 accumulation chain; slabs are then summed in f64).
+  // Accuracy sets the upper bound, parallelism the lower one: every slab is ONE
+  // f32 accumulation chain (relative error ~ eps/2 * sqrt(len/3)), slabs are then
+  // summed in float64, so 2048-sample slabs keep the moments ~1e-7 * sqrt(2048/N)
+  // from exact at the price of (N/2048) slab writes+reads (~0.5 kB per sample,
+  // <10 % of the kernel at C2).  Small problems get one-tile slabs.
+  const long long per_item_wgs = (long long)p.n_groups * p.n_cat * p.n_cbt;
+  long long want_items = 2048 / per_item_wgs;
+  if (want_items < 1) want_items = 1;
+  long long slab = td_round_up(td_ceil_div(total, want_items), kTile);
+  if (slab < kTile) slab = kTile;
+  if (slab > 2048) slab = 2048;
+  std::vector<LagWork> works = split_work(segs, slab);
+  p.n_work = (int)works.size();
+
+  const size_t slab_elems = (size_t)p.e_pad * p.ca_pad * p.cb_pad;
+  const size_t table_bytes = td_round_up(works.size() * sizeof(LagWork), 256);
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, table_bytes + slab_elems * works.size() * sizeof(float), &scratch));
+  TD_TRY(td_upload_async(h, works.data(), works.size() * sizeof(LagWork), scratch));
+  p.works = reinterpret_cast<const LagWork*>(scratch);
+  p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + table_bytes);
+
+  const bool b_aligned = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+  const bool a_aligned = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+  // the skinny-A kernel reads A with scalar loads: only B's alignment matters
+  const bool aligned = small ? b_aligned : (a_aligned && b_aligned);
+  const long long nwg = (long long)p.n_work * per_item_wgs;
+  TD_REQUIRE(h, nwg < (1LL << 31), "lagcov: too many workgroups");
+  if (small) {
+    const int ni = ca_eff <= 1 ? 1 : ca_eff <= 2 ? 2 : ca_eff <= 4 ? 4 : 8;
+#define TD_LAUNCH_SMALL(NI)                                                              \
+  do {                                                                                   \
+    if (aligned)                                                                         \
+      hipLaunchKernelGGL((lagcov_small_kernel<NI, true>), dim3((unsigned)nwg),           \
+                         dim3(kThreads), 0, h->stream, p);                               \
+    else                                                                                 \
+      hipLaunchKernelGGL((lagcov_small_kernel<NI, false>), dim3((unsigned)nwg),          \
+                         dim3(kThreads), 0, h->stream, p);                               \
+  } while (0)
+    if (ni == 1) TD_LAUNCH_SMALL(1);
+    else if (ni == 2) TD_LAUNCH_SMALL(2);
+    else if (ni == 4) TD_LAUNCH_SMALL(4);
+    else TD_LAUNCH_SMALL(8);
+#undef TD_LAUNCH_SMALL
+  } else {
+    if (aligned)
+      hipLaunchKernelGGL(lagcov_mfma_kernel<true>, dim3((unsigned)nwg), dim3(kThreads), 0,
+                         h->stream, p);
+    else
+      hipLaunchKernelGGL(lagcov_mfma_kernel<false>, dim3((unsigned)nwg), dim3(kThreads), 0,
+                         h->stream, p);
+  }
+  TD_HIP(h, hipGetLastError());
+  const long long outs = (long long)e_count * ca_eff * cb;
+  int rblocks = (int)td_ceil_div(outs, 256);
+  if (rblocks > 4096) rblocks = 4096;
+  hipLaunchKernelGGL(lagcov_reduce_kernel, dim3(rblocks), dim3(256), 0, h->stream, p.partial,
+                     p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff, cb, g_dev,
+                     accumulate ? 1 : 0);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vector<LagSeg>& segs,
+              double* out_dev, bool accumulate) {
+  if (ca <= 0) return TD_OK;
+  std::vector<LagWork> works = split_work(segs, 1 << 12);
+  if (works.empty()) {
+    if (!accumulate) TD_HIP(h, hipMemsetAsync(out_dev, 0, sizeof(double) * ca, h->stream));
+    return TD_OK;
+  }
+  const size_t table_bytes = td_round_up(works.size() * sizeof(LagWork), 256);
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, table_bytes + works.size() * ca * sizeof(double), &scratch));
+  TD_TRY(td_upload_async(h, works.data(), works.size() * sizeof(LagWork), scratch));
+  double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + table_bytes);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)works.size()), dim3(kThreads), 0, h->stream,
+                     a, (long long)lda, ca, reinterpret_cast<const LagWork*>(scratch),
+                     (int)works.size(), partial);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)td_ceil_div(ca, 64)), dim3(64), 0,
+                     h->stream, partial, (int)works.size(), ca, out_dev, accumulate ? 1 : 0);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}

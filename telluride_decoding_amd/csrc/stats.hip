@@ -1,0 +1,530 @@
+// Device-resident sufficient statistics of lagged regression / CCA inputs
+// (SURVEY.md 8a rows A1+A2, A4's accumulate) and their expansion into the dense
+// moment matrices the reference accumulates literally.
+//
+// Identity used (x~ = stream zero-extended outside its file; a = l - pre the
+// signed lag of lagged column block l; N' = rows of the file that enter the
+// sums, N' <= file length because of batch(drop_remainder) / input_offset):
+//
+//   M[(la,i),(lb,j)] = sum_{t=0}^{N'-1} A~[t+a][i] B~[t+b][j]
+//                    = G'[e][i][j] + corr(a, e)[i][j],          e = b - a,
+//   G'[e]      = sum_{u=0}^{N'-1} A~[u]^T B~[u+e]               (lagcov.hip)
+//   corr(a>0)  = - sum_{u=0}^{a-1} P[u][e] + sum_{u=N'}^{N'+a-1} P[u][e]
+//   corr(a<0)  = - sum_{u=N'+a}^{N'-1} P[u][e],   P[u][e] = A~[u]^T B~[u+e].
+//
+// The corrections only touch <= max(pre, post) samples at each end of each
+// file; those samples are kept in small per-file "boundary windows", so the
+// statistics stay compact (C x C x L instead of (C L)^2) and additive over
+// files, ranks and subjects.
+#include "td_common.h"
+
+struct td_stats {
+  int c1 = 0, pre1 = 0, post1 = 0, c2 = 0, pre2 = 0, post2 = 0, d = 0;
+  int l1 = 0, l2 = 0, k1 = 0, k2 = 0, hw = 0;  // hw: half width of a boundary window
+  // One device block of doubles, in this order (offsets below):
+  //   fxx [l1][c1][c1]            e = 0..l1-1            (A = B = x)
+  //   gxo [l1][d+1][c1]           e = -pre1..post1       (A = [y | 1], B = x)
+  //   sy  [d]  and  n [1]         sum of y rows, frame count
+  //   fyy [l2][c2][c2]            e = 0..l2-1            (A = B = x2)
+  //   gxy [l1+l2-1][c1][c2]       e = -(post1+pre2)..(pre1+post2)   (A = x, B = x2)
+  //   gyo [l2][1][c2]             e = -pre2..post2       (A = [1], B = x2)
+  double* g = nullptr;
+  int64_t off_fxx = 0, off_gxo = 0, off_sy = 0, off_n = 0, off_fyy = 0, off_gxy = 0,
+          off_gyo = 0, g_len = 0;
+  // Boundary windows, float32: [file][2 (head, tail)][2*hw][c].  Head row r holds
+  // x~[r - hw]; tail row r holds x~[N' + r - hw].
+  float* win1 = nullptr;
+  float* win2 = nullptr;
+  int64_t n_files = 0, cap_files = 0;
+  int64_t frames = 0;
+};
+
+namespace {
+
+struct WinJob {
+  long long row0, valid, nprime;  // stream rows of this file; rows used
+};
+
+__global__ void gather_windows_kernel(const float* __restrict__ x, long long ld, int c, int hw,
+                                      const WinJob* __restrict__ jobs, float* __restrict__ win,
+                                      long long first_slot) {
+  const WinJob j = jobs[blockIdx.x];
+  const int which = blockIdx.y;  // 0 head, 1 tail
+  float* dst = win + ((first_slot + blockIdx.x) * 2 + which) * (long long)(2 * hw) * c;
+  const long long base = which == 0 ? -hw : j.nprime - hw;
+  for (int idx = threadIdx.x; idx < 2 * hw * c; idx += blockDim.x) {
+    const int r = idx / c, col = idx % c;
+    const long long u = base + r;
+    dst[idx] = (u >= 0 && u < j.valid) ? x[(j.row0 + u) * ld + col] : 0.f;
+  }
+}
+
+// One workgroup per (e, 64x64 tile of the [ca x cb] block); walks the lag
+// diagonal a = 1..posta and a = -1..-prea carrying running edge sums, so the
+// whole expansion costs O(L * E * ca * cb * files) instead of O(L^3 ...).
+struct ExpandParams {
+  const double* g;   // [e_count][ca][cb]
+  int e_min, e_count;
+  int ca, prea, posta;
+  int cb, preb, postb;
+  const float* wina;  // [files][2][2hw][ca]
+  const float* winb;  // [files][2][2hw][cb]
+  int hw;
+  long long n_files;
+  double* m;          // dense output
+  long long ldm;
+  int symmetric;      // A == B: only e >= 0 is given; mirror into the lower part
+};
+
+__global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
+  const int e = p.e_min + blockIdx.x;
+  const int ti = blockIdx.y, tj = blockIdx.z;
+  const int i0 = ti * 64 + (threadIdx.x >> 4) * 4;
+  const int j0 = tj * 64 + (threadIdx.x & 15) * 4;
+  const long long wa = (long long)2 * p.hw * p.ca, wb = (long long)2 * p.hw * p.cb;
+
+  double base[4][4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int i = i0 + ii, j = j0 + jj;
+      base[ii][jj] = (i < p.ca && j < p.cb)
+                         ? p.g[((long long)(e - p.e_min) * p.ca + i) * p.cb + j]
+                         : 0.0;
+    }
+
+  auto emit = [&](int a, const double (&v)[4][4]) {
+    const int la = a + p.prea, lb = a + e + p.preb;
+    if (lb < 0 || lb >= p.preb + 1 + p.postb) return;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int i = i0 + ii, j = j0 + jj;
+        if (i < p.ca && j < p.cb) {
+          const long long r = (long long)la * p.ca + i, c = (long long)lb * p.cb + j;
+          p.m[r * p.ldm + c] = v[ii][jj];
+          if (p.symmetric && e != 0) p.m[c * p.ldm + r] = v[ii][jj];
+        }
+      }
+  };
+
+  // outer product of window rows (ra of stream A, rb of stream B) summed over files
+  auto add_outer = [&](int which, int ra, int rb, double sign, double (&acc)[4][4]) {
+    if (ra < 0 || ra >= 2 * p.hw || rb < 0 || rb >= 2 * p.hw) return;
+    for (long long f = 0; f < p.n_files; ++f) {
+      const float* pa = p.wina + (f * 2 + which) * wa + (long long)ra * p.ca;
+      const float* pb = p.winb + (f * 2 + which) * wb + (long long)rb * p.cb;
+      double av[4], bv[4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) av[ii] = (i0 + ii < p.ca) ? (double)pa[i0 + ii] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) bv[jj] = (j0 + jj < p.cb) ? (double)pb[j0 + jj] : 0.0;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += sign * av[ii] * bv[jj];
+    }
+  };
+
+  emit(0, base);
+  {
+    double v[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) v[ii][jj] = base[ii][jj];
+    for (int a = 1; a <= p.posta; ++a) {
+      const int u = a - 1;
+      add_outer(0, u + p.hw, u + e + p.hw, -1.0, v);   // - P[u][e], head
+      add_outer(1, u + p.hw, u + e + p.hw, +1.0, v);   // + P[N'+u][e], tail
+      emit(a, v);
+    }
+  }
+  {
+    double v[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) v[ii][jj] = base[ii][jj];
+    for (int a = -1; a >= -p.prea; --a) {
+      add_outer(1, a + p.hw, a + e + p.hw, -1.0, v);   // - P[N'+a][e], tail
+      emit(a, v);
+    }
+  }
+}
+
+// Fills the bias row/column of XtX and the whole XtY from gxo / sy / n.
+__global__ void bias_fill_kernel(const double* __restrict__ gxo, const double* __restrict__ sy,
+                                 const double* __restrict__ n, int l1, int c1, int d,
+                                 double* __restrict__ xtx, double* __restrict__ xty) {
+  const int k1 = l1 * c1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < k1) {
+    const int l = idx / c1, c = idx % c1;
+    const double* row = gxo + (long long)l * (d + 1) * c1;
+    if (xtx) {
+      const double s = row[(long long)d * c1 + c];   // ones row of A = [y | 1]
+      xtx[(long long)idx * (k1 + 1) + k1] = s;
+      xtx[(long long)k1 * (k1 + 1) + idx] = s;
+    }
+    if (xty)
+      for (int dd = 0; dd < d; ++dd) xty[(long long)idx * d + dd] = row[(long long)dd * c1 + c];
+  } else if (idx == k1) {
+    if (xtx) xtx[(long long)k1 * (k1 + 1) + k1] = n[0];
+    if (xty)
+      for (int dd = 0; dd < d; ++dd) xty[(long long)k1 * d + dd] = sy[dd];
+  }
+}
+
+__global__ void axpy_kernel(double* __restrict__ dst, const double* __restrict__ src, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+
+__global__ void f2d_kernel(double* __restrict__ dst, const float* __restrict__ src, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = (double)src[i];
+}
+
+__global__ void d2f_kernel(float* __restrict__ dst, const double* __restrict__ src, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = (float)src[i];
+}
+
+inline int blocks_for(long long n) {
+  long long b = td_ceil_div(n, 256);
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+int ensure_window_capacity(td_handle* h, td_stats* s, int64_t need) {
+  if (need <= s->cap_files) return TD_OK;
+  int64_t cap = s->cap_files ? s->cap_files : 64;
+  while (cap < need) cap *= 2;
+  const size_t per1 = (size_t)2 * 2 * s->hw * s->c1 * sizeof(float);
+  const size_t per2 = (size_t)2 * 2 * s->hw * s->c2 * sizeof(float);
+  float* n1 = nullptr;
+  float* n2 = nullptr;
+  TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&n1), per1 * cap));
+  if (s->c2) TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&n2), per2 * cap));
+  if (s->n_files) {
+    TD_HIP(h, hipMemcpyAsync(n1, s->win1, per1 * s->n_files, hipMemcpyDeviceToDevice, h->stream));
+    if (s->c2)
+      TD_HIP(h, hipMemcpyAsync(n2, s->win2, per2 * s->n_files, hipMemcpyDeviceToDevice, h->stream));
+  }
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  if (s->win1) TD_HIP(h, hipFree(s->win1));
+  if (s->win2) TD_HIP(h, hipFree(s->win2));
+  s->win1 = n1;
+  s->win2 = n2;
+  s->cap_files = cap;
+  return TD_OK;
+}
+
+int expand_block(td_handle* h, const double* g, int e_min, int e_count, int ca, int prea,
+                 int posta, int cb, int preb, int postb, const float* wina, const float* winb,
+                 int hw, int64_t n_files, double* m, int64_t ldm, bool symmetric) {
+  ExpandParams p;
+  p.g = g; p.e_min = e_min; p.e_count = e_count;
+  p.ca = ca; p.prea = prea; p.posta = posta;
+  p.cb = cb; p.preb = preb; p.postb = postb;
+  p.wina = wina; p.winb = winb; p.hw = hw; p.n_files = n_files;
+  p.m = m; p.ldm = ldm; p.symmetric = symmetric ? 1 : 0;
+  dim3 grid((unsigned)e_count, (unsigned)td_ceil_div(ca, 64), (unsigned)td_ceil_div(cb, 64));
+  hipLaunchKernelGGL(expand_kernel, grid, dim3(256), 0, h->stream, p);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+}  // namespace
+
+// Used by solve.hip.
+int td_stats_layout(const td_stats* s, int* k1, int* d, int64_t* frames) {
+  *k1 = s->k1;
+  *d = s->d;
+  *frames = s->frames;
+  return TD_OK;
+}
+
+extern "C" {
+
+int td_stats_create(td_handle* h, int c1, int pre1, int post1, int c2, int pre2, int post2,
+                    int d, td_stats** out) {
+  if (!h || !out) return td_fail(h, TD_ERR_INVALID, "td_stats_create: NULL argument");
+  *out = nullptr;
+  TD_REQUIRE(h, c1 > 0, "input_1 must have at least one channel, not %d", c1);
+  TD_REQUIRE(h, pre1 >= 0 && post1 >= 0 && pre2 >= 0 && post2 >= 0,
+             "context (pre/post) must be >= 0");
+  TD_REQUIRE(h, c2 >= 0 && d >= 0, "negative width");
+  td_stats* s = new td_stats();
+  s->c1 = c1; s->pre1 = pre1; s->post1 = post1;
+  s->c2 = c2; s->pre2 = c2 ? pre2 : 0; s->post2 = c2 ? post2 : 0; s->d = d;
+  s->l1 = pre1 + 1 + post1;
+  s->l2 = c2 ? s->pre2 + 1 + s->post2 : 0;
+  s->k1 = s->l1 * c1;
+  s->k2 = s->l2 * c2;
+  s->hw = s->pre1 + s->post1 + s->pre2 + s->post2 + 1;
+  int64_t o = 0;
+  s->off_fxx = o; o += (int64_t)s->l1 * c1 * c1;
+  s->off_gxo = o; o += (int64_t)s->l1 * (d + 1) * c1;
+  s->off_sy = o;  o += d;
+  s->off_n = o;   o += 1;
+  s->off_fyy = o; o += (int64_t)s->l2 * c2 * c2;
+  s->off_gxy = o; o += c2 ? (int64_t)(s->l1 + s->l2 - 1) * c1 * c2 : 0;
+  s->off_gyo = o; o += (int64_t)s->l2 * c2;
+  s->g_len = o;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->g), sizeof(double) * s->g_len);
+  if (e != hipSuccess) {
+    delete s;
+    return td_fail(h, TD_ERR_NOMEM, "statistics allocation failed: %s", hipGetErrorString(e));
+  }
+  TD_HIP(h, hipMemsetAsync(s->g, 0, sizeof(double) * s->g_len, h->stream));
+  *out = s;
+  return TD_OK;
+}
+
+int td_stats_destroy(td_handle* h, td_stats* s) {
+  if (!s) return TD_OK;
+  if (h) hipStreamSynchronize(h->stream);
+  if (s->g) hipFree(s->g);
+  if (s->win1) hipFree(s->win1);
+  if (s->win2) hipFree(s->win2);
+  delete s;
+  return TD_OK;
+}
+
+int td_stats_reset(td_handle* h, td_stats* s) {
+  if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_reset: NULL argument");
+  TD_HIP(h, hipMemsetAsync(s->g, 0, sizeof(double) * s->g_len, h->stream));
+  s->n_files = 0;
+  s->frames = 0;
+  return TD_OK;
+}
+
+int td_stats_counts(td_handle* h, const td_stats* s, int64_t* frames, int64_t* files) {
+  if (!s) return td_fail(h, TD_ERR_INVALID, "td_stats_counts: NULL statistics");
+  if (frames) *frames = s->frames;
+  if (files) *files = s->n_files;
+  return TD_OK;
+}
+
+int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
+                        const float* x2_dev, int64_t ldx2, const float* y_dev, int64_t ldy,
+                        const int64_t* file_offsets_host, int num_files, int input_offset,
+                        const int64_t* rows_used_host) {
+  if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_accumulate: NULL argument");
+  TD_REQUIRE(h, x_dev && file_offsets_host && num_files >= 0, "td_stats_accumulate: NULL input");
+  TD_REQUIRE(h, ldx >= s->c1, "ldx (%lld) < channels (%d)", (long long)ldx, s->c1);
+  TD_REQUIRE(h, !s->c2 || (x2_dev && ldx2 >= s->c2), "input_2 missing or ldx2 too small");
+  TD_REQUIRE(h, !s->d || (y_dev && ldy >= s->d), "y missing or ldy too small");
+  if (num_files == 0) return TD_OK;
+
+  const int64_t dx = input_offset > 0 ? input_offset : 0;    // rows dropped from x
+  const int64_t dy = input_offset < 0 ? -input_offset : 0;   // rows dropped from x2 and y
+  std::vector<LagSeg> sxx, syx, syy, sxy;
+  std::vector<WinJob> j1(num_files), j2(num_files);
+  int64_t new_frames = 0;
+  for (int f = 0; f < num_files; ++f) {
+    const int64_t r0 = file_offsets_host[f], r1 = file_offsets_host[f + 1];
+    TD_REQUIRE(h, r1 >= r0, "file_offsets must be non-decreasing");
+    const int64_t nf = r1 - r0;
+    const int64_t vx = nf - dx > 0 ? nf - dx : 0;
+    const int64_t vy = nf - dy > 0 ? nf - dy : 0;
+    // zip() of the four streams truncates to the shortest; the attention stream
+    // is never shifted (brain_data.py:466-483).
+    int64_t nz = vx < vy ? vx : vy;
+    if (nf < nz) nz = nf;
+    int64_t np = nz;
+    if (rows_used_host) {
+      TD_REQUIRE(h, rows_used_host[f] >= 0 && rows_used_host[f] <= nz,
+                 "rows_used[%d] = %lld outside [0, %lld]", f, (long long)rows_used_host[f],
+                 (long long)nz);
+      np = rows_used_host[f];
+    }
+    new_frames += np;
+    LagSeg a;
+    a.a_row0 = r0 + dx; a.a_valid = vx; a.b_row0 = r0 + dx; a.b_valid = vx;
+    a.u_begin = 0; a.u_end = np;
+    sxx.push_back(a);
+    LagSeg b;   // A = y stream, B = x
+    b.a_row0 = r0 + dy; b.a_valid = vy; b.b_row0 = r0 + dx; b.b_valid = vx;
+    b.u_begin = 0; b.u_end = np;
+    syx.push_back(b);
+    LagSeg c;   // A = B = x2
+    c.a_row0 = r0 + dy; c.a_valid = vy; c.b_row0 = r0 + dy; c.b_valid = vy;
+    c.u_begin = 0; c.u_end = np;
+    syy.push_back(c);
+    LagSeg e;   // A = x, B = x2
+    e.a_row0 = r0 + dx; e.a_valid = vx; e.b_row0 = r0 + dy; e.b_valid = vy;
+    e.u_begin = 0; e.u_end = np;
+    sxy.push_back(e);
+    j1[f].row0 = r0 + dx; j1[f].valid = vx; j1[f].nprime = np;
+    j2[f].row0 = r0 + dy; j2[f].valid = vy; j2[f].nprime = np;
+  }
+
+  // F'xx: lagged auto-covariance of x (the MFMA kernel).
+  TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
+                   s->g + s->off_fxx, true));
+  // [y | 1]^T x~ for every signed lag: Xty and the lagged column sums.
+  TD_TRY(td_lagcov(h, y_dev, ldy, s->d, true, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
+                   s->g + s->off_gxo, true));
+  if (s->d) TD_TRY(td_colsum(h, y_dev, ldy, s->d, syx, s->g + s->off_sy, true));
+  if (s->c2) {
+    TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
+                     s->g + s->off_fyy, true));
+    TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x2_dev, ldx2, s->c2, sxy,
+                     -(s->post1 + s->pre2), s->l1 + s->l2 - 1, s->g + s->off_gxy, true));
+    TD_TRY(td_lagcov(h, nullptr, 0, 0, true, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
+                     s->g + s->off_gyo, true));
+  }
+
+  // Boundary windows of the new files.
+  TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
+  {
+    void* scratch = nullptr;
+    const size_t bytes = sizeof(WinJob) * num_files;
+    TD_TRY(td_scratch(h, 2 * td_round_up(bytes, 256), &scratch));
+    WinJob* d1 = reinterpret_cast<WinJob*>(scratch);
+    WinJob* d2 = reinterpret_cast<WinJob*>(reinterpret_cast<char*>(scratch) + td_round_up(bytes, 256));
+    TD_TRY(td_upload_async(h, j1.data(), bytes, d1));
+    hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)num_files, 2), dim3(256), 0,
+                       h->stream, x_dev, (long long)ldx, s->c1, s->hw, d1, s->win1,
+                       (long long)s->n_files);
+    if (s->c2) {
+      TD_TRY(td_upload_async(h, j2.data(), bytes, d2));
+      hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)num_files, 2), dim3(256), 0,
+                         h->stream, x2_dev, (long long)ldx2, s->c2, s->hw, d2, s->win2,
+                         (long long)s->n_files);
+    }
+    TD_HIP(h, hipGetLastError());
+  }
+  s->n_files += num_files;
+  s->frames += new_frames;
+  // keep n on the device too (it travels in the all-reduce)
+  const double nd = (double)s->frames;
+  TD_TRY(td_upload_async(h, &nd, sizeof(double), s->g + s->off_n));
+  return TD_OK;
+}
+
+int td_stats_combine(td_handle* h, td_stats* dst, td_stats* const* srcs, int n) {
+  if (!h || !dst || (n > 0 && !srcs)) return td_fail(h, TD_ERR_INVALID, "td_stats_combine: NULL");
+  TD_TRY(td_stats_reset(h, dst));
+  int64_t files = 0;
+  for (int i = 0; i < n; ++i) {
+    const td_stats* s = srcs[i];
+    TD_REQUIRE(h, s && s->g_len == dst->g_len && s->c1 == dst->c1 && s->c2 == dst->c2 &&
+                      s->l1 == dst->l1 && s->l2 == dst->l2 && s->d == dst->d &&
+                      s->pre1 == dst->pre1 && s->pre2 == dst->pre2,
+               "td_stats_combine: layouts differ");
+    files += s->n_files;
+  }
+  TD_TRY(ensure_window_capacity(h, dst, files));
+  const size_t per1 = (size_t)2 * 2 * dst->hw * dst->c1 * sizeof(float);
+  const size_t per2 = (size_t)2 * 2 * dst->hw * dst->c2 * sizeof(float);
+  for (int i = 0; i < n; ++i) {
+    const td_stats* s = srcs[i];
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(s->g_len)), dim3(256), 0, h->stream, dst->g,
+                       s->g, (long long)s->g_len);
+    if (s->n_files) {
+      TD_HIP(h, hipMemcpyAsync(reinterpret_cast<char*>(dst->win1) + per1 * dst->n_files, s->win1,
+                               per1 * s->n_files, hipMemcpyDeviceToDevice, h->stream));
+      if (dst->c2)
+        TD_HIP(h, hipMemcpyAsync(reinterpret_cast<char*>(dst->win2) + per2 * dst->n_files,
+                                 s->win2, per2 * s->n_files, hipMemcpyDeviceToDevice, h->stream));
+    }
+    dst->n_files += s->n_files;
+    dst->frames += s->frames;
+  }
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_stats_packed_len(td_handle* h, const td_stats* s, int64_t total_file_slots,
+                        int64_t* num_doubles) {
+  if (!s || !num_doubles) return td_fail(h, TD_ERR_INVALID, "td_stats_packed_len: NULL");
+  const int64_t per = (int64_t)2 * 2 * s->hw * (s->c1 + s->c2);
+  *num_doubles = s->g_len + per * total_file_slots;
+  return TD_OK;
+}
+
+int td_stats_pack(td_handle* h, const td_stats* s, double* buf_dev, int64_t total_file_slots,
+                  int64_t file_slot) {
+  if (!h || !s || !buf_dev) return td_fail(h, TD_ERR_INVALID, "td_stats_pack: NULL");
+  TD_REQUIRE(h, file_slot >= 0 && file_slot + s->n_files <= total_file_slots,
+             "td_stats_pack: files [%lld, %lld) do not fit %lld slots", (long long)file_slot,
+             (long long)(file_slot + s->n_files), (long long)total_file_slots);
+  int64_t len = 0;
+  td_stats_packed_len(h, s, total_file_slots, &len);
+  TD_HIP(h, hipMemsetAsync(buf_dev, 0, sizeof(double) * len, h->stream));
+  TD_HIP(h, hipMemcpyAsync(buf_dev, s->g, sizeof(double) * s->g_len, hipMemcpyDeviceToDevice,
+                           h->stream));
+  const int64_t per1 = (int64_t)2 * 2 * s->hw * s->c1, per2 = (int64_t)2 * 2 * s->hw * s->c2;
+  double* w1 = buf_dev + s->g_len;
+  double* w2 = w1 + per1 * total_file_slots;
+  if (s->n_files) {
+    hipLaunchKernelGGL(f2d_kernel, dim3(blocks_for(per1 * s->n_files)), dim3(256), 0, h->stream,
+                       w1 + per1 * file_slot, s->win1, (long long)(per1 * s->n_files));
+    if (s->c2)
+      hipLaunchKernelGGL(f2d_kernel, dim3(blocks_for(per2 * s->n_files)), dim3(256), 0, h->stream,
+                         w2 + per2 * file_slot, s->win2, (long long)(per2 * s->n_files));
+    TD_HIP(h, hipGetLastError());
+  }
+  return TD_OK;
+}
+
+int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev, int64_t total_file_slots) {
+  if (!h || !s || !buf_dev) return td_fail(h, TD_ERR_INVALID, "td_stats_unpack: NULL");
+  TD_TRY(ensure_window_capacity(h, s, total_file_slots));
+  TD_HIP(h, hipMemcpyAsync(s->g, buf_dev, sizeof(double) * s->g_len, hipMemcpyDeviceToDevice,
+                           h->stream));
+  const int64_t per1 = (int64_t)2 * 2 * s->hw * s->c1, per2 = (int64_t)2 * 2 * s->hw * s->c2;
+  const double* w1 = buf_dev + s->g_len;
+  const double* w2 = w1 + per1 * total_file_slots;
+  if (total_file_slots) {
+    hipLaunchKernelGGL(d2f_kernel, dim3(blocks_for(per1 * total_file_slots)), dim3(256), 0,
+                       h->stream, s->win1, w1, (long long)(per1 * total_file_slots));
+    if (s->c2)
+      hipLaunchKernelGGL(d2f_kernel, dim3(blocks_for(per2 * total_file_slots)), dim3(256), 0,
+                         h->stream, s->win2, w2, (long long)(per2 * total_file_slots));
+    TD_HIP(h, hipGetLastError());
+  }
+  s->n_files = total_file_slots;
+  double nd = 0.0;
+  TD_HIP(h, hipMemcpyAsync(&nd, s->g + s->off_n, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  s->frames = (int64_t)(nd + 0.5);
+  return TD_OK;
+}
+
+int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev,
+                     double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev) {
+  if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_moments: NULL argument");
+  if (xtx_dev)
+    TD_TRY(expand_block(h, s->g + s->off_fxx, 0, s->l1, s->c1, s->pre1, s->post1, s->c1, s->pre1,
+                        s->post1, s->win1, s->win1, s->hw, s->n_files, xtx_dev, s->k1 + 1, true));
+  if (xtx_dev || xty_dev) {
+    hipLaunchKernelGGL(bias_fill_kernel, dim3((unsigned)td_ceil_div(s->k1 + 1, 256)), dim3(256), 0,
+                       h->stream, s->g + s->off_gxo, s->g + s->off_sy, s->g + s->off_n, s->l1,
+                       s->c1, s->d, xtx_dev, s->d ? xty_dev : nullptr);
+    TD_HIP(h, hipGetLastError());
+  }
+  if (s->c2) {
+    if (x2tx2_dev)
+      TD_TRY(expand_block(h, s->g + s->off_fyy, 0, s->l2, s->c2, s->pre2, s->post2, s->c2, s->pre2,
+                          s->post2, s->win2, s->win2, s->hw, s->n_files, x2tx2_dev, s->k2, true));
+    if (xtx2_dev)
+      TD_TRY(expand_block(h, s->g + s->off_gxy, -(s->post1 + s->pre2), s->l1 + s->l2 - 1, s->c1,
+                          s->pre1, s->post1, s->c2, s->pre2, s->post2, s->win1, s->win2, s->hw,
+                          s->n_files, xtx2_dev, s->k2, false));
+    if (sum_x2_dev)
+      TD_HIP(h, hipMemcpyAsync(sum_x2_dev, s->g + s->off_gyo, sizeof(double) * s->k2,
+                               hipMemcpyDeviceToDevice, h->stream));
+  }
+  return TD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// Internal definitions shared by the HIP translation units of libtd_hotpath.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "td_hotpath.h"
+
+struct td_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // the one work is queued on (own or adopted)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  std::string error;
+  // grow-only device scratch (partial slabs, expanded matrices, ...)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // ring of pinned host staging slots for small parameter tables (work lists):
+  // a slot is reused only after the copy that read it has completed.
+  struct PinSlot {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    bool used = false;
+  };
+  static constexpr int kPinSlots = 16;
+  PinSlot pin[kPinSlots];
+  int pin_next = 0;
+  int* dev_flag = nullptr;  // device int used for "not positive definite" reports
+};
+
+extern thread_local std::string td_global_error;
+
+int td_fail(td_handle* h, int code, const char* fmt, ...);
+
+#define TD_HIP(h, expr)                                                         \
+  do {                                                                          \
+    hipError_t _e = (expr);                                                     \
+    if (_e != hipSuccess)                                                       \
+      return td_fail((h), TD_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                     hipGetErrorString(_e), __FILE__, __LINE__);                \
+  } while (0)
+
+#define TD_TRY(expr)            \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != TD_OK) return _s; \
+  } while (0)
+
+#define TD_REQUIRE(h, cond, ...) \
+  do {                           \
+    if (!(cond)) return td_fail((h), TD_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// Scratch: returns a device pointer valid until the next td_scratch call that
+// needs more room (stream-ordered reuse is safe: one stream per handle).
+int td_scratch(td_handle* h, size_t bytes, void** out);
+
+// Stream-ordered upload of a small host block (work tables, parameters) through
+// the pinned ring; the host block may be reused as soon as this returns.
+int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst);
+
+static inline int64_t td_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t td_round_up(int64_t a, int64_t b) { return td_ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------------------
+// Generic lagged cross-covariance primitive (lagcov.hip).
+//
+//   G[e - e_min][i][j] (+)= sum over segments, sum_{u=u_begin}^{u_end-1}
+//                            A~[u][i] * B~[u + e][j],   e_min <= e < e_min+e_count
+//
+// A~ / B~ are the segment's rows of A / B, zero outside [0, a_valid) /
+// [0, b_valid).  If a_ones, A gets one extra column of ones (index ca) for
+// rows in [u_begin, u_end).  G is float64 [e_count][ca_eff][cb] with leading
+// dimensions given; `accumulate` adds to G instead of overwriting.
+struct LagSeg {
+  int64_t a_row0;   // global row of the segment's row 0 in A
+  int64_t a_valid;  // rows of A that exist in this segment
+  int64_t b_row0;
+  int64_t b_valid;
+  int64_t u_begin;  // first u (relative to the segment) to sum
+  int64_t u_end;    // one past the last u
+};
+
+int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
+              int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+              double* g_dev, bool accumulate);
+
+// Column sums in float64 of rows [r0, r1) per segment (lagcov.hip).
+int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vector<LagSeg>& segs,
+              double* out_dev, bool accumulate);

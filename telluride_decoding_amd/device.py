@@ -1,0 +1,222 @@
+"""Python host layer over the C-ABI: device handle and sufficient statistics.
+
+PyTorch is used ONLY as plumbing -- device memory (`torch.empty(..., device=
+'cuda')`), the current HIP stream and `torch.distributed` (RCCL).  All hot-path
+arithmetic runs in the hand-written HIP kernels of libtd_hotpath.so.
+"""
+import ctypes
+
+import numpy as np
+
+from telluride_decoding_amd import _lib
+
+_handles = {}
+
+
+def _torch():
+  import torch  # deferred: `import telluride_decoding_amd` stays cheap on CPU
+  return torch
+
+
+def gpu_available():
+  lib = _lib.load()
+  n = ctypes.c_int(0)
+  return lib.td_device_count(ctypes.byref(n)) == _lib.TD_OK and n.value > 0
+
+
+class Handle(object):
+  """One per (process, GPU).  Work is queued on torch's current stream."""
+
+  def __init__(self, device_id=None):
+    torch = _torch()
+    self.lib = _lib.load()
+    if device_id is None:
+      device_id = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    ptr = ctypes.c_void_p()
+    _lib.check(None, self.lib.td_create(int(device_id), ctypes.byref(ptr)))
+    self.ptr = ptr
+    self.device_id = int(device_id)
+    self.device = torch.device('cuda', self.device_id)
+    self.use_torch_stream()
+
+  def use_torch_stream(self):
+    torch = _torch()
+    stream = torch.cuda.current_stream(self.device)
+    self.check(self.lib.td_set_stream(self.ptr, ctypes.c_void_p(stream.cuda_stream)))
+
+  def check(self, status):
+    _lib.check(self.ptr, status)
+
+  def synchronize(self):
+    self.check(self.lib.td_synchronize(self.ptr))
+
+  def timer_start(self):
+    self.check(self.lib.td_timer_start(self.ptr))
+
+  def timer_stop(self):
+    ms = ctypes.c_float(0)
+    self.check(self.lib.td_timer_stop(self.ptr, ctypes.byref(ms)))
+    return float(ms.value)
+
+  # -- memory plumbing ------------------------------------------------------
+  def to_device(self, array, dtype=np.float32):
+    """Host array (or tensor) -> contiguous 2-D device tensor."""
+    torch = _torch()
+    if isinstance(array, torch.Tensor):
+      t = array.to(self.device)
+      want = {np.float32: torch.float32, np.float64: torch.float64}[dtype]
+      if t.dtype != want:
+        t = t.to(want)
+      return t.contiguous()
+    arr = np.ascontiguousarray(array, dtype=dtype)
+    return torch.from_numpy(arr).to(self.device)
+
+  def empty(self, shape, dtype='float32'):
+    torch = _torch()
+    return torch.empty(shape, dtype=getattr(torch, dtype), device=self.device)
+
+  def zeros(self, shape, dtype='float32'):
+    torch = _torch()
+    return torch.zeros(shape, dtype=getattr(torch, dtype), device=self.device)
+
+  def __del__(self):
+    try:
+      if getattr(self, 'ptr', None):
+        self.lib.td_destroy(self.ptr)
+        self.ptr = None
+    except Exception:  # interpreter shutdown
+      pass
+
+
+def default_handle():
+  """The handle of the current device (created on first use)."""
+  torch = _torch()
+  if not gpu_available():
+    raise _lib.HotPathUnavailable(
+        'No MI355X visible to HIP: the hot path has no CPU fallback.')
+  dev = torch.cuda.current_device()
+  if dev not in _handles:
+    _handles[dev] = Handle(dev)
+  h = _handles[dev]
+  h.use_torch_stream()
+  return h
+
+
+def _ptr(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class LagStats(object):
+  """Device-resident sufficient statistics of lagged inputs (C-ABI td_stats).
+
+  Replaces the accumulate loops of
+  brain_model.calculate_linear_regressor_parameters_from_dataset
+  (brain_model.py:422-446) and cca.calculate_cca_parameters_from_dataset
+  (cca.py:304-332) together with the lag-matrix builder (brain_data.py:425-483).
+  """
+
+  def __init__(self, c1, pre1=0, post1=0, c2=0, pre2=0, post2=0, d=0, handle=None):
+    self.h = handle or default_handle()
+    self.c1, self.pre1, self.post1 = int(c1), int(pre1), int(post1)
+    self.c2, self.pre2, self.post2, self.d = int(c2), int(pre2), int(post2), int(d)
+    self.l1 = self.pre1 + 1 + self.post1
+    self.l2 = (self.pre2 + 1 + self.post2) if self.c2 else 0
+    self.k1 = self.l1 * self.c1
+    self.k2 = self.l2 * self.c2
+    ptr = ctypes.c_void_p()
+    self.h.check(self.h.lib.td_stats_create(
+        self.h.ptr, self.c1, self.pre1, self.post1, self.c2, self.pre2, self.post2,
+        self.d, ctypes.byref(ptr)))
+    self.ptr = ptr
+
+  def like(self):
+    return LagStats(self.c1, self.pre1, self.post1, self.c2, self.pre2, self.post2,
+                    self.d, handle=self.h)
+
+  def reset(self):
+    self.h.check(self.h.lib.td_stats_reset(self.h.ptr, self.ptr))
+
+  def accumulate(self, x, x2=None, y=None, file_offsets=None, input_offset=0,
+                 rows_used=None):
+    """x [rows, c1], x2 [rows, c2] / y [rows, d]: device float32 tensors holding
+    the files concatenated along time; file_offsets has F+1 row offsets."""
+    rows = int(x.shape[0])
+    if file_offsets is None:
+      file_offsets = [0, rows]
+    offs, offs_p = _lib.i64_array(file_offsets)
+    if offs[-1] != rows:
+      raise ValueError('file_offsets[-1] (%d) != rows (%d)' % (offs[-1], rows))
+    used_p = None
+    if rows_used is not None:
+      used, used_p = _lib.i64_array(rows_used)
+    for t, w, name in ((x, self.c1, 'input_1'), (x2, self.c2, 'input_2'), (y, self.d, 'output')):
+      if w and (t is None or t.dim() != 2 or t.shape[1] != w or t.shape[0] != rows):
+        raise ValueError('%s must be [%d, %d], not %s' %
+                         (name, rows, w, None if t is None else tuple(t.shape)))
+      if t is not None and w and (str(t.dtype) != 'torch.float32' or not t.is_cuda):
+        raise TypeError('%s must be a float32 device tensor' % name)
+    self.h.check(self.h.lib.td_stats_accumulate(
+        self.h.ptr, self.ptr, _ptr(x), x.stride(0),
+        _ptr(x2 if self.c2 else None), x2.stride(0) if self.c2 else 0,
+        _ptr(y if self.d else None), y.stride(0) if self.d else 0,
+        offs_p, len(offs) - 1, int(input_offset), used_p))
+
+  def counts(self):
+    frames, files = ctypes.c_int64(0), ctypes.c_int64(0)
+    self.h.check(self.h.lib.td_stats_counts(self.h.ptr, self.ptr, ctypes.byref(frames),
+                                            ctypes.byref(files)))
+    return int(frames.value), int(files.value)
+
+  def combine(self, parts):
+    arr = (ctypes.c_void_p * len(parts))(*[p.ptr for p in parts])
+    self.h.check(self.h.lib.td_stats_combine(self.h.ptr, self.ptr, arr, len(parts)))
+    return self
+
+  def packed_len(self, total_file_slots):
+    n = ctypes.c_int64(0)
+    self.h.check(self.h.lib.td_stats_packed_len(self.h.ptr, self.ptr, int(total_file_slots),
+                                                ctypes.byref(n)))
+    return int(n.value)
+
+  def pack(self, total_file_slots, file_slot):
+    buf = self.h.empty((self.packed_len(total_file_slots),), 'float64')
+    self.h.check(self.h.lib.td_stats_pack(self.h.ptr, self.ptr, _ptr(buf),
+                                          int(total_file_slots), int(file_slot)))
+    return buf
+
+  def unpack(self, buf, total_file_slots):
+    self.h.check(self.h.lib.td_stats_unpack(self.h.ptr, self.ptr, _ptr(buf),
+                                            int(total_file_slots)))
+
+  def moments(self, want_xtx=True, want_xty=True, want_cca=False):
+    """Dense float64 device matrices (see td_stats_moments)."""
+    out = {}
+    n = self.k1 + 1
+    xtx = self.h.empty((n, n), 'float64') if want_xtx else None
+    xty = self.h.empty((n, self.d), 'float64') if (want_xty and self.d) else None
+    x2 = xx2 = s2 = None
+    if want_cca and self.c2:
+      x2 = self.h.empty((self.k2, self.k2), 'float64')
+      xx2 = self.h.empty((self.k1, self.k2), 'float64')
+      s2 = self.h.empty((self.k2,), 'float64')
+    self.h.check(self.h.lib.td_stats_moments(self.h.ptr, self.ptr, _ptr(xtx), _ptr(xty),
+                                             _ptr(x2), _ptr(xx2), _ptr(s2)))
+    out.update(xtx=xtx, xty=xty, x2tx2=x2, xtx2=xx2, sum_x2=s2)
+    return out
+
+  def ridge_solve(self, lambdas):
+    """Returns device tensors W [n_lambda, k1, d], b [n_lambda, d] (float32)."""
+    lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
+    w = self.h.empty((len(lam), self.k1, self.d), 'float32')
+    b = self.h.empty((len(lam), self.d), 'float32')
+    self.h.check(self.h.lib.td_ridge_solve(self.h.ptr, self.ptr, lam_p, len(lam), _ptr(w),
+                                           _ptr(b)))
+    return w, b
+
+  def __del__(self):
+    try:
+      if getattr(self, 'ptr', None):
+        self.h.lib.td_stats_destroy(self.h.ptr, self.ptr)
+        self.ptr = None
+    except Exception:
+      pass
