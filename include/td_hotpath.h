@@ -155,15 +155,18 @@ int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, 
  * (Keras Dense in brain_model.py:335-341, 376).  out_dev [rows, d] float32. */
 int td_predict_fir(td_handle* h, const float* x_dev, int64_t ldx,
                    const int64_t* file_offsets_host, int num_files, int c, int pre,
-                   int post, const float* w_dev, const float* b_dev, int d,
-                   float* out_dev, int64_t ldout);
+                   int post, int input_offset, const float* w_dev, const float* b_dev,
+                   int d, float* out_dev, int64_t ldout);
+/* input_offset > 0 drops that many leading rows of every file of x BEFORE the
+ * context is added (brain_data.py:466-475).  Output row file_offsets[f] + t is
+ * frame t of the zipped streams of file f. */
 
 /* CCA transform [(x - mean1).rot1 | (x2 - mean2).rot2] on lagged views
  * (cca.BrainCcaLayer.call, cca.py:150-161).  out_dev [rows, 2*dims]. */
 int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int pre1,
                      int post1, const float* x2_dev, int64_t ldx2, int c2, int pre2,
                      int post2, const int64_t* file_offsets_host, int num_files,
-                     const float* mean1_dev, const float* rot1_dev,
+                     int input_offset, const float* mean1_dev, const float* rot1_dev,
                      const float* mean2_dev, const float* rot2_dev, int dims,
                      float* out_dev, int64_t ldout);
 
@@ -201,8 +204,8 @@ int td_window_scores(td_handle* h, const double* sums_dev, int64_t total_windows
 /* Per-frame reduced correlation score (Decoder.infer_one, infer_decoder.py:439-455)
  * for reductions that are not linear in the window sums.
  *   reduction: 0 first, 1 second, 2 mean, 3 mean-squared, 4 lda (affine map
- *   lda_w_host[cols], slope, intercept of scaled_lda.py:344-355).
- * out_dev [rows] float64. */
+ *   lda_w_host[cols], slope, intercept of scaled_lda.py:344-355), 5 all.
+ * out_dev [rows] float64 ([rows, cols] for 'all'). */
 int td_frame_scores(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev,
                     int64_t ldb, int cols, int64_t rows, int reduction,
                     const double* mean_a_host, const double* mean_b_host,

@@ -1,0 +1,157 @@
+"""Attended-speaker decision on the HIP hot path.
+
+Same classes and call signatures as reference attention_decoder.py:
+`AttentionDecoder` (winner take all, :116-138), `StepAttentionDecoder`
+(:141-173), `StateSpaceAttentionDecoder` (:176-451) and
+`create_attention_decoder` (:455-485).  `plot_aad_results` (:27-113) is out of
+scope (matplotlib reporting).
+
+Two ways in:
+  * `attention(r1, r2)` -- the reference's streaming call, one window at a time,
+    stateful.  It runs the same HIP kernels on a one-trial problem so that the
+    streaming and the batched path cannot disagree.
+  * `attention_batch(r1, r2, window_offsets)` -- every window of every trial in
+    one launch (trials are independent; the step and state-space decoders are
+    sequential in time within a trial, one GPU lane per trial).
+"""
+import numpy as np
+
+from telluride_decoding_amd import device
+
+
+def _dev_f64(h, values):
+  return h.to_device(np.asarray(values, np.float64).reshape(-1, 1), np.float64).reshape(-1)
+
+
+class AttentionDecoder(object):
+  """Winner takes all: speaker 1 iff mean(r1) > mean(r2) (strict; ties go to 2)."""
+
+  def attention(self, r1, r2):
+    h = device.default_handle()
+    # np.mean over a vector argument, as the reference does (:134)
+    s1 = _dev_f64(h, [np.mean(r1)])
+    s2 = _dev_f64(h, [np.mean(r2)])
+    return bool(device.decide_wta(s1, s2, handle=h).cpu().numpy()[0]), 0, 0
+
+  def attention_batch(self, r1, r2, window_offsets=None):
+    """r1, r2: per-window scores (host arrays or float64 device tensors)."""
+    del window_offsets
+    h = device.default_handle()
+    s1 = r1 if hasattr(r1, 'is_cuda') else _dev_f64(h, r1)
+    s2 = r2 if hasattr(r2, 'is_cuda') else _dev_f64(h, r2)
+    out = device.decide_wta(s1, s2, handle=h).cpu().numpy().astype(bool)
+    zeros = np.zeros(out.shape[0])
+    return out, zeros, zeros
+
+  def tune(self, r1, r2):
+    """An optional training step for tuning parameters."""
+    del r1, r2
+
+
+class StepAttentionDecoder(AttentionDecoder):
+  """Hysteresis: a state starting at 0.5 moves +-0.1 per window inside
+  [0.1, 0.9]; the decision is state > 0.5."""
+
+  def __init__(self):
+    self.state = 0.5
+
+  def attention(self, r1, r2):
+    h = device.default_handle()
+    s1 = _dev_f64(h, [np.mean(r1)])
+    s2 = _dev_f64(h, [np.mean(r2)])
+    out, st = device.decide_step(s1, s2, [0, 1], state=[self.state], handle=h)
+    self.state = float(st[0])
+    return bool(out.cpu().numpy()[0]), 0, 0
+
+  def attention_batch(self, r1, r2, window_offsets=None):
+    h = device.default_handle()
+    s1 = r1 if hasattr(r1, 'is_cuda') else _dev_f64(h, r1)
+    s2 = r2 if hasattr(r2, 'is_cuda') else _dev_f64(h, r2)
+    if window_offsets is None:
+      window_offsets = [0, int(s1.shape[0])]
+    out, _ = device.decide_step(s1, s2, window_offsets, handle=h)
+    out = out.cpu().numpy().astype(bool)
+    zeros = np.zeros(out.shape[0])
+    return out, zeros, zeros
+
+
+class StateSpaceAttentionDecoder(AttentionDecoder):
+  """Fixed-lag state-space decoder (Miran/Akram et al.), reference :176-451."""
+
+  def __init__(self, outer_iter, inner_iter, newton_iter, fs_corr, forward_lag=0,
+               backward_lag=13, offset=0.0):
+    self._offset = offset
+    self.outer_iter, self.inner_iter, self.newton_iter = outer_iter, inner_iter, newton_iter
+    self.fs_corr = fs_corr
+    self.forward_lag, self.backward_lag = forward_lag, backward_lag
+    self.k_f, self.k_b = forward_lag, backward_lag
+    self.k_w = self.k_f + self.k_b + 1
+    self.calls = 0
+    self.r1, self.r2 = [], []
+    self._prior = None
+    # defaults of the reference (:266-271); replaced by tune()
+    self.alpha_0 = [6.4113e+02, 4.0434e+03]
+    self.beta_0 = [3.7581e+02, 6.2791e+03]
+    self.mu_0 = [-0.3994, -1.5103]
+    self.rho_d = [1.7060, 0.64395]
+    self.mu_d = [-0.3994, -1.5103]
+
+  def tune(self, r1, r2):
+    return self.tune_log_normal_priors(r1, r2)
+
+  def tune_log_normal_priors(self, r1, r2):
+    """Moment-matched log-normal priors from an initial attended/unattended
+    stretch (reference :277-327).  A handful of scalar reductions: host."""
+    a1 = np.absolute(np.asarray(r1, np.float64) + self._offset)
+    a2 = np.absolute(np.asarray(r2, np.float64) + self._offset)
+    n = a1.shape[0]
+
+    def fit(a):
+      u = np.sum(a) / n
+      v = np.sum((a - u) ** 2) / n
+      rho = 1 / np.log(v / u ** 2 + 1)
+      return rho, np.log(u) - 0.5 / rho
+
+    rho_a, mu_a = fit(a1)
+    rho_u, mu_u = fit(a2)
+    self.rho_d, self.mu_d = [rho_a, rho_u], [mu_a, mu_u]
+    self.mu_0 = [mu_a, mu_u]
+    self._prior = ([rho_a, rho_u], [mu_a, mu_u])
+
+  def _run(self, s1, s2, window_offsets, h):
+    return device.decode_ssd(s1, s2, window_offsets, self.outer_iter, self.inner_iter,
+                             self.newton_iter, self.k_f, self.k_b, self._offset, self._prior,
+                             handle=h)
+
+  def attention(self, r1, r2):
+    """Streaming call: the whole history of this decoder is replayed on the
+    device (one trial), the newest window's (p, lower, upper) is returned."""
+    self.calls += 1
+    self.r1.append(float(np.mean(r1)))
+    self.r2.append(float(np.mean(r2)))
+    if self.calls < self.k_w:
+      return (0.5, 0.5, 0.5)
+    h = device.default_handle()
+    out = self._run(_dev_f64(h, self.r1), _dev_f64(h, self.r2), [0, len(self.r1)], h)
+    return tuple(float(v) for v in out[-1].cpu().numpy())
+
+  def attention_batch(self, r1, r2, window_offsets=None):
+    h = device.default_handle()
+    s1 = r1 if hasattr(r1, 'is_cuda') else _dev_f64(h, r1)
+    s2 = r2 if hasattr(r2, 'is_cuda') else _dev_f64(h, r2)
+    if window_offsets is None:
+      window_offsets = [0, int(s1.shape[0])]
+    out = self._run(s1, s2, window_offsets, h).cpu().numpy()
+    return out[:, 0], out[:, 1], out[:, 2]
+
+
+def create_attention_decoder(type_name, window_step=100, frame_rate=100.0, ssd_offset=0.0):
+  """'wta', 'stepped'/'step' or 'ssd' (reference :455-485)."""
+  if type_name == 'wta':
+    return AttentionDecoder()
+  elif type_name == 'stepped' or type_name == 'step':
+    return StepAttentionDecoder()
+  elif type_name == 'ssd':
+    fs_corr = window_step * float(frame_rate) / 2.0
+    return StateSpaceAttentionDecoder(20, 1, 10, fs_corr, offset=ssd_offset)
+  raise ValueError('Unknown type (%s) requested from create_attention_decoder' % type_name)

@@ -1,0 +1,271 @@
+"""Linear regression ("TRF") model and Pearson metrics on the HIP hot path.
+
+Mirrors the call surface of the reference's brain_model.py for the linear path:
+`pearson_correlation[_first/_second]` (reference brain_model.py:34-91),
+`BrainModelLinearRegression` (:306-381) and
+`calculate_linear_regressor_parameters_from_dataset` (:384-481).  The Keras DNN /
+classifier shells and TensorBoard plumbing of that file are out of scope
+(SURVEY.md section 2).
+"""
+import numpy as np
+
+from telluride_decoding_amd import brain_data
+from telluride_decoding_amd import device
+
+
+def _is_dataset(obj):
+  return isinstance(obj, brain_data.Dataset)
+
+
+def _as_2d_device(h, a):
+  a = a.numpy() if hasattr(a, 'numpy') and not hasattr(a, 'is_cuda') else a
+  if hasattr(a, 'is_cuda'):
+    t = a if a.dim() == 2 else a.reshape(a.shape[0], -1)
+    return h.to_device(t)
+  a = np.asarray(a)
+  if a.ndim == 1:
+    a = a.reshape(-1, 1)
+  return h.to_device(a)
+
+
+def pearson_correlation(x, y):
+  """Column-wise Pearson correlation of two [frames, dims] blocks.
+
+  Reference brain_model.py:34-79, including its degenerate rule: if ANY column
+  of x or y is constant the result is all zeros, with the [frames, dims] shape of
+  `0*x_m` (:72-79).  Computed from five float64 sums per column produced by the
+  window-sums HIP kernel (one window = the whole block).
+  """
+  h = device.default_handle()
+  xd, yd = _as_2d_device(h, x), _as_2d_device(h, y)
+  if xd.shape[-1] != yd.shape[-1]:
+    raise AssertionError('x (%s) and y (%s) do not have the same final dimensionality' %
+                         (tuple(xd.shape), tuple(yd.shape)))
+  if xd.shape[1] > 16:
+    raise ValueError('pearson_correlation supports up to 16 columns')
+  rows = int(xd.shape[0])
+  sums = device.window_sums(xd, yd, [0, rows], rows, rows, handle=h)
+  r = device.window_scores(sums, rows, mode=1, handle=h).cpu().numpy()[0]
+  s = sums.cpu().numpy()[0]
+  var_a = s[:, 2] - s[:, 0] ** 2 / rows
+  var_b = s[:, 3] - s[:, 1] ** 2 / rows
+  if np.prod(var_a) <= 0 or np.prod(var_b) <= 0:
+    return np.zeros((rows, xd.shape[1]), np.float32)
+  return r.astype(np.float32 if str(xd.dtype) == 'torch.float32' else np.float64)
+
+
+def pearson_correlation_first(x, y):
+  return pearson_correlation(x, y)[0]
+
+
+def pearson_correlation_second(x, y):
+  return pearson_correlation(x, y)[1]
+
+
+def _dataset_stats(dataset, want_y=True, want_x2=False, handle=None):
+  """LagStats of a Dataset via the raw-array fast path."""
+  h = handle or device.default_handle()
+  x, x2, y, offs = dataset.device_arrays(h)
+  st = device.LagStats(dataset.c1, dataset.pre, dataset.post,
+                       dataset.c2 if want_x2 else 0, dataset.pre2, dataset.post2,
+                       dataset.d if want_y else 0, handle=h)
+  st.accumulate(x, x2 if want_x2 else None, y if want_y else None, offs,
+                input_offset=dataset.input_offset, rows_used=dataset.rows_used())
+  return st
+
+
+def _iterable_stats(batches, key2=None, handle=None):
+  """LagStats of a generic iterable of already-lagged (dict, y) minibatches:
+  each minibatch is a context-free 'file' of K feature channels."""
+  h = handle or device.default_handle()
+  st = None
+  n_batches = 0
+  last_rows = 0
+  for feats, y in batches:
+    x = _as_2d_device(h, feats['input_1'])
+    yd = _as_2d_device(h, y) if y is not None else None
+    x2 = _as_2d_device(h, feats[key2]) if key2 else None
+    if st is None:
+      st = device.LagStats(int(x.shape[1]), 0, 0, int(x2.shape[1]) if key2 else 0, 0, 0,
+                           int(yd.shape[1]) if yd is not None else 0, handle=h)
+    st.accumulate(x, x2, yd)
+    n_batches += 1
+    last_rows = int(x.shape[0])
+  return st, n_batches, last_rows
+
+
+def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_offset=True,
+                                                       use_ridge=True):
+  """Closed-form regression weights (reference brain_model.py:384-481).
+
+  Returns (W [K, D], b [1, D], cov_x, cov_xy, shrinkage) as float32 arrays.  The
+  accumulate (sum_xtx, sum_x, sum_xty, :429-444) runs in the lagged-covariance
+  MFMA kernel, the solve (:477) as a float64 Cholesky on the device.
+  `dataset` is a brain_data.Dataset (raw-array fast path) or any iterable of
+  (dict, y) minibatches whose 'input_1' is already lagged.
+  """
+  if not _is_dataset(dataset) and not hasattr(dataset, '__iter__'):
+    raise TypeError('dataset input to calculate_linear_regressor_parameters_from_database '
+                    'must be a tf.data.Dataset object')
+  if lamb == -1 and not use_ridge:
+    raise NotImplementedError('Ledoit-Wolf automatic shrinkage (lamb=-1) is not on the HIP '
+                              'path yet (SURVEY.md 8f, row F2)')
+  if not use_ridge and (lamb > 1 or lamb < 0):
+    raise ValueError('Regularization lambda must be between 0 and 1, not %g.' % lamb)
+  h = device.default_handle()
+  if _is_dataset(dataset):
+    st = _dataset_stats(dataset, handle=h)
+  else:
+    st, _, _ = _iterable_stats(dataset, handle=h)
+    if st is None:
+      raise ValueError('No minibatches in dataset')
+  frames, _ = st.counts()
+  k = st.k1
+  if use_ridge and use_offset:
+    w, b = st.ridge_solve([lamb])
+    w_np, b_np = w.cpu().numpy()[0], b.cpu().numpy()
+    m = st.moments()
+    cov_x = (m['xtx'] / frames)
+    cov_x.diagonal().add_(lamb)
+    return (w_np, b_np.reshape(1, -1), cov_x.cpu().numpy().astype(np.float32),
+            (m['xty'] / frames).cpu().numpy().astype(np.float32), lamb)
+  # Remaining branches share the device moments and the generic SPD solve.
+  import ctypes
+  m = st.moments()
+  n = k + 1 if use_offset else k
+  xtx = m['xtx'][:n, :n].contiguous()
+  xty = m['xty'][:n].contiguous()
+  cov_x = xtx / frames
+  cov_xy = xty / frames
+  if use_ridge:
+    cov_x.diagonal().add_(lamb)
+    shrinkage = lamb
+  else:
+    # Blankertz shrinkage, brain_model.py:449-476 (mean_x is the column-sum row).
+    sum_x = m['xtx'][k, :n] if use_offset else None
+    if sum_x is None:
+      raise NotImplementedError('shrinkage without an offset column is not supported')
+    mean_x = (sum_x / frames).reshape(1, -1)
+    cov_x_zc = xtx - mean_x.t() @ mean_x          # sum minus mean outer (sic, :450)
+    mu = float(cov_x_zc.diagonal().sum() / n)
+    shrinkage = lamb
+    cov_x = (1 - shrinkage) * cov_x
+    cov_x.diagonal().add_(shrinkage * mu)
+  a = cov_x.clone().contiguous()
+  rhs = cov_xy.clone().contiguous()
+  h.check(h.lib.td_spd_solve(h.ptr, ctypes.c_void_p(a.data_ptr()),
+                             ctypes.c_void_p(rhs.data_ptr()), n, int(rhs.shape[1]), 1))
+  sol = rhs.cpu().numpy().astype(np.float32)
+  cov_x_np = cov_x.cpu().numpy().astype(np.float32)
+  cov_xy_np = cov_xy.cpu().numpy().astype(np.float32)
+  if use_offset:
+    return sol[:-1], sol[-1:], cov_x_np, cov_xy_np, shrinkage
+  return sol, np.zeros((1,)), cov_x_np, cov_xy_np, shrinkage
+
+
+class BrainModelLinearRegression(object):
+  """Linear regression computed in closed form (reference brain_model.py:306-381).
+
+  fit() returns {} like the reference; `w_estimate` [K, D] and `b_estimate` [D]
+  hold the solution; calling the model (or `predict`) applies X.W + b with the
+  FIR kernel on the raw recordings.
+  """
+
+  def __init__(self, input_dataset, regularization_lambda=0.0, tensorboard_dir=None, **kwargs):
+    del tensorboard_dir, kwargs
+    if not _is_dataset(input_dataset):
+      raise ValueError('Dataset must be a tf.data.datasert, not a %s' % type(input_dataset))
+    self._input_width = input_dataset.element_spec[0]['input_1'].shape[-1]
+    self._output_width = input_dataset.element_spec[1].shape[-1]
+    self._regularization_lambda = regularization_lambda
+    self._pre, self._post, self._c1 = input_dataset.pre, input_dataset.post, input_dataset.c1
+    self.w_estimate = None
+    self.b_estimate = None
+    self._w_dev = self._b_dev = None
+    self.metrics_names = ['loss', 'pearson_correlation_first']
+
+  def compile(self, *args, **kwargs):
+    del args, kwargs   # nothing to compile: closed-form model
+
+  def fit(self, input_dataset, **kwargs):
+    del kwargs
+    if not _is_dataset(input_dataset) and not hasattr(input_dataset, '__iter__'):
+      raise TypeError('BrainModelLinearRegression.train must be called with '
+                      'tf.data.Dataset, not %s.' % type(input_dataset))
+    (self.w_estimate, b, _, _, _) = calculate_linear_regressor_parameters_from_dataset(
+        input_dataset, lamb=self._regularization_lambda)
+    self.b_estimate = np.reshape(b, (-1,))
+    self._w_dev = self._b_dev = None
+    return {}   # no training history (brain_model.py:377)
+
+  @property
+  def weight_matrices(self):
+    return [self.w_estimate, self.b_estimate]
+
+  def set_weights(self, weights):
+    self.w_estimate = np.asarray(weights[0], np.float32)
+    self.b_estimate = np.asarray(weights[1], np.float32).reshape(-1)
+    self._w_dev = self._b_dev = None
+
+  def _device_weights(self, h):
+    if self.w_estimate is None:
+      raise ValueError('Model has not been fit yet.')
+    if self._w_dev is None:
+      self._w_dev = h.to_device(self.w_estimate)
+      self._b_dev = h.to_device(self.b_estimate.reshape(1, -1)).reshape(-1)
+    return self._w_dev, self._b_dev
+
+  def __call__(self, input_data):
+    return self.call(input_data)
+
+  def call(self, input_data):
+    """input_data: dict with an already-lagged 'input_1' [B, K] -> [B, D]."""
+    h = device.default_handle()
+    w, b = self._device_weights(h)
+    x = _as_2d_device(h, input_data['input_1'])
+    out = device.predict_fir(x, [0, int(x.shape[0])], w, b, 0, 0, handle=h)
+    return brain_data._t(out.cpu().numpy())
+
+  def predict_device(self, dataset, handle=None):
+    """Predictions for every frame of every file, on the device: [rows, D]."""
+    h = handle or device.default_handle()
+    w, b = self._device_weights(h)
+    x, _, _, offs = dataset.device_arrays(h)
+    # row offs[f] + t of the result is frame t of file f's zipped streams
+    return device.predict_fir(x, offs, w, b, dataset.pre, dataset.post, handle=h,
+                              input_offset=dataset.input_offset)
+
+  def predict(self, dataset):
+    used = dataset.rows_used()
+    pred = self.predict_device(dataset).cpu().numpy()
+    offs = np.concatenate(([0], np.cumsum(dataset.file_lengths())))
+    return np.concatenate([pred[offs[i]:offs[i] + u] for i, u in enumerate(used)])
+
+  def evaluate(self, dataset, **kwargs):
+    """{'loss': mse, 'pearson_correlation_first': r} averaged over minibatches,
+    as Keras `evaluate` does (reference brain_model.py:206-253)."""
+    del kwargs
+    if not _is_dataset(dataset):
+      raise TypeError('BrainModel.evaluate must be called with tf.data.Dataset object.')
+    h = device.default_handle()
+    pred = self.predict_device(dataset, handle=h)
+    _, _, y, offs = dataset.device_arrays(h)
+    used = dataset.rows_used()
+    dy = max(-dataset.input_offset, 0)
+    bsz = dataset.batch_size
+    # Minibatches run across file boundaries in the reference; gather the zipped
+    # stream once (device copies), then window it with hop = width = batch.
+    import torch
+    p_parts = [pred[offs[i]:offs[i] + u] for i, u in enumerate(used)]
+    y_parts = [y[offs[i] + dy:offs[i] + dy + u] for i, u in enumerate(used)]
+    p_all = torch.cat(p_parts).contiguous()
+    y_all = torch.cat(y_parts).contiguous()
+    rows = int(p_all.shape[0])
+    if rows == 0:
+      return {'loss': float('nan'), 'pearson_correlation_first': float('nan')}
+    sums = device.window_sums(y_all, p_all, [0, rows], bsz, bsz, handle=h)
+    r = device.window_scores(sums, bsz, mode=1, handle=h).cpu().numpy()
+    s = sums.cpu().numpy()
+    sq = s[:, :, 2] - 2 * s[:, :, 4] + s[:, :, 3]     # sum (y - p)^2 per batch and column
+    loss = float(np.mean(np.sum(sq, axis=1) / (bsz * s.shape[1])))
+    return {'loss': loss, 'pearson_correlation_first': float(np.mean(r[:, 0]))}

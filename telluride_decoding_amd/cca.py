@@ -1,0 +1,200 @@
+"""Linear canonical-correlation analysis on the HIP hot path.
+
+Mirrors reference cca.py for the linear path: `cca_pearson_correlation[_first/
+_second]` (cca.py:39-78), `calculate_cca_parameters_from_dataset` (:272-369),
+`BrainCcaLayer.call` (:150-161) and `BrainModelCCA` (:169-244).  The TF-graph
+deep-CCA loss (`cca_loss`, :372-443) is out of scope.
+
+Split of work: the accumulate over all frames (cov_xx, cov_yy, cov_xy, sums --
+the cost that made one model "~1 hour on my workstation" in the codelab) and the
+transform run in HIP kernels; the K x K eigen/SVD stage is a small dense,
+latency-bound problem and is done with LAPACK in float64 on the host from the
+device-reduced moments (DESIGN.md "CCA dense stage").
+"""
+import numpy as np
+
+from telluride_decoding_amd import brain_data
+from telluride_decoding_amd import brain_model
+from telluride_decoding_amd import device
+
+
+def cca_pearson_correlation(x, y):
+  """Correlate the two halves of a CCA output (reference cca.py:60-68)."""
+  del x
+  y = y.numpy() if hasattr(y, 'numpy') and not hasattr(y, 'is_cuda') else y
+  width = y.shape[-1] // 2
+  if 2 * width != y.shape[-1]:
+    raise ValueError('CCA y matrix does not have even # dims (%d)' % y.shape[-1])
+  return brain_model.pearson_correlation(y[:, :width], y[:, width:])
+
+
+def cca_pearson_correlation_first(x, y):
+  return cca_pearson_correlation(x, y)[0]
+
+
+def cca_pearson_correlation_second(x, y):
+  return cca_pearson_correlation(x, y)[1]
+
+
+def _dense_stage(cov_xx, cov_yy, cov_xy, dim, eps_eig):
+  """cca.py:345-367 on the reduced moment matrices (float64, host LAPACK)."""
+  x_vals, x_vecs = np.linalg.eig(cov_xx)
+  y_vals, y_vecs = np.linalg.eig(cov_yy)
+  idx1 = np.where(x_vals > eps_eig)[0]
+  x_vals, x_vecs = x_vals[idx1], x_vecs[:, idx1]
+  idx2 = np.where(y_vals > eps_eig)[0]
+  y_vals, y_vecs = y_vals[idx2], y_vecs[:, idx2]
+  k11 = (x_vecs @ np.diag(np.reciprocal(np.sqrt(x_vals)))) @ x_vecs.T
+  k22 = (y_vecs @ np.diag(np.reciprocal(np.sqrt(y_vals)))) @ y_vecs.T
+  t = (k11 @ cov_xy) @ k22
+  u, e, v = np.linalg.svd(t, full_matrices=False)
+  v = v.T
+  return k11 @ u[:, 0:dim], k22 @ v[:, 0:dim], e[0:dim]
+
+
+def calculate_cca_parameters_from_dataset(dataset, dim, regularization=0.1,
+                                          mini_batch_count=1000, eps_eig=1e-12):
+  """(rot_x, rot_y, mean_x, mean_y, e) as reference cca.py:272-369.
+
+  Reproduces the reference's normalisation exactly: means over `total_frames`,
+  covariances `S / (num_mini_batches * n_row - 1) - mean^T mean` with n_row the
+  row count of the last minibatch (:337-343), `+ regularization * I` on both
+  auto-covariances.
+  """
+  is_ds = isinstance(dataset, brain_data.Dataset)
+  if not is_ds and not hasattr(dataset, '__iter__'):
+    raise TypeError('dataset input to calculate_regressor_from_database must be'
+                    ' a tf.data.Dataset object, not %s' % type(dataset))
+  if regularization < 0.0:
+    raise ValueError('regularization lambda must be >= 0')
+  h = device.default_handle()
+  if is_ds:
+    ds = dataset.take(mini_batch_count or -1)
+    if ds.c1 == 0:
+      raise ValueError('First input to CCA estimator must have more than 0 columns.')
+    if ds.c2 == 0:
+      raise ValueError('Second input to CCA estimator must have more than 0 columns.')
+    num_mini_batches = ds.num_batches()
+    n_row = ds.batch_size
+    if not num_mini_batches:
+      raise ValueError('No minibatches in dataset, can\'t compute CCA model.')
+    st = brain_model._dataset_stats(ds, want_y=False, want_x2=True, handle=h)
+  else:
+    def limited():
+      for i, item in enumerate(dataset):
+        if mini_batch_count and i >= mini_batch_count:
+          break
+        if not isinstance(item[0], dict):
+          raise TypeError('X_dict is a %s, not a dict.' % type(item[0]))
+        yield item[0], None
+    st, num_mini_batches, n_row = brain_model._iterable_stats(limited(), key2='input_2',
+                                                              handle=h)
+    if not num_mini_batches:
+      raise ValueError('No minibatches in dataset, can\'t compute CCA model.')
+  total_frames, _ = st.counts()
+  m = st.moments(want_xtx=True, want_xty=False, want_cca=True)
+  k1, k2 = st.k1, st.k2
+  xtx = m['xtx'].cpu().numpy()
+  s_xx = xtx[:k1, :k1]
+  sum_x = xtx[k1:k1 + 1, :k1]
+  s_yy = m['x2tx2'].cpu().numpy()
+  s_xy = m['xtx2'].cpu().numpy()
+  sum_y = m['sum_x2'].cpu().numpy().reshape(1, -1)
+  mean_x = sum_x / total_frames
+  mean_y = sum_y / total_frames
+  denom = num_mini_batches * n_row - 1
+  cov_xx = s_xx / denom - mean_x.T @ mean_x + regularization * np.eye(k1)
+  cov_yy = s_yy / denom - mean_y.T @ mean_y + regularization * np.eye(k2)
+  cov_xy = s_xy / denom - mean_x.T @ mean_y
+  rot_x, rot_y, e = _dense_stage(cov_xx, cov_yy, cov_xy, dim, eps_eig)
+  f32 = np.float32
+  return (np.real(rot_x).astype(f32), np.real(rot_y).astype(f32), mean_x.astype(f32),
+          mean_y.astype(f32), np.real(e).astype(f32))
+
+
+class BrainModelCCA(object):
+  """CCA model (reference cca.BrainModelCCA, cca.py:169-244)."""
+
+  def __init__(self, input_dataset, cca_dims=5, regularization_lambda=0.0, **kwargs):
+    del kwargs
+    self._cca_dims = cca_dims
+    self._regularization_lambda = regularization_lambda
+    self._input1_width = input_dataset.element_spec[0]['input_1'].shape[-1]
+    self._input2_width = input_dataset.element_spec[0]['input_2'].shape[-1]
+    if self._input1_width <= 1:
+      raise ValueError('Input 1 feature width (%d) should not be <= 1.' % self._input1_width)
+    if self._input2_width <= 1:
+      raise ValueError('Input 2 feature width (%d) should not be <= 1.' % self._input2_width)
+    self.rot_x = self.rot_y = self.mean_x = self.mean_y = None
+    self._dev = None
+    self.metrics_names = ['loss', 'cca_pearson_correlation_first']
+
+  def compile(self, *args, **kwargs):
+    del args, kwargs
+
+  def fit(self, dataset, epochs=1):
+    del epochs
+    if not isinstance(dataset, brain_data.Dataset) and not hasattr(dataset, '__iter__'):
+      raise TypeError('BrainModelLinearRegression.train must be called with tf.data.Dataset.')
+    (self.rot_x, self.rot_y, self.mean_x, self.mean_y, self.eigenvalues) = (
+        calculate_cca_parameters_from_dataset(dataset, self._cca_dims,
+                                              regularization=self._regularization_lambda,
+                                              mini_batch_count=0))
+    self._dev = None
+    return {}
+
+  def _device_params(self, h):
+    if self.rot_x is None:
+      raise ValueError('Model has not been fit yet.')
+    if self._dev is None:
+      self._dev = tuple(h.to_device(a) for a in (self.mean_x.reshape(1, -1), self.rot_x,
+                                                 self.mean_y.reshape(1, -1), self.rot_y))
+    return self._dev
+
+  @property
+  def output_dims(self):
+    return min(self._input1_width, self._input2_width, self._cca_dims)
+
+  def __call__(self, input_data):
+    return self.call(input_data)
+
+  def call(self, input_data):
+    """Already-lagged minibatch dict -> [B, 2*dims] (cca.py:150-161)."""
+    h = device.default_handle()
+    m1, r1, m2, r2 = self._device_params(h)
+    x = brain_model._as_2d_device(h, input_data['input_1'])
+    x2 = brain_model._as_2d_device(h, input_data['input_2'])
+    out = device.cca_transform(x, x2, [0, int(x.shape[0])], m1, r1, m2, r2, 0, 0, 0, 0, handle=h)
+    return brain_data._t(out.cpu().numpy())
+
+  def transform_device(self, dataset, handle=None):
+    h = handle or device.default_handle()
+    m1, r1, m2, r2 = self._device_params(h)
+    x, x2, _, offs = dataset.device_arrays(h)
+    return device.cca_transform(x, x2, offs, m1, r1, m2, r2, dataset.pre, dataset.post,
+                                dataset.pre2, dataset.post2, handle=h,
+                                input_offset=dataset.input_offset)
+
+  def predict(self, dataset):
+    used = dataset.rows_used()
+    out = self.transform_device(dataset).cpu().numpy()
+    offs = np.concatenate(([0], np.cumsum(dataset.file_lengths())))
+    return np.concatenate([out[offs[i]:offs[i] + u] for i, u in enumerate(used)])
+
+  def evaluate(self, dataset, **kwargs):
+    """Loss and metric are both cca_pearson_correlation_first (cca.py:196-199),
+    averaged over minibatches as Keras does."""
+    del kwargs
+    import torch
+    h = device.default_handle()
+    out = self.transform_device(dataset, handle=h)
+    _, _, _, offs = dataset.device_arrays(h)
+    used = dataset.rows_used()
+    z = torch.cat([out[offs[i]:offs[i] + u] for i, u in enumerate(used)]).contiguous()
+    rows, dims = int(z.shape[0]), int(z.shape[1]) // 2
+    bsz = dataset.batch_size
+    a, b = z[:, :dims].contiguous(), z[:, dims:].contiguous()
+    sums = device.window_sums(a, b, [0, rows], bsz, bsz, handle=h)
+    r = device.window_scores(sums, bsz, mode=1, handle=h).cpu().numpy()
+    val = float(np.mean(r[:, 0]))
+    return {'loss': val, 'cca_pearson_correlation_first': val}

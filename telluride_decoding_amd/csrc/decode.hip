@@ -15,9 +15,10 @@ constexpr int kThreads = 256;
 // that 64 lanes reading 64 consecutive rows hit 64 different banks), weights
 // are LDS broadcasts.  Lags are processed in chunks of 32, channels of 64.
 struct FirTile {
-  long long row0;     // global first row of the file
-  long long nrows;    // rows in the file
-  long long t0;       // first output frame (file relative) of this tile
+  long long row0;     // global first INPUT row of the (offset-shifted) file stream
+  long long nrows;    // rows in that stream
+  long long t0;       // first output frame (stream relative) of this tile
+  long long out0;     // global OUTPUT row of stream frame 0 (the zipped-stream index)
 };
 
 constexpr int kFirLagChunk = 32;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void predict_fir_kernel(
 #pragma unroll
     for (int q = 0; q < DB; ++q)
       if (q0 + q < d)
-        out[(tile.row0 + t) * ldout + q0 + q] = acc[q] + (bias ? bias[q0 + q] : 0.f);
+        out[(tile.out0 + t) * ldout + q0 + q] = acc[q] + (bias ? bias[q0 + q] : 0.f);
   }
 }
 
@@ -204,6 +205,12 @@ __global__ void frame_scores_kernel(const float* __restrict__ a, long long lda,
   for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < rows;
        r += (long long)gridDim.x * blockDim.x) {
     double acc = 0.0;
+    if (reduction == 5) {   // 'all': every column, out is [rows, cols]
+      for (int c = 0; c < cols; ++c)
+        out[r * cols + c] = ((double)a[r * lda + c] - sp.mean_a[c]) *
+                            ((double)b[r * ldb + c] - sp.mean_b[c]) / sp.power[c];
+      continue;
+    }
     if (reduction == 0 || reduction == 1) {
       const int c = reduction;
       acc = ((double)a[r * lda + c] - sp.mean_a[c]) * ((double)b[r * ldb + c] - sp.mean_b[c]) /
@@ -420,13 +427,16 @@ int fill_score_params(td_handle* h, ScoreParams* sp, int cols, const double* mea
 
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
                int c, int pre, int post, const float* w, const float* bias, int d, float* out,
-               int64_t ldout) {
+               int64_t ldout, int64_t shift = 0) {
+  // `shift` leading rows of every file are dropped from this input stream BEFORE
+  // context is added (brain_data.py:466-475); output row offs[f] + t is frame t of
+  // the shifted stream, i.e. the index of the zipped streams.
   std::vector<FirTile> tiles;
   for (int f = 0; f < num_files; ++f) {
-    const int64_t n = offs[f + 1] - offs[f];
+    const int64_t n = offs[f + 1] - offs[f] - shift;
     for (int64_t t0 = 0; t0 < n; t0 += kThreads) {
       FirTile t;
-      t.row0 = offs[f]; t.nrows = n; t.t0 = t0;
+      t.row0 = offs[f] + shift; t.nrows = n; t.t0 = t0; t.out0 = offs[f];
       tiles.push_back(t);
     }
   }
@@ -464,20 +474,21 @@ extern "C" {
 
 int td_predict_fir(td_handle* h, const float* x_dev, int64_t ldx,
                    const int64_t* file_offsets_host, int num_files, int c, int pre, int post,
-                   const float* w_dev, const float* b_dev, int d, float* out_dev, int64_t ldout) {
+                   int input_offset, const float* w_dev, const float* b_dev, int d,
+                   float* out_dev, int64_t ldout) {
   if (!h || !x_dev || !file_offsets_host || !w_dev || !out_dev)
     return td_fail(h, TD_ERR_INVALID, "td_predict_fir: NULL argument");
   TD_REQUIRE(h, c > 0 && pre >= 0 && post >= 0 && d > 0, "td_predict_fir: bad sizes");
   TD_REQUIRE(h, ldx >= c && ldout >= d, "td_predict_fir: leading dimension too small");
   return launch_fir(h, x_dev, ldx, file_offsets_host, num_files, c, pre, post, w_dev, b_dev, d,
-                    out_dev, ldout);
+                    out_dev, ldout, input_offset > 0 ? input_offset : 0);
 }
 
 int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int pre1, int post1,
                      const float* x2_dev, int64_t ldx2, int c2, int pre2, int post2,
-                     const int64_t* file_offsets_host, int num_files, const float* mean1_dev,
-                     const float* rot1_dev, const float* mean2_dev, const float* rot2_dev,
-                     int dims, float* out_dev, int64_t ldout) {
+                     const int64_t* file_offsets_host, int num_files, int input_offset,
+                     const float* mean1_dev, const float* rot1_dev, const float* mean2_dev,
+                     const float* rot2_dev, int dims, float* out_dev, int64_t ldout) {
   if (!h || !x_dev || !x2_dev || !file_offsets_host || !mean1_dev || !rot1_dev || !mean2_dev ||
       !rot2_dev || !out_dev)
     return td_fail(h, TD_ERR_INVALID, "td_cca_transform: NULL argument");
@@ -491,10 +502,11 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
   hipLaunchKernelGGL(neg_mean_rot_kernel, dim3((unsigned)dims), dim3(kThreads), 0, h->stream,
                      mean2_dev, rot2_dev, k2, dims, bias + dims);
   int rc = launch_fir(h, x_dev, ldx, file_offsets_host, num_files, c1, pre1, post1, rot1_dev, bias,
-                      dims, out_dev, ldout);
+                      dims, out_dev, ldout, input_offset > 0 ? input_offset : 0);
   if (rc == TD_OK)
     rc = launch_fir(h, x2_dev, ldx2, file_offsets_host, num_files, c2, pre2, post2, rot2_dev,
-                    bias + dims, dims, out_dev + dims, ldout);
+                    bias + dims, dims, out_dev + dims, ldout,
+                    input_offset < 0 ? -input_offset : 0);
   hipStreamSynchronize(h->stream);
   hipFree(bias);
   return rc;
@@ -575,7 +587,7 @@ int td_frame_scores(td_handle* h, const float* a_dev, int64_t lda, const float* 
                     const double* lda_w_host, double lda_slope, double lda_intercept,
                     double* out_dev) {
   if (!h || !a_dev || !b_dev || !out_dev) return td_fail(h, TD_ERR_INVALID, "td_frame_scores: NULL");
-  TD_REQUIRE(h, reduction >= 0 && reduction <= 4, "Unknown reduction technique: %d", reduction);
+  TD_REQUIRE(h, reduction >= 0 && reduction <= 5, "Unknown reduction technique: %d", reduction);
   TD_REQUIRE(h, reduction != 1 || cols >= 2, "reduction 'second' needs >= 2 columns");
   TD_REQUIRE(h, reduction != 4 || lda_w_host, "lda reduction needs its weights");
   ScoreParams sp;

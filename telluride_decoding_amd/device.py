@@ -220,3 +220,166 @@ class LagStats(object):
         self.ptr = None
     except Exception:
       pass
+
+
+# ---------------------------------------------------------------- decode wrappers
+REDUCTIONS = {'first': 0, 'second': 1, 'mean': 2, 'mean-squared': 3, 'lda': 4, 'all': 5}
+
+
+def predict_fir(x, file_offsets, w, b, pre, post, out=None, handle=None, input_offset=0):
+  """out[t] = b + sum_{l,c} x~[t+l-pre][c] W[l*C+c]   (td_predict_fir).
+
+  x [rows, C] device float32; w [K, D], b [D] device float32.  Output row
+  file_offsets[f] + t is frame t of file f's zipped streams."""
+  h = handle or default_handle()
+  rows, c = int(x.shape[0]), int(x.shape[1])
+  d = int(w.shape[1])
+  if int(w.shape[0]) != c * (pre + 1 + post):
+    raise ValueError('weight matrix has %d rows, expected %d' %
+                     (w.shape[0], c * (pre + 1 + post)))
+  if out is None:
+    out = h.empty((rows, d), 'float32')
+  offs, offs_p = _lib.i64_array(file_offsets)
+  h.check(h.lib.td_predict_fir(h.ptr, _ptr(x), x.stride(0), offs_p, len(offs) - 1, c, pre, post,
+                               int(input_offset), _ptr(w), _ptr(b), d, _ptr(out),
+                               out.stride(0)))
+  return out
+
+
+def cca_transform(x, x2, file_offsets, mean1, rot1, mean2, rot2, pre1, post1, pre2, post2,
+                  handle=None, input_offset=0):
+  h = handle or default_handle()
+  rows = int(x.shape[0])
+  dims = int(rot1.shape[1])
+  out = h.empty((rows, 2 * dims), 'float32')
+  offs, offs_p = _lib.i64_array(file_offsets)
+  h.check(h.lib.td_cca_transform(
+      h.ptr, _ptr(x), x.stride(0), int(x.shape[1]), pre1, post1, _ptr(x2), x2.stride(0),
+      int(x2.shape[1]), pre2, post2, offs_p, len(offs) - 1, int(input_offset), _ptr(mean1),
+      _ptr(rot1),
+      _ptr(mean2), _ptr(rot2), dims, _ptr(out), out.stride(0)))
+  return out
+
+
+def window_layout(trial_offsets, width, hop):
+  """(window_offsets[T+1], total_windows) for full windows of each trial."""
+  lib = _lib.load()
+  offs, offs_p = _lib.i64_array(trial_offsets)
+  wo = np.zeros(len(offs), np.int64)
+  total = ctypes.c_int64(0)
+  _lib.check(None, lib.td_window_count(offs_p, len(offs) - 1, int(width), int(hop),
+                                       wo.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                       ctypes.byref(total)))
+  return wo, int(total.value)
+
+
+def window_sums(a, b, trial_offsets, width, hop, handle=None):
+  """Five float64 sums per window and column: [n_windows, cols, 5]."""
+  h = handle or default_handle()
+  cols = int(a.shape[1])
+  _, total = window_layout(trial_offsets, width, hop)
+  out = h.zeros((total, cols, 5), 'float64')
+  offs, offs_p = _lib.i64_array(trial_offsets)
+  h.check(h.lib.td_window_sums(h.ptr, _ptr(a), a.stride(0), _ptr(b), b.stride(0), cols, offs_p,
+                               len(offs) - 1, int(width), int(hop), _ptr(out)))
+  return out
+
+
+def window_scores(sums, width, mode, reduction='first', mean_a=None, mean_b=None, power=None,
+                  handle=None):
+  h = handle or default_handle()
+  total, cols = int(sums.shape[0]), int(sums.shape[1])
+  out = h.zeros((total,) if mode == 0 else (total, cols), 'float64')
+  args = []
+  for v in (mean_a, mean_b, power):
+    if v is None:
+      args.append((None, None))
+    else:
+      args.append(_lib.f64_array(np.broadcast_to(np.asarray(v, np.float64).reshape(-1), (cols,))
+                                 if np.size(v) == 1 else v))
+  red = REDUCTIONS[reduction] if mode == 0 else 0
+  h.check(h.lib.td_window_scores(h.ptr, _ptr(sums), total, cols, int(width), int(mode), red,
+                                 args[0][1], args[1][1], args[2][1], _ptr(out)))
+  return out
+
+
+def frame_scores(a, b, reduction, mean_a, mean_b, power, lda_w=None, lda_slope=1.0,
+                 lda_intercept=0.0, handle=None):
+  """Per-frame reduced correlation score (Decoder.infer_one)."""
+  h = handle or default_handle()
+  if reduction not in REDUCTIONS:
+    raise ValueError('Unknown reduction technique: %s' % reduction)
+  rows, cols = int(a.shape[0]), int(a.shape[1])
+  red = REDUCTIONS[reduction]
+  out = h.zeros((rows, cols) if red == 5 else (rows,), 'float64')
+
+  def vec(v):
+    v = np.asarray(v, np.float64).reshape(-1)
+    if v.size == 1:
+      v = np.repeat(v, cols)
+    return _lib.f64_array(v)
+
+  ma, mb, pw = vec(mean_a), vec(mean_b), vec(power)
+  lw = vec(lda_w) if lda_w is not None else (None, None)
+  h.check(h.lib.td_frame_scores(h.ptr, _ptr(a), a.stride(0), _ptr(b), b.stride(0), cols, rows,
+                                red, ma[1], mb[1], pw[1], lw[1], float(lda_slope),
+                                float(lda_intercept), _ptr(out)))
+  return out
+
+
+def window_means(v, trial_offsets, width, hop, handle=None):
+  h = handle or default_handle()
+  _, total = window_layout(trial_offsets, width, hop)
+  out = h.zeros((total,), 'float64')
+  offs, offs_p = _lib.i64_array(trial_offsets)
+  h.check(h.lib.td_window_means(h.ptr, _ptr(v), offs_p, len(offs) - 1, int(width), int(hop),
+                                _ptr(out)))
+  return out
+
+
+def decide_wta(s1, s2, handle=None):
+  h = handle or default_handle()
+  out = h.zeros((int(s1.shape[0]),), 'uint8')
+  h.check(h.lib.td_decide_wta(h.ptr, _ptr(s1), _ptr(s2), int(s1.shape[0]), _ptr(out)))
+  return out
+
+
+def decide_step(s1, s2, window_offsets, state=None, handle=None):
+  h = handle or default_handle()
+  out = h.zeros((int(s1.shape[0]),), 'uint8')
+  wo, wo_p = _lib.i64_array(window_offsets)
+  st = np.full(len(wo) - 1, 0.5) if state is None else np.ascontiguousarray(state, np.float64)
+  h.check(h.lib.td_decide_step(h.ptr, _ptr(s1), _ptr(s2), wo_p, len(wo) - 1, _ptr(out),
+                               st.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+  return out, st
+
+
+def decode_ssd(s1, s2, window_offsets, outer_iter=20, inner_iter=1, newton_iter=10,
+               forward_lag=0, backward_lag=13, offset=0.0, prior=None, handle=None):
+  """prior = (rho_d[2], mu_d[2]) from tune_log_normal_priors, or None."""
+  h = handle or default_handle()
+  out = h.zeros((int(s1.shape[0]), 3), 'float64')
+  wo, wo_p = _lib.i64_array(window_offsets)
+  params, params_p = _lib.f64_array([outer_iter, inner_iter, newton_iter, forward_lag,
+                                     backward_lag, offset, 1.0 if prior is not None else 0.0, 0.0])
+  pr_p = None
+  if prior is not None:
+    pr, pr_p = _lib.f64_array(list(prior[0]) + list(prior[1]))
+  h.check(h.lib.td_decode_ssd(h.ptr, _ptr(s1), _ptr(s2), wo_p, len(wo) - 1, params_p, pr_p,
+                              _ptr(out)))
+  return out
+
+
+def decode_fused(eeg, env, trial_offsets, w, b, pre, post, width, hop, corr, handle=None):
+  """corr = [mean_truth, mean_pred, power] for speaker 1 then speaker 2."""
+  h = handle or default_handle()
+  _, total = window_layout(trial_offsets, width, hop)
+  scores = h.zeros((total, 2), 'float64')
+  decisions = h.zeros((total,), 'uint8')
+  offs, offs_p = _lib.i64_array(trial_offsets)
+  cr, cr_p = _lib.f64_array(np.asarray(corr, np.float64).reshape(-1))
+  h.check(h.lib.td_decode_fused(h.ptr, _ptr(eeg), eeg.stride(0), int(eeg.shape[1]), pre, post,
+                                _ptr(w), _ptr(b), _ptr(env), env.stride(0), offs_p,
+                                len(offs) - 1, int(width), int(hop), cr_p, _ptr(scores),
+                                _ptr(decisions)))
+  return scores, decisions

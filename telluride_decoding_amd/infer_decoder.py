@@ -1,0 +1,355 @@
+"""Correlate -> reduce -> window: the inference half of the linear path.
+
+Same public surface as reference infer_decoder.py: `Decoder` (:95-580) with its
+streaming correlator (`add_data_correlator` :288-310, `compute_correlation`
+:312-328), `train` (:330-400), `infer_one` (:416-455), `test_all` (:457-482),
+`test_by_window` (:484-504), LDA helpers (:506-550), JSON persistence
+(:75-92, 240-248); `LinearRegressionDecoder` (:583-604), `CCADecoder` (:607-632),
+`create_decoder` (:635-666), `calculate_dprime` (:717-745), `average_data`
+(:748-783).  SavedModel loading and TFRecord datasets (:250-286, :669-713) are TF
+file formats and out of scope.
+
+All per-frame arithmetic (five running sums, normalised products, reductions,
+window means) runs in HIP kernels; this file is host orchestration.  Besides
+the reference's minibatch-streaming methods there is a batched fast path,
+`decode_windows`, that scores every window of every trial in a few launches.
+"""
+import collections
+import json
+
+import numpy as np
+
+from telluride_decoding_amd import brain_data
+from telluride_decoding_amd import brain_model
+from telluride_decoding_amd import device
+from telluride_decoding_amd import result_store
+from telluride_decoding_amd import scaled_lda
+
+
+class NumpyEncoder(json.JSONEncoder):
+  """JSON encoder that writes ndarrays as (nested) lists; complex arrays as
+  [real, imag] (reference :75-86)."""
+
+  def default(self, obj):
+    if isinstance(obj, np.ndarray):
+      if np.iscomplexobj(obj):
+        return [np.real(obj).tolist(), np.imag(obj).tolist()]
+      return obj.tolist()
+    if isinstance(obj, (np.floating, np.integer)):
+      return obj.item()
+    return json.JSONEncoder.default(self, obj)
+
+
+CorrelationParamsTuple = collections.namedtuple('CorrelationParamsTuple', [
+    'count', 'sum_x', 'sum_y', 'sum_x2', 'sum_y2', 'mean_x', 'mean_y', 'power'])
+ModelParamsTuple = collections.namedtuple('ModelParamsTuple',
+                                          ['correlation_params', 'lda_params'])
+
+_REDUCTIONS = ('mean-squared', 'first', 'second', 'lda', 'all', 'mean')
+
+
+def _host(a):
+  if hasattr(a, 'is_cuda'):
+    return a.cpu().numpy()
+  if hasattr(a, 'numpy'):
+    return a.numpy()
+  return np.asarray(a)
+
+
+class Decoder(object):
+  """Generic decode pipeline: model output -> correlation -> scalar score."""
+
+  def __init__(self, decoding_model=None, reduction='mean-squared'):
+    if decoding_model is not None and not callable(decoding_model):
+      raise TypeError('Must supply a callable model when initializing a Decoder, not a %s.' %
+                      type(decoding_model))
+    if reduction not in _REDUCTIONS:
+      raise ValueError('Unknown reduction technique: %s' % reduction)
+    self._decoding_model = decoding_model
+    self._decoding_model_params = {}
+    self._model_inputs = {}
+    self._model_output = []
+    self._reduction = reduction
+    self._lda = None
+    self.reset_correlation_statistics()
+
+  # -- bookkeeping properties (reference :148-238) ------------------------------
+  @property
+  def decoding_model(self):
+    return self._decoding_model
+
+  @property
+  def decoding_model_params(self):
+    return self._decoding_model_params
+
+  @decoding_model_params.setter
+  def decoding_model_params(self, values):
+    self._decoding_model_params = values
+
+  @property
+  def correlation_params(self):
+    return CorrelationParamsTuple(self._count, self._sum_x, self._sum_y, self._sum_x2,
+                                  self._sum_y2, self._mean_x, self._mean_y, self._power)
+
+  def _set_correlation_params(self, values):
+    values = CorrelationParamsTuple(*values)
+    self._count = values.count
+    self._sum_x, self._sum_y = np.asarray(values.sum_x), np.asarray(values.sum_y)
+    self._sum_x2, self._sum_y2 = np.asarray(values.sum_x2), np.asarray(values.sum_y2)
+    self._mean_x, self._mean_y = np.asarray(values.mean_x), np.asarray(values.mean_y)
+    self._power = np.asarray(values.power)
+
+  @property
+  def lda_params(self):
+    if self._lda is None:
+      self._lda = scaled_lda.ScaledLinearDiscriminantAnalysis()
+    return self._lda.model_parameters
+
+  def _set_lda_params(self, values):
+    if self._lda is None:
+      self._lda = scaled_lda.ScaledLinearDiscriminantAnalysis()
+    self._lda.model_parameters = values
+
+  @property
+  def model_params(self):
+    return ModelParamsTuple(self.correlation_params, self.lda_params)
+
+  @model_params.setter
+  def model_params(self, values):
+    self._set_correlation_params(values.correlation_params)
+    self._set_lda_params(values.lda_params)
+
+  @property
+  def model_inputs(self):
+    return self._model_inputs
+
+  @property
+  def model_output(self):
+    return self._model_output
+
+  def reset_correlation_statistics(self):
+    self._count = 0
+    self._sum_x = self._sum_y = self._sum_x2 = self._sum_y2 = 0.0
+    self._mean_x = self._mean_y = 0.0
+    self._power = 1.0
+
+  def save_parameters(self, param_filename):
+    with open(param_filename, 'w') as f:
+      json.dump(self.model_params._asdict(), f, cls=NumpyEncoder)
+
+  def restore_parameters(self, param_filename):
+    with open(param_filename, 'r') as f:
+      loaded = json.load(f)
+    self.model_params = ModelParamsTuple(**loaded)
+
+  # -- streaming correlator (reference :288-328) --------------------------------
+  def _add_sums(self, count, s):
+    """s: [cols, 5] float64 sums {x, y, x^2, y^2, xy} of `count` frames."""
+    self._count += count
+    self._sum_x = self._sum_x + s[:, 0]
+    self._sum_y = self._sum_y + s[:, 1]
+    self._sum_x2 = self._sum_x2 + s[:, 2]
+    self._sum_y2 = self._sum_y2 + s[:, 3]
+    self._mean_x = self._sum_x / self._count
+    self._mean_y = self._sum_y / self._count
+    self._power = (np.sqrt((self._sum_x2 - self._sum_x ** 2 / self._count) *
+                           (self._sum_y2 - self._sum_y ** 2 / self._count)) / self._count)
+
+  def add_data_correlator(self, x, y):
+    """Adds a [frames, dims] block to the running statistics; the five sums come
+    from the window-sums kernel (one window = the block), the scalar update of
+    means and power (reference :306-310) is host bookkeeping in float64."""
+    h = device.default_handle()
+    xd, yd = brain_model._as_2d_device(h, x), brain_model._as_2d_device(h, y)
+    rows = int(xd.shape[0])
+    if rows == 0:
+      return
+    s = device.window_sums(xd, yd, [0, rows], rows, rows, handle=h).cpu().numpy()[0]
+    self._add_sums(rows, s)
+
+  def _stat_vectors(self, cols):
+    vec = lambda v: np.broadcast_to(np.asarray(v, np.float64).reshape(-1), (cols,)).copy()
+    return vec(self._mean_x), vec(self._mean_y), vec(self._power)
+
+  def compute_correlation(self, x, y):
+    """Per-frame (x - mean_x)(y - mean_y) / power with the TRAINED statistics
+    (not per-window Pearson): [frames, dims]."""
+    h = device.default_handle()
+    xd, yd = brain_model._as_2d_device(h, x), brain_model._as_2d_device(h, y)
+    mx, my, pw = self._stat_vectors(int(xd.shape[1]))
+    out = device.frame_scores(xd, yd, 'all', mx, my, pw, handle=h)
+    return out.cpu().numpy()
+
+  # -- training (reference :330-400) ------------------------------------------
+  def train(self, data0, data1, window_size=0):
+    for name, data in (('data0', data0), ('data1', data1)):
+      if not isinstance(data, brain_data.Dataset) and not hasattr(data, '__iter__'):
+        raise TypeError('Must feed training routine %s with a tf.data.Dataset not a %s.' %
+                        (name, type(data)))
+    for data in (data0, data1):
+      for input_dict, output in data:
+        r1, r2 = self.decode_one(input_dict, output)
+        self.add_data_correlator(r1, r2)
+    stores = []
+    for data in (data0, data1):
+      store = result_store.NumpyStore()
+      for input_dict, output in data:
+        r1, r2 = self.decode_one(input_dict, output)
+        store.add_data(self.compute_correlation(r1, r2))
+      stores.append(store.all_data)
+    if stores[0] is None or stores[0].shape[0] == 0:
+      raise ValueError('No data for class 0')
+    if stores[1] is None or stores[1].shape[0] == 0:
+      raise ValueError('No data for class 1')
+    return self.compute_lda_model(average_data(stores[0], window_size),
+                                  average_data(stores[1], window_size))
+
+  def decode_one(self, input_dict, ground_truth):
+    raise NotImplementedError('Must be implemented by a subclass.')
+
+  # -- inference (reference :416-504) -----------------------------------------
+  def _reduce_kwargs(self):
+    kw = {}
+    if self._reduction == 'lda':
+      if self._lda is None or self._lda.coef_array is None:
+        raise ValueError('Must compute the LDA model before reducing data.')
+      kw = dict(lda_w=np.real(self._lda.coef_array[:, 0]), lda_slope=self._lda._slope,
+                lda_intercept=self._lda._intercept)
+    return kw
+
+  def infer_one(self, input_dict, output):
+    """One minibatch -> per-frame scalar score ([frames]; [frames, dims] for
+    reduction 'all')."""
+    r1, r2 = self.decode_one(input_dict, output)
+    h = device.default_handle()
+    xd, yd = brain_model._as_2d_device(h, r1), brain_model._as_2d_device(h, r2)
+    cols = int(xd.shape[1])
+    if self._reduction == 'second' and cols < 2:
+      raise IndexError('index 1 is out of bounds for axis 1 with size %d' % cols)
+    mx, my, pw = self._stat_vectors(cols)
+    out = device.frame_scores(xd, yd, self._reduction, mx, my, pw, handle=h,
+                              **self._reduce_kwargs())
+    return out.cpu().numpy()
+
+  def test_all(self, exp_data):
+    predictions = result_store.NumpyStore(name='test_all predictions')
+    labels = result_store.NumpyStore(name='test_all labels')
+    for input_dict, output in exp_data:
+      predictions.add_data(self.infer_one(input_dict, output))
+      labels.add_data(_host(input_dict['attended_speaker']))
+    return predictions.all_data, labels.all_data
+
+  def test_by_window(self, dataset, window_size):
+    """Generator of (scores, labels) windows, step = window_size // 2."""
+    storage = result_store.TwoResultStore(window_width=window_size,
+                                          window_step=window_size // 2)
+    for input_dict, output in dataset:
+      storage.add_data(np.reshape(self.infer_one(input_dict, output), (-1, 1))
+                       if self._reduction != 'all' else self.infer_one(input_dict, output),
+                       _host(input_dict['attended_speaker']))
+      for r1, r2 in storage.next_window():
+        yield r1, r2
+
+  # -- LDA (reference :506-550) -------------------------------------------------
+  def compute_lda_model(self, d1, d2):
+    if not isinstance(d1, np.ndarray):
+      raise TypeError('Input d1 must be an numpy array, not %s.' % type(d1))
+    if not isinstance(d2, np.ndarray):
+      raise TypeError('Input d2 must be an numpy array, not %s.' % type(d2))
+    data = np.concatenate((d1, d2), axis=0)
+    labels = np.concatenate((1 * np.ones(d1.shape[0],), 2 * np.ones(d2.shape[0],)))
+    self._lda = scaled_lda.ScaledLinearDiscriminantAnalysis()
+    predictions = self._lda.fit_transform(data, labels)
+    return calculate_dprime(predictions[labels == 1, 0], predictions[labels == 2, 0])
+
+  def reduce_with_lda(self, d1):
+    if self._lda is None:
+      raise ValueError('Must compute the LDA model before reducing data.')
+    if not isinstance(d1, np.ndarray):
+      raise TypeError('Input data must be an numpy array, not %s.' % type(d1))
+    return self._lda.transform(d1)
+
+  # -- batched fast path ----------------------------------------------------------
+  def decode_windows(self, truth, prediction, trial_offsets, window_size, window_step=None):
+    """Window scores of every trial at once.
+
+    truth / prediction: [frames, dims] float32 device tensors (trials
+    concatenated, `trial_offsets` [T+1]).  Returns (scores [n_windows] float64
+    device tensor, window_offsets [T+1]).  Equivalent to walking
+    test_by_window + np.mean per window (reference infer.py:261-266).
+    """
+    h = device.default_handle()
+    if window_step is None:
+      window_step = window_size // 2
+    cols = int(truth.shape[1])
+    mx, my, pw = self._stat_vectors(cols)
+    wo, _ = device.window_layout(trial_offsets, window_size, window_step)
+    if self._reduction in ('first', 'second', 'mean'):
+      sums = device.window_sums(truth, prediction, trial_offsets, window_size, window_step,
+                                handle=h)
+      return device.window_scores(sums, window_size, 0, self._reduction, mx, my, pw,
+                                  handle=h), wo
+    if self._reduction == 'all':
+      raise ValueError('decode_windows needs a scalar reduction')
+    frames = device.frame_scores(truth, prediction, self._reduction, mx, my, pw, handle=h,
+                                 **self._reduce_kwargs())
+    return device.window_means(frames, trial_offsets, window_size, window_step, handle=h), wo
+
+
+class LinearRegressionDecoder(Decoder):
+  """Ground truth vs the linear model's prediction (reference :583-604)."""
+
+  def decode_one(self, input_dict, ground_truth):
+    predictions = self._decoding_model(input_dict)
+    return _host(ground_truth), _host(predictions)
+
+
+class CCADecoder(Decoder):
+  """The two halves of the CCA model's output (reference :607-632)."""
+
+  def decode_one(self, input_dict, ground_truth):
+    del ground_truth
+    predictions = _host(self._decoding_model(input_dict))
+    dims = predictions.shape[1] // 2
+    return predictions[:, :dims], predictions[:, dims:]
+
+
+def create_decoder(model_tag, reduction='lda', model=None):
+  """Picks the decoder class from a tag / model path (reference :635-666)."""
+  tag = model_tag.lower()
+  if 'linear' in tag or 'fullyconnected' in tag:
+    return LinearRegressionDecoder(model, reduction=reduction)
+  elif 'cca' in tag:
+    return CCADecoder(model, reduction=reduction)
+  raise ValueError('Couldn\'t determine model type for tag %s.' % model_tag)
+
+
+def calculate_dprime(d1, d2):
+  """(mean2 - mean1) / sqrt((var1 + var2) / 2), reference :717-745."""
+  d1, d2 = np.asarray(d1), np.asarray(d2)
+  if d1.ndim > 2 or (d1.ndim == 2 and d1.shape[1] > 1):
+    raise TypeError('d1 array must be a vector, not size %s.' % str(d1.shape))
+  if d2.ndim > 2 or (d2.ndim == 2 and d2.shape[1] > 1):
+    raise TypeError('d2 array must be a vector, not size %s.' % str(d2.shape))
+  return (np.mean(d2) - np.mean(d1)) / np.sqrt((np.var(d1) + np.var(d2)) / 2.0)
+
+
+def average_data(data, window_size):
+  """Means over consecutive blocks of `window_size` frames; the tail is dropped
+  (reference :748-783).  Runs as non-overlapping windows on the device."""
+  if not isinstance(data, np.ndarray):
+    raise TypeError('Data to be averaged must be a numpy array, not %s.' % type(data))
+  if data.ndim != 2:
+    raise TypeError('Averaging data must be two dimensional, not %s.' % data.ndim)
+  if not window_size >= 0:
+    raise ValueError('Window size (%s) must be greater-than or equal to zero.' % window_size)
+  if window_size <= 1:
+    return data
+  h = device.default_handle()
+  rows, cols = data.shape
+  out = np.empty((rows // window_size, cols))
+  for c in range(cols):
+    col = h.to_device(np.ascontiguousarray(data[:, c:c + 1], np.float64), np.float64).reshape(-1)
+    out[:, c] = device.window_means(col, [0, rows], window_size, window_size,
+                                    handle=h).cpu().numpy()
+  return out

@@ -1,0 +1,463 @@
+"""GPU parity tests of the decode path (A3' forward, A5-A9) and of CCA (A4).
+
+HIP kernels through the C-ABI vs the CPU oracle on the same seeded inputs and
+vs the golden fixtures generated from the reference itself.
+"""
+import numpy as np
+import pytest
+
+from oracle import attention as o_att
+from oracle import cca as o_cca
+from oracle import correlator as o_cor
+from oracle import lag as o_lag
+from oracle import pearson as o_p
+from oracle import regression as o_reg
+from tests.conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+  from telluride_decoding_amd import device
+  return device
+
+
+def _d64(h, v):
+  return h.to_device(np.asarray(v, np.float64).reshape(-1, 1), np.float64).reshape(-1)
+
+
+@pytest.mark.parametrize('c,pre,post,d,lens,off', [
+    (64, 0, 31, 1, (1000, 300, 257), 0),
+    (16, 2, 3, 2, (700, 64), 0),
+    (5, 0, 0, 1, (513,), 0),
+    (70, 3, 40, 3, (900,), 0),          # > 64 channels and > 32 lags: chunk loops
+    (8, 1, 2, 1, (400, 300), 2),        # input_offset drops leading x rows per file
+    (4, 6, 6, 1, (5, 3, 700), 0),       # files shorter than the context
+])
+def test_predict_fir_matches_dense_forward(dev, c, pre, post, d, lens, off):
+  rng = np.random.default_rng(c * 100 + pre)
+  h = dev.default_handle()
+  k = c * (pre + 1 + post)
+  w = (rng.standard_normal((k, d)) / np.sqrt(k)).astype(np.float32)
+  b = rng.standard_normal(d).astype(np.float32)
+  xs = [rng.standard_normal((n, c)).astype(np.float32) for n in lens]
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  out = dev.predict_fir(h.to_device(np.concatenate(xs)), offs, h.to_device(w),
+                        h.to_device(b.reshape(1, -1)).reshape(-1), pre, post, handle=h,
+                        input_offset=off).cpu().numpy()
+  for i, x in enumerate(xs):
+    xl = o_lag.lag_matrix(x[off:].astype(np.float64), pre, post)
+    want = xl @ w.astype(np.float64) + b
+    got = out[offs[i]:offs[i] + want.shape[0]]
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
+def test_window_sums_and_scores(dev):
+  rng = np.random.default_rng(3)
+  h = dev.default_handle()
+  lens = (2400, 999, 3100)
+  cols = 3
+  a = (rng.standard_normal((sum(lens), cols)) + 0.5).astype(np.float32)
+  b = (0.6 * a + rng.standard_normal(a.shape)).astype(np.float32)
+  b[2400:3399, 1] = 2.0                     # a constant column inside trial 1
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  width, hop = 1000, 100
+  sums = dev.window_sums(h.to_device(a), h.to_device(b), offs, width, hop, handle=h)
+  wo, total = dev.window_layout(offs, width, hop)
+  assert total == sum(max(0, (n - width) // hop + 1) for n in lens) == sums.shape[0]
+  np.testing.assert_array_equal(wo, [0, 15, 15, 37])     # trial 1 is shorter than a window
+  s = sums.cpu().numpy()
+  a64, b64 = a.astype(np.float64), b.astype(np.float64)
+  starts = np.concatenate([offs[t] + o_cor.window_starts(lens[t], width, hop) for t in range(3)])
+  for wi in (0, 7, 14, 15, 36):
+    r = slice(starts[wi], starts[wi] + width)
+    want = np.stack([a64[r].sum(0), b64[r].sum(0), (a64[r] ** 2).sum(0), (b64[r] ** 2).sum(0),
+                     (a64[r] * b64[r]).sum(0)], axis=1)
+    np.testing.assert_allclose(s[wi], want, rtol=1e-12, atol=1e-9)
+  # flavour A6/A7: trained global statistics, mean over the window
+  cor = o_cor.Correlator()
+  cor.add(a64, b64)
+  for red in ('first', 'second', 'mean'):
+    got = dev.window_scores(sums, width, 0, red, cor.mean_x, cor.mean_y, cor.power,
+                            handle=h).cpu().numpy()
+    frames = o_cor.reduce_correlations(cor.correlate(a64, b64), red)
+    want = np.array([np.mean(frames[st:st + width]) for st in starts])
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+  # flavour A5: per-window Pearson, incl. the constant-column -> zeros rule
+  got = dev.window_scores(sums, width, 1, handle=h).cpu().numpy()
+  for wi in (0, 14, 20, 36):
+    r = slice(starts[wi], starts[wi] + width)
+    want = o_p.pearson_correlation(a64[r], b64[r])
+    want = want if want.ndim == 1 else np.zeros(cols)
+    np.testing.assert_allclose(got[wi], want, rtol=1e-9, atol=1e-12)
+
+
+def test_window_sums_at_c4_size_properties(dev):
+  """BASELINE C4 size (200 trials x 6000 frames, W = 1000, hop = 100): size-independent
+  checks -- windows tile the trial, sums of non-overlapping windows add up."""
+  import torch
+  h = dev.default_handle()
+  trials, frames = 200, 6000
+  torch.manual_seed(4)
+  a = torch.randn(trials * frames, 1, device='cuda')
+  b = torch.randn(trials * frames, 1, device='cuda')
+  offs = np.arange(trials + 1) * frames
+  s = dev.window_sums(a, b, offs, 1000, 100, handle=h)
+  assert s.shape[0] == trials * 51
+  s = s.reshape(trials, 51, 5).cpu().numpy()
+  whole = dev.window_sums(a, b, offs, 6000, 6000, handle=h).reshape(trials, 5).cpu().numpy()
+  np.testing.assert_allclose(s[:, 0::10, :].sum(axis=1), whole, rtol=1e-12, atol=1e-9)
+  ad = a.double().reshape(trials, frames)
+  np.testing.assert_allclose(whole[:, 0], ad.sum(1).cpu().numpy(), rtol=1e-12, atol=1e-9)
+
+
+def test_frame_scores_reductions_match_golden(dev):
+  g = golden('g5_correlator')
+  h = dev.default_handle()
+  x, y = g['x'], g['y']
+  xd, yd = h.to_device(x), h.to_device(y)
+  args = (g['mean_x'], g['mean_y'], g['power'])
+  got = dev.frame_scores(xd, yd, 'all', *args, handle=h).cpu().numpy()
+  np.testing.assert_allclose(got, g['corr'], rtol=2e-5, atol=2e-6)   # reference is float32
+  for red in ('first', 'second', 'mean', 'mean-squared'):
+    got = dev.frame_scores(xd, yd, red, *args, handle=h).cpu().numpy()
+    np.testing.assert_allclose(got, g['red_' + red.replace('-', '_')], rtol=5e-5, atol=5e-6)
+  with pytest.raises(ValueError, match='Unknown reduction technique'):
+    dev.frame_scores(xd, yd, 'bogus', *args, handle=h)
+
+
+def test_wta_and_step_match_reference_sequences(dev):
+  g = golden('g7_decoders')
+  h = dev.default_handle()
+  for a, b, want in ((g['cor1'], g['cor2'], g['wta_lit']), (g['rand1'], g['rand2'], g['wta_rand'])):
+    got = dev.decide_wta(_d64(h, a), _d64(h, b), handle=h).cpu().numpy()
+    np.testing.assert_array_equal(got, want)            # bit exact, ties -> speaker 2
+  for a, b, want in ((g['cor1'], g['cor2'], g['step_lit']), (g['short1'], g['cor2'], g['step_short']),
+                     (g['rand1'], g['rand2'], g['step_rand'])):
+    got, _ = dev.decide_step(_d64(h, a), _d64(h, b), [0, len(a)], handle=h)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+  # several trials in one launch, states independent; chunked calls carry the state
+  a = np.concatenate((g['cor1'], g['short1'], g['rand1']))
+  b = np.concatenate((g['cor2'], g['cor2'], g['rand2']))
+  got, st = dev.decide_step(_d64(h, a), _d64(h, b), [0, 13, 26, 526], handle=h)
+  np.testing.assert_array_equal(got.cpu().numpy(),
+                                np.concatenate((g['step_lit'], g['step_short'], g['step_rand'])))
+  first, st1 = dev.decide_step(_d64(h, g['rand1'][:200]), _d64(h, g['rand2'][:200]), [0, 200], handle=h)
+  second, _ = dev.decide_step(_d64(h, g['rand1'][200:]), _d64(h, g['rand2'][200:]), [0, 300],
+                              state=st1, handle=h)
+  np.testing.assert_array_equal(np.concatenate((first.cpu().numpy(), second.cpu().numpy())),
+                                g['step_rand'])
+
+
+@pytest.mark.parametrize('name,tune,offset', [('ssd_tuned', True, 0.0), ('ssd_default', False, 0.0),
+                                              ('ssd_offset', True, 1.0)])
+def test_state_space_decoder_matches_reference_trajectory(dev, name, tune, offset):
+  g = golden('g7_decoders')
+  h = dev.default_handle()
+  c = g[name + '_corr']
+  prior = o_att.tune_log_normal_priors(c[:30, 0], c[:30, 1], offset) if tune else None
+  out = dev.decode_ssd(_d64(h, c[:, 0]), _d64(h, c[:, 1]), [0, c.shape[0]], offset=offset,
+                       prior=prior, handle=h).cpu().numpy()
+  want = g[name + '_traj']
+  np.testing.assert_allclose(out, want, rtol=1e-7, atol=1e-9)
+  np.testing.assert_array_equal(out[:, 0] >= 0.5, want[:, 0] >= 0.5)
+  # batched: the same trial three times plus a short one stays independent
+  s1 = np.concatenate((c[:, 0], c[:40, 0], c[:, 0]))
+  s2 = np.concatenate((c[:, 1], c[:40, 1], c[:, 1]))
+  n = c.shape[0]
+  out3 = dev.decode_ssd(_d64(h, s1), _d64(h, s2), [0, n, n + 40, 2 * n + 40], offset=offset,
+                        prior=prior, handle=h).cpu().numpy()
+  np.testing.assert_array_equal(out3[:n], out)
+  np.testing.assert_array_equal(out3[n + 40:], out)
+  np.testing.assert_array_equal(out3[n:n + 40], out[:40])
+
+
+def test_attention_decoder_classes(dev):
+  from telluride_decoding_amd import attention_decoder as ad
+  g = golden('g7_decoders')
+  wta = ad.create_attention_decoder('wta')
+  assert wta.attention(0.6, 0.4)[0] and not wta.attention(0.4, 0.6)[0]
+  assert wta.attention(0.6 * np.ones(5), 0.4 * np.ones(5)) == (True, 0, 0)
+  stp = ad.create_attention_decoder('stepped')
+  got = [stp.attention(a, b)[0] for a, b in zip(g['cor1'], g['cor2'])]
+  np.testing.assert_array_equal(got, g['step_lit'])
+  np.testing.assert_array_equal(ad.StepAttentionDecoder().attention_batch(g['cor1'], g['cor2'])[0],
+                                g['step_lit'])
+  c = g['ssd_tuned_corr']
+  ssd = ad.create_attention_decoder('ssd')
+  ssd.tune(c[:30, 0], c[:30, 1])
+  np.testing.assert_allclose(ssd.mu_d, g['ssd_tuned_mu_d_tuned'], rtol=1e-12)
+  stream = np.array([ssd.attention(a, b) for a, b in c[:40]])
+  np.testing.assert_allclose(stream, g['ssd_tuned_traj'][:40], rtol=1e-7, atol=1e-9)
+  batch = ad.create_attention_decoder('ssd')
+  batch.tune(c[:30, 0], c[:30, 1])
+  p, lo, hi = batch.attention_batch(c[:, 0], c[:, 1])
+  np.testing.assert_allclose(np.stack((p, lo, hi), 1), g['ssd_tuned_traj'], rtol=1e-7, atol=1e-9)
+  with pytest.raises(ValueError, match=r'Unknown type \(bogus\) requested from create_attention_decoder'):
+    ad.create_attention_decoder('bogus')
+
+
+def test_end_to_end_two_speaker_decode_matches_reference(dev):
+  """G9: fit -> predict -> correlate -> window -> decide, every decision equal to
+  the reference's (attended-speaker argmax bit-exact), scores within 1e-5."""
+  from telluride_decoding_amd import brain_data, brain_model, infer_decoder, attention_decoder
+  g = golden('g9_end_to_end')
+  c, pre, post, batch = (int(v) for v in g['cfg'])
+  lamb = float(g['lamb'])
+  h = dev.default_handle()
+  bd = brain_data.TestBrainData('eeg', 'envelope', 100, pre_context=pre, post_context=post,
+                                final_batch_size=batch)
+  for i in range(4):
+    eeg, env = g['train_eeg%d' % i], g['train_env%d' % i]
+    bd.add_file(eeg, env[:, 0:1], env[:, 1:2])
+  train = bd.create_dataset('train')
+  model = brain_model.BrainModelLinearRegression(train, regularization_lambda=lamb)
+  assert model.fit(train) == {}
+  scale = np.max(np.abs(g['w']))
+  assert np.max(np.abs(model.w_estimate - g['w'])) / scale < 1e-4   # reference is float32
+  # trained correlation statistics: truth = attended envelope, prediction = model
+  dec = infer_decoder.LinearRegressionDecoder(model, reduction='first')
+  pred = model.predict_device(train)
+  _, _, y, offs = train.device_arrays(h)
+  used = train.rows_used()
+  import torch
+  rows = torch.cat([torch.arange(offs[i], offs[i] + u) for i, u in enumerate(used)]).cuda()
+  dec.add_data_correlator(y[rows], pred[rows])
+  np.testing.assert_allclose(dec.correlation_params.power, g['power'], rtol=1e-4)
+  width = int(g['width'])
+  flips = total = 0
+  margins = []
+  for step_name, step in (('half', None), ('hop50', 50)):
+    for i in range(3):
+      eeg, env, att = g['test_eeg%d' % i], g['test_env%d' % i], g['test_att%d' % i]
+      n_used = (eeg.shape[0] // 200) * 200        # the reference's 200-frame minibatches
+      x = h.to_device(eeg)
+      p = dev.predict_fir(x, [0, eeg.shape[0]], *model._device_weights(h), pre, post, handle=h)
+      scores = []
+      for spk in (0, 1):
+        s, _ = dec.decode_windows(h.to_device(env[:n_used, spk:spk + 1]), p[:n_used].contiguous(),
+                                  [0, n_used], width, step)
+        scores.append(s)
+      k = '%s_t%d_' % (step_name, i)
+      got1, got2 = scores[0].cpu().numpy(), scores[1].cpu().numpy()
+      np.testing.assert_allclose(got1, g[k + 's1'], rtol=1e-5, atol=2e-6)
+      np.testing.assert_allclose(got2, g[k + 's2'], rtol=1e-5, atol=2e-6)
+      wta = attention_decoder.AttentionDecoder().attention_batch(scores[0], scores[1])[0]
+      stp = attention_decoder.StepAttentionDecoder().attention_batch(scores[0], scores[1])[0]
+      flips += int(np.sum(wta != g[k + 'wta'])) + int(np.sum(stp != g[k + 'step']))
+      total += 2 * len(wta)
+      margins.append(np.min(np.abs(g[k + 's1'] - g[k + 's2'])))
+  print('end-to-end: %d decisions, %d flips, min |s1 - s2| margin %.3e' % (total, flips, min(margins)))
+  assert flips == 0
+
+
+def test_decode_fused_equals_unfused_at_scale(dev):
+  """td_decode_fused vs the separate kernels on a C4-shaped problem (smaller trial
+  count), plus accuracy of the winner-take-all decision on planted attention."""
+  from telluride_decoding_amd import synth
+  h = dev.default_handle()
+  trials = synth.make_trials(7, 12, 6000, 64, switch_half=True)
+  eeg = np.concatenate([t[0] for t in trials])
+  env = np.concatenate([t[1] for t in trials])
+  att = np.concatenate([t[2] for t in trials])
+  offs = np.arange(13) * 6000
+  attended = np.where(att > 0.5, env[:, 1:2], env[:, 0:1]).astype(np.float32)
+  st = dev.LagStats(64, 0, 31, d=1)
+  xd, envd = h.to_device(eeg), h.to_device(env)
+  st.accumulate(xd, None, h.to_device(attended), offs)
+  w, b = st.ridge_solve([0.1])
+  w, b = w[0].contiguous(), b[0].contiguous()
+  pred = dev.predict_fir(xd, offs, w, b, 0, 31, handle=h)
+  corr = []
+  for spk in (0, 1):
+    s = dev.window_sums(envd[:, spk:spk + 1], pred, [0, eeg.shape[0]], eeg.shape[0],
+                        eeg.shape[0], handle=h).cpu().numpy()[0, 0]
+    n = eeg.shape[0]
+    mean_t, mean_p = s[0] / n, s[1] / n
+    power = np.sqrt((s[2] - s[0] ** 2 / n) * (s[3] - s[1] ** 2 / n)) / n
+    corr += [mean_t, mean_p, power]
+  scores, decisions = dev.decode_fused(xd, envd, offs, w, b, 0, 31, 1000, 100, corr, handle=h)
+  scores, decisions = scores.cpu().numpy(), decisions.cpu().numpy()
+  assert scores.shape == (12 * 51, 2)
+  for spk in (0, 1):
+    sums = dev.window_sums(envd[:, spk:spk + 1], pred, offs, 1000, 100, handle=h)
+    want = dev.window_scores(sums, 1000, 0, 'first', corr[3 * spk], corr[3 * spk + 1],
+                             corr[3 * spk + 2], handle=h).cpu().numpy()
+    np.testing.assert_array_equal(scores[:, spk], want)
+  np.testing.assert_array_equal(decisions, scores[:, 0] > scores[:, 1])
+  labels = dev.window_means(h.to_device(att.astype(np.float64), np.float64).reshape(-1), offs, 1000,
+                            100, handle=h).cpu().numpy()
+  clear = (labels < 0.05) | (labels > 0.95)          # windows with one attended speaker
+  acc = np.mean((decisions[clear] == 1) == (labels[clear] < 0.5))
+  assert acc > 0.95, acc                              # reference floor: infer_test.py:171-176
+
+
+def test_pearson_functions(dev):
+  from telluride_decoding_amd import brain_model, cca
+  g = golden('g3_pearson')
+  kat = g['kat']
+  r = brain_model.pearson_correlation(kat[:, 1:2], kat[:, 2:3])
+  assert abs(float(r[0]) - 0.5298) < 1e-4                      # brain_model_test.py:1065
+  np.testing.assert_allclose(brain_model.pearson_correlation(g['x'], g['y']), g['r'], atol=2e-6)
+  z = brain_model.pearson_correlation(g['x_const'], g['y'])
+  assert z.shape == g['r_zero'].shape and not z.any()
+  assert abs(brain_model.pearson_correlation_first(g['x'], g['y']) - g['r_first']) < 2e-6
+  assert abs(brain_model.pearson_correlation_second(g['x'], g['y']) - g['r_second']) < 2e-6
+  yy = np.concatenate((g['x'], g['y']), axis=1)
+  np.testing.assert_allclose(cca.cca_pearson_correlation(None, yy), g['r_cca'], atol=2e-6)
+  with pytest.raises(ValueError, match='CCA y matrix does not have even # dims'):
+    cca.cca_pearson_correlation(None, yy[:, :7])
+
+
+def _aligned(a, ref):
+  """Fix the per-component sign ambiguity of CCA rotations."""
+  sign = np.sign(np.sum(a * ref, axis=0))
+  sign[sign == 0] = 1
+  return a * sign
+
+
+@pytest.mark.parametrize('name', ['t42', 'r10'])
+def test_cca_matches_reference_golden(dev, name):
+  from telluride_decoding_amd import brain_data, cca
+  g = golden('g4_cca')
+  dim, batch = (int(v) for v in g[name + '_cfg'])
+  bd = brain_data.TestBrainData('input_1', 'input_2', 100.0, final_batch_size=batch)
+  bd.preserve_test_data(g['x1'], np.ones((g['x1'].shape[0], 1), np.float32), g['x2'])
+  ds = bd.create_dataset('program_test', temporal_context=False)
+  a, b, mx, my, e = cca.calculate_cca_parameters_from_dataset(
+      ds, dim, regularization=float(g[name + '_reg']), mini_batch_count=1000)
+  np.testing.assert_allclose(e, g[name + '_e'], rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(mx, g[name + '_mean_x'], atol=1e-6)
+  np.testing.assert_allclose(my, g[name + '_mean_y'], atol=1e-6)
+  # singular vectors of well separated singular values, up to a joint sign
+  nsep = 2
+  np.testing.assert_allclose(_aligned(a[:, :nsep], g[name + '_rot_x'][:, :nsep]),
+                             g[name + '_rot_x'][:, :nsep], atol=3e-4)
+  np.testing.assert_allclose(_aligned(b[:, :nsep], g[name + '_rot_y'][:, :nsep]),
+                             g[name + '_rot_y'][:, :nsep], atol=3e-4)
+  if name == 't42':                                             # cca_test.py:111-123
+    assert e[0] > 0.90 and e[1] > 0.60 and e[2] < 0.02
+  with pytest.raises(ValueError, match='regularization lambda must be >= 0'):
+    cca.calculate_cca_parameters_from_dataset(ds, dim, regularization=-1)
+
+
+def test_cca_lagged_fit_transform_and_model(dev):
+  from telluride_decoding_amd import brain_data, cca
+  g = golden('g4_cca')
+  pre, post, pre2, post2, batch, dim = (int(v) for v in g['lag_cfg'])
+  bd = brain_data.TestBrainData('eeg', 'env', 100.0, pre_context=pre, post_context=post,
+                                in2_fields='env', in2_pre_context=pre2, in2_post_context=post2,
+                                final_batch_size=batch)
+  for i in range(2):
+    bd.add_file(g['lag_eeg%d' % i], g['lag_env%d' % i][:, 0:1], g['lag_env%d' % i])
+  ds = bd.create_dataset('train')
+  a, b, mx, my, e = cca.calculate_cca_parameters_from_dataset(ds, dim, regularization=0.1,
+                                                              mini_batch_count=0)
+  np.testing.assert_allclose(e, g['lag_e'], rtol=1e-4, atol=1e-5)
+  model = cca.BrainModelCCA(ds, cca_dims=dim, regularization_lambda=0.1)
+  assert model.fit(ds) == {}
+  # transform vs the oracle using the SAME rotations (isolates the kernel)
+  out = model.predict(ds)
+  files = [(g['lag_eeg%d' % i], g['lag_env%d' % i], g['lag_env%d' % i][:, 0:1],
+            np.zeros((3000, 1), np.float32)) for i in range(2)]
+  want = np.concatenate([o_cca.cca_transform(f['input_1'].astype(np.float64),
+                                             f['input_2'].astype(np.float64), model.mean_x,
+                                             model.mean_y, model.rot_x, model.rot_y)
+                         for f, _ in o_lag.minibatches(files, batch, pre=pre, post=post,
+                                                       pre2=pre2, post2=post2)])
+  np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4)
+  ev = model.evaluate(ds)
+  r_batches = [o_p.cca_pearson_correlation(None, want[s:s + batch])[0]
+               for s in range(0, want.shape[0], batch)]
+  assert abs(ev['cca_pearson_correlation_first'] - np.mean(r_batches)) < 1e-5
+  assert ev['cca_pearson_correlation_first'] > 0.5
+  with pytest.raises(ValueError, match=r'Input 2 feature width \(1\) should not be <= 1'):
+    bd1 = brain_data.TestBrainData('eeg', 'env', 100.0, final_batch_size=100)
+    bd1.preserve_test_data(g['lag_eeg0'], g['lag_env0'][:, 0:1])
+    cca.BrainModelCCA(bd1.create_dataset('train'))
+
+
+def test_linear_regression_model_api(dev):
+  """BrainModelLinearRegression: the W/b known answer, predict, evaluate."""
+  from telluride_decoding_amd import brain_data, brain_model
+  g = golden('g2_ridge')
+  x, y = g['kat_x'], g['kat_y']
+  bd = brain_data.TestBrainData('input_1', 'output', 100.0, final_batch_size=100)
+  bd.preserve_test_data(x, y)
+  ds = bd.create_dataset('train')
+  w, b, cov_x, cov_xy, shrink = brain_model.calculate_linear_regressor_parameters_from_dataset(
+      ds, lamb=0.0)
+  np.testing.assert_allclose(w, [[1, 3], [2, 4]], atol=1e-4)     # brain_model_test.py:192-193
+  np.testing.assert_allclose(b, [[5, 6]], atol=1e-4)
+  np.testing.assert_allclose(cov_x, g['kat_cov_x'], rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(cov_xy, g['kat_cov_xy'], rtol=1e-5, atol=1e-6)
+  assert shrink == 0.0
+  # the same through a plain iterable of already-lagged minibatches
+  batches = [({'input_1': x[i:i + 100]}, y[i:i + 100]) for i in range(0, 10000, 100)]
+  w2, b2, _, _, _ = brain_model.calculate_linear_regressor_parameters_from_dataset(batches, lamb=0.0)
+  np.testing.assert_allclose(w2, w, atol=2e-5)
+  model = brain_model.BrainModelLinearRegression(ds, regularization_lambda=0.0)
+  model.fit(ds)
+  pred = model.predict(ds)
+  np.testing.assert_allclose(pred, y, rtol=1e-5, atol=1e-4)       # brain_model_test.py:243-249
+  np.testing.assert_allclose(model({'input_1': x[:50]}), y[:50], rtol=1e-5, atol=1e-4)
+  ev = model.evaluate(ds)
+  assert ev['loss'] < 1e-6 and ev['pearson_correlation_first'] > 0.9999
+  # shrinkage branch against the reference's golden output
+  files = [g['c1_eeg%d' % i] for i in range(3)]
+  bd = brain_data.TestBrainData('eeg', 'env', 100.0, final_batch_size=100)
+  for i in range(3):
+    bd.add_file(g['c1_eeg%d' % i], g['c1_env%d' % i][:, 0:1])
+  ws, bs, cs, _, sh = brain_model.calculate_linear_regressor_parameters_from_dataset(
+      bd.create_dataset('train'), lamb=0.3, use_ridge=False)
+  np.testing.assert_allclose(ws, g['shrink_0p3_w'], rtol=1e-3, atol=2e-5)
+  np.testing.assert_allclose(cs, g['shrink_0p3_cov_x'], rtol=1e-4, atol=1e-4)
+  with pytest.raises(ValueError, match='Regularization lambda must be between 0 and 1'):
+    brain_model.calculate_linear_regressor_parameters_from_dataset(ds, lamb=2.0, use_ridge=False)
+
+
+def test_decoder_streaming_api_and_persistence(dev, tmp_path):
+  from telluride_decoding_amd import infer_decoder
+  g = golden('g5_correlator')
+  x, y = g['x'], g['y']
+  dec = infer_decoder.Decoder(lambda v: v, reduction='all')
+  for s in range(0, x.shape[0], 400):
+    dec.add_data_correlator(x[s:s + 400], y[s:s + 400])
+  p = dec.correlation_params
+  assert p.count == int(g['count'])
+  for k in ('sum_x', 'sum_y', 'sum_x2', 'sum_y2', 'mean_x', 'mean_y', 'power'):
+    np.testing.assert_allclose(getattr(p, k), g[k], rtol=2e-5)
+  np.testing.assert_allclose(dec.compute_correlation(x, y), g['corr'], rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(np.mean(dec.compute_correlation(g['x64'], g['y64'])) * 0 + 1, 1)
+  d64 = infer_decoder.Decoder(lambda v: v)
+  for s in range(0, 3000, 300):
+    d64.add_data_correlator(g['x64'][s:s + 300].astype(np.float32), g['y64'][s:s + 300].astype(np.float32))
+  r = np.mean(d64.compute_correlation(g['x64'].astype(np.float32), g['y64'].astype(np.float32)))
+  np.testing.assert_allclose(r, 1, rtol=1e-5)                     # infer_decoder_test.py:191-203
+  # windows (average_data) and d'
+  gw = golden('g6_windows')
+  np.testing.assert_array_equal(infer_decoder.average_data(np.reshape(np.arange(12), (6, 2)), 3),
+                                [[2, 3], [8, 9]])                 # infer_decoder_test.py:350-354
+  np.testing.assert_allclose(infer_decoder.average_data(gw['avg_in'], 10), gw['avg_out'], rtol=1e-12)
+  gl = golden('g8_lda')
+  assert abs(infer_decoder.calculate_dprime(gl['dp_d1'], gl['dp_d2']) - float(gl['dp'])) < 1e-12
+  # LDA + JSON round trip (infer_decoder_test.py:487-508)
+  d1 = infer_decoder.average_data(gl['c0'], 1)
+  dprime = dec.compute_lda_model(gl['c0'], gl['c1'])
+  np.testing.assert_allclose(dprime, gl['dprime'], rtol=1e-6)
+  path = str(tmp_path / 'decoder_model.json')
+  dec.save_parameters(path)
+  loaded = infer_decoder.Decoder(lambda v: v, reduction='lda')
+  loaded.restore_parameters(path)
+  np.testing.assert_array_equal(loaded.reduce_with_lda(d1)[:, 0], dec.reduce_with_lda(d1)[:, 0])
+  np.testing.assert_allclose(loaded.correlation_params.power, dec.correlation_params.power)
+  # errors the reference's tests match on
+  with pytest.raises(ValueError, match='Unknown reduction technique'):
+    infer_decoder.Decoder(lambda v: v, reduction='bogus')
+  with pytest.raises(TypeError, match='Must supply a callable model'):
+    infer_decoder.Decoder(3)
+  with pytest.raises(ValueError, match='Couldn\'t determine model type'):
+    infer_decoder.create_decoder('mystery')
+  assert isinstance(infer_decoder.create_decoder('my_linear_model'), infer_decoder.LinearRegressionDecoder)
+  assert isinstance(infer_decoder.create_decoder('CCA'), infer_decoder.CCADecoder)
