@@ -72,6 +72,12 @@ int td_memset(td_handle* h, void* dst_dev, int value, size_t bytes);
 /* hipEvent timing on the handle's stream (bench.py's roofline leg). */
 int td_timer_start(td_handle* h);
 int td_timer_stop(td_handle* h, float* elapsed_ms); /* synchronises the stop event */
+/* Per-launch hipEvent timing of the DOMINANT kernel (the lagged-covariance MFMA
+ * accumulate): while enabled every launch is bracketed by two events on the
+ * handle's stream; td_profile_read synchronises, returns the number of launches,
+ * their summed duration and the samples they covered, and resets the counters. */
+int td_profile_enable(td_handle* h, int on);
+int td_profile_read(td_handle* h, int64_t* launches, double* total_ms, double* samples);
 
 /* ------------------------------------------------------------------ A1 + A2
  * Sufficient statistics of lagged regression / CCA inputs WITHOUT building the

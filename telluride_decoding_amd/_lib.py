@@ -52,6 +52,8 @@ SIGNATURES = {
     'td_memset': [_vp, _vp, _i, _sz],
     'td_timer_start': [_vp],
     'td_timer_stop': [_vp, _c.POINTER(_f)],
+    'td_profile_enable': [_vp, _i],
+    'td_profile_read': [_vp, _pi64, _pd, _pd],
     'td_stats_create': [_vp, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)],
     'td_stats_destroy': [_vp, _vp],
     'td_stats_reset': [_vp, _vp],
@@ -98,6 +100,13 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
+  try:
+    # PyTorch-ROCm ships its own libamdhip64; it must be the one HIP runtime of the
+    # process.  Loading ours first (it resolves libamdhip64 from /opt/rocm) and torch
+    # afterwards leaves torch without devices ("No HIP GPUs are available").
+    import torch  # noqa: F401
+  except ImportError:
+    pass
   if not os.path.exists(LIB_PATH):
     raise HotPathUnavailable(
         'HIP extension %s is missing: build it with '

@@ -58,9 +58,47 @@ int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst)
   return TD_OK;
 }
 
+int td_profile_mark(td_handle* h, bool start, double samples) {
+  if (!h->profile) return TD_OK;
+  if (h->prof_used == h->prof_events.size()) {
+    hipEvent_t ev = nullptr;
+    TD_HIP(h, hipEventCreate(&ev));
+    h->prof_events.push_back(ev);
+  }
+  TD_HIP(h, hipEventRecord(h->prof_events[h->prof_used++], h->stream));
+  if (start) h->prof_samples += samples;
+  return TD_OK;
+}
+
 extern "C" {
 
 int td_version(void) { return 1; }
+
+int td_profile_enable(td_handle* h, int on) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  h->profile = on != 0;
+  h->prof_used = 0;
+  h->prof_samples = 0;
+  return TD_OK;
+}
+
+int td_profile_read(td_handle* h, int64_t* launches, double* total_ms, double* samples) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    float t = 0.f;
+    TD_HIP(h, hipEventElapsedTime(&t, h->prof_events[i], h->prof_events[i + 1]));
+    ms += t;
+  }
+  if (launches) *launches = (int64_t)(h->prof_used / 2);
+  if (total_ms) *total_ms = ms;
+  if (samples) *samples = h->prof_samples;
+  h->prof_used = 0;
+  h->prof_samples = 0;
+  return TD_OK;
+}
 
 int td_device_count(int* count) {
   if (!count) return td_fail(nullptr, TD_ERR_INVALID, "count is NULL");

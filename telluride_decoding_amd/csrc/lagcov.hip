@@ -414,12 +414,14 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
     else TD_LAUNCH_SMALL(8);
 #undef TD_LAUNCH_SMALL
   } else {
+    TD_TRY(td_profile_mark(h, true, (double)total));
     if (aligned)
       hipLaunchKernelGGL(lagcov_mfma_kernel<true>, dim3((unsigned)nwg), dim3(kThreads), 0,
                          h->stream, p);
     else
       hipLaunchKernelGGL(lagcov_mfma_kernel<false>, dim3((unsigned)nwg), dim3(kThreads), 0,
                          h->stream, p);
+    TD_TRY(td_profile_mark(h, false, 0.0));
   }
   TD_HIP(h, hipGetLastError());
   const long long outs = (long long)e_count * ca_eff * cb;

@@ -34,7 +34,16 @@ struct td_handle {
   PinSlot pin[kPinSlots];
   int pin_next = 0;
   int* dev_flag = nullptr;  // device int used for "not positive definite" reports
+  // Optional per-kernel hipEvent timing of the dominant kernel (td_profile_*):
+  // event pairs recorded on h->stream around every lagcov MFMA launch.
+  bool profile = false;
+  std::vector<hipEvent_t> prof_events;   // pairs: start, stop
+  size_t prof_used = 0;                  // events in use
+  double prof_samples = 0;               // samples (u range) covered by those launches
 };
+
+// Brackets a launch of the dominant kernel when profiling is on.
+int td_profile_mark(td_handle* h, bool start, double samples);
 
 extern thread_local std::string td_global_error;
 

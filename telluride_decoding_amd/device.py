@@ -58,6 +58,16 @@ class Handle(object):
     self.check(self.lib.td_timer_stop(self.ptr, ctypes.byref(ms)))
     return float(ms.value)
 
+  def profile_enable(self, on=True):
+    self.check(self.lib.td_profile_enable(self.ptr, 1 if on else 0))
+
+  def profile_read(self):
+    """(launches, total_ms, samples) of the dominant kernel since the last read."""
+    n, ms, smp = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    self.check(self.lib.td_profile_read(self.ptr, ctypes.byref(n), ctypes.byref(ms),
+                                        ctypes.byref(smp)))
+    return int(n.value), float(ms.value), float(smp.value)
+
   # -- memory plumbing ------------------------------------------------------
   def to_device(self, array, dtype=np.float32):
     """Host array (or tensor) -> contiguous 2-D device tensor."""

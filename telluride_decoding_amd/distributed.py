@@ -1,0 +1,95 @@
+"""Sharding of the fit across the GPUs of one node.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The
+fit statistics are sums over frames, so any partition of the recordings works:
+every rank accumulates its own files, then ONE all-reduce(sum) of the packed
+float64 buffer gives every rank the global statistics.  The buffer holds the
+compact lag statistics (additive) followed by one slot per file for the
+file-boundary samples; a rank fills only its own slots, so the sum over ranks
+is the concatenation -- no second collective is needed.
+
+The reference has no communication layer at all (process-level fan-out only,
+doc/DecodingCodelab.md:354-381); this module is new.
+"""
+import numpy as np
+
+
+def _dist():
+  import torch.distributed as dist
+  return dist
+
+
+class ShardPlan(object):
+  """Which files go to which rank, and where their boundary slots live.
+
+  Files are dealt in contiguous runs balanced by frame count (greedy), so a
+  rank's files stay one concatenated array.
+  """
+
+  def __init__(self, file_lengths, world_size):
+    self.file_lengths = [int(n) for n in file_lengths]
+    self.world_size = int(world_size)
+    total = float(sum(self.file_lengths)) or 1.0
+    owner = []
+    before = 0.0
+    for n in self.file_lengths:       # a file goes to the rank its midpoint falls in
+      mid = (before + n / 2.0) / total
+      owner.append(min(self.world_size - 1, int(mid * self.world_size)))
+      before += n
+    self.bounds = [0] * (self.world_size + 1)
+    for r in range(self.world_size):
+      self.bounds[r + 1] = self.bounds[r] + sum(1 for o in owner if o == r)
+
+  @property
+  def total_files(self):
+    return len(self.file_lengths)
+
+  def files_of(self, rank):
+    return list(range(self.bounds[rank], self.bounds[rank + 1]))
+
+  def slot_of(self, rank):
+    """First boundary slot of `rank` in the packed buffer."""
+    return self.bounds[rank]
+
+  def frames_of(self, rank):
+    return sum(self.file_lengths[f] for f in self.files_of(rank))
+
+
+def allreduce_packed(buf, group=None):
+  """Sum a packed statistics buffer over ranks, in place (RCCL on GPU tensors,
+  gloo on CPU tensors in the tests)."""
+  dist = _dist()
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+  return buf
+
+
+def allreduce_stats(stats, plan, rank, group=None):
+  """Every rank ends with the statistics of all files (one all-reduce)."""
+  buf = stats.pack(plan.total_files, plan.slot_of(rank))
+  allreduce_packed(buf, group)
+  stats.unpack(buf, plan.total_files)
+  return stats
+
+
+def split_round_robin(items, rank, world_size):
+  """Embarrassingly parallel work (folds, lambdas): item i goes to rank i % world."""
+  return [it for i, it in enumerate(items) if i % world_size == rank]
+
+
+def gather_rows(local_rows, n_total, index, group=None):
+  """Each rank computed rows `index` of an [n_total, ...] result; returns the full
+  array on every rank (sum of disjoint contributions)."""
+  import torch
+  local_rows = np.asarray(local_rows, np.float64)
+  full = np.zeros((n_total,) + local_rows.shape[1:], np.float64)
+  for j, i in enumerate(index):
+    full[i] = local_rows[j]
+  dist = _dist()
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    t = torch.from_numpy(full)
+    if dist.get_backend(group) == 'nccl':
+      t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    full = t.cpu().numpy()
+  return full
