@@ -31,7 +31,11 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int kTile = 128;     // time samples per LDS tile
+constexpr int kTile = 128;     // time samples per LDS tile (unified mode; skinny-A kernel)
+constexpr int kTileG = 64;     // time samples per tile, general (A != B) mode
+constexpr int kNpfU = 10;      // prefetch float4 per thread, unified: 160 staged rows (e0 <= 24)
+constexpr int kNpfU2 = 13;     // 208 staged rows (e0 <= 72)
+constexpr int kNpfG = 9;       // general: 64 + 72 = 136 rows
 constexpr int kLagsPerWg = 8;  // lags per workgroup (2 per wave)
 constexpr int kHalo = 8;       // extra B rows (7 needed)
 
@@ -62,72 +66,171 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + within;
 }
 
-// ---- tile staging: global -> LDS, zero-filled outside the segment ----------
-// rows [row_lo, row_lo + nrows) of the segment-relative stream; valid rows are
-// [0, valid) AND (for A) < u_limit.  64 channels starting at c0; channels >= c
-// are zero.  `ones_col` (>= 0) is filled with 1.0 on valid-or-not rows inside
-// [ones_lo, ones_hi).
-template <bool kAligned>
-__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ g,
-                                           long long ld, long long row0_global,
-                                           long long row_lo, int nrows, long long valid,
-                                           long long row_limit, int c0, int c, int tid) {
-  // 16 threads cover one 64-channel row with float4; 16 rows per pass.
+// ---- tile staging: global -> registers -> LDS ---------------------------------
+// The rows of the NEXT tile are fetched into registers before the MFMA loop of
+// the current one and written to LDS after it, so the global-load latency hides
+// behind the matrix work of the same workgroup.  (The first version staged
+// synchronously and relied on the second resident workgroup for overlap; both
+// workgroups of a CU then run phase-locked -- stage together, compute together
+// -- and the matrix pipe idled for a quarter of the time: 70 % of peak.)
+//
+// Unified mode (A and B are the same stream and channel tile, e_min >= 0): ONE
+// staged tile of kTile + kHalo + e0 rows serves both operands; rows of A beyond
+// u_end are cut by the MFMA loop bound instead of by zero-filling.
+// General mode: an A tile (kTile rows, zero beyond u_end) followed by a B tile
+// (kTile + kHalo rows starting at ut + e0).
+//
+// Flat float4 slot f = tid + 256 * i  ->  tile row f >> 4, channels (f & 15) * 4.
+// Branch-free: the tile-relative row index is clamped into the segment (32-bit
+// v_med3) and the result is selected to zero afterwards, so every slot is one
+// unconditional 16-byte load from a wave-uniform base plus a 32-bit offset
+// (kVec4: 16-byte aligned rows and a channel count that is a multiple of 4), or
+// four clamped scalar loads.  split_work points empty segments at row 0 of the
+// array, and a tile never starts more than a context away from its segment, so
+// the clamped offsets stay small.
+struct RowWindow {
+  const float* base;   // &g[(row0 + ut) * ld + c0]   (wave-uniform)
+  int lo, hi;          // tile-relative rows that exist: lo <= r <= hi
+  int ld, last;        // row stride; last channel of the tile that exists (c - 1 - c0)
+};
+
+__device__ __forceinline__ RowWindow row_window(const float* g, long long ld, long long row0,
+                                                long long ut, long long valid, int c0, int c) {
+  RowWindow rw;
+  rw.base = g + (row0 + ut) * ld + c0;
+  const long long lo = -ut, hi = valid - 1 - ut, lim = 1 << 20;
+  rw.lo = (int)(lo < -lim ? -lim : (lo > lim ? lim : lo));
+  rw.hi = (int)(hi < -lim ? -lim : (hi > lim ? lim : hi));
+  rw.ld = (int)ld;
+  rw.last = c - 1 - c0;
+  return rw;
+}
+
+template <bool kVec4>
+__device__ __forceinline__ float4 load_row4(const RowWindow& rw, int r, bool row_ok, int c4) {
+  const int rc = max(rw.lo, min(r, rw.hi));           // max last: lo wins for an empty segment
+  const bool ok = row_ok && r >= rw.lo && r <= rw.hi;
+  const float* p = rw.base + rc * rw.ld;
+  float4 v;
+  if (kVec4) {
+    const bool ch_ok = c4 <= rw.last;
+    v = *reinterpret_cast<const float4*>(p + (ch_ok ? c4 : 0));
+    const bool k = ok && ch_ok;
+    v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+  } else {
+    const int last = rw.last;   // >= 0: the channel tile is not empty
+    v.x = p[min(c4, last)]; v.y = p[min(c4 + 1, last)];
+    v.z = p[min(c4 + 2, last)]; v.w = p[min(c4 + 3, last)];
+    v.x = (ok && c4 + 0 <= last) ? v.x : 0.f;
+    v.y = (ok && c4 + 1 <= last) ? v.y : 0.f;
+    v.z = (ok && c4 + 2 <= last) ? v.z : 0.f;
+    v.w = (ok && c4 + 3 <= last) ? v.w : 0.f;
+  }
+  return v;
+}
+
+template <bool kUnified, int kTileT, int kNPF, bool kVec4>
+__device__ __forceinline__ void prefetch_tile(const LagParams& p, const LagWork& w, long long ut,
+                                              int e0, int rows, int cat, int cbt, int tid,
+                                              float4 (&pf)[kNPF]) {
   const int c4 = (tid & 15) * 4;
-  for (int r = tid >> 4; r < nrows; r += kThreads / 16) {
-    const long long u = row_lo + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (u >= 0 && u < valid && u < row_limit) {
-      const float* p = g + (row0_global + u) * ld + c0 + c4;
-      if (kAligned) {
-        if (c0 + c4 + 3 < c) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (c0 + c4 + 0 < c) v.x = p[0];
-          if (c0 + c4 + 1 < c) v.y = p[1];
-          if (c0 + c4 + 2 < c) v.z = p[2];
-        }
-      } else {
-        if (c0 + c4 + 0 < c) v.x = p[0];
-        if (c0 + c4 + 1 < c) v.y = p[1];
-        if (c0 + c4 + 2 < c) v.z = p[2];
-        if (c0 + c4 + 3 < c) v.w = p[3];
-      }
+  const int r0 = tid >> 4;
+  if (kUnified) {
+    const RowWindow rw = row_window(p.a, p.lda, w.a_row0, ut, w.a_valid, cat * 64, p.ca);
+#pragma unroll
+    for (int i = 0; i < kNPF; ++i) {
+      const int r = r0 + 16 * i;
+      pf[i] = load_row4<kVec4>(rw, r, r < rows, c4);
+    }
+  } else {
+    const RowWindow ra = row_window(p.a, p.lda, w.a_row0, ut, w.a_valid, cat * 64, p.ca);
+    const RowWindow rb = row_window(p.b, p.ldb, w.b_row0, ut + e0, w.b_valid, cbt * 64, p.cb);
+    const long long a_left = w.u_end - ut;                 // A rows beyond u_end are cut
+    const int a_lim = (int)(a_left < kTileT ? a_left : kTileT);
+#pragma unroll
+    for (int i = 0; i < kNPF; ++i) {
+      const int r = r0 + 16 * i;
+      if (16 * i + 15 < kTileT)                            // compile-time: slot i is in the A tile
+        pf[i] = load_row4<kVec4>(ra, r, r < a_lim, c4);
+      else
+        pf[i] = load_row4<kVec4>(rb, r - kTileT, r < rows, c4);
+    }
+  }
+}
+
+// Writes every slot (rows beyond `rows` were loaded as zeros; the LDS tile has
+// 16 * kNPF rows).
+template <bool kUnified, int kTileT, int kNPF>
+__device__ __forceinline__ void store_tile(float* lds, const LagWork& w, long long ut,
+                                           int ones_col, int tid, float4 (&pf)[kNPF]) {
+  const int c4 = (tid & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < kNPF; ++i) {
+    const int r = (tid >> 4) + 16 * i;
+    float4 v = pf[i];
+    if (!kUnified && 16 * i + 15 < kTileT && ones_col >= c4 && ones_col < c4 + 4) {
+      const long long u = ut + r;
+      const float one = (u >= w.u_begin && u < w.u_end) ? 1.f : 0.f;
+      if (ones_col == c4) v.x = one;
+      else if (ones_col == c4 + 1) v.y = one;
+      else if (ones_col == c4 + 2) v.z = one;
+      else v.w = one;
     }
     *reinterpret_cast<float4*>(lds + r * 64 + c4) = v;
   }
 }
 
-template <bool kM2, bool kN2>
+// One tile of MFMAs, software-pipelined by hand: the six LDS operands of step
+// kk + 1 are read before the eight MFMAs of step kk issue.  nk = rows of A that
+// count (kTileT except in the last tile of a slab in unified mode).
+template <int kTileT, bool kM2, bool kN2>
 __device__ __forceinline__ void mfma_tile(const float* __restrict__ as,
-                                          const float* __restrict__ bs, int wave, int lane,
+                                          const float* __restrict__ bs, int wave, int lane, int nk,
                                           f32x16 (&acc)[2][2][2]) {
   const int lr = lane & 31, lk = lane >> 5;
   const float* ap = as + lk * 64 + lr;
   const float* bp = bs + (lk + 2 * wave) * 64 + lr;
-#pragma unroll 4
-  for (int kk = 0; kk < kTile / 2; ++kk) {
-    const float a0 = ap[kk * 128];
-    const float a1 = kM2 ? ap[kk * 128 + 32] : 0.f;
+  auto ld = [&](int kk, float (&o)[6]) {
+    o[0] = ap[kk * 128];
+    o[1] = kM2 ? ap[kk * 128 + 32] : 0.f;
+    o[2] = bp[kk * 128];
+    o[3] = kN2 ? bp[kk * 128 + 32] : 0.f;
+    o[4] = bp[kk * 128 + 64];
+    o[5] = kN2 ? bp[kk * 128 + 96] : 0.f;
+  };
+  auto mm = [&](const float (&o)[6]) {
 #pragma unroll
     for (int le = 0; le < 2; ++le) {
-      const float b0 = bp[kk * 128 + le * 64];
-      acc[le][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[le][0][0], 0, 0, 0);
-      if (kM2) acc[le][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[le][1][0], 0, 0, 0);
+      const float b0 = o[2 + 2 * le], b1 = o[3 + 2 * le];
+      acc[le][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[0], b0, acc[le][0][0], 0, 0, 0);
+      if (kM2) acc[le][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[1], b0, acc[le][1][0], 0, 0, 0);
       if (kN2) {
-        const float b1 = bp[kk * 128 + le * 64 + 32];
-        acc[le][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[le][0][1], 0, 0, 0);
-        if (kM2) acc[le][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[le][1][1], 0, 0, 0);
+        acc[le][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[0], b1, acc[le][0][1], 0, 0, 0);
+        if (kM2) acc[le][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[1], b1, acc[le][1][1], 0, 0, 0);
       }
     }
+  };
+  const int nfull = nk >> 1;
+  float c[6], n[6];
+  ld(0, c);
+  int kk = 0;
+  for (; kk + 1 < nfull; kk += 2) {
+    ld(kk + 1, n);
+    mm(c);
+    ld(kk + 2 < nfull ? kk + 2 : kk + 1, c);
+    mm(n);
+  }
+  if (kk < nfull) mm(c);
+  if (nk & 1) {          // odd row count: only the k = 0 half of the last step counts
+    ld(nfull, c);
+    if (lk) { c[0] = 0.f; c[1] = 0.f; }
+    mm(c);
   }
 }
 
-template <bool kAligned>
+template <bool kUnified, int kTileT, int kNPF, bool kVec4>
 __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[(kTile + kTile + kHalo) * 64];
-  float* as = lds;
-  float* bs = lds + kTile * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -140,9 +243,15 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
   const LagWork w = p.works[id];
   const int e0 = p.e_min + group * kLagsPerWg;
 
+  // staged rows and operand bases
+  const int rows = kUnified ? kTileT + kHalo + e0 : 2 * kTileT + kHalo;
+  const float* as = lds;
+  const float* bs = kUnified ? lds + e0 * 64 : lds + kTileT * 64;
+
   const int ca_eff = p.ca + p.a_ones;
   const bool m2 = ca_eff - cat * 64 > 32;
   const bool n2 = p.cb - cbt * 64 > 32;
+  const int ones_col = p.a_ones ? p.ca - cat * 64 : -1;  // local column or out of tile
 
   f32x16 acc[2][2][2];
 #pragma unroll
@@ -154,29 +263,30 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][k][r] = 0.f;
 
-  const int ones_col = p.a_ones ? p.ca - cat * 64 : -1;  // local column or out of tile
+  float4 pf[kNPF];
+  prefetch_tile<kUnified, kTileT, kNPF, kVec4>(p, w, w.u_begin, e0, rows, cat, cbt, tid, pf);
+  store_tile<kUnified, kTileT, kNPF>(lds, w, w.u_begin, ones_col, tid, pf);
+  __syncthreads();
 
-  for (long long ut = w.u_begin; ut < w.u_end; ut += kTile) {
-    stage_tile<kAligned>(as, p.a, p.lda, w.a_row0, ut, kTile, w.a_valid, w.u_end, cat * 64, p.ca,
-                         tid);
-    stage_tile<kAligned>(bs, p.b, p.ldb, w.b_row0, ut + e0, kTile + kHalo, w.b_valid,
-                         0x7fffffffffffffffLL, cbt * 64, p.cb, tid);
-    if (ones_col >= 0 && ones_col < 64) {
-      __syncthreads();
-      for (int r = tid; r < kTile; r += kThreads) {
-        const long long u = ut + r;
-        as[r * 64 + ones_col] = (u >= w.u_begin && u < w.u_end) ? 1.f : 0.f;
-      }
-    }
-    __syncthreads();
+  for (long long ut = w.u_begin; ut < w.u_end; ut += kTileT) {
+    const bool more = ut + kTileT < w.u_end;
+    if (more)
+      prefetch_tile<kUnified, kTileT, kNPF, kVec4>(p, w, ut + kTileT, e0, rows, cat, cbt, tid,
+                                                      pf);
+    const long long left = w.u_end - ut;
+    const int nk = (kUnified && left < kTileT) ? (int)left : kTileT;
     if (m2) {
-      if (n2) mfma_tile<true, true>(as, bs, wave, lane, acc);
-      else    mfma_tile<true, false>(as, bs, wave, lane, acc);
+      if (n2) mfma_tile<kTileT, true, true>(as, bs, wave, lane, nk, acc);
+      else    mfma_tile<kTileT, true, false>(as, bs, wave, lane, nk, acc);
     } else {
-      if (n2) mfma_tile<false, true>(as, bs, wave, lane, acc);
-      else    mfma_tile<false, false>(as, bs, wave, lane, acc);
+      if (n2) mfma_tile<kTileT, false, true>(as, bs, wave, lane, nk, acc);
+      else    mfma_tile<kTileT, false, false>(as, bs, wave, lane, nk, acc);
     }
-    __syncthreads();
+    if (more) {
+      __syncthreads();
+      store_tile<kUnified, kTileT, kNPF>(lds, w, ut + kTileT, ones_col, tid, pf);
+      __syncthreads();
+    }
   }
 
   // Epilogue: one partial slab per workgroup.  32x32 C/D map: col = lane & 31,
@@ -198,6 +308,18 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
           pe[(size_t)i * p.cb_pad + j] = acc[le][m][n][r];
         }
   }
+}
+
+// Synchronous staging of one tile (skinny-A kernel).
+template <bool kVec4>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ g,
+                                           long long ld, long long row0_global,
+                                           long long row_lo, int nrows, long long valid,
+                                           int c0, int c, int tid) {
+  const int c4 = (tid & 15) * 4;
+  const RowWindow rw = row_window(g, ld, row0_global, row_lo, valid, c0, c);
+  for (int r = tid >> 4; r < nrows; r += kThreads / 16)
+    *reinterpret_cast<float4*>(lds + r * 64 + c4) = load_row4<kVec4>(rw, r, true, c4);
 }
 
 // ---- skinny-A variant (ca_eff <= 8: regression targets [y | 1]) -------------
@@ -240,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
       as[idx] = v;
     }
     stage_tile<kAligned>(bs, p.b, p.ldb, w.b_row0, ut + e0, kTile + kSmallLags, w.b_valid,
-                         0x7fffffffffffffffLL, cbt * 64, p.cb, tid);
+                         cbt * 64, p.cb, tid);
     __syncthreads();
 #pragma unroll 2
     for (int r = 0; r < kTile; ++r) {
@@ -332,6 +454,10 @@ std::vector<LagWork> split_work(const std::vector<LagSeg>& segs, long long slab)
       LagWork w;
       w.a_row0 = s.a_row0; w.a_valid = s.a_valid;
       w.b_row0 = s.b_row0; w.b_valid = s.b_valid;
+      // the kernels clamp row indices into [0, valid) before loading: give an
+      // empty stream a base that is always addressable
+      if (w.a_valid <= 0) { w.a_valid = 0; w.a_row0 = 0; }
+      if (w.b_valid <= 0) { w.b_valid = 0; w.b_row0 = 0; }
       w.u_begin = u;
       w.u_end = (u + slab < s.u_end) ? u + slab : s.u_end;
       works.push_back(w);
@@ -391,8 +517,10 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   p.works = reinterpret_cast<const LagWork*>(scratch);
   p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + table_bytes);
 
-  const bool b_aligned = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
-  const bool a_aligned = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+  const bool b_aligned =
+      (ldb % 4 == 0) && (cb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+  const bool a_aligned =
+      (lda % 4 == 0) && (ca % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
   // the skinny-A kernel reads A with scalar loads: only B's alignment matters
   const bool aligned = small ? b_aligned : (a_aligned && b_aligned);
   const long long nwg = (long long)p.n_work * per_item_wgs;
@@ -414,13 +542,27 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
     else TD_LAUNCH_SMALL(8);
 #undef TD_LAUNCH_SMALL
   } else {
+    // Unified mode: both operands are the same stream and channel tile.
+    const int rows_u = kTile + kHalo + e_min + (p.n_groups - 1) * kLagsPerWg;
+    bool unified = (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min >= 0 &&
+                   p.n_cat == 1 && p.n_cbt == 1 && rows_u <= 16 * kNpfU2;
+    for (const LagSeg& sg : segs)
+      if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) unified = false;
     TD_TRY(td_profile_mark(h, true, (double)total));
-    if (aligned)
-      hipLaunchKernelGGL(lagcov_mfma_kernel<true>, dim3((unsigned)nwg), dim3(kThreads), 0,
-                         h->stream, p);
-    else
-      hipLaunchKernelGGL(lagcov_mfma_kernel<false>, dim3((unsigned)nwg), dim3(kThreads), 0,
-                         h->stream, p);
+#define TD_LAUNCH_MFMA(UNI, TILE, NPF)                                                       \
+  do {                                                                                       \
+    const size_t lds_bytes = sizeof(float) * 64 * 16 * (NPF);                                \
+    if (aligned)                                                                             \
+      hipLaunchKernelGGL((lagcov_mfma_kernel<UNI, TILE, NPF, true>), dim3((unsigned)nwg),    \
+                         dim3(kThreads), lds_bytes, h->stream, p);                           \
+    else                                                                                     \
+      hipLaunchKernelGGL((lagcov_mfma_kernel<UNI, TILE, NPF, false>), dim3((unsigned)nwg),   \
+                         dim3(kThreads), lds_bytes, h->stream, p);                           \
+  } while (0)
+    if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU);
+    else if (unified) TD_LAUNCH_MFMA(true, kTile, kNpfU2);
+    else TD_LAUNCH_MFMA(false, kTileG, kNpfG);
+#undef TD_LAUNCH_MFMA
     TD_TRY(td_profile_mark(h, false, 0.0));
   }
   TD_HIP(h, hipGetLastError());
