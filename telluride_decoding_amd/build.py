@@ -40,6 +40,7 @@ def build(force=False, verbose=False):
   os.makedirs(obj_dir, exist_ok=True)
   flags = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17',
            '-Wno-unused-result', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+  flags += os.environ.get('TD_EXTRA_HIPCC_FLAGS', '').split()   # development: ablation macros
   procs = []
   for src in sources():
     obj = os.path.join(obj_dir, os.path.basename(src) + '.o')

@@ -83,6 +83,268 @@ __global__ __launch_bounds__(kThreads) void predict_fir_kernel(
   }
 }
 
+// ---------------------------------------------------------------- FIR predict on MFMA
+// The same forward as predict_fir_kernel, restated for the matrix cores:
+//   P[u][(l, q)] = sum_c x~[u][c] * W[l*C + c][q]        (a [frames x C] . [C x L*D] GEMM:
+//                                                          v_mfma_f32_32x32x2_f32, exact f32)
+//   out[t][q]    = b[q] + sum_l P[t + l - pre][(l, q)]    (diagonal sums of P)
+// so every x row is read from HBM exactly once (2.6 flop/B of VALU work left) and
+// the 2*K*D flops per frame run on the matrix pipe instead of LDS-fed VALU FMAs
+// (the VALU kernel above needs 1 ms at C4; the HBM floor is 50 us).
+//
+// One WAVE owns a strip of consecutive frames of one file and walks it in blocks
+// of 32 rows: lane (i, h) holds row i's channels [32h, 32h+32) of each 64-channel
+// chunk (8 x 16-byte loads, the next block prefetched while this one multiplies),
+// the B operands (weights in MFMA order) sit in LDS, the 32x32 P tile goes
+// through a per-wave LDS tile and is summed along its diagonals into a per-wave
+// ring of output accumulators; 32 outputs become final per block.  No
+// workgroup barrier after the weight staging.
+// Per-file descriptor: the host uploads one of these per file / trial (not per
+// strip, block or window); kernels find their file with a binary search on
+// `first`, the running count of work items (strips, blocks) before the file.
+struct FileDesc {
+  long long row0;   // global first INPUT row of the file's (offset-shifted) stream
+  long long nrows;  // rows in that stream
+  long long out0;   // global OUTPUT row of stream frame 0
+  long long first;  // index of the file's first work item
+};
+
+// Largest f in [0, n) with files[f].first <= idx (files with no items share their
+// successor's `first` and are skipped).
+__device__ __forceinline__ int find_file(const FileDesc* __restrict__ files, int n, long long idx) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (files[mid].first <= idx) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef TD_FIR_ABL
+#define TD_FIR_ABL 0   // development ablations: 1 no global loads, 2 no diagonal sums, 3 no MFMA, 4 no transposition
+#endif
+
+// Column order of P: q-major, every output's L lags padded to whole tiles of 32
+// (tpq tiles per output), so one 32x32 tile belongs to ONE output q and 32
+// consecutive lags.  (Scattering the accumulator registers into the output ring
+// with ds_add_f32 was tried: LDS float atomics retire about one lane per clock and
+// the kernel ran 2.4x slower than with the tile + diagonal reads below.)
+template <int NCH, bool kVec4>
+__global__ __launch_bounds__(kThreads) void predict_fir_mfma_kernel(
+    const float* __restrict__ x, long long ldx, const FileDesc* __restrict__ files, int n_files,
+    long long n_strips, int strip_len, int c, int pre, int post, const float* __restrict__ w,
+    const float* __restrict__ bias, int d_total, int q0, int dq, int tpq, int ring,
+    float* __restrict__ out, long long ldout) {
+  extern __shared__ __attribute__((aligned(16))) float fir_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = pre + 1 + post;
+  const int nt_count = dq * tpq;
+
+  // ---- weights in MFMA B-operand order: wl[(nt*NCH + ch)*32 + s][lane] ----------
+  float* wl = fir_lds;
+  const int w_elems = nt_count * NCH * 32 * 64;
+  for (int idx = tid; idx < w_elems; idx += kThreads) {
+    const int ln = idx & 63, s = (idx >> 6) & 31, blk = idx >> 11;
+    const int ch = blk % NCH, nt = blk / NCH;
+    const int q = nt / tpq, l = (nt - q * tpq) * 32 + (ln & 31);
+    const int ci = ch * 64 + (ln >> 5) * 32 + s;
+    float v = 0.f;
+    if (l < nl && ci < c) v = w[((long long)l * c + ci) * d_total + q0 + q];
+    wl[idx] = v;
+  }
+  // per wave: a [NCH][32][64] x tile (transposition buffer of the loads; its space is
+  // reused as the [32][33] P tile during the MFMA chain) and the output ring [ring][dq]
+  float* xt = fir_lds + w_elems + wave * (NCH * 2048 + ring * dq);
+  float* tbuf = xt;
+  float* oacc = xt + NCH * 2048;
+  for (int idx = lane; idx < ring * dq; idx += 64) oacc[idx] = 0.f;
+  __syncthreads();
+
+  const long long sidx = blockIdx.x * (long long)(kThreads / 64) + wave;
+  if (sidx >= n_strips) return;
+  const FileDesc st = files[find_file(files, n_files, sidx)];
+  const long long ts = (sidx - st.first) * strip_len;
+  const int st_len = (int)(st.nrows - ts < strip_len ? st.nrows - ts : strip_len);
+  const long long rb = ts - pre;
+  const int nb = (st_len + nl - 1 + 31) / 32;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // Loads of one 32-row block, fully coalesced: instruction m of chunk ch covers rows
+  // 4m..4m+3 (1 KiB contiguous when ldx = 64); lane l fetches row 4m + (l >> 4), 16-byte
+  // granule (l & 15) ^ (row & 15).  The registers are written to the wave's LDS tile
+  // linearly (lane * 16 B), which makes the tile an XOR-swizzled [32][64] image, and read
+  // back in MFMA A-operand order -- lane (li, lh): row li, granules 8*lh .. 8*lh+7 -- with
+  // conflict-free ds_read_b128.  (Loading in operand order directly makes every load
+  // instruction touch 64 different cache lines 16 bytes at a time: the texture-address
+  // path, not HBM, then bounds the kernel.)
+  auto load_block = [&](long long row0, float4 (&a)[NCH][8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int r = 4 * m + (lane >> 4);
+      const long long u = row0 + r;
+      const bool row_ok = u >= 0 && u < st.nrows;
+      long long uc = u < st.nrows ? u : st.nrows - 1;
+      uc = uc < 0 ? 0 : uc;
+      const float* p = x + (st.row0 + uc) * ldx;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c0 = ch * 64 + 4 * ((lane & 15) ^ (r & 15));
+        float4 v;
+        if (kVec4) {
+          const bool ok = c0 < c;
+          v = *reinterpret_cast<const float4*>(p + (ok ? c0 : 0));
+          const bool keep = ok && row_ok;
+          v.x = keep ? v.x : 0.f; v.y = keep ? v.y : 0.f; v.z = keep ? v.z : 0.f; v.w = keep ? v.w : 0.f;
+        } else {
+          const int last = c - 1;
+          v.x = p[min(c0, last)]; v.y = p[min(c0 + 1, last)];
+          v.z = p[min(c0 + 2, last)]; v.w = p[min(c0 + 3, last)];
+          v.x = (row_ok && c0 + 0 <= last) ? v.x : 0.f;
+          v.y = (row_ok && c0 + 1 <= last) ? v.y : 0.f;
+          v.z = (row_ok && c0 + 2 <= last) ? v.z : 0.f;
+          v.w = (row_ok && c0 + 3 <= last) ? v.w : 0.f;
+        }
+        a[ch][m] = v;
+      }
+    }
+  };
+  // registers (load order) -> LDS tile -> registers (operand order)
+  auto transpose_block = [&](float4 (&ld)[NCH][8], float4 (&op)[NCH][8]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        *reinterpret_cast<float4*>(xt + ch * 2048 + m * 256 + lane * 4) = ld[ch][m];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        op[ch][k] = *reinterpret_cast<const float4*>(xt + ch * 2048 + li * 64 +
+                                                     4 * ((8 * lh + k) ^ (li & 15)));
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // B operands (weights) of one tile: 32 * NCH registers, read in one batch.
+  auto load_weights = [&](int nt, float (&bw)[NCH * 32]) {
+    const float* wb = wl + (nt * NCH) * 32 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < NCH * 32; ++k) bw[k] = wb[k * 64];
+  };
+  // The P tile of the previous step goes through the per-wave LDS tile and is summed
+  // along its diagonals WHILE the MFMA chain of the current step runs: the chain is
+  // one dependent accumulator (an MFMA issues every 64 cycles), and the LDS traffic
+  // of the diagonal sums is placed in its issue gaps -- 16 tile writes behind MFMAs
+  // 0..15, 16 diagonal reads behind MFMAs 16..31 (with NCH = 2: every other MFMA).
+  // Element (row r, col n) belongs to output o = r - n + 31 of the 63 outputs a tile
+  // touches.  Lane (li, lh) reads the 16 columns n = 16*lh .. 16*lh + 15 at row
+  // (li + 1 + n) & 31: that element belongs to output li when li + n >= 31 and to
+  // output li + 32 otherwise, so all reads are useful, unconditional and
+  // bank-conflict free (row*33 + n).
+  float4 cur[NCH][8], nxt[NCH][8];
+  float bw[NCH * 32];
+  f32x16 accp;                 // P tile of the previous step
+  int p_rel0 = 0, p_nt = 0;    // its rel0 and tile index
+  bool have_prev = false;
+  load_block(rb, nxt);
+  transpose_block(nxt, cur);
+  if (nt_count == 1) load_weights(0, bw);
+
+  auto finish_prev = [&](float s_lo, float s_hi) {
+    s_lo += __shfl_xor(s_lo, 32, 64);
+    s_hi += __shfl_xor(s_hi, 32, 64);
+    const int q = p_nt / tpq;
+    const int l_lo = (p_nt - q * tpq) * 32;
+    // lanes of half 0 own output li, lanes of half 1 output li + 32
+    const int rel = p_rel0 - l_lo - 31 + li + 32 * lh;
+    const float sv = lh ? s_hi : s_lo;
+    if ((unsigned)rel < (unsigned)st_len) oacc[(rel & (ring - 1)) * dq + q] += sv;
+    if (p_nt == nt_count - 1) {
+      // the block of the previous step is complete: 32 outputs are final,
+      // strip-relative frames [row0 - post - ts, +32) = [p_rel0 - pre - post, +32)
+      const int relf = p_rel0 - pre - post + li;
+      if (lh == 0 && (unsigned)relf < (unsigned)st_len) {
+        const int slot = (relf & (ring - 1)) * dq;
+        for (int qq = 0; qq < dq; ++qq) {
+          out[(st.out0 + ts + relf) * ldout + q0 + qq] =
+              oacc[slot + qq] + (bias ? bias[q0 + qq] : 0.f);
+          oacc[slot + qq] = 0.f;
+        }
+      }
+    }
+  };
+
+  for (int j = 0; j < nb; ++j) {
+    const long long row0 = rb + 32LL * j;
+    if (j + 1 < nb && TD_FIR_ABL != 1) load_block(row0 + 32, nxt);
+    const int rel0 = (int)(row0 - ts) + pre;      // strip-relative output frame of (row 0, lag 0)
+    for (int nt = 0; nt < nt_count; ++nt) {
+      if (nt_count != 1) load_weights(nt, bw);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      float s_lo = 0.f, s_hi = 0.f;
+      float dv[16];
+#pragma unroll
+      for (int m = 0; m < NCH * 32; ++m) {
+        const float4 av = cur[m >> 5][(m & 31) >> 2];
+        const float a = (m & 3) == 0 ? av.x : (m & 3) == 1 ? av.y : (m & 3) == 2 ? av.z : av.w;
+        if (TD_FIR_ABL != 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[m], acc, 0, 0, 0);
+        else acc[m & 15] += a * bw[m];
+        if (have_prev && m % NCH == 0 && TD_FIR_ABL != 2) {
+          const int k = m / NCH;               // 0..31
+          if (k < 16) {
+            // P tile -> LDS: C/D map col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * lh
+            tbuf[((k & 3) + 8 * (k >> 2) + 4 * lh) * 33 + li] = accp[k];
+          } else {
+            const int n = 16 * lh + (k - 16);
+            dv[k - 16] = tbuf[((li + 1 + n) & 31) * 33 + n];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (have_prev) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const bool lo = li + 16 * lh + k >= 31;
+          s_lo += lo ? dv[k] : 0.f;
+          s_hi += lo ? 0.f : dv[k];
+        }
+        finish_prev(s_lo, s_hi);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[r] = acc[r];
+      p_rel0 = rel0;
+      p_nt = nt;
+      have_prev = true;
+    }
+    // the P tile of this block's last step now lives in accp (registers): the LDS tile
+    // is free for the transposition of the next block
+    if (j + 1 < nb && TD_FIR_ABL != 4) transpose_block(nxt, cur);
+  }
+  // drain: the last tile
+  if (have_prev) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      tbuf[((k & 3) + 8 * (k >> 2) + 4 * lh) * 33 + li] = accp[k];
+    __builtin_amdgcn_wave_barrier();
+    float s_lo = 0.f, s_hi = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int n = 16 * lh + k;
+      const float v = tbuf[((li + 1 + n) & 31) * 33 + n];
+      const bool lo = li + n >= 31;
+      s_lo += lo ? v : 0.f;
+      s_hi += lo ? 0.f : v;
+    }
+    finish_prev(s_lo, s_hi);
+  }
+}
+
 // bias[k] = -sum_f mean[f] * rot[f][k]   (CCA centring folded into the FIR bias)
 __global__ void neg_mean_rot_kernel(const float* __restrict__ mean, const float* __restrict__ rot,
                                     int k, int dims, float* __restrict__ bias) {
@@ -136,6 +398,98 @@ __global__ __launch_bounds__(kThreads) void window_sums_kernel(
           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     __syncthreads();
   }
+}
+
+// ---- two-stage window sums: block partials, then windows from blocks ---------
+// Overlapping windows share frames (width / hop = 10 at C4): with g = gcd(width,
+// hop) every window is a run of width / g whole blocks of g frames, so the frames
+// are read ONCE into per-block float64 partial sums (one wave per block, lane-
+// strided accumulation + fixed shuffle tree: bitwise reproducible) and a window
+// is the sum of its blocks in ascending order.
+__global__ __launch_bounds__(kThreads) void block_sums_kernel(
+    const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
+    int cols, int b_cols, const FileDesc* __restrict__ trials, int n_trials, long long n_blocks,
+    int g, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long blk = blockIdx.x * (long long)(kThreads / 64) + (threadIdx.x >> 6);
+  if (blk >= n_blocks) return;
+  const FileDesc tr = trials[find_file(trials, n_trials, blk)];
+  const long long r0 = tr.row0 + (blk - tr.first) * g;
+  for (int col = 0; col < cols; ++col) {
+    const int bc = col % b_cols;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int r = lane; r < g; r += 64) {
+      const double av = (double)a[(r0 + r) * lda + col];
+      const double bv = (double)b[(r0 + r) * ldb + bc];
+      s[0] += av; s[1] += bv; s[2] += av * av; s[3] += bv * bv; s[4] += av * bv;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double v = wave_sum(s[k]);
+      if (lane == 0) out[(blk * cols + col) * 5 + k] = v;
+    }
+  }
+}
+
+// Window w of trial t (FileDesc: first = first WINDOW of the trial, out0 = first
+// BLOCK of the trial) starts at block out0 + (w - first) * blocks_per_hop.
+__device__ __forceinline__ long long window_first_block(const FileDesc* __restrict__ trials,
+                                                        int n_trials, long long w,
+                                                        int blocks_per_hop) {
+  const FileDesc tr = trials[find_file(trials, n_trials, w)];
+  return tr.out0 + (w - tr.first) * blocks_per_hop;
+}
+
+__global__ void window_from_blocks_kernel(const double* __restrict__ bsums,
+                                          const FileDesc* __restrict__ trials, int n_trials,
+                                          long long n_win, int cols, int blocks_per_win,
+                                          int blocks_per_hop, double* __restrict__ out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n_win * cols * 5) return;
+  const long long w = i / (cols * 5);
+  const int ck = (int)(i % (cols * 5));
+  const double* p = bsums + window_first_block(trials, n_trials, w, blocks_per_hop) * cols * 5 + ck;
+  double s = 0.0;
+  for (int j = 0; j < blocks_per_win; ++j) s += p[(long long)j * cols * 5];
+  out[i] = s;
+}
+
+// Fused tail of the two-speaker decode: window sums from block partials (column
+// spk = envelope of speaker spk vs the shared prediction), global-statistics
+// correlation score per speaker (infer_decoder.py:326-328 averaged over the
+// window, infer.py:263-265) and the winner-take-all decision
+// (attention_decoder.py:128-134: strict >).
+struct FusedCorr {
+  double mean_a[2], mean_b[2], power[2];
+};
+
+__global__ void decode_finalize_kernel(const double* __restrict__ bsums,
+                                       const FileDesc* __restrict__ trials, int n_trials,
+                                       long long n_win, int blocks_per_win, int blocks_per_hop,
+                                       int width, FusedCorr fc,
+                                       double* __restrict__ scores,
+                                       unsigned char* __restrict__ decisions) {
+  const long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (w >= n_win) return;
+  const double n = (double)width;
+  const long long blk0 = window_first_block(trials, n_trials, w, blocks_per_hop);
+  double sc[2];
+#pragma unroll
+  for (int spk = 0; spk < 2; ++spk) {
+    const double* p = bsums + (blk0 * 2 + spk) * 5;
+    double sa = 0.0, sb = 0.0, sab = 0.0;
+    for (int j = 0; j < blocks_per_win; ++j) {
+      sa += p[(long long)j * 10 + 0];
+      sb += p[(long long)j * 10 + 1];
+      sab += p[(long long)j * 10 + 4];
+    }
+    const double num = sab - fc.mean_a[spk] * sb - fc.mean_b[spk] * sa +
+                       n * fc.mean_a[spk] * fc.mean_b[spk];
+    sc[spk] = num / (fc.power[spk] * n);
+  }
+  scores[w * 2 + 0] = sc[0];
+  scores[w * 2 + 1] = sc[1];
+  decisions[w] = sc[0] > sc[1] ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kThreads) void window_means_kernel(
@@ -409,6 +763,50 @@ int build_windows(const int64_t* trial_offsets, int num_trials, int width, int h
   return TD_OK;
 }
 
+int64_t gcd64(int64_t a, int64_t b) {
+  while (b) { const int64_t t = a % b; a = b; b = t; }
+  return a;
+}
+
+// Block size for the two-stage window sums: the largest divisor of gcd(width,
+// hop) that is <= 4096 (a block is summed by one wave), or 0 if the only usable
+// divisors are tiny / the windows would span too many blocks (then the
+// one-workgroup-per-window kernel is used).
+int window_block_size(int width, int hop) {
+  const int64_t g = gcd64(width, hop);
+  int best = 0;
+  for (int64_t dv = g < 4096 ? g : 4096; dv >= 32; --dv)
+    if (g % dv == 0) { best = (int)dv; break; }
+  if (best == 0 || width / best > 4096) return 0;
+  return best;
+}
+
+// Per-trial descriptors for the block and window kernels (blocks of g frames of
+// every trial that has at least one full window).
+void build_block_tables(const int64_t* trial_offsets, int num_trials, int width, int hop, int g,
+                        std::vector<FileDesc>* blk_tab, std::vector<FileDesc>* win_tab,
+                        int64_t* n_blocks, int64_t* n_windows) {
+  blk_tab->resize(num_trials);
+  win_tab->resize(num_trials);
+  int64_t nb = 0, nw = 0;
+  for (int t = 0; t < num_trials; ++t) {
+    const int64_t n = trial_offsets[t + 1] - trial_offsets[t];
+    int64_t tw = 0, tb = 0;
+    if (n >= width) {
+      tw = (n - width) / hop + 1;
+      tb = ((tw - 1) * hop + width) / g;
+    }
+    FileDesc& b = (*blk_tab)[t];
+    b.row0 = trial_offsets[t]; b.nrows = n; b.out0 = trial_offsets[t]; b.first = nb;
+    FileDesc& w = (*win_tab)[t];
+    w.row0 = trial_offsets[t]; w.nrows = n; w.out0 = nb; w.first = nw;
+    nb += tb;
+    nw += tw;
+  }
+  *n_blocks = nb;
+  *n_windows = nw;
+}
+
 int fill_score_params(td_handle* h, ScoreParams* sp, int cols, const double* mean_a,
                       const double* mean_b, const double* power, const double* lda_w,
                       double slope, double intercept) {
@@ -425,12 +823,105 @@ int fill_score_params(td_handle* h, ScoreParams* sp, int cols, const double* mea
   return TD_OK;
 }
 
+// Upper bound of the device table launch_fir needs (per-file descriptors for the
+// matrix-core kernel, per-tile ones for the VALU fallback).
+size_t fir_table_bytes(const int64_t* offs, int num_files, int64_t shift) {
+  size_t tiles = 0;
+  for (int f = 0; f < num_files; ++f) {
+    const int64_t n = offs[f + 1] - offs[f] - shift;
+    if (n > 0) tiles += (size_t)td_ceil_div(n, kThreads);
+  }
+  const size_t a = (size_t)num_files * sizeof(FileDesc), b = tiles * sizeof(FirTile);
+  return td_round_up((int64_t)((a > b ? a : b) + 256), 256);
+}
+
+template <int NCH>
+void launch_fir_mfma(td_handle* h, bool vec4, unsigned blocks, size_t lds, const float* x,
+                     int64_t ldx, const FileDesc* files, int n_files, long long n_strips,
+                     int strip_len, int c, int pre, int post, const float* w, const float* bias,
+                     int d, int q0, int dq, int tpq, int ring, float* out, int64_t ldout) {
+  if (vec4)
+    hipLaunchKernelGGL((predict_fir_mfma_kernel<NCH, true>), dim3(blocks), dim3(kThreads), lds,
+                       h->stream, x, (long long)ldx, files, n_files, n_strips, strip_len, c, pre,
+                       post, w, bias, d, q0, dq, tpq, ring, out, (long long)ldout);
+  else
+    hipLaunchKernelGGL((predict_fir_mfma_kernel<NCH, false>), dim3(blocks), dim3(kThreads), lds,
+                       h->stream, x, (long long)ldx, files, n_files, n_strips, strip_len, c, pre,
+                       post, w, bias, d, q0, dq, tpq, ring, out, (long long)ldout);
+}
+
+// table_dev: optional caller-provided device block of fir_table_bytes() bytes (so
+// that a caller holding other td_scratch data is not disturbed); NULL = td_scratch.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
                int c, int pre, int post, const float* w, const float* bias, int d, float* out,
-               int64_t ldout, int64_t shift = 0) {
+               int64_t ldout, int64_t shift = 0, void* table_dev = nullptr) {
   // `shift` leading rows of every file are dropped from this input stream BEFORE
   // context is added (brain_data.py:466-475); output row offs[f] + t is frame t of
   // the shifted stream, i.e. the index of the zipped streams.
+  const int nl = pre + 1 + post;
+  int64_t total = 0;
+  for (int f = 0; f < num_files; ++f) {
+    const int64_t n = offs[f + 1] - offs[f] - shift;
+    if (n > 0) total += n;
+  }
+  if (total == 0) return TD_OK;
+  if (!table_dev) {
+    void* scratch = nullptr;
+    TD_TRY(td_scratch(h, fir_table_bytes(offs, num_files, shift), &scratch));
+    table_dev = scratch;
+  }
+
+  // ---- matrix-core path: C <= 128 and the weights (MFMA order, each output's lags padded
+  // to whole 32-column tiles) + per-wave output rings fit 64 KB of LDS; outputs go in
+  // groups of dq_max per launch
+  const int nch = (int)td_ceil_div(c, 64);
+  const int tpq = (int)td_ceil_div(nl, 32);
+  int ring = 64;
+  while (ring < 32 + nl) ring *= 2;
+  auto lds_for = [&](int dq) {
+    return sizeof(float) * ((size_t)dq * tpq * nch * 2048 +
+                            (kThreads / 64) * ((size_t)nch * 2048 + (size_t)ring * dq));
+  };
+  int dq_max = d < 16 ? d : 16;
+  while (dq_max > 1 && lds_for(dq_max) > 64 * 1024) --dq_max;
+  const bool mfma_ok = c <= 128 && lds_for(dq_max) <= 64 * 1024;
+  if (mfma_ok) {
+    // strip length: one wave per resident slot -- the kernel holds 2 waves per SIMD =
+    // 8 per CU (register-limited), so total / (256 CUs * 8) frames per wave runs the
+    // whole input in ONE round (a second, partly filled round costs as much as a full
+    // one); a multiple of 32, in [128, 4096]
+    int64_t strip = td_round_up(td_ceil_div(total, 256 * 8), 32);
+    if (strip < 128) strip = 128;
+    if (strip > 4096) strip = 4096;
+    std::vector<FileDesc> files(num_files);
+    long long n_strips = 0;
+    for (int f = 0; f < num_files; ++f) {
+      const int64_t n = offs[f + 1] - offs[f] - shift;
+      files[f].row0 = offs[f] + shift;
+      files[f].nrows = n > 0 ? n : 0;
+      files[f].out0 = offs[f];
+      files[f].first = n_strips;
+      if (n > 0) n_strips += td_ceil_div(n, strip);
+    }
+    TD_TRY(td_upload_async(h, files.data(), files.size() * sizeof(FileDesc), table_dev));
+    const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
+    const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const unsigned blocks = (unsigned)td_ceil_div(n_strips, kThreads / 64);
+    for (int q0 = 0; q0 < d; q0 += dq_max) {
+      const int dq = d - q0 < dq_max ? d - q0 : dq_max;
+      const size_t lds = lds_for(dq);
+      if (nch == 1)
+        launch_fir_mfma<1>(h, vec4, blocks, lds, x, ldx, df, num_files, n_strips, (int)strip, c, pre,
+                           post, w, bias, d, q0, dq, tpq, ring, out, ldout);
+      else
+        launch_fir_mfma<2>(h, vec4, blocks, lds, x, ldx, df, num_files, n_strips, (int)strip, c, pre,
+                           post, w, bias, d, q0, dq, tpq, ring, out, ldout);
+    }
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
+
+  // ---- VALU fallback (wide inputs / very long filters)
   std::vector<FirTile> tiles;
   for (int f = 0; f < num_files; ++f) {
     const int64_t n = offs[f + 1] - offs[f] - shift;
@@ -441,10 +932,8 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     }
   }
   if (tiles.empty()) return TD_OK;
-  void* scratch = nullptr;
-  TD_TRY(td_scratch(h, tiles.size() * sizeof(FirTile), &scratch));
-  TD_TRY(td_upload_async(h, tiles.data(), tiles.size() * sizeof(FirTile), scratch));
-  const FirTile* dt = reinterpret_cast<const FirTile*>(scratch);
+  TD_TRY(td_upload_async(h, tiles.data(), tiles.size() * sizeof(FirTile), table_dev));
+  const FirTile* dt = reinterpret_cast<const FirTile*>(table_dev);
   for (int q0 = 0; q0 < d;) {
     const int left = d - q0;
     if (left >= 4) {
@@ -531,6 +1020,32 @@ int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b
   if (!h || !a_dev || !b_dev || !trial_offsets_host || !out_dev)
     return td_fail(h, TD_ERR_INVALID, "td_window_sums: NULL argument");
   TD_REQUIRE(h, cols > 0 && width > 0 && hop > 0, "td_window_sums: bad sizes");
+  const int g = window_block_size(width, hop);
+  if (g > 0) {
+    // shared frames are read once: block partials, then windows from blocks
+    std::vector<FileDesc> blk_tab, win_tab;
+    int64_t n_blocks = 0, n_win = 0;
+    build_block_tables(trial_offsets_host, num_trials, width, hop, g, &blk_tab, &win_tab, &n_blocks,
+                       &n_win);
+    if (n_win == 0) return TD_OK;
+    const size_t tb = td_round_up(sizeof(FileDesc) * num_trials, 256);
+    void* scratch = nullptr;
+    TD_TRY(td_scratch(h, 2 * tb + sizeof(double) * n_blocks * cols * 5, &scratch));
+    FileDesc* d_blk = reinterpret_cast<FileDesc*>(scratch);
+    FileDesc* d_win = reinterpret_cast<FileDesc*>(reinterpret_cast<char*>(scratch) + tb);
+    double* bsums = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + 2 * tb);
+    TD_TRY(td_upload_async(h, blk_tab.data(), sizeof(FileDesc) * num_trials, d_blk));
+    TD_TRY(td_upload_async(h, win_tab.data(), sizeof(FileDesc) * num_trials, d_win));
+    hipLaunchKernelGGL(block_sums_kernel, dim3((unsigned)td_ceil_div(n_blocks, kThreads / 64)),
+                       dim3(kThreads), 0, h->stream, a_dev, (long long)lda, b_dev, (long long)ldb,
+                       cols, cols, d_blk, num_trials, (long long)n_blocks, g, bsums);
+    const long long outs = (long long)n_win * cols * 5;
+    hipLaunchKernelGGL(window_from_blocks_kernel, dim3((unsigned)td_ceil_div(outs, 256)), dim3(256),
+                       0, h->stream, bsums, d_win, num_trials, (long long)n_win, cols, width / g,
+                       hop / g, out_dev);
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
   std::vector<long long> row0;
   std::vector<int64_t> off;
   build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
@@ -682,42 +1197,82 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
       !decisions_dev)
     return td_fail(h, TD_ERR_INVALID, "td_decode_fused: NULL argument");
   TD_REQUIRE(h, num_trials > 0 && width > 0 && hop > 0, "td_decode_fused: bad sizes");
+  TD_REQUIRE(h, ldenv >= 2, "td_decode_fused: the envelope stream needs two columns");
   const int64_t rows = trial_offsets_host[num_trials];
-  std::vector<long long> row0;
-  std::vector<int64_t> off;
-  build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
-  const int64_t nwin = (int64_t)row0.size();
-  // workspace: pred [rows] f32, sums [nwin][2][5] f64, s1/s2 [nwin] f64
-  float* pred = nullptr;
-  const size_t bytes = td_round_up(sizeof(float) * rows, 256) +
-                       sizeof(double) * (size_t)nwin * (10 + 2) + 256;
-  TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&pred), bytes));
-  double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(pred) +
-                                           td_round_up(sizeof(float) * rows, 256));
-  double* s1 = sums + (size_t)nwin * 10;
-  double* s2 = s1 + nwin;
-  int rc = launch_fir(h, eeg_dev, ldx, trial_offsets_host, num_trials, c, pre, post, w_dev, b_dev,
-                      1, pred, 1);
-  for (int spk = 0; spk < 2 && rc == TD_OK && nwin > 0; ++spk) {
-    // a = envelope of speaker spk (the "truth" stream), b = prediction
-    rc = td_window_sums(h, env_dev + spk, ldenv, pred, 1, 1, trial_offsets_host, num_trials, width,
-                        hop, sums + (size_t)spk * nwin * 5);
-    if (rc == TD_OK)
-      rc = td_window_scores(h, sums + (size_t)spk * nwin * 5, nwin, 1, width, 0, 0,
-                            corr_host + 3 * spk, corr_host + 3 * spk + 1, corr_host + 3 * spk + 2,
-                            spk == 0 ? s1 : s2);
+  const int g = window_block_size(width, hop);
+  if (g == 0) {
+    // windows that do not share whole blocks (gcd(width, hop) < 32): unfused chain
+    std::vector<long long> row0;
+    std::vector<int64_t> off;
+    build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
+    const int64_t nw = (int64_t)row0.size();
+    float* pred = nullptr;
+    const size_t bytes = td_round_up(sizeof(float) * rows, 256) +
+                         sizeof(double) * (size_t)nw * (10 + 2) + 256;
+    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&pred), bytes));
+    double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(pred) +
+                                             td_round_up(sizeof(float) * rows, 256));
+    double* s1 = sums + (size_t)nw * 10;
+    double* s2 = s1 + nw;
+    int rc = launch_fir(h, eeg_dev, ldx, trial_offsets_host, num_trials, c, pre, post, w_dev, b_dev,
+                        1, pred, 1);
+    for (int spk = 0; spk < 2 && rc == TD_OK && nw > 0; ++spk) {
+      rc = td_window_sums(h, env_dev + spk, ldenv, pred, 1, 1, trial_offsets_host, num_trials, width,
+                          hop, sums + (size_t)spk * nw * 5);
+      if (rc == TD_OK)
+        rc = td_window_scores(h, sums + (size_t)spk * nw * 5, nw, 1, width, 0, 0,
+                              corr_host + 3 * spk, corr_host + 3 * spk + 1, corr_host + 3 * spk + 2,
+                              spk == 0 ? s1 : s2);
+    }
+    if (rc == TD_OK && nw > 0) {
+      rc = td_decide_wta(h, s1, s2, nw, decisions_dev);
+      hipMemcpy2DAsync(scores_dev, 2 * sizeof(double), s1, sizeof(double), sizeof(double), nw,
+                       hipMemcpyDeviceToDevice, h->stream);
+      hipMemcpy2DAsync(scores_dev + 1, 2 * sizeof(double), s2, sizeof(double), sizeof(double), nw,
+                       hipMemcpyDeviceToDevice, h->stream);
+    }
+    hipStreamSynchronize(h->stream);
+    hipFree(pred);
+    return rc;
   }
-  if (rc == TD_OK && nwin > 0) {
-    rc = td_decide_wta(h, s1, s2, nwin, decisions_dev);
-    // interleave scores [nwin][2]
-    hipMemcpy2DAsync(scores_dev, 2 * sizeof(double), s1, sizeof(double), sizeof(double), nwin,
-                     hipMemcpyDeviceToDevice, h->stream);
-    hipMemcpy2DAsync(scores_dev + 1, 2 * sizeof(double), s2, sizeof(double), sizeof(double), nwin,
-                     hipMemcpyDeviceToDevice, h->stream);
+  // Three launches, one scratch block, one small upload (per-trial descriptors),
+  // no allocation and no host synchronisation:
+  //   FIR prediction (matrix cores) -> block partial sums of (envelope_spk, prediction)
+  //   -> window scores of both speakers + winner-take-all.
+  std::vector<FileDesc> tabs, win_tab;
+  int64_t n_blocks = 0, nwin = 0;
+  build_block_tables(trial_offsets_host, num_trials, width, hop, g, &tabs, &win_tab, &n_blocks,
+                     &nwin);
+  tabs.insert(tabs.end(), win_tab.begin(), win_tab.end());
+  const size_t s_fir = fir_table_bytes(trial_offsets_host, num_trials, 0);
+  const size_t s_tab = td_round_up(sizeof(FileDesc) * tabs.size(), 256);
+  const size_t s_pred = td_round_up(sizeof(float) * rows, 256);
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, s_fir + s_tab + s_pred + sizeof(double) * n_blocks * 10 + 256, &scratch));
+  char* base = reinterpret_cast<char*>(scratch);
+  FileDesc* d_blk = reinterpret_cast<FileDesc*>(base + s_fir);
+  FileDesc* d_win = d_blk + num_trials;
+  float* pred = reinterpret_cast<float*>(base + s_fir + s_tab);
+  double* bsums = reinterpret_cast<double*>(base + s_fir + s_tab + s_pred);
+  TD_TRY(launch_fir(h, eeg_dev, ldx, trial_offsets_host, num_trials, c, pre, post, w_dev, b_dev, 1,
+                    pred, 1, 0, base));
+  if (nwin == 0) return TD_OK;
+  TD_TRY(td_upload_async(h, tabs.data(), sizeof(FileDesc) * tabs.size(), d_blk));
+  // a = envelope of speaker spk (the "truth" stream), b = the shared prediction
+  hipLaunchKernelGGL(block_sums_kernel, dim3((unsigned)td_ceil_div(n_blocks, kThreads / 64)),
+                     dim3(kThreads), 0, h->stream, env_dev, (long long)ldenv, pred, 1LL, 2, 1, d_blk,
+                     num_trials, (long long)n_blocks, g, bsums);
+  FusedCorr fc;
+  for (int spk = 0; spk < 2; ++spk) {
+    fc.mean_a[spk] = corr_host[3 * spk];
+    fc.mean_b[spk] = corr_host[3 * spk + 1];
+    fc.power[spk] = corr_host[3 * spk + 2];
   }
-  hipStreamSynchronize(h->stream);
-  hipFree(pred);
-  return rc;
+  hipLaunchKernelGGL(decode_finalize_kernel, dim3((unsigned)td_ceil_div(nwin, 256)), dim3(256), 0,
+                     h->stream, bsums, d_win, num_trials, (long long)nwin, width / g, hop / g, width,
+                     fc, scores_dev, decisions_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,30 @@
+"""Runs only the hot kernels a few times (for rocprofv3 kernel-trace / PMC passes):
+   python tools/prof_kernels.py [fit] [decode]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from telluride_decoding_amd import device
+
+what = sys.argv[1:] or ['fit', 'decode']
+h = device.default_handle()
+torch.manual_seed(0)
+if 'fit' in what:
+  n, c = 1000000, 64
+  x = torch.randn(n, c, device='cuda'); y = torch.randn(n, 1, device='cuda')
+  offs = np.arange(11, dtype=np.int64) * 100000
+  st = device.LagStats(c, 0, 31, d=1)
+  for rep in range(3):
+    st.reset(); st.accumulate(x, None, y, offs)
+  w, b = st.ridge_solve([0.1])
+  torch.cuda.synchronize()
+if 'decode' in what:
+  trials, t, c = 200, 6000, 64
+  n = trials * t
+  x = torch.randn(n, c, device='cuda'); env = torch.randn(n, 2, device='cuda')
+  w = torch.randn(c * 32, 1, device='cuda') * 0.01; b = torch.zeros(1, device='cuda')
+  offs = np.arange(trials + 1, dtype=np.int64) * t
+  corr = [0.0, 0.0, 1.0, 0.0, 0.0, 1.0]
+  for rep in range(3):
+    scores, dec = device.decode_fused(x, env, offs, w, b, 0, 31, 1000, 100, corr, handle=h)
+  torch.cuda.synchronize()
