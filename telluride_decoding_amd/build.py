@@ -38,7 +38,9 @@ def build(force=False, verbose=False):
   objs = []
   obj_dir = os.path.join(PKG, 'csrc', '_obj')
   os.makedirs(obj_dir, exist_ok=True)
-  flags = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17',
+  # -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 FMAs into v_pk_fma_f32, which
+  # issues slower than the two v_fma_f32 it replaces on gfx950 (measured on the FIR kernel)
+  flags = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-fno-slp-vectorize',
            '-Wno-unused-result', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
   flags += os.environ.get('TD_EXTRA_HIPCC_FLAGS', '').split()   # development: ablation macros
   procs = []

@@ -345,6 +345,112 @@ __global__ __launch_bounds__(kThreads) void predict_fir_mfma_kernel(
   }
 }
 
+// ---------------------------------------------------------------- FIR predict, lane = channel
+// out[t][q] = sum_c sum_l x~[t + l - pre][c] * W[l*C + c][q]  with one LANE per channel:
+// a wave streams the rows of its strip (one coalesced 256-byte load per row: lane c gets
+// x[u][c]), keeps the filter taps of its channel in NL*DQ registers and NL*DQ running
+// partial sums -- row u adds x[u][c] * W[l][c] to the output that is l taps behind -- so
+// the 2*K*D flops per frame run as register-only v_fma_f32 at the vector rate (which on
+// gfx950 equals the f32 matrix rate) with every byte read once.  An output is complete NL
+// rows after its first tap; the 64 per-channel partials of NL*DQ completed outputs are
+// parked in a per-wave LDS tile and summed by columns once per body (a transposing
+// reduction: 1 LDS write + 1 LDS read per row and lane instead of a 6-step shuffle
+// reduction per output).  Filters shorter than NL taps are zero-padded at the END (extra
+// "post" lags with zero weight), which keeps every slot index a compile-time constant.
+template <int NL, int DQ>
+__global__ __launch_bounds__(NL * DQ == 32 ? 256 : 128) void predict_fir_wave_kernel(
+    const float* __restrict__ x, long long ldx, const FileDesc* __restrict__ files, int n_files,
+    long long n_strips, int strip_len, int c, int cb, int pre, int post,
+    const float* __restrict__ w, const float* __restrict__ bias, int d_total, int q0, int dq,
+    int accumulate, float* __restrict__ out, long long ldout) {
+  constexpr int V = NL * DQ;          // completed values per body and lane (32 or 64)
+  constexpr int P = NL < 8 ? NL : 8;  // rows of load prefetch (divides NL)
+  static_assert(V == 32 || V == 64, "tile width");
+  extern __shared__ float wave_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* tile = wave_lds + wave * (64 * (V + 1));
+  const long long sidx = blockIdx.x * (long long)(blockDim.x / 64) + wave;
+  if (sidx >= n_strips) return;
+  const FileDesc st = files[find_file(files, n_files, sidx)];
+  const long long ts = (sidx - st.first) * strip_len;
+  const int st_len = (int)(st.nrows - ts < strip_len ? st.nrows - ts : strip_len);
+  const int nl = pre + 1 + post;
+
+  // taps of this lane's channel
+  const int cg = cb + lane;
+  const bool ch_ok = cg < c;
+  float wt[NL][DQ];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int q = 0; q < DQ; ++q)
+      wt[l][q] = (ch_ok && l < nl && q < dq) ? w[((long long)l * c + cg) * d_total + q0 + q] : 0.f;
+  const int voff = ch_ok ? cg : cb;                 // lane's column (clamped: its taps are 0)
+
+  float acc[NL][DQ];
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) acc[l][q] = 0.f;
+
+  // row u (stream relative) of the strip walk; rows outside the file read row 0 and count 0
+  const long long u0 = ts - pre;
+  const int n_rows = st_len + NL - 1;
+  const int n_body = (n_rows + NL - 1) / NL;
+  auto load_row = [&](long long u) -> float {
+    const bool ok = u >= 0 && u < st.nrows;           // wave-uniform
+    const float* rowp = x + (st.row0 + (ok ? u : 0)) * ldx;   // wave-uniform base
+    const float v = rowp[voff];
+    return ok ? v : 0.f;
+  };
+  float xr[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) xr[k] = load_row(u0 + k);
+
+  for (int b = 0; b < n_body; ++b) {
+    const long long ub = u0 + (long long)b * NL;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float xv = xr[i % P];
+      xr[i % P] = load_row(ub + i + P);
+      // tap l of row i belongs to the output in slot (i - l) mod NL
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const int slot = (i - l) & (NL - 1);
+#pragma unroll
+        for (int q = 0; q < DQ; ++q)
+          acc[slot][q] = (l == 0) ? xv * wt[0][q] : fmaf(xv, wt[l][q], acc[slot][q]);
+      }
+      // slot (i + 1) mod NL has now seen all NL taps: output frame ub + i - (NL - 1) + pre
+      const int done = (i + 1) & (NL - 1);
+#pragma unroll
+      for (int q = 0; q < DQ; ++q) tile[lane * (V + 1) + i * DQ + q] = acc[done][q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // column sums of the [64 lanes][V] tile: lane (j, h) sums rows 32h..32h+31 of column j
+    // (V = 32) or lane j all 64 rows (V = 64); bank = (row + j) mod 32: conflict free
+    float s = 0.f;
+    if (V == 32) {
+      const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) s += tile[(32 * h + r) * (V + 1) + j];
+      s += __shfl_xor(s, 32, 64);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 64; ++r) s += tile[r * (V + 1) + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int vi = (V == 32) ? (lane & 31) : lane;
+    const int i = vi / DQ, q = vi - i * DQ;
+    const long long t = ub + i - (NL - 1) + pre;                 // stream-relative output frame
+    if ((V == 64 || lane < 32) && q < dq && t >= ts && t < ts + st_len) {
+      float* o = out + (st.out0 + t) * ldout + q0 + q;
+      *o = s + (accumulate ? *o : (bias ? bias[q0 + q] : 0.f));
+    }
+  }
+}
+
 // bias[k] = -sum_f mean[f] * rot[f][k]   (CCA centring folded into the FIR bias)
 __global__ void neg_mean_rot_kernel(const float* __restrict__ mean, const float* __restrict__ rot,
                                     int k, int dims, float* __restrict__ bias) {
@@ -835,21 +941,6 @@ size_t fir_table_bytes(const int64_t* offs, int num_files, int64_t shift) {
   return td_round_up((int64_t)((a > b ? a : b) + 256), 256);
 }
 
-template <int NCH>
-void launch_fir_mfma(td_handle* h, bool vec4, unsigned blocks, size_t lds, const float* x,
-                     int64_t ldx, const FileDesc* files, int n_files, long long n_strips,
-                     int strip_len, int c, int pre, int post, const float* w, const float* bias,
-                     int d, int q0, int dq, int tpq, int ring, float* out, int64_t ldout) {
-  if (vec4)
-    hipLaunchKernelGGL((predict_fir_mfma_kernel<NCH, true>), dim3(blocks), dim3(kThreads), lds,
-                       h->stream, x, (long long)ldx, files, n_files, n_strips, strip_len, c, pre,
-                       post, w, bias, d, q0, dq, tpq, ring, out, (long long)ldout);
-  else
-    hipLaunchKernelGGL((predict_fir_mfma_kernel<NCH, false>), dim3(blocks), dim3(kThreads), lds,
-                       h->stream, x, (long long)ldx, files, n_files, n_strips, strip_len, c, pre,
-                       post, w, bias, d, q0, dq, tpq, ring, out, (long long)ldout);
-}
-
 // table_dev: optional caller-provided device block of fir_table_bytes() bytes (so
 // that a caller holding other td_scratch data is not disturbed); NULL = td_scratch.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
@@ -871,7 +962,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     table_dev = scratch;
   }
 
-  // ---- matrix-core path: C <= 128 and the weights (MFMA order, each output's lags padded
+  // ---- matrix-core path: C <= 64 and the weights (MFMA order, each output's lags padded
   // to whole 32-column tiles) + per-wave output rings fit 64 KB of LDS; outputs go in
   // groups of dq_max per launch
   const int nch = (int)td_ceil_div(c, 64);
@@ -884,7 +975,9 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   };
   int dq_max = d < 16 ? d : 16;
   while (dq_max > 1 && lds_for(dq_max) > 64 * 1024) --dq_max;
-  const bool mfma_ok = c <= 128 && lds_for(dq_max) <= 64 * 1024;
+  // (16-byte aligned rows of at most 64 channels; everything else takes the lane-per-channel path)
+  const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const bool mfma_ok = c <= 64 && vec4 && lds_for(dq_max) <= 64 * 1024;
   if (mfma_ok) {
     // strip length: one wave per resident slot -- the kernel holds 2 waves per SIMD =
     // 8 per CU (register-limited), so total / (256 CUs * 8) frames per wave runs the
@@ -905,23 +998,62 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     }
     TD_TRY(td_upload_async(h, files.data(), files.size() * sizeof(FileDesc), table_dev));
     const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
-    const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const unsigned blocks = (unsigned)td_ceil_div(n_strips, kThreads / 64);
     for (int q0 = 0; q0 < d; q0 += dq_max) {
       const int dq = d - q0 < dq_max ? d - q0 : dq_max;
-      const size_t lds = lds_for(dq);
-      if (nch == 1)
-        launch_fir_mfma<1>(h, vec4, blocks, lds, x, ldx, df, num_files, n_strips, (int)strip, c, pre,
-                           post, w, bias, d, q0, dq, tpq, ring, out, ldout);
-      else
-        launch_fir_mfma<2>(h, vec4, blocks, lds, x, ldx, df, num_files, n_strips, (int)strip, c, pre,
-                           post, w, bias, d, q0, dq, tpq, ring, out, ldout);
+      hipLaunchKernelGGL((predict_fir_mfma_kernel<1, true>), dim3(blocks), dim3(kThreads),
+                         lds_for(dq), h->stream, x, (long long)ldx, df, num_files, n_strips,
+                         (int)strip, c, pre, post, w, bias, d, q0, dq, tpq, ring, out,
+                         (long long)ldout);
     }
     TD_HIP(h, hipGetLastError());
     return TD_OK;
   }
 
-  // ---- VALU fallback (wide inputs / very long filters)
+  // ---- lane-per-channel path: filters of up to 32 taps, any channel count (64 per pass)
+  if (nl <= 32) {
+    const int nlv = nl <= 4 ? 4 : 32;
+    const int dqv = nl <= 4 ? 8 : (nl <= 32 && d > 1) ? 2 : 1;
+    const int v = nlv * dqv;
+    const int waves = v == 32 ? 4 : 2;                 // per workgroup (LDS tile 64 x (v + 1) per wave)
+    const size_t lds = sizeof(float) * waves * 64 * (v + 1);
+    // one strip per resident wave slot (~16 waves per CU), a multiple of 32 frames, >= 128:
+    // the (nlv - 1)-row warm-up of a strip is pure overhead
+    int64_t strip = td_round_up(td_ceil_div(total, 256 * 16), 32);
+    if (strip < 128) strip = 128;
+    if (strip < 8 * nlv) strip = 8 * nlv;
+    if (strip > 8192) strip = 8192;
+    std::vector<FileDesc> files(num_files);
+    long long n_strips = 0;
+    for (int f = 0; f < num_files; ++f) {
+      const int64_t n = offs[f + 1] - offs[f] - shift;
+      files[f].row0 = offs[f] + shift;
+      files[f].nrows = n > 0 ? n : 0;
+      files[f].out0 = offs[f];
+      files[f].first = n_strips;
+      if (n > 0) n_strips += td_ceil_div(n, strip);
+    }
+    TD_TRY(td_upload_async(h, files.data(), files.size() * sizeof(FileDesc), table_dev));
+    const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
+    const unsigned blocks = (unsigned)td_ceil_div(n_strips, waves);
+    for (int q0 = 0; q0 < d; q0 += dqv) {
+      const int dq = d - q0 < dqv ? d - q0 : dqv;
+      for (int cb = 0; cb < c; cb += 64) {
+#define TD_FIR_WAVE(NL, DQ)                                                                    \
+  hipLaunchKernelGGL((predict_fir_wave_kernel<NL, DQ>), dim3(blocks), dim3(64 * waves), lds,   \
+                     h->stream, x, (long long)ldx, df, num_files, n_strips, (int)strip, c, cb, \
+                     pre, post, w, bias, d, q0, dq, cb > 0 ? 1 : 0, out, (long long)ldout)
+        if (nlv == 4) TD_FIR_WAVE(4, 8);
+        else if (nlv == 32 && dqv == 1) TD_FIR_WAVE(32, 1);
+        else TD_FIR_WAVE(32, 2);
+#undef TD_FIR_WAVE
+      }
+    }
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
+
+  // ---- LDS-tiled VALU fallback (filters longer than 32 taps that do not fit the matrix-core path)
   std::vector<FirTile> tiles;
   for (int f = 0; f < num_files; ++f) {
     const int64_t n = offs[f + 1] - offs[f] - shift;

@@ -34,6 +34,10 @@ def _d64(h, v):
     (70, 3, 40, 3, (900,), 0),          # > 64 channels and > 32 lags: chunk loops
     (8, 1, 2, 1, (400, 300), 2),        # input_offset drops leading x rows per file
     (4, 6, 6, 1, (5, 3, 700), 0),       # files shorter than the context
+    (63, 0, 31, 1, (1500, 200), 0),     # unaligned rows: lane-per-channel kernel, 32 taps
+    (69, 2, 10, 3, (800, 333), 1),      # two channel passes, outputs in pairs
+    (7, 0, 0, 9, (640,), 0),            # no lags, more outputs than one pass holds
+    (130, 1, 1, 2, (300, 77), 0),       # three channel passes of the short-filter variant
 ])
 def test_predict_fir_matches_dense_forward(dev, c, pre, post, d, lens, off):
   rng = np.random.default_rng(c * 100 + pre)

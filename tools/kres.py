@@ -2,7 +2,7 @@
 import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 else ''
-out = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + ROOT + '/include',
+out = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-I' + ROOT + '/include',
                       '-I' + ROOT + '/telluride_decoding_amd/csrc', '-c', src, '-o', '/tmp/kres.o',
                       '-Rpass-analysis=kernel-resource-usage'], stderr=subprocess.PIPE, text=True).stderr
 cur = None; rows = {}
