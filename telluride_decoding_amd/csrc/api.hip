@@ -37,6 +37,24 @@ int td_scratch(td_handle* h, size_t bytes, void** out) {
   return TD_OK;
 }
 
+int td_workspace(td_handle* h, size_t bytes, void** out) {
+  if (bytes > h->work_bytes) {
+    if (h->work) {
+      TD_HIP(h, hipStreamSynchronize(h->stream));
+      TD_HIP(h, hipFree(h->work));
+      h->work = nullptr;
+      h->work_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&h->work, bytes);
+    if (e != hipSuccess)
+      return td_fail(h, TD_ERR_NOMEM, "workspace allocation of %zu bytes failed: %s", bytes,
+                     hipGetErrorString(e));
+    h->work_bytes = bytes;
+  }
+  *out = h->work;
+  return TD_OK;
+}
+
 int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst) {
   if (bytes == 0) return TD_OK;
   td_handle::PinSlot& slot = h->pin[h->pin_next];
@@ -139,6 +157,7 @@ int td_destroy(td_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   if (h->scratch) hipFree(h->scratch);
+  if (h->work) hipFree(h->work);
   for (auto& slot : h->pin) {
     if (slot.p) hipHostFree(slot.p);
     if (slot.ev) hipEventDestroy(slot.ev);
@@ -157,6 +176,7 @@ const char* td_last_error(const td_handle* h) {
 
 int td_set_stream(td_handle* h, void* hip_stream) {
   if (!h) return td_fail(nullptr, TD_ERR_INVALID, "handle is NULL");
+  if (h->stream == reinterpret_cast<hipStream_t>(hip_stream)) return TD_OK;
   TD_HIP(h, hipStreamSynchronize(h->stream));
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL is HIP's default stream
   return TD_OK;

@@ -7,13 +7,23 @@
 // regularised matrix is symmetric positive definite, so Cholesky in float64 gives
 // the same solution to well below the reference's own float32 rounding noise.
 //
-// Structure (right-looking, 64-wide panels; row-major lower triangle):
-//   panel kernel  : every workgroup re-factors the 64x64 diagonal block in LDS
-//                   (cheaper than a launch), solves z_k = L_kk^-1 b_k, then owns 64
-//                   rows of the panel: X = A_ik L_kk^-T, b_i -= X z_k
-//   update kernel : trailing A_ij -= X_i X_j^T, 64x64 tiles, lower triangle only
-//   back kernel   : w_k = L_kk^-T z_k, then z_m -= L_km^T w_k for m < k
+// Structure (right-looking, 64-wide block columns, row-major lower triangle, the
+// matrix padded with an identity to a multiple of 64 so that every tile is full and
+// 16-byte aligned):
+//   diag    : L_kk and L_kk^-1 of one 64x64 block in ONE sweep of 64 column steps --
+//             the elimination is applied to the augmented tile [A_kk | I], whose right
+//             half ends as L_kk^-1 (register-resident 4x4 sub-tiles, one barrier per step)
+//   panel   : X_i = A_ik L_kk^-T as a 64x64x64 GEMM on the float64 matrix cores
+//             (v_mfma_f64_16x16x4_f64) -- the triangular solve became a product
+//   update  : A_ij -= X_i X_j^T, same GEMM; the workgroup that owns tile (k+1, k+1) goes
+//             on to factor it (look-ahead), so the diag sweep of the NEXT step overlaps
+//             the trailing update of this one
+//   back    : w_k = L_kk^-T z_k, z_m -= L_km^T w_k (m < k), one small launch per block
+// The right-hand sides ride along as `nrhs` extra matrix ROWS (rt = B^T, [nrhs][n]):
+// panel and update then perform the forward substitution z = L^-1 b for free.
 // Small dense, latency-bound: reported as time, not against a roofline.
+// (v1 solved the panel by 64-step substitution in every workgroup and ran the update
+// on LDS-fed VALU FMAs: 56 + 24 + 22 us per block step, 3.3 ms at n = 2049.)
 #include "td_common.h"
 
 int td_stats_layout(const td_stats* s, int* k1, int* d, int64_t* frames);
@@ -21,192 +31,311 @@ int td_stats_layout(const td_stats* s, int* k1, int* d, int64_t* frames);
 namespace {
 
 constexpr int NB = 64;
-constexpr int LD = NB + 1;  // LDS row stride in doubles (bank-conflict padding)
+constexpr int LS = NB + 2;   // LDS row stride in doubles: conflict-free ds_read_b64 of MFMA operands
 constexpr int kMaxRhs = 8;
 
-// The right-hand sides ride along as `nrhs` extra matrix ROWS (rt = B^T,
-// [nrhs][n]): the panel solve and the trailing update then perform the forward
-// substitution z = L^-1 b for free ("virtual" block row index nblk).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 struct CholParams {
-  double* a;        // [batch][n][n]   lower triangle in, L out
-  double* rt;       // [batch][nrhs][n] B^T in, z^T then w^T out
-  double* linv;     // [batch][nblk][64][64]  L_kk^-T per diagonal block
+  double* a;        // [batch][n][n]   n = nblk * 64 (identity padded); lower triangle in, L out
+  double* rt;       // [batch][kMaxRhs][n]  B^T in (rows >= nrhs zero), z^T out
+  double* linv;     // [batch][nblk][64][64]  L_kk^-1 (lower triangular, zeros above)
+  double* sol;      // [batch][kMaxRhs][n]  w^T out of the backward pass
   int n, nrhs, nblk, k;
   int* flag;        // set to 1 when a pivot is not positive
+  const double* tol; // [batch] pivots at or below this are "not positive" (64 n eps max diag):
+                     // an exactly singular matrix leaves a pivot of +-rounding noise, which
+                     // LAPACK's exact-zero test (np.linalg.solve -> "Singular matrix") catches
+                     // only because LU happens to cancel exactly there
 };
 
-// Both 64x64 tile routines keep the tile in REGISTERS: thread (ty, tx) =
-// (tid >> 4, tid & 15) owns rows ty*4 + a, columns tx*4 + b, a, b = 0..3.  Per
-// column step only the 64 values of the active column travel through LDS
-// (double-buffered: one barrier per step).  The first version kept the tile
-// in LDS and read-modify-wrote it element by element; every store serialised
-// the next loads and a panel took 198 us instead of ~10.
-
-// Cholesky of the diagonal block (identity padding beyond the matrix).  On exit
-// d holds L (lower part valid) and inv_diag[j] = 1 / L[j][j].
-__device__ __forceinline__ void factor_diag_reg(double (&d)[4][4], double* colbuf,
-                                                double* inv_diag, int tid, int* flag) {
-  const int ty = tid >> 4, tx = tid & 15;
-#pragma unroll 1
-  for (int j4 = 0; j4 < NB / 4; ++j4) {
+// ---- 64x64 tile <-> LDS ------------------------------------------------------------
+// Thread t moves column t & 63 of rows (t >> 6) + 4 i: every instruction is one 512-byte row.
+__device__ __forceinline__ void tile_to_lds(double* lds, const double* __restrict__ g, int ld,
+                                            int rows_valid, int tid) {
+  const int c = tid & 63, r0 = tid >> 6;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int j = j4 * 4 + b;
-      double* cb = colbuf + (j & 1) * NB;
-      if (tx == j4) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) cb[ty * 4 + a] = d[a][b];
-      }
-      __syncthreads();
-      const double piv = cb[j];
-      if (!(piv > 0.0) && tid == 0) atomicExch(flag, 1);
-      const double rs = 1.0 / sqrt(piv);
-      double lr[4], lc[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) lr[a] = cb[ty * 4 + a] * rs;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) lc[q] = cb[tx * 4 + q] * rs;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (ty * 4 + a > j && tx * 4 + q > j) d[a][q] -= lr[a] * lc[q];
-      if (tx == j4) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int r = ty * 4 + a;
-          if (r == j) d[a][b] = piv * rs;
-          else if (r > j) d[a][b] = lr[a];
-        }
-      }
-      if (tid == 0) inv_diag[j] = rs;
-    }
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + 4 * i;
+    lds[r * LS + c] = (r < rows_valid) ? g[(size_t)r * ld + c] : 0.0;
   }
-  __syncthreads();
 }
 
-// X L^T = A for a 64-row tile held in registers (x in, X out).  dl holds L in
-// LDS (LD stride), inv_diag its inverted diagonal.
-__device__ __forceinline__ void trsm_reg(double (&x)[4][4], const double* dl,
-                                         const double* inv_diag, double* colbuf, int tid) {
-  const int ty = tid >> 4, tx = tid & 15;
-#pragma unroll 1
-  for (int j4 = 0; j4 < NB / 4; ++j4) {
+// C (64x64) = As . Bs^T on the float64 matrix cores; 4 waves, wave w owns the 32x32
+// quadrant (w >> 1, w & 1) as 2x2 tiles of v_mfma_f64_16x16x4_f64.  Operand lane map:
+// A[i = lane & 15][k = lane >> 4]; C/D: col = lane & 15, row = (lane >> 4) + 4 * reg.
+__device__ __forceinline__ void gemm_nt_64(const double* __restrict__ as,
+                                           const double* __restrict__ bs, int wave, int lane,
+                                           f64x4 (&acc)[2][2]) {
+  const int li = lane & 15, lk = lane >> 4;
+  const double* ap = as + ((wave >> 1) * 32 + li) * LS + lk;
+  const double* bp = bs + ((wave & 1) * 32 + li) * LS + lk;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int j = j4 * 4 + b;
-      double* cb = colbuf + (j & 1) * NB;
-      if (tx == j4) {
-        const double inv = inv_diag[j];
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          x[a][b] *= inv;
-          cb[ty * 4 + a] = x[a][b];
-        }
-      }
-      __syncthreads();
-      double xr[4], lc[4];
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xr[a] = cb[ty * 4 + a];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) lc[q] = dl[(tx * 4 + q) * LD + j];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (tx * 4 + q > j) x[a][q] -= xr[a] * lc[q];
-    }
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.0;
+#pragma unroll 4
+  for (int s = 0; s < NB / 4; ++s) {
+    const double a0 = ap[4 * s], a1 = ap[16 * LS + 4 * s];
+    const double b0 = bp[4 * s], b1 = bp[16 * LS + 4 * s];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
   }
-  __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(CholParams p) {
-  __shared__ double dl[NB * LD];        // L_kk
-  __shared__ double colbuf[2 * NB];
-  __shared__ double inv_diag[NB];
-  const int tid = threadIdx.x;
-  const int ty = tid >> 4, tx = tid & 15;
-  const int n = p.n, k0 = p.k * NB;
-  const int nb = (n - k0 < NB) ? n - k0 : NB;
-  double* a = p.a + (size_t)blockIdx.y * n * n;
+// (row, col) of accumulator element acc[m][n][r] inside the 64x64 tile
+__device__ __forceinline__ int acc_row(int wave, int lane, int m, int r) {
+  return (wave >> 1) * 32 + 16 * m + (lane >> 4) + 4 * r;
+}
+__device__ __forceinline__ int acc_col(int wave, int lane, int n) {
+  return (wave & 1) * 32 + 16 * n + (lane & 15);
+}
 
-  double d[4][4];
+// 1 / sqrt(x) to float64 accuracy: v_rsq_f64 seed + two Newton steps (the seed is good to
+// ~2^-26; a correctly rounded sqrt + divide is a long dependent software sequence and this
+// sits on the serial path of the factorisation, once per column).
+__device__ __forceinline__ double rsqrt_f64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// ---- 64x64 diagonal block: L and L^-1 -------------------------------------------------
+// This is the serial chain of the whole solve (every block step waits for it), so it is
+// blocked once more: four 16-column sub-panels, each
+//   S  one wave factors the 16x16 diagonal sub-block together with its inverse (augmented
+//      [D | I] elimination, 16 column steps, operands through a wave-private LDS line, no
+//      workgroup barrier inside),
+//   T  the rows below become X = A D^-T (float64 MFMA), and
+//   U  the trailing lower tiles take the rank-16 update A -= X X^T (float64 MFMA);
+// afterwards the off-diagonal 16x16 blocks of L^-1 follow from
+//   Linv_ij = -D_i^-1 sum_{m=j}^{i-1} L_im Linv_mj      (one wave per block column j).
+// A column step of the 16x16 elimination costs ~300 cycles against ~1500 for a step of the
+// register-tiled 64x64 sweep it replaces (whose rank-1 updates ran as predicated float64
+// VALU over the whole augmented tile): 43 us -> ~12 us per block.
+//
+// at: the tile (LDS, stride LS, lower triangle valid on entry; L with zeros above on exit)
+// wt: second LDS tile, receives L^-1 (lower triangular, zeros above)
+// sc: LDS scratch, kFactorScratch doubles (column/row lines + one 16x16 strip per wave)
+constexpr int kStripLd = 18;
+constexpr int kFactorScratch = 3 * 16 * kStripLd;   // doubles: wave 0 uses two strips in phase S
+
+__device__ __forceinline__ f64x4 mfma16(const double* __restrict__ arow, const double* __restrict__ brow,
+                                        int lane, f64x4 acc) {
+  // acc += A(16x16) . B^T with A[i][k] = arow[i * LS + k], B^T: b[j][k] = brow[j * LS + k]
+  const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[li * LS + 4 * s + lk], brow[li * LS + 4 * s + lk],
+                                               acc, 0, 0, 0);
+  return acc;
+}
+
+// acc += A(16x16) . B with A[i][k] = arow[i * LS + k], B[k][j] = bmat[k * LS + j]
+template <int BLD>
+__device__ __forceinline__ f64x4 mfma16_nn(const double* __restrict__ arow,
+                                           const double* __restrict__ bmat, int lane, f64x4 acc) {
+  const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = ty * 4 + i, c = tx * 4 + q;
-      double v = (r == c) ? 1.0 : 0.0;
-      if (r < nb && c < nb) v = (c <= r) ? a[(size_t)(k0 + r) * n + k0 + c]
-                                         : a[(size_t)(k0 + c) * n + k0 + r];
-      d[i][q] = v;
-    }
-  factor_diag_reg(d, colbuf, inv_diag, tid, p.flag);
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[li * LS + 4 * s + lk],
+                                               bmat[(4 * s + lk) * BLD + li], acc, 0, 0, 0);
+  return acc;
+}
+
+// C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+template <int DLD>
+__device__ __forceinline__ void store16(double* dst, int lane, const f64x4& v, double scale) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = ty * 4 + i, c = tx * 4 + q;
-      dl[r * LD + c] = (c <= r) ? d[i][q] : 0.0;
-    }
+  for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * DLD + (lane & 15)] = v[r] * scale;
+}
+
+__device__ __forceinline__ void factor_inv_tile(double* at, double* wt, double* sc, int tid,
+                                                int* flag, double tol) {
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int idx = tid; idx < NB * LS; idx += 256) wt[idx] = 0.0;
   __syncthreads();
-
-  double x[4][4];
-  if (blockIdx.x == 0) {
-    // publish L_kk and L_kk^-T (the latter for the backward substitution)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int p = 0; p < 4; ++p) {
+    const int o = 16 * p;
+    // ---- S: 16x16 diagonal sub-block and its inverse, wave 0 ---------------------------
+    // Lane (r, cq) keeps A[r][4cq..4cq+3] and the matching piece of the right half of the
+    // augmented [D | I] in registers.  Every step republishes both 16x16 matrices to a
+    // wave-private LDS image and reads back column j / row j -- no predicates anywhere:
+    // the rank-1 update runs over ALL rows and columns, finished rows and columns simply
+    // turn into garbage that nobody reads again, because column j of L (= cr * rs, which
+    // is also L[j][j] on the pivot row) and row j of the inverse are stored to the tiles
+    // the moment they are final.  (With the triangular structure expressed as branches or
+    // selects hipcc needed 160 instructions and a dozen exec-mask spills per step.)
+    if (wave == 0) {
+      const int r = lane & 15, cq = lane >> 4;
+      double a[4], w[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int r = ty * 4 + i, c = tx * 4 + q;
-        if (r < nb && c < nb && c <= r) a[(size_t)(k0 + r) * n + k0 + c] = d[i][q];
-        x[i][q] = (r == c) ? 1.0 : 0.0;
+        a[q] = at[(o + r) * LS + o + 4 * cq + q];
+        w[q] = (r == 4 * cq + q) ? 1.0 : 0.0;
       }
-    trsm_reg(x, dl, inv_diag, colbuf, tid);   // X = I L^-T
-    double* li = p.linv + ((size_t)blockIdx.y * p.nblk + p.k) * NB * NB;
+      double* al = sc;                       // [16][kStripLd]
+      double* wl = sc + 16 * kStripLd;       // [16][kStripLd]
+      double pmin = 1e300;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 16; ++j) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) li[(ty * 4 + i) * NB + tx * 4 + q] = x[i][q];
-    return;
-  }
-
-  // rows of this workgroup: block row bi = k + blockIdx.x; bi == nblk is the
-  // virtual block row holding the right-hand sides.
-  const int bi = p.k + blockIdx.x;
-  double* rows;
-  int ni;
-  if (bi == p.nblk) {
-    rows = p.rt + (size_t)blockIdx.y * p.nrhs * n;
-    ni = p.nrhs;
-  } else {
-    rows = a + (size_t)bi * NB * n;
-    ni = (n - bi * NB < NB) ? n - bi * NB : NB;
-  }
+        for (int q = 0; q < 4; ++q) {
+          al[r * kStripLd + 4 * cq + q] = a[q];
+          wl[r * kStripLd + 4 * cq + q] = w[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double piv = al[j * kStripLd + j];
+        const double cr = al[r * kStripLd + j];
+        double cc[4], rr[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < 4; ++q) {
+          cc[q] = al[(4 * cq + q) * kStripLd + j];
+          rr[q] = wl[j * kStripLd + 4 * cq + q];
+        }
+        pmin = fmin(pmin, piv);
+        const double rs = rsqrt_f64(piv);
+        const double lr = cr * rs;                     // L[r][j]  (valid for r >= j)
+        at[(o + r) * LS + o + j] = lr;                 // all four cq groups store the same value
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = ty * 4 + i, c = tx * 4 + q;
-      x[i][q] = (r < ni && c < nb) ? rows[(size_t)r * n + k0 + c] : 0.0;
+        for (int q = 0; q < 4; ++q) {
+          const double wr = rr[q] * rs;                // row j of the inverse
+          a[q] -= lr * (cc[q] * rs);
+          w[q] -= lr * wr;
+          wt[(o + j) * LS + o + 4 * cq + q] = wr;      // every r stores the same value
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (!(pmin > tol) && lane == 0) atomicExch(flag, 1);
     }
-  trsm_reg(x, dl, inv_diag, colbuf, tid);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = ty * 4 + i, c = tx * 4 + q;
-      if (r < ni && c < nb) rows[(size_t)r * n + k0 + c] = x[i][q];
+    __syncthreads();
+    // zero the strictly upper part of the sub-block of L (garbage of the unpredicated sweep)
+    if (tid < 256) {
+      const int r = tid >> 4, c = tid & 15;
+      if (c > r) at[(o + r) * LS + o + c] = 0.0;
     }
+    __syncthreads();
+    if (p == 3) break;
+    // ---- T: rows below the sub-block: X = A D^-T, row tile (wave) of 16 rows -------------
+    const int nrt = 3 - p;                       // row tiles below
+    f64x4 x = {0.0, 0.0, 0.0, 0.0};
+    if (wave < nrt)
+      x = mfma16(at + (o + 16 + 16 * wave) * LS + o, wt + o * LS + o, lane, x);
+    __syncthreads();                             // all operand reads done before the overwrite
+    if (wave < nrt) store16<LS>(at + (o + 16 + 16 * wave) * LS + o, lane, x, 1.0);
+    __syncthreads();
+    // ---- U: trailing lower tiles A_rc -= X_r X_c^T ----------------------------------------
+    int t = 0;
+    for (int rt = 0; rt < nrt; ++rt)
+      for (int ct = 0; ct <= rt; ++ct, ++t) {
+        if ((t & 3) != wave) continue;
+        f64x4 u = {0.0, 0.0, 0.0, 0.0};
+        u = mfma16(at + (o + 16 + 16 * rt) * LS + o, at + (o + 16 + 16 * ct) * LS + o, lane, u);
+        double* dst = at + (o + 16 + 16 * rt) * LS + o + 16 + 16 * ct;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * LS + (lane & 15)] -= u[r];
+      }
+    __syncthreads();
+  }
+  // ---- off-diagonal blocks of the inverse, block column j handled by wave j ---------------
+  if (wave < 3) {
+    const int j = wave;
+    double* s_lds = sc + wave * 16 * kStripLd;   // per-wave 16 x 16 strip for the partial sums
+    for (int i = j + 1; i < 4; ++i) {
+      f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int m = j; m < i; ++m)
+        acc = mfma16_nn<LS>(at + (16 * i) * LS + 16 * m, wt + (16 * m) * LS + 16 * j, lane, acc);
+      store16<kStripLd>(s_lds, lane, acc, 1.0);
+      __builtin_amdgcn_wave_barrier();
+      f64x4 v = {0.0, 0.0, 0.0, 0.0};
+      v = mfma16_nn<kStripLd>(wt + (16 * i) * LS + 16 * i, s_lds, lane, v);
+      __builtin_amdgcn_wave_barrier();
+      store16<LS>(wt + (16 * i) * LS + 16 * j, lane, v, -1.0);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
 }
 
-// Trailing update: A_ij -= X_i X_j^T for block rows i > k (incl. the virtual
-// right-hand-side row) and real block columns k < j <= i.
-__global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tri) {
-  __shared__ double xi[NB * LD];
-  __shared__ double xj[NB * LD];
+// Factors the tile held in `at` (LDS) and publishes L_kk (the global tile: lower part, zeros
+// above) and L_kk^-1.
+__device__ __forceinline__ void factor_and_publish(const CholParams& p, int kb, double* a_b,
+                                                   double* at, double* wt, double* sc, int tid) {
+  factor_inv_tile(at, wt, sc, tid, p.flag, p.tol[blockIdx.y]);
+  double* g = a_b + (size_t)kb * NB * p.n + (size_t)kb * NB;
+  double* li = p.linv + ((size_t)blockIdx.y * p.nblk + kb) * NB * NB;
+  const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + 4 * i;
+    g[(size_t)r * p.n + c] = (c <= r) ? at[r * LS + c] : 0.0;
+    li[r * NB + c] = wt[r * LS + c];
+  }
+}
+
+// First diagonal block (the later ones are factored by the update kernel).
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(CholParams p) {
+  __shared__ double at[NB * LS];
+  __shared__ double wt[NB * LS];
+  __shared__ double sc[kFactorScratch];
+  double* a_b = p.a + (size_t)blockIdx.y * p.n * p.n;
+  tile_to_lds(at, a_b + (size_t)p.k * NB * p.n + (size_t)p.k * NB, p.n, NB, threadIdx.x);
+  __syncthreads();
+  factor_and_publish(p, p.k, a_b, at, wt, sc, threadIdx.x);
+}
+
+// Panel: block rows i = k+1 .. nblk-1 and the virtual right-hand-side row (blockIdx.x ==
+// nblk - k - 1): X = A_ik L_kk^-T.
+__global__ __launch_bounds__(256) void chol_panel_kernel(CholParams p) {
+  __shared__ double as[NB * LS];
+  __shared__ double bs[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = p.n, k0 = p.k * NB;
-  double* a = p.a + (size_t)blockIdx.y * n * n;
+  double* a_b = p.a + (size_t)blockIdx.y * n * n;
+  const int bi = p.k + 1 + blockIdx.x;
+  double* rows;
+  int rows_valid;
+  if (bi == p.nblk) {
+    rows = p.rt + (size_t)blockIdx.y * kMaxRhs * n + k0;
+    rows_valid = p.nrhs;
+  } else {
+    rows = a_b + (size_t)bi * NB * n + k0;
+    rows_valid = NB;
+  }
+  tile_to_lds(as, rows, n, rows_valid, tid);
+  tile_to_lds(bs, p.linv + ((size_t)blockIdx.y * p.nblk + p.k) * NB * NB, NB, NB, tid);
+  __syncthreads();
+  f64x4 acc[2][2];
+  gemm_nt_64(as, bs, wave, lane, acc);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
+        if (row < rows_valid) rows[(size_t)row * n + col] = acc[m][nn][r];
+      }
+}
+
+// Trailing update A_ij -= X_i X_j^T for k < j <= i < nblk and for the right-hand-side
+// row; tile 0 is (k+1, k+1) and its workgroup factors the block afterwards (look-ahead).
+__global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tri) {
+  __shared__ double xi[NB * LS];
+  __shared__ double xj[NB * LS];
+  __shared__ double sc[kFactorScratch];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = p.n, k0 = p.k * NB;
+  double* a_b = p.a + (size_t)blockIdx.y * n * n;
   int t = blockIdx.x;
   int bi, bj;
   if (t < n_tri) {
@@ -218,125 +347,123 @@ __global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tr
     bi = p.nblk;
     bj = p.k + 1 + (t - n_tri);
   }
-  const int tid = threadIdx.x;
   double* rows_i;
-  int ni;
-  long long row_i0;   // global row index of the tile's first row (for the triangle test)
+  int rows_valid;
   if (bi == p.nblk) {
-    rows_i = p.rt + (size_t)blockIdx.y * p.nrhs * n;
-    ni = p.nrhs;
-    row_i0 = n;
+    rows_i = p.rt + (size_t)blockIdx.y * kMaxRhs * n;
+    rows_valid = p.nrhs;
   } else {
-    rows_i = a + (size_t)bi * NB * n;
-    ni = (n - bi * NB < NB) ? n - bi * NB : NB;
-    row_i0 = (long long)bi * NB;
+    rows_i = a_b + (size_t)bi * NB * n;
+    rows_valid = NB;
   }
-  const int j0 = bj * NB;
-  const int nj = (n - j0 < NB) ? n - j0 : NB;
-  const double* rows_j = a + (size_t)j0 * n;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    xi[r * LD + c] = (r < ni) ? rows_i[(size_t)r * n + k0 + c] : 0.0;
-    xj[r * LD + c] = (r < nj) ? rows_j[(size_t)r * n + k0 + c] : 0.0;
-  }
+  tile_to_lds(xi, rows_i + k0, n, rows_valid, tid);
+  tile_to_lds(xj, a_b + (size_t)bj * NB * n + k0, n, NB, tid);
   __syncthreads();
-  const int r0 = (tid >> 4) * 4, c0 = (tid & 15) * 4;
-  double acc[4][4];
+  f64x4 acc[2][2];
+  gemm_nt_64(xi, xj, wave, lane, acc);
+  const bool lookahead = (t == 0);
+  if (lookahead) __syncthreads();     // every wave is done reading xi before it is reused
+  double* dst = rows_i + (size_t)bj * NB;
 #pragma unroll
-  for (int ii = 0; ii < 4; ++ii)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-#pragma unroll 4
-  for (int m = 0; m < NB; ++m) {
-    double av[4], bv[4];
+    for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) av[ii] = xi[(r0 + ii) * LD + m];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) bv[jj] = xj[(c0 + jj) * LD + m];
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = fma(av[ii], bv[jj], acc[ii][jj]);
+      for (int r = 0; r < 4; ++r) {
+        const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
+        if (row < rows_valid) {
+          const double v = dst[(size_t)row * n + col] - acc[m][nn][r];
+          if (lookahead) xi[row * LS + col] = v;      // tile (k+1, k+1), kept on chip
+          else dst[(size_t)row * n + col] = v;
+        }
+      }
+  if (lookahead) {
+    __syncthreads();
+    factor_and_publish(p, p.k + 1, a_b, xi, xj, sc, tid);
   }
-#pragma unroll
-  for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int r = r0 + ii, c = c0 + jj;
-      if (r < ni && c < nj && (long long)(j0 + c) <= row_i0 + r)
-        rows_i[(size_t)r * n + j0 + c] -= acc[ii][jj];
-    }
 }
 
-// Backward substitution step for block k (descending): w_k = L_kk^-T z_k;
-// workgroup m < k then applies z_m -= L_km^T w_k.  rt holds z^T / w^T.
+// Backward substitution step for block k (descending): every workgroup forms
+// w_k = L_kk^-T z_k from the stored inverse; workgroup m < k applies z_m -= L_km^T w_k, the
+// last workgroup (m == k) publishes w_k to `sol` (z_k itself is still being read by the
+// others).  Thread (c, g) = (tid & 63, tid >> 6) sums 16 of the 64 terms of column c.
 __global__ __launch_bounds__(256) void chol_back_kernel(CholParams p) {
-  __shared__ double zs[NB * kMaxRhs];
-  __shared__ double ws[NB * kMaxRhs];
-  const int tid = threadIdx.x;
+  __shared__ double zs[kMaxRhs][NB];
+  __shared__ double ws[kMaxRhs][NB];
+  __shared__ double part[4][NB];
+  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
   const int n = p.n, k0 = p.k * NB;
-  const int nb = (n - k0 < NB) ? n - k0 : NB;
-  const double* a = p.a + (size_t)blockIdx.y * n * n;
-  double* rt = p.rt + (size_t)blockIdx.y * p.nrhs * n;
+  const double* a_b = p.a + (size_t)blockIdx.y * n * n;
+  double* rt = p.rt + (size_t)blockIdx.y * kMaxRhs * n;
   const double* li = p.linv + ((size_t)blockIdx.y * p.nblk + p.k) * NB * NB;
-  for (int idx = tid; idx < NB * p.nrhs; idx += 256) {
-    const int r = idx % NB, q = idx / NB;
-    zs[r * kMaxRhs + q] = (r < nb) ? rt[(size_t)q * n + k0 + r] : 0.0;
-  }
+  for (int idx = tid; idx < p.nrhs * NB; idx += 256) zs[idx >> 6][idx & 63] = rt[(size_t)(idx >> 6) * n + k0 + (idx & 63)];
   __syncthreads();
-  for (int idx = tid; idx < NB * p.nrhs; idx += 256) {
-    const int r = idx % NB, q = idx / NB;
+  // w[c] = sum_r Linv[r][c] * z[r]
+  double lcol[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lcol[i] = li[(g + 4 * i) * NB + c];
+  for (int q = 0; q < p.nrhs; ++q) {
     double s = 0.0;
-    for (int c = r; c < NB; ++c) s += li[r * NB + c] * zs[c * kMaxRhs + q];   // upper triangular
-    ws[r * kMaxRhs + q] = s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += lcol[i] * zs[q][g + 4 * i];
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0) ws[q][c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    __syncthreads();
   }
-  __syncthreads();
-  if ((int)blockIdx.x == p.k) {   // the "diagonal" workgroup publishes w_k
-    for (int idx = tid; idx < NB * p.nrhs; idx += 256) {
-      const int r = idx % NB, q = idx / NB;
-      if (r < nb) rt[(size_t)q * n + k0 + r] = ws[r * kMaxRhs + q];
-    }
+  const int m = blockIdx.x;
+  if (m == p.k) {
+    double* sol = p.sol + (size_t)blockIdx.y * kMaxRhs * n;
+    for (int idx = tid; idx < p.nrhs * NB; idx += 256) sol[(size_t)(idx >> 6) * n + k0 + (idx & 63)] = ws[idx >> 6][idx & 63];
     return;
   }
-  const int m0 = blockIdx.x * NB;  // column block m < k (always full width)
-  for (int idx = tid; idx < NB * p.nrhs; idx += 256) {
-    const int c = idx % NB, q = idx / NB;
-    double s = rt[(size_t)q * n + m0 + c];
-    for (int r = 0; r < nb; ++r) s -= a[(size_t)(k0 + r) * n + m0 + c] * ws[r * kMaxRhs + q];
-    rt[(size_t)q * n + m0 + c] = s;
+  const int m0 = m * NB;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lcol[i] = a_b[(size_t)(k0 + g + 4 * i) * n + m0 + c];   // L[k-block][m-block]
+  for (int q = 0; q < p.nrhs; ++q) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += lcol[i] * ws[q][g + 4 * i];
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0) rt[(size_t)q * n + m0 + c] -= (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    __syncthreads();
   }
 }
 
-__global__ void transpose_rhs_kernel(const double* __restrict__ src, double* __restrict__ dst,
-                                     int rows, int cols, int batch) {
-  // src [batch][rows][cols] -> dst [batch][cols][rows]
-  const long long total = (long long)batch * rows * cols;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cols);
-    const int r = (int)((i / cols) % rows);
-    const long long b = i / ((long long)rows * cols);
-    dst[(b * cols + c) * rows + r] = src[i];
+// tol[b] = 64 n eps max_i a[i][i]
+__global__ __launch_bounds__(256) void diag_tol_kernel(const double* __restrict__ a, int n,
+                                                       double* __restrict__ tol) {
+  __shared__ double red[256];
+  const double* ab = a + (size_t)blockIdx.x * n * n;
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, fabs(ab[(size_t)i * n + i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
   }
+  if (threadIdx.x == 0) tol[blockIdx.x] = 64.0 * n * 2.220446049250313e-16 * red[0];
 }
 
-// Core: a [batch][n][n], rt [batch][nrhs][n]; solution returned in rt.
-int spd_solve_rt(td_handle* h, double* a_dev, double* rt_dev, int n, int nrhs, int batch) {
+// Core: a [batch][n][n] (n a multiple of 64), rt [batch][kMaxRhs][n]; solution in sol.
+int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
+                     double* linv_dev, double* tol_dev, int n, int nrhs, int batch) {
   TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
-  const int nblk = (int)td_ceil_div(n, NB);
-  double* linv = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&linv),
-                           sizeof(double) * (size_t)batch * nblk * NB * NB);
-  if (e != hipSuccess)
-    return td_fail(h, TD_ERR_NOMEM, "cholesky workspace failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(diag_tol_kernel, dim3((unsigned)batch), dim3(256), 0, h->stream, a_dev, n,
+                     tol_dev);
+  const int nblk = n / NB;
   CholParams p;
-  p.a = a_dev; p.rt = rt_dev; p.linv = linv; p.n = n; p.nrhs = nrhs; p.nblk = nblk;
-  p.flag = h->dev_flag;
+  p.a = a_dev; p.rt = rt_dev; p.linv = linv_dev; p.sol = sol_dev; p.tol = tol_dev;
+  p.n = n; p.nrhs = nrhs; p.nblk = nblk; p.flag = h->dev_flag;
+  p.k = 0;
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(1, (unsigned)batch), dim3(256), 0, h->stream, p);
   for (int k = 0; k < nblk; ++k) {
     p.k = k;
-    // block rows k (diagonal), k+1 .. nblk-1 (real) and nblk (right-hand sides)
-    hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nblk - k + 1), (unsigned)batch),
-                       dim3(256), 0, h->stream, p);
+    // block rows k+1 .. nblk-1 and the right-hand-side row
+    hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nblk - k), (unsigned)batch), dim3(256),
+                       0, h->stream, p);
     const int rem = nblk - k - 1;
     if (rem > 0) {
       const int tri = rem * (rem + 1) / 2;
@@ -349,37 +476,63 @@ int spd_solve_rt(td_handle* h, double* a_dev, double* rt_dev, int n, int nrhs, i
     hipLaunchKernelGGL(chol_back_kernel, dim3((unsigned)(k + 1), (unsigned)batch), dim3(256), 0,
                        h->stream, p);
   }
-  int rc = TD_OK;
-  if (hipGetLastError() != hipSuccess) rc = td_fail(h, TD_ERR_HIP, "cholesky launch failed");
+  if (hipGetLastError() != hipSuccess) return td_fail(h, TD_ERR_HIP, "cholesky launch failed");
+  return TD_OK;
+}
+
+int spd_check_flag(td_handle* h) {
   int flag = 0;
-  hipMemcpyAsync(&flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream);
-  hipStreamSynchronize(h->stream);
-  hipFree(linv);
-  if (rc == TD_OK && flag)
-    rc = td_fail(h, TD_ERR_SINGULAR, "Singular matrix: covariance is not positive definite");
-  return rc;
+  TD_HIP(h, hipMemcpyAsync(&flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  if (flag)
+    return td_fail(h, TD_ERR_SINGULAR, "Singular matrix: covariance is not positive definite");
+  return TD_OK;
 }
 
-// cov = M / n + lambda I for each lambda; rhs = xty / n.
-__global__ void ridge_build_kernel(const double* __restrict__ xtx, const double* __restrict__ xty,
-                                   int n, int d, double inv_frames, const double* lambdas,
-                                   double* __restrict__ a, double* __restrict__ rhs) {
+// ---- padding / unpadding --------------------------------------------------------------
+// dst [batch][np][np] = src [batch][n][n] * scale + lambda_b * I, identity beyond n.
+__global__ void pad_matrix_kernel(const double* __restrict__ src, long long src_batch_stride,
+                                  int n, int np, double scale, const double* __restrict__ lambdas,
+                                  double* __restrict__ dst) {
   const int b = blockIdx.y;
-  const double lam = lambdas[b];
-  const long long nn = (long long)n * n;
-  double* ab = a + (size_t)b * nn;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nn;
+  const double lam = lambdas ? lambdas[b] : 0.0;
+  const double* s = src + (size_t)b * src_batch_stride;
+  double* d = dst + (size_t)b * np * np;
+  const long long total = (long long)np * np;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(i / n), c = (int)(i % n);
-    ab[i] = xtx[i] * inv_frames + (r == c ? lam : 0.0);
+    const int r = (int)(i / np), c = (int)(i % np);
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < n && c < n) v = s[(size_t)r * n + c] * scale + (r == c ? lam : 0.0);
+    d[i] = v;
   }
-  double* rb = rhs + (size_t)b * n * d;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)n * d;
-       i += (long long)gridDim.x * blockDim.x)
-    rb[i] = xty[i] * inv_frames;
 }
 
-__global__ void ridge_emit_kernel(const double* __restrict__ sol, int k1, int d, int batch,
+// rt [batch][kMaxRhs][np] = scale * rhs^T (rhs [batch][n][nrhs]), zero padded.
+__global__ void pad_rhs_kernel(const double* __restrict__ rhs, long long rhs_batch_stride, int n,
+                               int nrhs, int np, double scale, double* __restrict__ rt) {
+  const int b = blockIdx.y;
+  const double* s = rhs + (size_t)b * rhs_batch_stride;
+  double* d = rt + (size_t)b * kMaxRhs * np;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kMaxRhs * np; i += gridDim.x * blockDim.x) {
+    const int q = i / np, r = i % np;
+    d[i] = (q < nrhs && r < n) ? s[(size_t)r * nrhs + q] * scale : 0.0;
+  }
+}
+
+// rhs [batch][n][nrhs] = sol^T
+__global__ void unpad_sol_kernel(const double* __restrict__ sol, int n, int nrhs, int np,
+                                 double* __restrict__ rhs) {
+  const int b = blockIdx.y;
+  const double* s = sol + (size_t)b * kMaxRhs * np;
+  double* d = rhs + (size_t)b * n * nrhs;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * nrhs; i += gridDim.x * blockDim.x) {
+    const int r = i / nrhs, q = i % nrhs;
+    d[i] = s[(size_t)q * np + r];
+  }
+}
+
+__global__ void ridge_emit_kernel(const double* __restrict__ sol, int k1, int d, int np, int batch,
                                   float* __restrict__ w, float* __restrict__ bias) {
   const long long total = (long long)batch * (k1 + 1) * d;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -387,10 +540,30 @@ __global__ void ridge_emit_kernel(const double* __restrict__ sol, int k1, int d,
     const int q = (int)(i % d);
     const int r = (int)((i / d) % (k1 + 1));
     const int b = (int)(i / ((long long)d * (k1 + 1)));
-    const float v = (float)sol[i];
+    const float v = (float)sol[((size_t)b * kMaxRhs + q) * np + r];
     if (r < k1) w[((size_t)b * k1 + r) * d + q] = v;
     else bias[(size_t)b * d + q] = v;
   }
+}
+
+// workspace layout for a batch of padded systems
+struct SolveWs {
+  double* a; double* rt; double* sol; double* linv; double* lams; double* tol;
+  size_t bytes;
+};
+
+SolveWs carve(void* base, int np, int batch) {
+  SolveWs w;
+  char* p = reinterpret_cast<char*>(base);
+  const size_t nblk = np / NB;
+  w.a = reinterpret_cast<double*>(p);    p += sizeof(double) * (size_t)batch * np * np;
+  w.rt = reinterpret_cast<double*>(p);   p += sizeof(double) * (size_t)batch * kMaxRhs * np;
+  w.sol = reinterpret_cast<double*>(p);  p += sizeof(double) * (size_t)batch * kMaxRhs * np;
+  w.linv = reinterpret_cast<double*>(p); p += sizeof(double) * (size_t)batch * nblk * NB * NB;
+  w.lams = reinterpret_cast<double*>(p); p += sizeof(double) * td_round_up(batch, 32);
+  w.tol = reinterpret_cast<double*>(p);  p += sizeof(double) * td_round_up(batch, 32);
+  w.bytes = (size_t)(p - reinterpret_cast<char*>(base));
+  return w;
 }
 
 }  // namespace
@@ -402,21 +575,19 @@ int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, 
   TD_REQUIRE(h, n > 0 && batch > 0, "td_spd_solve: empty problem");
   TD_REQUIRE(h, nrhs > 0 && nrhs <= kMaxRhs, "td_spd_solve: nrhs must be in [1, %d], not %d",
              kMaxRhs, nrhs);
-  if (nrhs == 1) return spd_solve_rt(h, a_dev, rhs_dev, n, 1, batch);
-  double* rt = nullptr;
-  const size_t len = (size_t)batch * n * nrhs;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&rt), sizeof(double) * len);
-  if (e != hipSuccess)
-    return td_fail(h, TD_ERR_NOMEM, "rhs workspace failed: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(transpose_rhs_kernel, dim3(256), dim3(256), 0, h->stream, rhs_dev, rt, n, nrhs,
-                     batch);
-  int rc = spd_solve_rt(h, a_dev, rt, n, nrhs, batch);
-  if (rc == TD_OK)
-    hipLaunchKernelGGL(transpose_rhs_kernel, dim3(256), dim3(256), 0, h->stream, rt, rhs_dev, nrhs,
-                       n, batch);
-  hipStreamSynchronize(h->stream);
-  hipFree(rt);
-  return rc;
+  const int np = (int)td_round_up(n, NB);
+  void* base = nullptr;
+  TD_TRY(td_workspace(h, carve(nullptr, np, batch).bytes, &base));
+  const SolveWs w = carve(base, np, batch);
+  hipLaunchKernelGGL(pad_matrix_kernel, dim3(512, (unsigned)batch), dim3(256), 0, h->stream, a_dev,
+                     (long long)n * n, n, np, 1.0, (const double*)nullptr, w.a);
+  hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)batch), dim3(256), 0, h->stream, rhs_dev,
+                     (long long)n * nrhs, n, nrhs, np, 1.0, w.rt);
+  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, nrhs, batch));
+  hipLaunchKernelGGL(unpad_sol_kernel, dim3(16, (unsigned)batch), dim3(256), 0, h->stream, w.sol, n,
+                     nrhs, np, rhs_dev);
+  TD_HIP(h, hipGetLastError());
+  return spd_check_flag(h);
 }
 
 int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
@@ -428,39 +599,31 @@ int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_
   td_stats_layout(s, &k1, &d, &frames);
   TD_REQUIRE(h, n_lambda > 0, "td_ridge_solve: need at least one lambda");
   TD_REQUIRE(h, d > 0, "td_ridge_solve: statistics were created without a target (d = 0)");
+  TD_REQUIRE(h, d <= kMaxRhs, "td_ridge_solve: at most %d outputs per solve, not %d", kMaxRhs, d);
   if (frames <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve: no data accumulated");
   const int n = k1 + 1;
+  const int np = (int)td_round_up(n, NB);
   const size_t nn = (size_t)n * n;
-  // scratch: [xtx nn][xty n*d][lambdas][a batch*nn][rhs batch*n*d]
-  const size_t lam_slots = td_round_up(n_lambda, 32);
-  const size_t doubles = nn + (size_t)n * d + lam_slots + (size_t)n_lambda * (nn + (size_t)n * d);
-  // The moments use their own scratch-free outputs: allocate a dedicated block
-  // (td_scratch is used by nested calls).
-  double* block = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&block), sizeof(double) * doubles);
-  if (e != hipSuccess)
-    return td_fail(h, TD_ERR_NOMEM, "ridge workspace of %zu bytes failed: %s",
-                   sizeof(double) * doubles, hipGetErrorString(e));
-  double* xtx = block;
+  // workspace (grow-only, owned by the handle): [xtx nn][xty n*d][padded systems ...]
+  const size_t head = td_round_up((int64_t)(sizeof(double) * (nn + (size_t)n * d)), 256);
+  void* base = nullptr;
+  TD_TRY(td_workspace(h, head + carve(nullptr, np, n_lambda).bytes, &base));
+  double* xtx = reinterpret_cast<double*>(base);
   double* xty = xtx + nn;
-  double* lams = xty + (size_t)n * d;
-  double* a = lams + lam_slots;
-  double* rhs = a + (size_t)n_lambda * nn;
-  int rc = td_stats_moments(h, s, xtx, xty, nullptr, nullptr, nullptr);
-  if (rc == TD_OK) rc = td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, lams);
-  if (rc == TD_OK) {
-    hipLaunchKernelGGL(ridge_build_kernel, dim3(1024, (unsigned)n_lambda), dim3(256), 0, h->stream,
-                       xtx, xty, n, d, 1.0 / (double)frames, lams, a, rhs);
-    rc = td_spd_solve(h, a, rhs, n, d, n_lambda);
-  }
-  if (rc == TD_OK) {
-    hipLaunchKernelGGL(ridge_emit_kernel, dim3(256), dim3(256), 0, h->stream, rhs, k1, d, n_lambda,
-                       w_dev, b_dev);
-    if (hipGetLastError() != hipSuccess) rc = td_fail(h, TD_ERR_HIP, "ridge_emit launch failed");
-  }
-  hipStreamSynchronize(h->stream);
-  hipFree(block);
-  return rc;
+  const SolveWs w = carve(reinterpret_cast<char*>(base) + head, np, n_lambda);
+  TD_TRY(td_stats_moments(h, s, xtx, xty, nullptr, nullptr, nullptr));
+  TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, w.lams));
+  const double inv = 1.0 / (double)frames;
+  // cov = M / n + lambda I for each lambda (same xtx for the whole batch: stride 0); rhs = xty / n
+  hipLaunchKernelGGL(pad_matrix_kernel, dim3(512, (unsigned)n_lambda), dim3(256), 0, h->stream, xtx,
+                     0LL, n, np, inv, w.lams, w.a);
+  hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)n_lambda), dim3(256), 0, h->stream, xty, 0LL,
+                     n, d, np, inv, w.rt);
+  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, d, n_lambda));
+  hipLaunchKernelGGL(ridge_emit_kernel, dim3(256), dim3(256), 0, h->stream, w.sol, k1, d, np,
+                     n_lambda, w_dev, b_dev);
+  TD_HIP(h, hipGetLastError());
+  return spd_check_flag(h);
 }
 
 }  // extern "C"

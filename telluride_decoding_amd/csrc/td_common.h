@@ -22,6 +22,10 @@ struct td_handle {
   // grow-only device scratch (partial slabs, expanded matrices, ...)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // second grow-only arena for the solver workspaces (its users call functions that
+  // use `scratch` themselves)
+  void* work = nullptr;
+  size_t work_bytes = 0;
   // ring of pinned host staging slots for small parameter tables (work lists):
   // a slot is reused only after the copy that read it has completed.
   struct PinSlot {
@@ -71,6 +75,9 @@ int td_fail(td_handle* h, int code, const char* fmt, ...);
 // Scratch: returns a device pointer valid until the next td_scratch call that
 // needs more room (stream-ordered reuse is safe: one stream per handle).
 int td_scratch(td_handle* h, size_t bytes, void** out);
+
+// Solver workspace: like td_scratch, a separate arena.
+int td_workspace(td_handle* h, size_t bytes, void** out);
 
 // Stream-ordered upload of a small host block (work tables, parameters) through
 // the pinned ring; the host block may be reused as soon as this returns.
