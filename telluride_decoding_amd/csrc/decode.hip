@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NL * DQ == 32 ? 256 : 128) void predict_fir_wave_ke
     const float* __restrict__ w, const float* __restrict__ bias, int d_total, int q0, int dq,
     int accumulate, float* __restrict__ out, long long ldout) {
   constexpr int V = NL * DQ;          // completed values per body and lane (32 or 64)
-  constexpr int P = NL < 8 ? NL : 8;  // rows of load prefetch (divides NL)
+  constexpr int P = NL;               // rows of load prefetch: a whole body (HBM latency, see lagcov.hip)
   static_assert(V == 32 || V == 64, "tile width");
   extern __shared__ float wave_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -398,12 +398,15 @@ __global__ __launch_bounds__(NL * DQ == 32 ? 256 : 128) void predict_fir_wave_ke
   const long long u0 = ts - pre;
   const int n_rows = st_len + NL - 1;
   const int n_body = (n_rows + NL - 1) / NL;
+  // unconditional loads from a clamped row; validity applied as a 0/1 factor at use (a
+  // select on the loaded value makes hipcc branch around the load and wait on the spot)
   auto load_row = [&](long long u) -> float {
-    const bool ok = u >= 0 && u < st.nrows;           // wave-uniform
-    const float* rowp = x + (st.row0 + (ok ? u : 0)) * ldx;   // wave-uniform base
-    const float v = rowp[voff];
-    return ok ? v : 0.f;
+    long long uc = u < st.nrows ? u : st.nrows - 1;
+    uc = uc < 0 ? 0 : uc;
+    const float* rowp = x + (st.row0 + uc) * ldx;             // wave-uniform base
+    return rowp[voff];
   };
+  auto row_mask = [&](long long u) -> float { return (u >= 0 && u < st.nrows) ? 1.f : 0.f; };
   float xr[P];
 #pragma unroll
   for (int k = 0; k < P; ++k) xr[k] = load_row(u0 + k);
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(NL * DQ == 32 ? 256 : 128) void predict_fir_wave_ke
     const long long ub = u0 + (long long)b * NL;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const float xv = xr[i % P];
+      const float xv = xr[i % P] * row_mask(ub + i);
       xr[i % P] = load_row(ub + i + P);
       // tap l of row i belongs to the output in slot (i - l) mod NL
 #pragma unroll

@@ -388,30 +388,229 @@ __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
   }
 }
 
+// ---- regression targets: [y]^T x~ per signed lag, lane = channel -----------------------
+//   G[e - e_min][i][j] = sum_{u in [us, ue)} Y~[u][i] * X~[u + e][j]      (i < NI target columns)
+// One WAVE streams the rows v = us + e_min .. of its strip of X (one coalesced 256-byte load
+// per row: lane j gets x[v][j]) and keeps E running sums per target in registers: row v adds
+// x[v][j] * y[v - e] to the sum of every lag e.  The y values are the same for all lanes: the
+// strip's targets sit in a wave-private LDS line (broadcast reads) and move through a ring of
+// E registers whose slot indices are compile-time constants in the unrolled body.  Rows of Y
+// outside [us, ue) are zero, which handles every strip and file edge.  The kernel also
+// returns the plain column sums of X over [us, ue) and of Y: the all-ones row of [y | 1]^T x~
+// (the bias moments) follows from those and the per-file boundary windows (stats.hip) instead
+// of a second set of FMAs.  f32 FMA chains of at most kWaveStrip rows, summed in float64 by
+// the reduction kernels.
+// (The first version was an LDS-tiled workgroup kernel whose FMAs each read an operand from
+// LDS: 233 us at C2 for 8 GFLOP.)
+constexpr int kWaveStrip = 512;
+
+template <int E, int NI>
+__global__ __launch_bounds__(kThreads) void lagcov_wave_kernel(LagParams p, double* __restrict__ part64,
+                                                              double* __restrict__ csum,
+                                                              double* __restrict__ ysum) {
+  // rows of load prefetch: a row is one 256-byte load, HBM latency ~2 us -- with 8 rows in
+  // flight per wave the kernel was latency-bound at 0.85 TB/s
+  constexpr int P = 32;
+  constexpr int NY = NI > 0 ? NI : 1;
+  constexpr int kRowsMax = ((kWaveStrip + 2 * E - 2) / E) * E;   // whole bodies
+  __shared__ float ylds[kThreads / 64][kRowsMax * NY];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  long long id = blockIdx.x * (long long)(kThreads / 64) + wave;
+  if (id >= (long long)p.n_work * p.n_cbt) return;
+  const int cbt = (int)(id % p.n_cbt);
+  const int wi = (int)(id / p.n_cbt);
+  const LagWork w = p.works[wi];
+  const int len = (int)(w.u_end - w.u_begin);
+  const int n_body = (len + E - 1 + E - 1) / E;      // rows streamed: len + E - 1, whole bodies
+  float* ya = ylds[wave];
+
+  // targets of the strip, zero outside [u_begin, u_end) and beyond the stream
+  if (NI > 0) {
+    for (int t = lane; t < n_body * E; t += 64) {
+      const long long u = w.u_begin + t;
+      const bool ok = t < len && u >= 0 && u < w.a_valid;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        ya[t * NY + i] = (ok && i < p.ca) ? p.a[(w.a_row0 + (ok ? u : 0)) * p.lda + (i < p.ca ? i : 0)] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (cbt == 0 && ysum) {
+      // column sums of Y over the strip (float64), lane-strided + shuffle tree
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        double sy = 0.0;
+        for (int t = lane; t < len; t += 64) sy += (double)ya[t * NY + i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sy += __shfl_down(sy, off, 64);
+        if (lane == 0) ysum[(size_t)wi * NI + i] = sy;
+      }
+    }
+  }
+
+  const int cg = cbt * 64 + lane;
+  const bool ch_ok = cg < p.cb;
+  const int voff = ch_ok ? cg : cbt * 64;
+  const long long vs = w.u_begin + p.e_min;           // first streamed row
+  // Loads are unconditional (row index clamped into the stream) and the row's validity is
+  // applied as a 0/1 factor when the value is USED: a select on the loaded value makes hipcc
+  // branch around the load and wait for it on the spot (vmcnt(0) after every load: no
+  // prefetch at all, 0.8 TB/s).
+  auto load_row = [&](long long v) -> float {
+    long long vc = v < w.b_valid ? v : w.b_valid - 1;
+    vc = vc < 0 ? 0 : vc;
+    const float* rowp = p.b + (w.b_row0 + vc) * p.ldb;    // wave-uniform base
+    return rowp[voff];
+  };
+  auto row_mask = [&](long long v) -> float { return (v >= 0 && v < w.b_valid) ? 1.f : 0.f; };
+  // f32 FMA chains of one body (E rows), flushed into float64 sums after every body: the
+  // targets correlate with x, so the running sums drift away from zero and a long f32 chain
+  // loses ~1e-7 relative (which the ridge solve amplifies)
+  float acc[E][NY], ring[E][NY];
+  double acc64[E][NY];
+#pragma unroll
+  for (int k = 0; k < E; ++k)
+#pragma unroll
+    for (int i = 0; i < NY; ++i) { acc[k][i] = 0.f; ring[k][i] = 0.f; acc64[k][i] = 0.0; }
+  double cs = 0.0;   // column sum of x over [u_begin, u_end): float64 (it feeds the bias moments)
+  float xr[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) xr[k] = load_row(vs + k);
+  const int t_lo = -p.e_min, t_hi = len - p.e_min;    // rows of [u_begin, u_end) in stream time
+
+  for (int b = 0; b < n_body; ++b) {
+    const int tb = b * E;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+      const float xv = xr[s % P] * row_mask(vs + tb + s);
+      xr[s % P] = load_row(vs + tb + s + P);
+      const int t = tb + s;
+      cs += (t >= t_lo && t < t_hi) ? (double)xv : 0.0;
+      if (NI > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) ring[s][i] = ya[t * NY + i];
+        // lag e_min + k pairs row v with the target k rows back: ring slot (s - k) mod E
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+            acc[k][i] = fmaf(xv, ring[(s - k) & (E - 1)][i], acc[k][i]);
+      }
+    }
+    if (NI > 0) {
+#pragma unroll
+      for (int k = 0; k < E; ++k)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { acc64[k][i] += (double)acc[k][i]; acc[k][i] = 0.f; }
+    }
+  }
+  if (ch_ok || true) {
+    if (NI > 0) {
+      double* slab = part64 + (size_t)wi * p.e_pad * p.ca_pad * p.cb_pad;
+#pragma unroll
+      for (int k = 0; k < E; ++k)
+        if (k < p.e_count) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+            slab[((size_t)k * p.ca_pad + i) * p.cb_pad + cbt * 64 + lane] = acc64[k][i];
+        }
+    }
+    csum[(size_t)wi * p.cb_pad + cbt * 64 + lane] = cs;
+  }
+}
+
+// per-file float64 column sums from the per-strip float32 ones: out[f][j] (+)= sum over the
+// strips of file f
+// (one workgroup per file and 64-channel tile: 4 strip-strided partial sums per channel,
+// combined in a fixed order)
+__global__ __launch_bounds__(256) void colsum_file_reduce_kernel(
+    const double* __restrict__ csum, int cb_pad, int cb, const int* __restrict__ file_work0,
+    double* __restrict__ out) {
+  __shared__ double part[4][64];
+  const int f = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  double s = 0.0;
+  if (j < cb)
+    for (int wk = file_work0[f] + q; wk < file_work0[f + 1]; wk += 4) s += csum[(size_t)wk * cb_pad + j];
+  part[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && j < cb)
+    out[(size_t)f * cb + j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                              (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// sy[i] (+)= sum over strips; one workgroup per target column
+__global__ __launch_bounds__(256) void ysum_reduce_kernel(const double* __restrict__ ysum, int n_work,
+                                                          int ni, double* __restrict__ sy,
+                                                          int accumulate) {
+  __shared__ double red[256];
+  const int i = blockIdx.x;
+  double s = 0.0;
+  for (int wk = threadIdx.x; wk < n_work; wk += 256) s += ysum[(size_t)wk * ni + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sy[i] = accumulate ? sy[i] + red[0] : red[0];
+}
+
 // ---- slab reduction in float64 ----------------------------------------------
-__global__ void lagcov_reduce_kernel(const float* __restrict__ partial, int n_work, int e_pad,
-                                     int ca_pad, int cb_pad, int e_count, int ca_eff, int cb,
-                                     double* __restrict__ g, int accumulate) {
+// Workgroup = 64 consecutive outputs x Q slab phases: thread (o, q) sums slabs q, q + Q, ...
+// (four independent chains for memory-level parallelism), the Q partial sums of an output
+// are combined through LDS in a fixed order: bitwise reproducible, no float atomics.
+template <typename T, int Q>
+__global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
+    const T* __restrict__ partial, int n_work, int e_pad, int ca_pad, int cb_pad, int e_count,
+    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst) {
+  __shared__ double part[Q][64];
   const long long total = (long long)e_count * ca_eff * cb;
   const size_t slab = (size_t)e_pad * ca_pad * cb_pad;
-  for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total;
-       o += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(o % cb);
-    const int i = (int)((o / cb) % ca_eff);
-    const int e = (int)(o / ((long long)cb * ca_eff));
-    const float* src = partial + ((size_t)e * ca_pad + i) * cb_pad + j;
+  const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long long o = blockIdx.x * 64LL + ol;
+  double s = 0.0;
+  int j = 0, i = 0, e = 0;
+  if (o < total) {
+    j = (int)(o % cb);
+    i = (int)((o / cb) % ca_eff);
+    e = (int)(o / ((long long)cb * ca_eff));
+    const T* src = partial + ((size_t)e * ca_pad + i) * cb_pad + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int w = 0;
-    for (; w + 3 < n_work; w += 4) {
-      s0 += (double)src[(size_t)(w + 0) * slab];
-      s1 += (double)src[(size_t)(w + 1) * slab];
-      s2 += (double)src[(size_t)(w + 2) * slab];
-      s3 += (double)src[(size_t)(w + 3) * slab];
+    int w = q;
+    for (; w + 3 * Q < n_work; w += 4 * Q) {
+      s0 += (double)src[(size_t)(w + 0 * Q) * slab];
+      s1 += (double)src[(size_t)(w + 1 * Q) * slab];
+      s2 += (double)src[(size_t)(w + 2 * Q) * slab];
+      s3 += (double)src[(size_t)(w + 3 * Q) * slab];
     }
-    for (; w < n_work; ++w) s0 += (double)src[(size_t)w * slab];
-    const double s = (s0 + s1) + (s2 + s3);
-    g[o] = accumulate ? g[o] + s : s;
+    for (; w < n_work; w += Q) s0 += (double)src[(size_t)w * slab];
+    s = (s0 + s1) + (s2 + s3);
   }
+  part[q][ol] = s;
+  __syncthreads();
+  if (q == 0 && o < total) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) t += part[k][ol];
+    double* dst = g + ((long long)e * ca_dst + i) * cb + j;   // ca_dst >= ca_eff rows per lag
+    *dst = accumulate ? *dst + t : t;
+  }
+}
+
+template <typename T>
+void launch_lagcov_reduce(td_handle* h, const T* partial, int n_work, int e_pad, int ca_pad,
+                          int cb_pad, int e_count, int ca_eff, int cb, double* g, bool accumulate,
+                          int ca_dst) {
+  const long long outs = (long long)e_count * ca_eff * cb;
+  const unsigned blocks = (unsigned)td_ceil_div(outs, 64);
+  if (outs < 32768)
+    hipLaunchKernelGGL((lagcov_reduce_kernel<T, 16>), dim3(blocks), dim3(1024), 0, h->stream, partial,
+                       n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
+                       ca_dst);
+  else
+    hipLaunchKernelGGL((lagcov_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 0, h->stream, partial,
+                       n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
+                       ca_dst);
 }
 
 // ---- float64 column sums (sum of y over the rows that enter the fit) --------
@@ -566,12 +765,87 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
     TD_TRY(td_profile_mark(h, false, 0.0));
   }
   TD_HIP(h, hipGetLastError());
-  const long long outs = (long long)e_count * ca_eff * cb;
-  int rblocks = (int)td_ceil_div(outs, 256);
-  if (rblocks > 4096) rblocks = 4096;
-  hipLaunchKernelGGL(lagcov_reduce_kernel, dim3(rblocks), dim3(256), 0, h->stream, p.partial,
-                     p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff, cb, g_dev,
-                     accumulate ? 1 : 0);
+  launch_lagcov_reduce<float>(h, p.partial, p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff, cb,
+                              g_dev, accumulate, ca_eff);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+// Targets path (see lagcov_wave_kernel).  g_dev is [e_count][d + 1][cb]: rows i < d receive
+// y_i^T x~ (accumulated), row d (the all-ones row) is left to the caller, who gets the
+// per-segment column sums of B over [u_begin, u_end) in colsum_seg_dev [n_segs][cb]
+// (overwritten) and, if sy_dev, the accumulated column sums of Y.  Returns TD_ERR_STATE-free
+// false in *handled when the shape needs the generic kernel (more than 32 lags / 4 targets).
+int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
+                      int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled) {
+  *handled = false;
+  if (e_count > 32 || d > 4 || e_min > 0 || e_min + e_count - 1 < 0) return TD_OK;
+  *handled = true;
+  if (segs.empty()) return TD_OK;
+  const int n_segs = (int)segs.size();
+  // strips of kWaveStrip rows; every segment gets at least one (possibly empty) strip so
+  // that the per-segment column sums are defined
+  std::vector<LagWork> works;
+  std::vector<int> seg_work0(n_segs + 1, 0);
+  for (int f = 0; f < n_segs; ++f) {
+    seg_work0[f] = (int)works.size();
+    std::vector<LagSeg> one(1, segs[f]);
+    std::vector<LagWork> ws = split_work(one, kWaveStrip);
+    works.insert(works.end(), ws.begin(), ws.end());
+  }
+  seg_work0[n_segs] = (int)works.size();
+  const int n_work = (int)works.size();
+  if (n_work == 0) {
+    TD_HIP(h, hipMemsetAsync(colsum_seg_dev, 0, sizeof(double) * n_segs * cb, h->stream));
+    return TD_OK;
+  }
+  const int ni = d > 0 ? 1 : 0;     // one target column per launch (float64 sums: 2 VGPRs per lag)
+  LagParams p;
+  p.a = y; p.b = b; p.lda = ldy; p.ldb = ldb; p.ca = d; p.cb = cb; p.a_ones = 0;
+  p.e_min = e_min; p.e_count = e_count;
+  p.n_groups = 1; p.n_cat = 1; p.n_cbt = (int)td_ceil_div(cb, 64);
+  p.e_pad = e_count; p.ca_pad = ni > 0 ? ni : 1; p.cb_pad = p.n_cbt * 64;
+  p.n_work = n_work;
+  const size_t slab_elems = ni > 0 ? (size_t)p.e_pad * p.ca_pad * p.cb_pad : 0;
+  const size_t s_tab = td_round_up(works.size() * sizeof(LagWork), 256);
+  const size_t s_seg = td_round_up((n_segs + 1) * sizeof(int), 256);
+  const size_t s_part = td_round_up(slab_elems * n_work * sizeof(double), 256);
+  const size_t s_cs = td_round_up((size_t)n_work * p.cb_pad * sizeof(double), 256);
+  const size_t s_ys = td_round_up((size_t)n_work * (ni > 0 ? ni : 1) * sizeof(double), 256);
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, s_tab + s_seg + s_part + s_cs + s_ys, &scratch));
+  char* base = reinterpret_cast<char*>(scratch);
+  TD_TRY(td_upload_async(h, works.data(), works.size() * sizeof(LagWork), base));
+  TD_TRY(td_upload_async(h, seg_work0.data(), (n_segs + 1) * sizeof(int), base + s_tab));
+  p.works = reinterpret_cast<const LagWork*>(base);
+  const int* d_seg = reinterpret_cast<const int*>(base + s_tab);
+  p.partial = nullptr;
+  double* part64 = reinterpret_cast<double*>(base + s_tab + s_seg);
+  double* csum = reinterpret_cast<double*>(base + s_tab + s_seg + s_part);
+  double* ysum = reinterpret_cast<double*>(base + s_tab + s_seg + s_part + s_cs);
+  const unsigned blocks = (unsigned)td_ceil_div((int64_t)n_work * p.n_cbt, kThreads / 64);
+  if (ni == 0) {
+    hipLaunchKernelGGL((lagcov_wave_kernel<32, 0>), dim3(blocks), dim3(kThreads), 0, h->stream, p,
+                       part64, csum, ysum);
+  } else {
+    for (int i = 0; i < d; ++i) {
+      // target column i: A = y + i (one column), output row i of every lag
+      LagParams pi = p;
+      pi.a = y + i;
+      pi.ca = 1;
+      hipLaunchKernelGGL((lagcov_wave_kernel<32, 1>), dim3(blocks), dim3(kThreads), 0, h->stream, pi,
+                         part64, csum, ysum);
+      launch_lagcov_reduce<double>(h, part64, n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, 1, cb,
+                                   g_dev + (size_t)i * cb, true, d + 1);
+      if (sy_dev)
+        hipLaunchKernelGGL(ysum_reduce_kernel, dim3(1), dim3(256), 0, h->stream, ysum, n_work, 1,
+                           sy_dev + i, 1);
+    }
+  }
+  TD_HIP(h, hipGetLastError());
+  hipLaunchKernelGGL(colsum_file_reduce_kernel, dim3((unsigned)n_segs, (unsigned)p.n_cbt), dim3(256), 0,
+                     h->stream, csum, p.cb_pad, cb, d_seg, colsum_seg_dev);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

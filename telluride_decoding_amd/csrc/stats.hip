@@ -59,6 +59,53 @@ __global__ void gather_windows_kernel(const float* __restrict__ x, long long ld,
   }
 }
 
+// The all-ones row of [y | 1]^T x~ (the bias moments, lagged column sums of x) for the files
+// just added, from their column sums over the rows that enter the fit and their boundary
+// windows (x~ zero-extended outside the file):
+//   sum_{t=0}^{N'-1} x~[t+e] = colsum[0,N') - sum_{v<e} x[v] + sum_{v=N'}^{N'+e-1} x~[v]   (e > 0)
+//                            = colsum[0,N') - sum_{v=N'+e}^{N'-1} x[v]                     (e < 0)
+// g is [l][rows][c]; the ones row is row `row`.
+// Two launches: (file, lag, channel) contributions in parallel, then a fixed-order sum over
+// the files.
+__global__ void ones_contrib_kernel(int c, int l, int e_min, const double* __restrict__ colsum_seg,
+                                    const float* __restrict__ win, int hw, long long first_slot,
+                                    double* __restrict__ contrib) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= l * c) return;
+  const int f = blockIdx.y;
+  const int k = idx / c, j = idx % c;
+  const int e = e_min + k;
+  double v = colsum_seg[(size_t)f * c + j];
+  const float* head = win + ((first_slot + f) * 2 + 0) * (long long)(2 * hw) * c;
+  const float* tail = win + ((first_slot + f) * 2 + 1) * (long long)(2 * hw) * c;
+  for (int m = 0; m < e; ++m)
+    v += (double)tail[(long long)(m + hw) * c + j] - (double)head[(long long)(m + hw) * c + j];
+  for (int m = e; m < 0; ++m) v -= (double)tail[(long long)(m + hw) * c + j];
+  contrib[(size_t)f * l * c + idx] = v;
+}
+
+// g is [l][rows][c]; the ones row is row `row`.
+__global__ void ones_rows_kernel(double* __restrict__ g, int rows, int row, int c, int l,
+                                 const double* __restrict__ contrib, int n_files) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= l * c) return;
+  const int k = idx / c, j = idx % c;
+  double s = 0.0;
+  for (int f = 0; f < n_files; ++f) s += contrib[(size_t)f * l * c + idx];
+  g[((long long)k * rows + row) * c + j] += s;
+}
+
+// Launches both; `contrib` is caller-provided device memory of n_files * l * c doubles.
+inline void launch_ones_rows(td_handle* h, double* g, int rows, int row, int c, int l, int e_min,
+                             const double* colsum_seg, const float* win, int hw, long long first_slot,
+                             int n_files, double* contrib) {
+  const unsigned bx = (unsigned)td_ceil_div((int64_t)l * c, 256);
+  hipLaunchKernelGGL(ones_contrib_kernel, dim3(bx, (unsigned)n_files), dim3(256), 0, h->stream, c, l,
+                     e_min, colsum_seg, win, hw, first_slot, contrib);
+  hipLaunchKernelGGL(ones_rows_kernel, dim3(bx), dim3(256), 0, h->stream, g, rows, row, c, l, contrib,
+                     n_files);
+}
+
 // Expansion in two phases (both fill the chip, neither depends on the number of
 // files beyond phase 1's short loop):
 //   1. edge_outer_kernel: D[s][e] = the edge correction that lag step s adds,
@@ -427,23 +474,7 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
     j2[f].row0 = r0 + dy; j2[f].valid = vy; j2[f].nprime = np;
   }
 
-  // F'xx: lagged auto-covariance of x (the MFMA kernel).
-  TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
-                   s->g + s->off_fxx, true));
-  // [y | 1]^T x~ for every signed lag: Xty and the lagged column sums.
-  TD_TRY(td_lagcov(h, y_dev, ldy, s->d, true, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
-                   s->g + s->off_gxo, true));
-  if (s->d) TD_TRY(td_colsum(h, y_dev, ldy, s->d, syx, s->g + s->off_sy, true));
-  if (s->c2) {
-    TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
-                     s->g + s->off_fyy, true));
-    TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x2_dev, ldx2, s->c2, sxy,
-                     -(s->post1 + s->pre2), s->l1 + s->l2 - 1, s->g + s->off_gxy, true));
-    TD_TRY(td_lagcov(h, nullptr, 0, 0, true, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
-                     s->g + s->off_gyo, true));
-  }
-
-  // Boundary windows of the new files.
+  // Boundary windows of the new files (also feed the all-ones rows below).
   TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
   {
     void* scratch = nullptr;
@@ -462,6 +493,48 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
                          (long long)s->n_files);
     }
     TD_HIP(h, hipGetLastError());
+  }
+
+  // F'xx: lagged auto-covariance of x (the MFMA kernel).
+  TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
+                   s->g + s->off_fxx, true));
+  // [y | 1]^T x~ for every signed lag: Xty and the lagged column sums.  Per-file column
+  // sums of x live in the solver workspace arena (td_scratch is used by the kernels' own
+  // tables and partial slabs).
+  void* ws = nullptr;
+  const int cmax = s->c1 > s->c2 ? s->c1 : s->c2;
+  const int lmax = s->l1 > s->l2 ? s->l1 : s->l2;
+  TD_TRY(td_workspace(h, sizeof(double) * (size_t)num_files * cmax * (1 + lmax), &ws));
+  double* colsum_seg = reinterpret_cast<double*>(ws);
+  double* contrib = colsum_seg + (size_t)num_files * cmax;
+  bool handled = false;
+  TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
+                           s->g + s->off_gxo, s->d ? s->g + s->off_sy : nullptr, colsum_seg,
+                           &handled));
+  if (handled) {
+    launch_ones_rows(h, s->g + s->off_gxo, s->d + 1, s->d, s->c1, s->l1, -s->pre1, colsum_seg,
+                     s->win1, s->hw, (long long)s->n_files, num_files, contrib);
+    TD_HIP(h, hipGetLastError());
+  } else {
+    TD_TRY(td_lagcov(h, y_dev, ldy, s->d, true, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
+                     s->g + s->off_gxo, true));
+    if (s->d) TD_TRY(td_colsum(h, y_dev, ldy, s->d, syx, s->g + s->off_sy, true));
+  }
+  if (s->c2) {
+    TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
+                     s->g + s->off_fyy, true));
+    TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x2_dev, ldx2, s->c2, sxy,
+                     -(s->post1 + s->pre2), s->l1 + s->l2 - 1, s->g + s->off_gxy, true));
+    TD_TRY(td_lagcov_targets(h, nullptr, 0, 0, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
+                             s->g + s->off_gyo, nullptr, colsum_seg, &handled));
+    if (handled) {
+      launch_ones_rows(h, s->g + s->off_gyo, 1, 0, s->c2, s->l2, -s->pre2, colsum_seg, s->win2,
+                       s->hw, (long long)s->n_files, num_files, contrib);
+      TD_HIP(h, hipGetLastError());
+    } else {
+      TD_TRY(td_lagcov(h, nullptr, 0, 0, true, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
+                       s->g + s->off_gyo, true));
+    }
   }
   s->n_files += num_files;
   s->frames += new_frames;

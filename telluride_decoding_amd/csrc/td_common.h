@@ -109,6 +109,13 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
               double* g_dev, bool accumulate);
 
+// [y]^T x~ per signed lag on the lane-per-channel kernel, plus the per-segment column sums
+// of B over [u_begin, u_end) and the column sums of Y (lagcov.hip).  *handled = false when
+// the shape is outside that kernel's range (nothing was done).
+int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
+                      int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled);
+
 // Column sums in float64 of rows [r0, r1) per segment (lagcov.hip).
 int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vector<LagSeg>& segs,
               double* out_dev, bool accumulate);
