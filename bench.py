@@ -9,6 +9,12 @@ statistics] -> edge-exact expansion -> float64 Cholesky solve -> W, b.  Inputs a
 resident in HBM before the timed region.  Weak scaling: every GPU holds its own
 1e6 samples (10 recordings x 100 000 frames), `value` is the whole-job samples/s.
 
+Consecutive fits are independent (the reference refits from scratch per fold /
+lambda / subject), so by default they are software-pipelined on two HIP streams
+(pipeline.FitPipeline): the latency-bound solve of fit i runs underneath the
+throughput-bound accumulate of fit i + 1.  All K fits, solves included, complete
+inside the timed region.  --serial runs them back to back on one stream.
+
 The JSON line also carries
   roofline      the dominant kernel (lagcov MFMA accumulate) timed live with
                 hipEvents on the stream it runs on (td_profile_*),
@@ -141,6 +147,10 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--no-decode', action='store_true', help='skip the informational decode leg')
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
+  ap.add_argument('--solve-cus', type=int, default=32,
+                  help='CUs set aside for the solve stream of the pipeline (0 = no CU masks)')
+  ap.add_argument('--serial', action='store_true',
+                  help='one stream, fits back to back (no accumulate/solve overlap)')
   args = ap.parse_args()
 
   import torch
@@ -159,7 +169,6 @@ def main():
   eeg, env, offs = make_workload(rank)
   x, y = h.to_device(eeg), h.to_device(env)
   plan = distributed.ShardPlan([FRAMES_PER_FILE] * (FILES_PER_GPU * world), world)
-  st = device.LagStats(C, PRE, POST, d=D, handle=h)
   lam = [LAMBDA]
 
   def barrier():
@@ -168,24 +177,43 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
-  def step():
-    st.reset()
-    st.accumulate(x, None, y, offs)
-    if world > 1:
-      distributed.allreduce_stats(st, plan, rank)
-    return st.ridge_solve(lam)
+  if args.serial:
+    st = device.LagStats(C, PRE, POST, d=D, handle=h)
+    h_prof = h
 
-  for _ in range(args.warmup):
-    w, b = step()
-  h.profile_enable(True)
+    def run(k):
+      out = None
+      for _ in range(k):
+        st.reset()
+        st.accumulate(x, None, y, offs)
+        if world > 1:
+          distributed.allreduce_stats(st, plan, rank)
+        out = st.ridge_solve(lam)
+      return out
+  else:
+    from telluride_decoding_amd import pipeline
+    pipe = pipeline.FitPipeline(
+        C, PRE, POST, d=D, solve_cus=args.solve_cus,
+        allreduce=(lambda s: distributed.allreduce_stats(s, plan, rank)) if world > 1 else None)
+    h_prof = pipe.h_acc
+
+    def run(k):
+      out = None
+      for _ in range(k):
+        r = pipe.submit(x, y, offs, lam)
+        out = r if r is not None else out
+      r = pipe.flush()                      # every fit is solved before the clock stops
+      return r if r is not None else out
+
+  w, b = run(args.warmup) if args.warmup > 0 else (None, None)
+  h_prof.profile_enable(True)
   barrier()
   t0 = time.perf_counter()
-  for _ in range(args.steps):
-    w, b = step()
+  w, b = run(args.steps)
   barrier()
   elapsed = time.perf_counter() - t0
-  launches, kernel_ms, kernel_samples = h.profile_read()
-  h.profile_enable(False)
+  launches, kernel_ms, kernel_samples = h_prof.profile_read()
+  h_prof.profile_enable(False)
   if world > 1:
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,6 +244,7 @@ def main():
             'samples_per_gpu': FILES_PER_GPU * FRAMES_PER_FILE, 'channels': C, 'lags': POST + 1,
             'parallelism': ('recordings sharded over %d GPU(s), one all-reduce of the packed '
                             'statistics' % world) if world > 1 else 'single GPU',
+            'pipelining': 'serial' if args.serial else 'accumulate(i+1) || solve(i) on two HIP streams',
         },
         'roofline': {
             'kernel': 'lagcov_mfma_kernel', 'bound': 'mfma', 'achieved': achieved,

@@ -60,6 +60,14 @@ const char* td_last_error(const td_handle* h); /* h may be NULL: last global */
  * td_use_own_stream goes back to the private one. */
 int td_set_stream(td_handle* h, void* hip_stream);
 int td_use_own_stream(td_handle* h);
+/* A HIP stream restricted to CUs [cu_first, cu_first + cu_count) of the device
+ * (hipExtStreamCreateWithCUMask), for running the latency-bound solve stage beside the
+ * throughput-bound accumulate stage of the next fit (pipeline.FitPipeline): a grid
+ * that fills every CU otherwise starves the other stream until it has drained.  The
+ * reference has no counterpart (single Python thread, regression.py:151-242 refits
+ * serially).  *stream_out is a hipStream_t; free it with td_stream_destroy. */
+int td_stream_create_masked(int device_id, int cu_first, int cu_count, void** stream_out);
+int td_stream_destroy(void* hip_stream);
 int td_synchronize(td_handle* h);
 
 /* Device memory helpers for callers that do not bring their own allocator. */

@@ -65,7 +65,10 @@ int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst)
     if (slot.p) TD_HIP(h, hipHostFree(slot.p));
     slot.p = nullptr;
     slot.bytes = 0;
-    const size_t want = bytes * 2 < 16384 ? 16384 : bytes * 2;
+    // generous first size: growing a slot later means hipHostFree + hipHostMalloc, which
+    // wait for the device -- with 16 slots and a 94 KB work table rotating through them that
+    // stalled the host behind the running accumulate kernel on most calls
+    const size_t want = bytes * 2 < (256u << 10) ? (256u << 10) : bytes * 2;
     TD_HIP(h, hipHostMalloc(&slot.p, want, hipHostMallocDefault));
     slot.bytes = want;
   }
@@ -172,6 +175,35 @@ int td_destroy(td_handle* h) {
 
 const char* td_last_error(const td_handle* h) {
   return h ? h->error.c_str() : td_global_error.c_str();
+}
+
+int td_stream_create_masked(int device_id, int cu_first, int cu_count, void** stream_out) {
+  if (!stream_out) return td_fail(nullptr, TD_ERR_INVALID, "td_stream_create_masked: NULL output");
+  *stream_out = nullptr;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+    return td_fail(nullptr, TD_ERR_HIP, "td_stream_create_masked: no device %d", device_id);
+  const int n_cu = prop.multiProcessorCount;
+  if (cu_first < 0 || cu_count <= 0 || cu_first + cu_count > n_cu)
+    return td_fail(nullptr, TD_ERR_INVALID, "CU range [%d, %d) outside the device's %d CUs", cu_first,
+                   cu_first + cu_count, n_cu);
+  std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+  for (int cu = cu_first; cu < cu_first + cu_count; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+  if (hipSetDevice(device_id) != hipSuccess)
+    return td_fail(nullptr, TD_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data());
+  if (e != hipSuccess)
+    return td_fail(nullptr, TD_ERR_HIP, "hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+  *stream_out = st;
+  return TD_OK;
+}
+
+int td_stream_destroy(void* hip_stream) {
+  if (!hip_stream) return TD_OK;
+  hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream));
+  return hipStreamDestroy(reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess
+             ? TD_OK : td_fail(nullptr, TD_ERR_HIP, "hipStreamDestroy failed");
 }
 
 int td_set_stream(td_handle* h, void* hip_stream) {

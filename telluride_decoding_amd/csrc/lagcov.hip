@@ -691,21 +691,58 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   p.ca_pad = small ? 8 : p.n_cat * 64;
   p.cb_pad = p.n_cbt * 64;
 
-  // Slab length: aim at ~1024 workgroups (2 resident per CU x 256 CUs x 2
-  // rounds), never shorter than 4 tiles, never longer than 16384 samples (bounds
-  // the length of one f32 accumulation chain; slabs are then summed in f64).
-  // Accuracy sets the upper bound, parallelism the lower one: every slab is ONE
-  // f32 accumulation chain (relative error ~ eps/2 * sqrt(len/3)), slabs are then
-  // summed in float64, so 2048-sample slabs keep the moments ~1e-7 * sqrt(2048/N)
-  // from exact at the price of (N/2048) slab writes+reads (~0.5 kB per sample,
-  // <10 % of the kernel at C2).  Small problems get one-tile slabs.
+  // Slab plan.  Every slab is ONE f32 accumulation chain (relative error ~ eps/2 *
+  // sqrt(len/3)) and slabs are summed in float64, so at most 2048 samples per slab keep the
+  // moments ~1e-7 * sqrt(2048/N) from exact at the price of (N/2048) slab writes+reads.
+  // Within that bound the slab COUNT is chosen so that the grid fills whole rounds of the
+  // 512 resident workgroup slots (2 per CU): a last round that is 83 % full costs as much
+  // as a full one.  Slabs need not be multiples of the tile (the kernels cut the last tile).
   const long long per_item_wgs = (long long)p.n_groups * p.n_cat * p.n_cbt;
-  long long want_items = 2048 / per_item_wgs;
-  if (want_items < 1) want_items = 1;
-  long long slab = td_round_up(td_ceil_div(total, want_items), kTile);
-  if (slab < kTile) slab = kTile;
-  if (slab > 2048) slab = 2048;
-  std::vector<LagWork> works = split_work(segs, slab);
+  const long long kMaxSlab = 2048;
+  std::vector<long long> n_slabs(segs.size(), 0);
+  long long min_items = 0, max_items = 0;
+  for (size_t f = 0; f < segs.size(); ++f) {
+    const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
+    n_slabs[f] = td_ceil_div(len, kMaxSlab);
+    min_items += n_slabs[f];
+    max_items += td_ceil_div(len, kTile);          // never cut below one tile per slab
+  }
+  long long items_per_round = 512 / per_item_wgs;
+  if (items_per_round < 1) items_per_round = 1;
+  long long target = td_ceil_div(min_items, items_per_round) * items_per_round;
+  if (target > max_items) target = max_items;
+  if (target > min_items) {
+    // proportional share first, then the remainder to the segments with the longest slabs
+    long long have = 0;
+    for (size_t f = 0; f < segs.size(); ++f) {
+      const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
+      long long share = (long long)((double)target * (double)len / (double)total);
+      const long long cap = td_ceil_div(len, kTile);
+      if (share > cap) share = cap;
+      if (share > n_slabs[f]) n_slabs[f] = share;
+      have += n_slabs[f];
+    }
+    for (long long extra = target - have; extra > 0; --extra) {
+      size_t best = segs.size();
+      double best_len = 0.0;
+      for (size_t f = 0; f < segs.size(); ++f) {
+        const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
+        if (n_slabs[f] == 0 || n_slabs[f] >= td_ceil_div(len, kTile)) continue;
+        const double sl = (double)len / (double)n_slabs[f];
+        if (sl > best_len) { best_len = sl; best = f; }
+      }
+      if (best == segs.size()) break;
+      ++n_slabs[best];
+    }
+  }
+  std::vector<LagWork> works;
+  for (size_t f = 0; f < segs.size(); ++f) {
+    if (n_slabs[f] == 0) continue;
+    const long long len = segs[f].u_end - segs[f].u_begin;
+    std::vector<LagSeg> one(1, segs[f]);
+    std::vector<LagWork> ws = split_work(one, td_ceil_div(len, n_slabs[f]));
+    works.insert(works.end(), ws.begin(), ws.end());
+  }
   p.n_work = (int)works.size();
 
   const size_t slab_elems = (size_t)p.e_pad * p.ca_pad * p.cb_pad;

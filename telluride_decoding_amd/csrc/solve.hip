@@ -50,14 +50,20 @@ struct CholParams {
 };
 
 // ---- 64x64 tile <-> LDS ------------------------------------------------------------
-// Thread t moves column t & 63 of rows (t >> 6) + 4 i: every instruction is one 512-byte row.
+// Rows are 16-byte aligned (the matrix is padded to a multiple of 64): thread t moves the
+// 16-byte pair (t & 31) of rows (t >> 5) + 8 i -- every wave instruction covers two whole
+// 512-byte rows.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void tile_to_lds(double* lds, const double* __restrict__ g, int ld,
                                             int rows_valid, int tid) {
-  const int c = tid & 63, r0 = tid >> 6;
+  const int c = (tid & 31) * 2, r0 = tid >> 5;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = r0 + 4 * i;
-    lds[r * LS + c] = (r < rows_valid) ? g[(size_t)r * ld + c] : 0.0;
+  for (int i = 0; i < 8; ++i) {
+    const int r = r0 + 8 * i;
+    f64x2 v = {0.0, 0.0};
+    if (r < rows_valid) v = *reinterpret_cast<const f64x2*>(g + (size_t)r * ld + c);
+    *reinterpret_cast<f64x2*>(lds + r * LS + c) = v;
   }
 }
 

@@ -17,6 +17,8 @@
 // statistics stay compact (C x C x L instead of (C L)^2) and additive over
 // files, ranks and subjects.
 #include "td_common.h"
+#include <chrono>
+#define TD_T(label) do { if (getenv("TD_TRACE")) { auto _n = std::chrono::steady_clock::now(); fprintf(stderr, "  [%s] +%.3f ms\n", label, std::chrono::duration<double, std::milli>(_n - _t0).count()); _t0 = _n; } } while (0)
 
 struct td_stats {
   int c1 = 0, pre1 = 0, post1 = 0, c2 = 0, pre2 = 0, post2 = 0, d = 0;
@@ -474,6 +476,7 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
     j2[f].row0 = r0 + dy; j2[f].valid = vy; j2[f].nprime = np;
   }
 
+  auto _t0 = std::chrono::steady_clock::now();
   // Boundary windows of the new files (also feed the all-ones rows below).
   TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
   {
@@ -495,9 +498,11 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
     TD_HIP(h, hipGetLastError());
   }
 
+  TD_T("windows");
   // F'xx: lagged auto-covariance of x (the MFMA kernel).
   TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
                    s->g + s->off_fxx, true));
+  TD_T("lagcov main");
   // [y | 1]^T x~ for every signed lag: Xty and the lagged column sums.  Per-file column
   // sums of x live in the solver workspace arena (td_scratch is used by the kernels' own
   // tables and partial slabs).
@@ -507,10 +512,12 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
   TD_TRY(td_workspace(h, sizeof(double) * (size_t)num_files * cmax * (1 + lmax), &ws));
   double* colsum_seg = reinterpret_cast<double*>(ws);
   double* contrib = colsum_seg + (size_t)num_files * cmax;
+  TD_T("workspace");
   bool handled = false;
   TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
                            s->g + s->off_gxo, s->d ? s->g + s->off_sy : nullptr, colsum_seg,
                            &handled));
+  TD_T("targets");
   if (handled) {
     launch_ones_rows(h, s->g + s->off_gxo, s->d + 1, s->d, s->c1, s->l1, -s->pre1, colsum_seg,
                      s->win1, s->hw, (long long)s->n_files, num_files, contrib);

@@ -214,13 +214,15 @@ class LagStats(object):
     out.update(xtx=xtx, xty=xty, x2tx2=x2, xtx2=xx2, sum_x2=s2)
     return out
 
-  def ridge_solve(self, lambdas):
-    """Returns device tensors W [n_lambda, k1, d], b [n_lambda, d] (float32)."""
+  def ridge_solve(self, lambdas, handle=None):
+    """Returns device tensors W [n_lambda, k1, d], b [n_lambda, d] (float32).  `handle`
+    selects the handle (stream, workspaces) the solve runs on; the caller orders it after
+    the accumulation (pipeline.FitPipeline)."""
+    h = handle or self.h
     lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
-    w = self.h.empty((len(lam), self.k1, self.d), 'float32')
-    b = self.h.empty((len(lam), self.d), 'float32')
-    self.h.check(self.h.lib.td_ridge_solve(self.h.ptr, self.ptr, lam_p, len(lam), _ptr(w),
-                                           _ptr(b)))
+    w = h.empty((len(lam), self.k1, self.d), 'float32')
+    b = h.empty((len(lam), self.d), 'float32')
+    h.check(h.lib.td_ridge_solve(h.ptr, self.ptr, lam_p, len(lam), _ptr(w), _ptr(b)))
     return w, b
 
   def __del__(self):

@@ -1,0 +1,109 @@
+"""Two-stream pipelining of independent fits on one GPU.
+
+The accumulate stage of a ridge fit (lagcov MFMA kernel) is throughput-bound and fills
+every CU; the solve stage (blocked Cholesky) is a latency-bound chain of small launches
+that occupies a handful of CUs.  Back to back they add up; on two HIP streams the solve of
+fit i runs underneath the accumulate of fit i + 1 (jackknife folds, subjects, sessions:
+the reference refits from scratch for every one of them, regression.py:151-242).  Each
+stream has its own C-ABI handle (stream, scratch arenas, error state); the statistics are
+double buffered and ordered with events.
+"""
+import numpy as np
+
+from telluride_decoding_amd import device
+
+
+class FitPipeline(object):
+  """submit() queues accumulate(i) and returns the solution of fit i - 1."""
+
+  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32):
+    """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
+    accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
+    stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
+    3.4 with only the accumulate stream masked, 3.1 with disjoint masks), so the two
+    stages get disjoint CU masks (hipExtStreamCreateWithCUMask): the first `solve_cus`
+    CUs solve, the rest accumulate.  solve_cus = 0: ordinary streams."""
+    import ctypes
+    import torch
+    from telluride_decoding_amd import _lib
+    self.torch = torch
+    self._masked = []
+    lib = _lib.load()
+    dev = torch.cuda.current_device()
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    self.s_acc = self.s_solve = None
+    if solve_cus and 0 < solve_cus < n_cu:
+      ptrs = []
+      for first, count in ((solve_cus, n_cu - solve_cus), (0, solve_cus)):
+        p = ctypes.c_void_p()
+        if lib.td_stream_create_masked(dev, first, count, ctypes.byref(p)) != _lib.TD_OK:
+          break
+        ptrs.append(p)
+      if len(ptrs) == 2:
+        self._masked = ptrs
+        self.s_acc = torch.cuda.ExternalStream(ptrs[0].value)
+        self.s_solve = torch.cuda.ExternalStream(ptrs[1].value)
+      else:
+        for p in ptrs:
+          lib.td_stream_destroy(p)
+    if self.s_acc is None:
+      self.s_acc = torch.cuda.Stream()
+      self.s_solve = torch.cuda.Stream()
+    with torch.cuda.stream(self.s_acc):
+      self.h_acc = device.Handle()
+    with torch.cuda.stream(self.s_solve):
+      self.h_solve = device.Handle()
+    self.stats = [device.LagStats(c, pre, post, d=d, handle=self.h_acc) for _ in range(2)]
+    self.ev_acc = [torch.cuda.Event() for _ in range(2)]
+    self.ev_solved = [None, None]
+    self.pending = None          # (buffer index, lambdas) of the fit whose solve is outstanding
+    self.count = 0
+    self.allreduce = allreduce   # optional callable(stats) run on the accumulate stream
+
+  def _solve(self, buf, lambdas):
+    torch = self.torch
+    with torch.cuda.stream(self.s_solve):
+      self.s_solve.wait_event(self.ev_acc[buf])
+      w, b = self.stats[buf].ridge_solve(lambdas, handle=self.h_solve)   # blocks the host
+      ev = torch.cuda.Event()
+      ev.record(self.s_solve)
+      self.ev_solved[buf] = ev
+    return w, b
+
+  def submit(self, x, y, file_offsets, lambdas, **kw):
+    torch = self.torch
+    buf = self.count % 2
+    self.count += 1
+    with torch.cuda.stream(self.s_acc):
+      if self.ev_solved[buf] is not None:
+        self.s_acc.wait_event(self.ev_solved[buf])
+      st = self.stats[buf]
+      st.reset()
+      st.accumulate(x, None, y, file_offsets, **kw)
+      if self.allreduce is not None:
+        self.allreduce(st)
+      self.ev_acc[buf].record(self.s_acc)
+    out = None
+    if self.pending is not None:
+      out = self._solve(*self.pending)
+    self.pending = (buf, np.atleast_1d(lambdas))
+    return out
+
+  def flush(self):
+    out = None
+    if self.pending is not None:
+      out = self._solve(*self.pending)
+      self.pending = None
+    return out
+
+  def __del__(self):
+    try:
+      from telluride_decoding_amd import _lib
+      self.torch.cuda.synchronize()
+      self.stats = []
+      self.h_acc = self.h_solve = None
+      for p in self._masked:
+        _lib.load().td_stream_destroy(p)
+      self._masked = []
+    except Exception:  # interpreter shutdown
+      pass

@@ -248,3 +248,41 @@ def test_c2_shape_fit_against_float64_oracle(dev):
   assert d_gpu_64 < max(1e-5, d_32_64)
   assert d_gpu_32 < 1e-5 + 1.01 * d_32_64
   assert abs(float(b.cpu().numpy()[0, 0]) - sol[-1, 0]) < 1e-5 * max(1.0, np.max(np.abs(sol)))
+
+
+@pytest.mark.gpu
+def test_pipelined_fits_equal_serial_fits(dev):
+  """pipeline.FitPipeline (accumulate of fit i+1 under the solve of fit i, two streams,
+  double-buffered statistics) returns, fit by fit, exactly what back-to-back fits return."""
+  import torch
+  from telluride_decoding_amd import pipeline
+  rng = np.random.default_rng(21)
+  h = dev.default_handle()
+  c, pre, post, n = 16, 1, 6, 6000
+  offs = np.array([0, 2500, 6000], np.int64)
+  data = []
+  for i in range(5):
+    x = rng.standard_normal((n, c)).astype(np.float32)
+    y = (x[:, :1] * (i + 1) + 0.1 * rng.standard_normal((n, 1))).astype(np.float32)
+    data.append((h.to_device(x), h.to_device(y)))
+  torch.cuda.synchronize()
+  want = []
+  st = dev.LagStats(c, pre, post, d=1)
+  for x, y in data:
+    st.reset()
+    st.accumulate(x, None, y, offs)
+    w, b = st.ridge_solve([0.1, 1.0])
+    want.append((w.cpu().numpy(), b.cpu().numpy()))
+  pipe = pipeline.FitPipeline(c, pre, post, d=1)
+  got = []
+  for x, y in data:
+    r = pipe.submit(x, y, offs, [0.1, 1.0])
+    if r is not None:
+      got.append(r)
+  got.append(pipe.flush())
+  assert pipe.flush() is None
+  torch.cuda.synchronize()
+  assert len(got) == len(want)
+  for (w, b), (w0, b0) in zip(got, want):
+    np.testing.assert_array_equal(w.cpu().numpy(), w0)
+    np.testing.assert_array_equal(b.cpu().numpy(), b0)
