@@ -286,3 +286,88 @@ def test_pipelined_fits_equal_serial_fits(dev):
   for (w, b), (w0, b0) in zip(got, want):
     np.testing.assert_array_equal(w.cpu().numpy(), w0)
     np.testing.assert_array_equal(b.cpu().numpy(), b0)
+
+
+def _lag_block_f64(torch, x, offs, a, b, rows_used=None):
+  """sum over files of sum_t x~[t+a]^T x~[t+b] in float64 (x~ zero outside the file), the
+  (signed lag a, signed lag b) block of X^T X, by direct shifted-slice products."""
+  c = x.shape[1]
+  out = torch.zeros((c, c), dtype=torch.float64, device=x.device)
+  for f in range(len(offs) - 1):
+    xf = x[offs[f]:offs[f + 1]].double()
+    n = xf.shape[0]
+    t_lo = max(0, -a, -b)
+    t_hi = min(n if rows_used is None else rows_used[f], n - a, n - b)
+    if t_hi > t_lo:
+      out += xf[t_lo + a:t_hi + a].T @ xf[t_lo + b:t_hi + b]
+  return out
+
+
+def test_c2_full_size_moments_properties(dev):
+  """BASELINE config C2 at full size (64 ch x 1e6 samples, 32 lags, 10 recordings): selected
+  blocks of the 2049 x 2049 moment matrix against direct float64 shifted products, exact
+  structural properties, additivity over recordings, and a solve whose residual is small."""
+  import torch
+  h = dev.default_handle()
+  torch.manual_seed(5)
+  n, c, pre, post = 1000000, 64, 0, 31
+  x = torch.randn(n, c, device='cuda')
+  x += 0.3 * torch.roll(x, 1, 0) + 0.2 * torch.roll(x, 7, 1)         # temporal and spatial correlation
+  y = (x[:, 3:4] * 0.7 + torch.roll(x[:, 10:11], -5, 0) * 0.4 + 0.5 * torch.randn(n, 1, device='cuda'))
+  offs = np.arange(11, dtype=np.int64) * 100000
+  st = dev.LagStats(c, pre, post, d=1)
+  st.accumulate(x, None, y, offs)
+  assert st.counts() == (n, 10)
+  m = st.moments()
+  xtx, xty = m['xtx'], m['xty']
+  k = c * 32
+  assert torch.equal(xtx, xtx.T)
+  assert float(xtx[k, k]) == n
+  scale = float(xtx.abs().max())
+  for (la, lb) in ((0, 0), (0, 31), (3, 17), (31, 31), (12, 13)):
+    want = _lag_block_f64(torch, x, offs, la - pre, lb - pre)
+    got = xtx[la * c:(la + 1) * c, lb * c:(lb + 1) * c]
+    assert float((got - want).abs().max()) / scale < 2e-7, (la, lb)
+  # bias row = lagged column sums, Xty = lagged cross products with y
+  for l in (0, 9, 31):
+    want = torch.zeros(c, dtype=torch.float64, device='cuda')
+    wy = torch.zeros(c, dtype=torch.float64, device='cuda')
+    for f in range(10):
+      xf = x[offs[f]:offs[f + 1]].double(); yf = y[offs[f]:offs[f + 1], 0].double()
+      a = l - pre
+      want += xf[a:].sum(0)
+      wy += xf[a:].T @ yf[:xf.shape[0] - a]
+    assert float((xtx[k, l * c:(l + 1) * c] - want).abs().max()) < 1e-6 * n ** 0.5
+    assert float((xty[l * c:(l + 1) * c, 0] - wy).abs().max()) / float(xty.abs().max()) < 2e-7
+  # additivity: two halves of the recordings, combined
+  a_st, b_st = st.like(), st.like()
+  a_st.accumulate(x[:400000], None, y[:400000], offs[:5])
+  b_st.accumulate(x[400000:], None, y[400000:], offs[4:] - 400000)
+  both = st.like().combine([a_st, b_st])
+  m2 = both.moments()
+  assert float((m2['xtx'] - xtx).abs().max()) / scale < 1e-7
+  # the solve: residual of (XtX/n + lam I) w = Xty/n in float64
+  lam = 0.1
+  w, b = st.ridge_solve([lam])
+  sol = torch.cat([w[0, :, 0].double(), b[0].double()])
+  cov = xtx / n + lam * torch.eye(k + 1, dtype=torch.float64, device='cuda')
+  res = cov @ sol - xty[:, 0] / n
+  assert float(res.abs().max()) / float((xty[:, 0] / n).abs().max()) < 1e-5    # f32 output rounding
+
+
+def test_c3_full_size_cca_moments(dev):
+  """BASELINE config C3 at full size (64-ch EEG vs 8-band envelope, 1e6 samples, no lags):
+  every CCA moment against a direct float64 product."""
+  import torch
+  torch.manual_seed(6)
+  n = 1000000
+  x = torch.randn(n, 64, device='cuda')
+  x2 = torch.randn(n, 8, device='cuda') + 0.5 * x[:, :8]
+  st = dev.LagStats(64, 0, 0, 8, 0, 0, 0)
+  st.accumulate(x, x2, None, np.array([0, 300000, 1000000], np.int64))
+  m = st.moments(want_cca=True)
+  xd, x2d = x.double(), x2.double()
+  for got, want in ((m['xtx'][:64, :64], xd.T @ xd), (m['x2tx2'], x2d.T @ x2d), (m['xtx2'], xd.T @ x2d)):
+    assert float((got - want).abs().max()) / float(want.abs().max()) < 2e-7
+  assert float((m['sum_x2'] - x2d.sum(0)).abs().max()) < 1e-6 * n ** 0.5
+  assert float((m['xtx'][64, :64] - xd.sum(0)).abs().max()) < 1e-6 * n ** 0.5
