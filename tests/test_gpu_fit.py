@@ -371,3 +371,35 @@ def test_c3_full_size_cca_moments(dev):
     assert float((got - want).abs().max()) / float(want.abs().max()) < 2e-7
   assert float((m['sum_x2'] - x2d.sum(0)).abs().max()) < 1e-6 * n ** 0.5
   assert float((m['xtx'][64, :64] - xd.sum(0)).abs().max()) < 1e-6 * n ** 0.5
+
+
+def test_loso_lambda_sweep_matches_refit_from_scratch(dev):
+  """Row A10 (config C5's shape, small): regression.jackknife_over_regularizations -- one
+  accumulate per file, fold = sum of the others, all lambdas in one batched solve -- against the
+  reference's procedure restated with the oracle: refit from scratch for every (lambda, held-out
+  file) (regression.py:151-242, 326-420) and score pearson_correlation_first per minibatch."""
+  from oracle import pearson as o_pear
+  from telluride_decoding_amd import brain_data, regression, synth
+  c, pre, post, batch, n_files, n = 8, 1, 4, 100, 5, 1200
+  trials = synth.make_trials(77, n_files, n, c)
+  files = []
+  for eeg, env, att in trials:
+    files.append((eeg, env, env[:, 0:1].astype(np.float32), att))
+  ds = brain_data.Dataset(files, batch, pre_context=pre, post_context=post)
+  lambdas = [1e-3, 0.1, 10.0]
+  got = regression.jackknife_over_regularizations(ds, lambdas)
+  want = np.zeros((len(lambdas), n_files))
+  f64 = [tuple(a.astype(np.float64) for a in f) for f in files]
+  for li, lam in enumerate(lambdas):
+    for f in range(n_files):
+      train = [f64[g] for g in range(n_files) if g != f]
+      w, b, _, _, _ = o_reg.linear_regressor_from_batches(
+          o_lag.minibatches(train, batch, pre=pre, post=post), lamb=lam)
+      test_b = list(o_lag.minibatches([f64[f]], batch, pre=pre, post=post))
+      preds = [o_reg.dense_forward(bx['input_1'], w, b) for bx, _ in test_b]
+      want[li, f] = o_pear.evaluate_mean_over_batches(o_pear.pearson_correlation_first, preds,
+                                                      [by for _, by in test_b])
+  np.testing.assert_allclose(got['all_runs'], want, rtol=1e-4, atol=2e-5)
+  for li, lam in enumerate(lambdas):
+    assert got[lam][0] == pytest.approx(want[li].mean(), abs=2e-5)
+    assert got[lam][1] == pytest.approx(want[li].std(), abs=2e-5)
