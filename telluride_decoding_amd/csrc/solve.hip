@@ -333,16 +333,19 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(CholParams p) {
 }
 
 // Trailing update A_ij -= X_i X_j^T for k < j <= i < nblk and for the right-hand-side
-// row; tile 0 is (k+1, k+1) and its workgroup factors the block afterwards (look-ahead).
-__global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tri) {
-  __shared__ double xi[NB * LS];
-  __shared__ double xj[NB * LS];
-  __shared__ double sc[kFactorScratch];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = p.n, k0 = p.k * NB;
-  double* a_b = p.a + (size_t)blockIdx.y * n * n;
-  int t = blockIdx.x;
+// row.  Workgroup 0 owns tile 0 = (k+1, k+1) and goes on to factor it (look-ahead: the serial
+// chain of the solve).  The other workgroups each walk a strided list of tiles with the next
+// tile's operands AND the old values of its output tile prefetched into registers under the
+// current GEMM, so a tile costs about its 64 MFMAs per wave instead of a load-GEMM-store
+// round trip (which made the bulk of the update 5x slower than the look-ahead path when the
+// solve runs on a 32-CU partition beside the accumulate kernel).
+struct UpdTile {
+  double* rows_i;      // block row i (or the right-hand-side rows)
+  const double* rows_j;
+  int rows_valid, bj;
+};
+
+__device__ __forceinline__ UpdTile upd_tile(const CholParams& p, double* a_b, int t, int n_tri) {
   int bi, bj;
   if (t < n_tri) {
     int ti = 0;
@@ -353,39 +356,119 @@ __global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tr
     bi = p.nblk;
     bj = p.k + 1 + (t - n_tri);
   }
-  double* rows_i;
-  int rows_valid;
+  UpdTile u;
   if (bi == p.nblk) {
-    rows_i = p.rt + (size_t)blockIdx.y * kMaxRhs * n;
-    rows_valid = p.nrhs;
+    u.rows_i = p.rt + (size_t)blockIdx.y * kMaxRhs * p.n;
+    u.rows_valid = p.nrhs;
   } else {
-    rows_i = a_b + (size_t)bi * NB * n;
-    rows_valid = NB;
+    u.rows_i = a_b + (size_t)bi * NB * p.n;
+    u.rows_valid = NB;
   }
-  tile_to_lds(xi, rows_i + k0, n, rows_valid, tid);
-  tile_to_lds(xj, a_b + (size_t)bj * NB * n + k0, n, NB, tid);
-  __syncthreads();
-  f64x4 acc[2][2];
-  gemm_nt_64(xi, xj, wave, lane, acc);
-  const bool lookahead = (t == 0);
-  if (lookahead) __syncthreads();     // every wave is done reading xi before it is reused
-  double* dst = rows_i + (size_t)bj * NB;
+  u.rows_j = a_b + (size_t)bj * NB * p.n;
+  u.bj = bj;
+  return u;
+}
+
+// operand tile -> registers (same thread map as tile_to_lds) and registers -> LDS
+__device__ __forceinline__ void tile_to_regs(f64x2 (&v)[8], const double* __restrict__ g, int ld,
+                                             int rows_valid, int tid) {
+  const int c = (tid & 31) * 2, r0 = tid >> 5;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int i = 0; i < 8; ++i) {
+    const int r = r0 + 8 * i;
+    const int rc = r < rows_valid ? r : 0;                 // clamped, zeroed below
+    const f64x2 x = *reinterpret_cast<const f64x2*>(g + (size_t)rc * ld + c);
+    const double m = r < rows_valid ? 1.0 : 0.0;
+    v[i][0] = x[0] * m; v[i][1] = x[1] * m;
+  }
+}
+__device__ __forceinline__ void regs_to_lds(double* lds, const f64x2 (&v)[8], int tid) {
+  const int c = (tid & 31) * 2, r0 = tid >> 5;
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<f64x2*>(lds + (r0 + 8 * i) * LS + c) = v[i];
+}
+
+__global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tri, int n_tiles) {
+  __shared__ double xi[NB * LS];
+  __shared__ double xj[NB * LS];
+  __shared__ double sc[kFactorScratch];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = p.n, k0 = p.k * NB;
+  double* a_b = p.a + (size_t)blockIdx.y * n * n;
+
+  if (blockIdx.x == 0) {
+    // ---- tile (k+1, k+1): update, then factor it on chip --------------------------------
+    const UpdTile u = upd_tile(p, a_b, 0, n_tri);
+    tile_to_lds(xi, u.rows_i + k0, n, NB, tid);
+    tile_to_lds(xj, u.rows_j + k0, n, NB, tid);
+    __syncthreads();
+    f64x4 acc[2][2];
+    gemm_nt_64(xi, xj, wave, lane, acc);
+    __syncthreads();                  // every wave is done reading xi before it is reused
+    const double* src = u.rows_i + (size_t)u.bj * NB;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
-        if (row < rows_valid) {
-          const double v = dst[(size_t)row * n + col] - acc[m][nn][r];
-          if (lookahead) xi[row * LS + col] = v;      // tile (k+1, k+1), kept on chip
-          else dst[(size_t)row * n + col] = v;
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
+          xi[row * LS + col] = src[(size_t)row * n + col] - acc[m][nn][r];
         }
-      }
-  if (lookahead) {
     __syncthreads();
     factor_and_publish(p, p.k + 1, a_b, xi, xj, sc, tid);
+    return;
+  }
+
+  // ---- bulk: tiles 1 + (blockIdx.x - 1), stride gridDim.x - 1 ------------------------------
+  const int stride = gridDim.x - 1;
+  int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  f64x2 ra[8], rb[8];
+  UpdTile cur = upd_tile(p, a_b, t, n_tri);
+  tile_to_regs(ra, cur.rows_i + k0, n, cur.rows_valid, tid);
+  tile_to_regs(rb, cur.rows_j + k0, n, NB, tid);
+  while (true) {
+    regs_to_lds(xi, ra, tid);
+    regs_to_lds(xj, rb, tid);
+    __syncthreads();
+    // loads that fly under the GEMM: the old values of this output tile, the operands of the next
+    double* dst = cur.rows_i + (size_t)cur.bj * NB;
+    double cold[2][2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
+          const int rc = row < cur.rows_valid ? row : 0;
+          cold[m][nn][r] = dst[(size_t)rc * n + col];
+        }
+    const int tn = t + stride;
+    const bool more = tn < n_tiles;
+    UpdTile nxt = cur;
+    if (more) {
+      nxt = upd_tile(p, a_b, tn, n_tri);
+      tile_to_regs(ra, nxt.rows_i + k0, n, nxt.rows_valid, tid);
+      tile_to_regs(rb, nxt.rows_j + k0, n, NB, tid);
+    }
+    f64x4 acc[2][2];
+    gemm_nt_64(xi, xj, wave, lane, acc);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
+          if (row < cur.rows_valid) dst[(size_t)row * n + col] = cold[m][nn][r] - acc[m][nn][r];
+        }
+    if (!more) break;
+    __syncthreads();                  // LDS operands are free for the next tile
+    cur = nxt;
+    t = tn;
   }
 }
 
@@ -473,8 +556,13 @@ int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_de
     const int rem = nblk - k - 1;
     if (rem > 0) {
       const int tri = rem * (rem + 1) / 2;
-      hipLaunchKernelGGL(chol_update_kernel, dim3((unsigned)(tri + rem), (unsigned)batch),
-                         dim3(256), 0, h->stream, p, tri);
+      const int n_tiles = tri + rem;
+      // workgroup 0 = look-ahead tile; the bulk gets at most ~3 tiles per workgroup
+      int bulk_wgs = (n_tiles - 1 + 2) / 3;
+      if (bulk_wgs > n_tiles - 1) bulk_wgs = n_tiles - 1;
+      if (bulk_wgs < 1) bulk_wgs = 1;
+      hipLaunchKernelGGL(chol_update_kernel, dim3((unsigned)(1 + bulk_wgs), (unsigned)batch),
+                         dim3(256), 0, h->stream, p, tri, n_tiles);
     }
   }
   for (int k = nblk - 1; k >= 0; --k) {
