@@ -257,6 +257,24 @@ def main():
             'algorithmic_flops_per_launch': flops_per_launch,
         },
     }
+    if not args.serial:
+      # the same kernel alone on the whole chip (the pipelined region gives it 224 of the 256
+      # CUs and runs the solve beside it): 5 launches after the timed region, informational
+      line['roofline']['cus'] = '%d of 256 (CU-masked accumulate stream)' % (256 - args.solve_cus) \
+          if args.solve_cus else '256'
+      st1 = device.LagStats(C, PRE, POST, d=D, handle=h)
+      st1.accumulate(x, None, y, offs)
+      h.profile_enable(True)
+      for _ in range(5):
+        st1.reset()
+        st1.accumulate(x, None, y, offs)
+      l1, ms1, smp1 = h.profile_read()
+      h.profile_enable(False)
+      a1 = 2.0 * C * k * (smp1 / max(l1, 1)) / (ms1 / max(l1, 1) / 1e3) / 1e12
+      line['roofline_whole_chip'] = {'kernel': 'lagcov_mfma_kernel', 'achieved': a1,
+                                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                     'frac': a1 / PEAK_F32_MFMA_TFLOPS, 'launches': l1,
+                                     'avg_launch_ms': ms1 / max(l1, 1)}
     if world == 1 and not args.no_cpu:
       line['cpu_baseline'] = cpu_baseline(eeg, env)
     if world == 1 and not args.no_decode:
