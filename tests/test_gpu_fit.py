@@ -403,3 +403,27 @@ def test_loso_lambda_sweep_matches_refit_from_scratch(dev):
   for li, lam in enumerate(lambdas):
     assert got[lam][0] == pytest.approx(want[li].mean(), abs=2e-5)
     assert got[lam][1] == pytest.approx(want[li].std(), abs=2e-5)
+
+
+def test_tfrecord_ingress_to_trf_fit(dev):
+  """F3 end to end on real data: a slice of the reference's MEG recording (148 channels: three
+  channel tiles) read by the dependency-free TFRecord parser, z-scored, ridge TRF envelope <-
+  MEG with 2 lags (K = 296 < 400 frames), against the oracle on the materialised lag matrix."""
+  import os
+  from telluride_decoding_amd import brain_data, brain_model, tfrecord
+  name = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'meg_subj01_400.tfrecords')
+  assert tfrecord.count_tfrecords(name) == (400, False)
+  feats = tfrecord.read_file(name, fields=['meg', 'envelope'], verify=True)
+  assert feats['meg'].shape == (400, 148)
+  x, x2, y, att = tfrecord.select_streams(feats, 'meg', 'envelope')
+  x = ((x - x.mean(0)) / x.std(0)).astype(np.float32)
+  y = ((y - y.mean(0)) / y.std(0)).astype(np.float32)
+  ds = brain_data.Dataset([(x, x[:, :1], y, att)], 100, pre_context=0, post_context=1)
+  model = brain_model.BrainModelLinearRegression(ds, regularization_lambda=1.0)
+  model.fit(ds)
+  f64 = [tuple(a.astype(np.float64) for a in ds.files[0])]
+  w, b, _, _, _ = o_reg.linear_regressor_from_batches(
+      o_lag.minibatches(f64, 100, pre=0, post=1), lamb=1.0)
+  scale = np.max(np.abs(w))
+  assert np.max(np.abs(model.w_estimate - w)) / scale < 1e-5
+  assert abs(float(model.b_estimate[0]) - float(np.ravel(b)[0])) < 1e-6
