@@ -54,6 +54,7 @@ struct LagParams {
   int e_min, e_count;
   float* partial;    // [n_work][e_pad][ca_pad][cb_pad]
   int e_pad, ca_pad, cb_pad;
+  int lag_g, lag_lg;   // lags per workgroup (8, or 4/2/1 with the 8 wave slots split over time) and log2
 };
 
 // Bijective XCD-aware remap: physical block b runs on XCD b % 8 (observed
@@ -228,7 +229,44 @@ __device__ __forceinline__ void mfma_tile(const float* __restrict__ as,
   }
 }
 
-template <bool kUnified, int kTileT, int kNPF, bool kVec4>
+// Few-lags variant (fewer than 5 lags, e.g. CCA without context): the eight (wave, le)
+// slots of a workgroup become G lags x S = 8 / G time phases -- slot s works on lag s % G and
+// on the row pairs kk = s / G, s / G + S, ... of the tile -- so no matrix work is spent on lags
+// nobody asked for (with one lag the 8-lag shape wasted 7/8 of it) and the kernel turns
+// HBM-bound.  The phases of a lag land in separate slab entries and meet in the float64 reduce.
+template <int kTileT, bool kM2, bool kN2>
+__device__ __forceinline__ void mfma_tile_few(const float* __restrict__ as,
+                                              const float* __restrict__ bs, int wave, int lane,
+                                              int nk, int g, int lg, f32x16 (&acc)[2][2][2]) {
+  const int lr = lane & 31, lk = lane >> 5;
+  const int s_phases = 8 >> lg;
+  const int nfull = nk >> 1;
+#pragma unroll
+  for (int le = 0; le < 2; ++le) {
+    const int slot = 2 * wave + le;
+    const int lag = slot & (g - 1), phase = slot >> lg;
+    const float* ap = as + lk * 64 + lr;
+    const float* bp = bs + (lk + lag) * 64 + lr;
+    auto step = [&](int kk, bool tail) {
+      const bool live = !tail || lk == 0;
+      const float a0 = live ? ap[kk * 128] : 0.f;
+      const float a1 = (kM2 && live) ? ap[kk * 128 + 32] : 0.f;
+      const float b0 = bp[kk * 128];
+      acc[le][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[le][0][0], 0, 0, 0);
+      if (kM2) acc[le][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[le][1][0], 0, 0, 0);
+      if (kN2) {
+        const float b1 = bp[kk * 128 + 32];
+        acc[le][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[le][0][1], 0, 0, 0);
+        if (kM2) acc[le][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[le][1][1], 0, 0, 0);
+      }
+    };
+#pragma unroll 4
+    for (int kk = phase; kk < nfull; kk += s_phases) step(kk, false);
+    if ((nk & 1) && (nfull & (s_phases - 1)) == phase) step(nfull, true);
+  }
+}
+
+template <bool kUnified, int kTileT, int kNPF, bool kVec4, bool kFew>
 __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -241,7 +279,7 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
   const int cbt = id % p.n_cbt; id /= p.n_cbt;
   const int cat = id % p.n_cat; id /= p.n_cat;
   const LagWork w = p.works[id];
-  const int e0 = p.e_min + group * kLagsPerWg;
+  const int e0 = p.e_min + group * (kFew ? p.lag_g : kLagsPerWg);
 
   // staged rows and operand bases
   const int rows = kUnified ? kTileT + kHalo + e0 : 2 * kTileT + kHalo;
@@ -275,7 +313,15 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
                                                       pf);
     const long long left = w.u_end - ut;
     const int nk = (kUnified && left < kTileT) ? (int)left : kTileT;
-    if (m2) {
+    if (kFew) {
+      if (m2) {
+        if (n2) mfma_tile_few<kTileT, true, true>(as, bs, wave, lane, nk, p.lag_g, p.lag_lg, acc);
+        else    mfma_tile_few<kTileT, true, false>(as, bs, wave, lane, nk, p.lag_g, p.lag_lg, acc);
+      } else {
+        if (n2) mfma_tile_few<kTileT, false, true>(as, bs, wave, lane, nk, p.lag_g, p.lag_lg, acc);
+        else    mfma_tile_few<kTileT, false, false>(as, bs, wave, lane, nk, p.lag_g, p.lag_lg, acc);
+      }
+    } else if (m2) {
       if (n2) mfma_tile<kTileT, true, true>(as, bs, wave, lane, nk, acc);
       else    mfma_tile<kTileT, true, false>(as, bs, wave, lane, nk, acc);
     } else {
@@ -295,7 +341,11 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
   float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
   for (int le = 0; le < 2; ++le) {
-    const int e_idx = group * kLagsPerWg + 2 * wave + le;
+    int e_idx = group * kLagsPerWg + 2 * wave + le;
+    if (kFew) {   // [phase][group][lag]: the reduce sees n_work * S slabs of n_groups * G lags
+      const int slot = 2 * wave + le;
+      e_idx = ((slot >> p.lag_lg) * p.n_groups + group) * p.lag_g + (slot & (p.lag_g - 1));
+    }
     float* pe = slab + (size_t)e_idx * p.ca_pad * p.cb_pad;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -521,21 +571,31 @@ __global__ __launch_bounds__(kThreads) void lagcov_wave_kernel(LagParams p, doub
 
 // per-file float64 column sums from the per-strip float32 ones: out[f][j] (+)= sum over the
 // strips of file f
-// (one workgroup per file and 64-channel tile: 4 strip-strided partial sums per channel,
-// combined in a fixed order)
-__global__ __launch_bounds__(256) void colsum_file_reduce_kernel(
+// (one workgroup of 1024 threads per file and 64-channel tile: 16 strip-strided partial sums
+// per channel, combined in a fixed order)
+__global__ __launch_bounds__(1024) void colsum_file_reduce_kernel(
     const double* __restrict__ csum, int cb_pad, int cb, const int* __restrict__ file_work0,
     double* __restrict__ out) {
-  __shared__ double part[4][64];
+  __shared__ double part[16][64];
   const int f = blockIdx.x, j = blockIdx.y * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  double s = 0.0;
-  if (j < cb)
-    for (int wk = file_work0[f] + q; wk < file_work0[f + 1]; wk += 4) s += csum[(size_t)wk * cb_pad + j];
-  part[q][threadIdx.x & 63] = s;
+  double s0 = 0.0, s1 = 0.0;
+  if (j < cb) {
+    int wk = file_work0[f] + q;
+    const int end = file_work0[f + 1];
+    for (; wk + 16 < end; wk += 32) {
+      s0 += csum[(size_t)wk * cb_pad + j];
+      s1 += csum[(size_t)(wk + 16) * cb_pad + j];
+    }
+    if (wk < end) s0 += csum[(size_t)wk * cb_pad + j];
+  }
+  part[q][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
-  if (q == 0 && j < cb)
-    out[(size_t)f * cb + j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
-                              (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (q == 0 && j < cb) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+    out[(size_t)f * cb + j] = t;
+  }
 }
 
 // sy[i] (+)= sum over strips; one workgroup per target column
@@ -679,15 +739,23 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
       TD_HIP(h, hipMemsetAsync(g_dev, 0, sizeof(double) * e_count * ca_eff * cb, h->stream));
     return TD_OK;
   }
-  const bool small = ca_eff <= 8;
-  const int lags_per_wg = small ? kSmallLags : kLagsPerWg;
+  // the LDS-tiled VALU kernel only serves skinny [y | 1] operands that the streaming targets
+  // kernel does not take; narrow real operands (an 8-band envelope) go to the matrix cores
+  const bool small = a_ones && ca_eff <= 8;
+  // matrix-core path: 8 lags per workgroup, or 4 / 2 / 1 when fewer are asked for (the 8
+  // (wave, le) slots then split the tile's rows: mfma_tile_few)
+  const int few_g = e_count >= 5 ? 8 : e_count >= 3 ? 4 : e_count;
+  const bool few = !small && few_g < 8;
+  const int lags_per_wg = small ? kSmallLags : few_g;
   LagParams p;
+  p.lag_g = few_g;
+  p.lag_lg = few_g == 8 ? 3 : few_g == 4 ? 2 : few_g == 2 ? 1 : 0;
   p.a = a; p.b = b; p.lda = lda; p.ldb = ldb; p.ca = ca; p.cb = cb; p.a_ones = a_ones ? 1 : 0;
   p.e_min = e_min; p.e_count = e_count;
   p.n_groups = (int)td_ceil_div(e_count, lags_per_wg);
   p.n_cat = small ? 1 : (int)td_ceil_div(ca_eff, 64);
   p.n_cbt = (int)td_ceil_div(cb, 64);
-  p.e_pad = p.n_groups * lags_per_wg;
+  p.e_pad = p.n_groups * (small ? kSmallLags : kLagsPerWg);   // slab entries per work item
   p.ca_pad = small ? 8 : p.n_cat * 64;
   p.cb_pad = p.n_cbt * 64;
 
@@ -779,31 +847,38 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
 #undef TD_LAUNCH_SMALL
   } else {
     // Unified mode: both operands are the same stream and channel tile.
-    const int rows_u = kTile + kHalo + e_min + (p.n_groups - 1) * kLagsPerWg;
+    const int rows_u = kTile + kHalo + e_min + (p.n_groups - 1) * few_g;
     bool unified = (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min >= 0 &&
                    p.n_cat == 1 && p.n_cbt == 1 && rows_u <= 16 * kNpfU2;
     for (const LagSeg& sg : segs)
       if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) unified = false;
     TD_TRY(td_profile_mark(h, true, (double)total));
-#define TD_LAUNCH_MFMA(UNI, TILE, NPF)                                                       \
-  do {                                                                                       \
-    const size_t lds_bytes = sizeof(float) * 64 * 16 * (NPF);                                \
-    if (aligned)                                                                             \
-      hipLaunchKernelGGL((lagcov_mfma_kernel<UNI, TILE, NPF, true>), dim3((unsigned)nwg),    \
-                         dim3(kThreads), lds_bytes, h->stream, p);                           \
-    else                                                                                     \
-      hipLaunchKernelGGL((lagcov_mfma_kernel<UNI, TILE, NPF, false>), dim3((unsigned)nwg),   \
-                         dim3(kThreads), lds_bytes, h->stream, p);                           \
+#define TD_LAUNCH_MFMA(UNI, TILE, NPF, FEW)                                                       \
+  do {                                                                                            \
+    const size_t lds_bytes = sizeof(float) * 64 * 16 * (NPF);                                     \
+    if (aligned)                                                                                  \
+      hipLaunchKernelGGL((lagcov_mfma_kernel<UNI, TILE, NPF, true, FEW>), dim3((unsigned)nwg),    \
+                         dim3(kThreads), lds_bytes, h->stream, p);                                \
+    else                                                                                          \
+      hipLaunchKernelGGL((lagcov_mfma_kernel<UNI, TILE, NPF, false, FEW>), dim3((unsigned)nwg),   \
+                         dim3(kThreads), lds_bytes, h->stream, p);                                \
   } while (0)
-    if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU);
-    else if (unified) TD_LAUNCH_MFMA(true, kTile, kNpfU2);
-    else TD_LAUNCH_MFMA(false, kTileG, kNpfG);
+    if (few) {
+      if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU, true);
+      else { unified = false; TD_LAUNCH_MFMA(false, kTileG, kNpfG, true); }
+    } else if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU, false);
+    else if (unified) TD_LAUNCH_MFMA(true, kTile, kNpfU2, false);
+    else TD_LAUNCH_MFMA(false, kTileG, kNpfG, false);
 #undef TD_LAUNCH_MFMA
     TD_TRY(td_profile_mark(h, false, 0.0));
   }
   TD_HIP(h, hipGetLastError());
-  launch_lagcov_reduce<float>(h, p.partial, p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff, cb,
-                              g_dev, accumulate, ca_eff);
+  if (few)   // [work][phase][n_groups * G lags]: S = 8 / G slabs per work item
+    launch_lagcov_reduce<float>(h, p.partial, p.n_work * (8 / few_g), p.n_groups * few_g, p.ca_pad,
+                                p.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, ca_eff);
+  else
+    launch_lagcov_reduce<float>(h, p.partial, p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff,
+                                cb, g_dev, accumulate, ca_eff);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
@@ -881,7 +956,7 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
     }
   }
   TD_HIP(h, hipGetLastError());
-  hipLaunchKernelGGL(colsum_file_reduce_kernel, dim3((unsigned)n_segs, (unsigned)p.n_cbt), dim3(256), 0,
+  hipLaunchKernelGGL(colsum_file_reduce_kernel, dim3((unsigned)n_segs, (unsigned)p.n_cbt), dim3(1024), 0,
                      h->stream, csum, p.cb_pad, cb, d_seg, colsum_seg_dev);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
