@@ -120,6 +120,19 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
                         const float* x2_dev, int64_t ldx2, const float* y_dev,
                         int64_t ldy, const int64_t* file_offsets_host, int num_files,
                         int input_offset, const int64_t* rows_used_host);
+/* The same in two independently schedulable parts, for callers that pipeline fits on two
+ * streams (pipeline.FitPipeline): TD_ACC_MAIN = boundary windows, the lagged auto- and
+ * cross-covariances (the matrix-core kernel) and the frame / file counters;
+ * TD_ACC_TARGETS = [y | 1]^T x~ (Xty, the bias moments, sum y) and the lagged column sums of
+ * input_2.  Both parts of a call take identical arguments; TARGETS must be ordered after
+ * MAIN of the same files (it reads their boundary windows).  parts = 3 is
+ * td_stats_accumulate. */
+#define TD_ACC_MAIN 1
+#define TD_ACC_TARGETS 2
+int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
+                              const float* x2_dev, int64_t ldx2, const float* y_dev,
+                              int64_t ldy, const int64_t* file_offsets_host, int num_files,
+                              int input_offset, const int64_t* rows_used_host, int parts);
 
 /* Frames summed so far (num_samples / total_frames) and number of files. */
 int td_stats_counts(td_handle* h, const td_stats* s, int64_t* frames, int64_t* files);

@@ -61,6 +61,8 @@ SIGNATURES = {
     'td_stats_reset': [_vp, _vp],
     'td_stats_accumulate': [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _pi64, _i, _i,
                             _pi64],
+    'td_stats_accumulate_parts': [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _pi64, _i, _i,
+                            _pi64, _i],
     'td_stats_counts': [_vp, _vp, _pi64, _pi64],
     'td_stats_combine': [_vp, _vp, _c.POINTER(_vp), _i],
     'td_stats_packed_len': [_vp, _vp, _i64, _pi64],

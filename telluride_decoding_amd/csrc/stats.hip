@@ -17,8 +17,6 @@
 // statistics stay compact (C x C x L instead of (C L)^2) and additive over
 // files, ranks and subjects.
 #include "td_common.h"
-#include <chrono>
-#define TD_T(label) do { if (getenv("TD_TRACE")) { auto _n = std::chrono::steady_clock::now(); fprintf(stderr, "  [%s] +%.3f ms\n", label, std::chrono::duration<double, std::milli>(_n - _t0).count()); _t0 = _n; } } while (0)
 
 struct td_stats {
   int c1 = 0, pre1 = 0, post1 = 0, c2 = 0, pre2 = 0, post2 = 0, d = 0;
@@ -426,7 +424,18 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
                         const float* x2_dev, int64_t ldx2, const float* y_dev, int64_t ldy,
                         const int64_t* file_offsets_host, int num_files, int input_offset,
                         const int64_t* rows_used_host) {
+  return td_stats_accumulate_parts(h, s, x_dev, ldx, x2_dev, ldx2, y_dev, ldy, file_offsets_host,
+                                   num_files, input_offset, rows_used_host,
+                                   TD_ACC_MAIN | TD_ACC_TARGETS);
+}
+
+int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
+                              const float* x2_dev, int64_t ldx2, const float* y_dev, int64_t ldy,
+                              const int64_t* file_offsets_host, int num_files, int input_offset,
+                              const int64_t* rows_used_host, int parts) {
   if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_accumulate: NULL argument");
+  TD_REQUIRE(h, parts >= 1 && parts <= 3, "td_stats_accumulate_parts: parts must be 1, 2 or 3");
+  const bool do_main = (parts & TD_ACC_MAIN) != 0, do_targets = (parts & TD_ACC_TARGETS) != 0;
   TD_REQUIRE(h, x_dev && file_offsets_host && num_files >= 0, "td_stats_accumulate: NULL input");
   TD_REQUIRE(h, ldx >= s->c1, "ldx (%lld) < channels (%d)", (long long)ldx, s->c1);
   TD_REQUIRE(h, !s->c2 || (x2_dev && ldx2 >= s->c2), "input_2 missing or ldx2 too small");
@@ -476,78 +485,84 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
     j2[f].row0 = r0 + dy; j2[f].valid = vy; j2[f].nprime = np;
   }
 
-  auto _t0 = std::chrono::steady_clock::now();
-  // Boundary windows of the new files (also feed the all-ones rows below).
-  TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
-  {
-    void* scratch = nullptr;
-    const size_t bytes = sizeof(WinJob) * num_files;
-    TD_TRY(td_scratch(h, 2 * td_round_up(bytes, 256), &scratch));
-    WinJob* d1 = reinterpret_cast<WinJob*>(scratch);
-    WinJob* d2 = reinterpret_cast<WinJob*>(reinterpret_cast<char*>(scratch) + td_round_up(bytes, 256));
-    TD_TRY(td_upload_async(h, j1.data(), bytes, d1));
-    hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)num_files, 2), dim3(256), 0,
-                       h->stream, x_dev, (long long)ldx, s->c1, s->hw, d1, s->win1,
-                       (long long)s->n_files);
-    if (s->c2) {
-      TD_TRY(td_upload_async(h, j2.data(), bytes, d2));
+  // window slot of the first new file: MAIN appends the files, a TARGETS-only call comes
+  // after the MAIN call of the same files
+  const int64_t first_slot = do_main ? s->n_files : s->n_files - num_files;
+  TD_REQUIRE(h, first_slot >= 0, "td_stats_accumulate_parts: TARGETS before MAIN");
+
+  if (do_main) {
+    // Boundary windows of the new files (also feed the all-ones rows below).
+    TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
+    {
+      void* scratch = nullptr;
+      const size_t bytes = sizeof(WinJob) * num_files;
+      TD_TRY(td_scratch(h, 2 * td_round_up(bytes, 256), &scratch));
+      WinJob* d1 = reinterpret_cast<WinJob*>(scratch);
+      WinJob* d2 = reinterpret_cast<WinJob*>(reinterpret_cast<char*>(scratch) + td_round_up(bytes, 256));
+      TD_TRY(td_upload_async(h, j1.data(), bytes, d1));
       hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)num_files, 2), dim3(256), 0,
-                         h->stream, x2_dev, (long long)ldx2, s->c2, s->hw, d2, s->win2,
-                         (long long)s->n_files);
+                         h->stream, x_dev, (long long)ldx, s->c1, s->hw, d1, s->win1,
+                         (long long)first_slot);
+      if (s->c2) {
+        TD_TRY(td_upload_async(h, j2.data(), bytes, d2));
+        hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)num_files, 2), dim3(256), 0,
+                           h->stream, x2_dev, (long long)ldx2, s->c2, s->hw, d2, s->win2,
+                           (long long)first_slot);
+      }
+      TD_HIP(h, hipGetLastError());
     }
-    TD_HIP(h, hipGetLastError());
+    // F'xx: lagged auto-covariance of x (the MFMA kernel), and the CCA auto / cross moments.
+    TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
+                     s->g + s->off_fxx, true));
+    if (s->c2) {
+      TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
+                       s->g + s->off_fyy, true));
+      TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x2_dev, ldx2, s->c2, sxy,
+                       -(s->post1 + s->pre2), s->l1 + s->l2 - 1, s->g + s->off_gxy, true));
+    }
+    s->n_files += num_files;
+    s->frames += new_frames;
+    // keep n on the device too (it travels in the all-reduce)
+    const double nd = (double)s->frames;
+    TD_TRY(td_upload_async(h, &nd, sizeof(double), s->g + s->off_n));
   }
 
-  TD_T("windows");
-  // F'xx: lagged auto-covariance of x (the MFMA kernel).
-  TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
-                   s->g + s->off_fxx, true));
-  TD_T("lagcov main");
-  // [y | 1]^T x~ for every signed lag: Xty and the lagged column sums.  Per-file column
-  // sums of x live in the solver workspace arena (td_scratch is used by the kernels' own
-  // tables and partial slabs).
-  void* ws = nullptr;
-  const int cmax = s->c1 > s->c2 ? s->c1 : s->c2;
-  const int lmax = s->l1 > s->l2 ? s->l1 : s->l2;
-  TD_TRY(td_workspace(h, sizeof(double) * (size_t)num_files * cmax * (1 + lmax), &ws));
-  double* colsum_seg = reinterpret_cast<double*>(ws);
-  double* contrib = colsum_seg + (size_t)num_files * cmax;
-  TD_T("workspace");
-  bool handled = false;
-  TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
-                           s->g + s->off_gxo, s->d ? s->g + s->off_sy : nullptr, colsum_seg,
-                           &handled));
-  TD_T("targets");
-  if (handled) {
-    launch_ones_rows(h, s->g + s->off_gxo, s->d + 1, s->d, s->c1, s->l1, -s->pre1, colsum_seg,
-                     s->win1, s->hw, (long long)s->n_files, num_files, contrib);
-    TD_HIP(h, hipGetLastError());
-  } else {
-    TD_TRY(td_lagcov(h, y_dev, ldy, s->d, true, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
-                     s->g + s->off_gxo, true));
-    if (s->d) TD_TRY(td_colsum(h, y_dev, ldy, s->d, syx, s->g + s->off_sy, true));
-  }
-  if (s->c2) {
-    TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
-                     s->g + s->off_fyy, true));
-    TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x2_dev, ldx2, s->c2, sxy,
-                     -(s->post1 + s->pre2), s->l1 + s->l2 - 1, s->g + s->off_gxy, true));
-    TD_TRY(td_lagcov_targets(h, nullptr, 0, 0, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
-                             s->g + s->off_gyo, nullptr, colsum_seg, &handled));
+  if (do_targets) {
+    // [y | 1]^T x~ for every signed lag: Xty and the lagged column sums.  Per-file column
+    // sums of x live in the solver workspace arena (td_scratch is used by the kernels' own
+    // tables and partial slabs).
+    void* ws = nullptr;
+    const int cmax = s->c1 > s->c2 ? s->c1 : s->c2;
+    const int lmax = s->l1 > s->l2 ? s->l1 : s->l2;
+    TD_TRY(td_workspace(h, sizeof(double) * (size_t)num_files * cmax * (1 + lmax), &ws));
+    double* colsum_seg = reinterpret_cast<double*>(ws);
+    double* contrib = colsum_seg + (size_t)num_files * cmax;
+    bool handled = false;
+    TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
+                             s->g + s->off_gxo, s->d ? s->g + s->off_sy : nullptr, colsum_seg,
+                             &handled));
     if (handled) {
-      launch_ones_rows(h, s->g + s->off_gyo, 1, 0, s->c2, s->l2, -s->pre2, colsum_seg, s->win2,
-                       s->hw, (long long)s->n_files, num_files, contrib);
+      launch_ones_rows(h, s->g + s->off_gxo, s->d + 1, s->d, s->c1, s->l1, -s->pre1, colsum_seg,
+                       s->win1, s->hw, (long long)first_slot, num_files, contrib);
       TD_HIP(h, hipGetLastError());
     } else {
-      TD_TRY(td_lagcov(h, nullptr, 0, 0, true, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
-                       s->g + s->off_gyo, true));
+      TD_TRY(td_lagcov(h, y_dev, ldy, s->d, true, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
+                       s->g + s->off_gxo, true));
+      if (s->d) TD_TRY(td_colsum(h, y_dev, ldy, s->d, syx, s->g + s->off_sy, true));
+    }
+    if (s->c2) {
+      TD_TRY(td_lagcov_targets(h, nullptr, 0, 0, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
+                               s->g + s->off_gyo, nullptr, colsum_seg, &handled));
+      if (handled) {
+        launch_ones_rows(h, s->g + s->off_gyo, 1, 0, s->c2, s->l2, -s->pre2, colsum_seg, s->win2,
+                         s->hw, (long long)first_slot, num_files, contrib);
+        TD_HIP(h, hipGetLastError());
+      } else {
+        TD_TRY(td_lagcov(h, nullptr, 0, 0, true, x2_dev, ldx2, s->c2, syy, -s->pre2, s->l2,
+                         s->g + s->off_gyo, true));
+      }
     }
   }
-  s->n_files += num_files;
-  s->frames += new_frames;
-  // keep n on the device too (it travels in the all-reduce)
-  const double nd = (double)s->frames;
-  TD_TRY(td_upload_async(h, &nd, sizeof(double), s->g + s->off_n));
   return TD_OK;
 }
 

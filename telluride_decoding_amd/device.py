@@ -147,9 +147,11 @@ class LagStats(object):
     self.h.check(self.h.lib.td_stats_reset(self.h.ptr, self.ptr))
 
   def accumulate(self, x, x2=None, y=None, file_offsets=None, input_offset=0,
-                 rows_used=None):
+                 rows_used=None, parts=3, handle=None):
     """x [rows, c1], x2 [rows, c2] / y [rows, d]: device float32 tensors holding
-    the files concatenated along time; file_offsets has F+1 row offsets."""
+    the files concatenated along time; file_offsets has F+1 row offsets.
+    parts: 1 = covariances + windows + counters, 2 = targets / bias moments (after part 1 of
+    the same files, possibly on another handle's stream), 3 = both."""
     rows = int(x.shape[0])
     if file_offsets is None:
       file_offsets = [0, rows]
@@ -165,11 +167,12 @@ class LagStats(object):
                          (name, rows, w, None if t is None else tuple(t.shape)))
       if t is not None and w and (str(t.dtype) != 'torch.float32' or not t.is_cuda):
         raise TypeError('%s must be a float32 device tensor' % name)
-    self.h.check(self.h.lib.td_stats_accumulate(
-        self.h.ptr, self.ptr, _ptr(x), x.stride(0),
+    h = handle or self.h
+    h.check(h.lib.td_stats_accumulate_parts(
+        h.ptr, self.ptr, _ptr(x), x.stride(0),
         _ptr(x2 if self.c2 else None), x2.stride(0) if self.c2 else 0,
         _ptr(y if self.d else None), y.stride(0) if self.d else 0,
-        offs_p, len(offs) - 1, int(input_offset), used_p))
+        offs_p, len(offs) - 1, int(input_offset), used_p, int(parts)))
 
   def counts(self):
     frames, files = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -60,10 +60,12 @@ class FitPipeline(object):
     self.count = 0
     self.allreduce = allreduce   # optional callable(stats) run on the accumulate stream
 
-  def _solve(self, buf, lambdas):
+  def _solve(self, buf, lambdas, args, kw):
     torch = self.torch
     with torch.cuda.stream(self.s_solve):
       self.s_solve.wait_event(self.ev_acc[buf])
+      # (running the targets part of the accumulate -- LagStats.accumulate(parts=2) -- on this
+      # stream was tried: it is throughput-bound and 4x slower on the solve stream's 32 CUs)
       w, b = self.stats[buf].ridge_solve(lambdas, handle=self.h_solve)   # blocks the host
       ev = torch.cuda.Event()
       ev.record(self.s_solve)
@@ -86,7 +88,7 @@ class FitPipeline(object):
     out = None
     if self.pending is not None:
       out = self._solve(*self.pending)
-    self.pending = (buf, np.atleast_1d(lambdas))
+    self.pending = (buf, np.atleast_1d(lambdas), (x, None, y, file_offsets), kw)
     return out
 
   def flush(self):

@@ -427,3 +427,25 @@ def test_tfrecord_ingress_to_trf_fit(dev):
   scale = np.max(np.abs(w))
   assert np.max(np.abs(model.w_estimate - w)) / scale < 1e-5
   assert abs(float(model.b_estimate[0]) - float(np.ravel(b)[0])) < 1e-6
+
+
+def test_accumulate_in_two_parts_equals_one_call(dev):
+  """td_stats_accumulate_parts: MAIN then TARGETS (second file batch included) gives bitwise the
+  statistics of the single call."""
+  rng = np.random.default_rng(31)
+  h = dev.default_handle()
+  c, pre, post = 16, 2, 5
+  x = h.to_device(rng.standard_normal((3000, c)).astype(np.float32))
+  y = h.to_device(rng.standard_normal((3000, 2)).astype(np.float32))
+  offs1, offs2 = np.array([0, 1200, 2000], np.int64), np.array([0, 1000], np.int64)
+  one = dev.LagStats(c, pre, post, d=2)
+  one.accumulate(x[:2000], None, y[:2000], offs1)
+  one.accumulate(x[2000:], None, y[2000:], offs2)
+  two = dev.LagStats(c, pre, post, d=2)
+  for xs, ys, offs in ((x[:2000], y[:2000], offs1), (x[2000:], y[2000:], offs2)):
+    two.accumulate(xs, None, ys, offs, parts=1)
+    two.accumulate(xs, None, ys, offs, parts=2)
+  assert one.counts() == two.counts() == (3000, 3)
+  m1, m2 = one.moments(), two.moments()
+  np.testing.assert_array_equal(m1['xtx'].cpu().numpy(), m2['xtx'].cpu().numpy())
+  np.testing.assert_array_equal(m1['xty'].cpu().numpy(), m2['xty'].cpu().numpy())
