@@ -21,6 +21,7 @@ struct FirTile {
   long long out0;     // global OUTPUT row of stream frame 0 (the zipped-stream index)
 };
 
+constexpr int kFirWavesPerCu = 12;   // predict_fir_mfma_kernel: 3 per SIMD
 constexpr int kFirLagChunk = 32;
 constexpr int kFirChChunk = 64;
 constexpr int kFirMaxD = 16;
@@ -132,7 +133,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // with ds_add_f32 was tried: LDS float atomics retire about one lane per clock and
 // the kernel ran 2.4x slower than with the tile + diagonal reads below.)
 template <int NCH, bool kVec4>
-__global__ __launch_bounds__(kThreads) void predict_fir_mfma_kernel(
+__global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
     const float* __restrict__ x, long long ldx, const FileDesc* __restrict__ files, int n_files,
     long long n_strips, int strip_len, int c, int pre, int post, const float* __restrict__ w,
     const float* __restrict__ bias, int d_total, int q0, int dq, int tpq, int ring,
@@ -180,10 +181,27 @@ __global__ __launch_bounds__(kThreads) void predict_fir_mfma_kernel(
   // conflict-free ds_read_b128.  (Loading in operand order directly makes every load
   // instruction touch 64 different cache lines 16 bytes at a time: the texture-address
   // path, not HBM, then bounds the kernel.)
+  // lane part of the load offsets (row lane >> 4 of each 4-row group, swizzled granule)
+  const int lr4 = lane >> 4;
   auto load_block = [&](long long row0, float4 (&a)[NCH][8]) {
+    const bool interior = row0 >= 0 && row0 + 32 <= st.nrows && (c & 3) == 0 && c >= NCH * 64;
+    if (kVec4 && interior) {
+      // every row and channel of the block exists (all blocks but those at file edges):
+      // wave-uniform base + 32-bit lane offsets, no masks
+      const float* base = x + (st.row0 + row0) * ldx;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int r = 4 * m + lr4;
+        const int off = r * (int)ldx + 4 * ((lane & 15) ^ (r & 15));
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          a[ch][m] = *reinterpret_cast<const float4*>(base + off + ch * 64);
+      }
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const int r = 4 * m + (lane >> 4);
+      const int r = 4 * m + lr4;
       const long long u = row0 + r;
       const bool row_ok = u >= 0 && u < st.nrows;
       long long uc = u < st.nrows ? u : st.nrows - 1;
@@ -229,30 +247,20 @@ __global__ __launch_bounds__(kThreads) void predict_fir_mfma_kernel(
     __builtin_amdgcn_wave_barrier();
   };
 
-  // B operands (weights) of one tile: 32 * NCH registers, read in one batch.
-  auto load_weights = [&](int nt, float (&bw)[NCH * 32]) {
-    const float* wb = wl + (nt * NCH) * 32 * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < NCH * 32; ++k) bw[k] = wb[k * 64];
-  };
   // The P tile of the previous step goes through the per-wave LDS tile and is summed
   // along its diagonals WHILE the MFMA chain of the current step runs: the chain is
   // one dependent accumulator (an MFMA issues every 64 cycles), and the LDS traffic
-  // of the diagonal sums is placed in its issue gaps -- 16 tile writes behind MFMAs
-  // 0..15, 16 diagonal reads behind MFMAs 16..31 (with NCH = 2: every other MFMA).
+  // of the diagonal sums is placed in its issue gaps -- one diagonal read per two MFMAs.
   // Element (row r, col n) belongs to output o = r - n + 31 of the 63 outputs a tile
   // touches.  Lane (li, lh) reads the 16 columns n = 16*lh .. 16*lh + 15 at row
   // (li + 1 + n) & 31: that element belongs to output li when li + n >= 31 and to
   // output li + 32 otherwise, so all reads are useful, unconditional and
   // bank-conflict free (row*33 + n).
   float4 cur[NCH][8], nxt[NCH][8];
-  float bw[NCH * 32];
-  f32x16 accp;                 // P tile of the previous step
   int p_rel0 = 0, p_nt = 0;    // its rel0 and tile index
   bool have_prev = false;
   load_block(rb, nxt);
   transpose_block(nxt, cur);
-  if (nt_count == 1) load_weights(0, bw);
 
   auto finish_prev = [&](float s_lo, float s_hi) {
     s_lo += __shfl_xor(s_lo, 32, 64);
@@ -283,55 +291,57 @@ __global__ __launch_bounds__(kThreads) void predict_fir_mfma_kernel(
     if (j + 1 < nb && TD_FIR_ABL != 1) load_block(row0 + 32, nxt);
     const int rel0 = (int)(row0 - ts) + pre;      // strip-relative output frame of (row 0, lag 0)
     for (int nt = 0; nt < nt_count; ++nt) {
-      if (nt_count != 1) load_weights(nt, bw);
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       float s_lo = 0.f, s_hi = 0.f;
-      float dv[16];
+      // B operands: a ring of 4 registers fed from LDS three MFMAs ahead (32 registers of
+      // preloaded weights cost a wave of occupancy)
+      const float* wb = wl + (nt * NCH) * 32 * 64 + lane;
+      float wv[4];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wv[k] = wb[k * 64];
+      float dprev = 0.f;           // diagonal read of the previous MFMA slot, consumed one slot later
 #pragma unroll
       for (int m = 0; m < NCH * 32; ++m) {
+        if (m + 3 < NCH * 32) wv[(m + 3) & 3] = wb[(m + 3) * 64];
         const float4 av = cur[m >> 5][(m & 31) >> 2];
         const float a = (m & 3) == 0 ? av.x : (m & 3) == 1 ? av.y : (m & 3) == 2 ? av.z : av.w;
-        if (TD_FIR_ABL != 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[m], acc, 0, 0, 0);
-        else acc[m & 15] += a * bw[m];
-        if (have_prev && m % NCH == 0 && TD_FIR_ABL != 2) {
-          const int k = m / NCH;               // 0..31
-          if (k < 16) {
-            // P tile -> LDS: C/D map col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * lh
-            tbuf[((k & 3) + 8 * (k >> 2) + 4 * lh) * 33 + li] = accp[k];
-          } else {
-            const int n = 16 * lh + (k - 16);
-            dv[k - 16] = tbuf[((li + 1 + n) & 31) * 33 + n];
+        if (TD_FIR_ABL != 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[m & 3], acc, 0, 0, 0);
+        else acc[m & 15] += a * wv[m & 3];
+        if (have_prev && m % (2 * NCH) == 0 && TD_FIR_ABL != 2) {
+          // one diagonal read of the previous P tile (already in the LDS tile) per two MFMAs
+          const int k = m / (2 * NCH);         // 0..15
+          if (k > 0) {
+            const bool lo = li + 16 * lh + (k - 1) >= 31;
+            s_lo += lo ? dprev : 0.f;
+            s_hi += lo ? 0.f : dprev;
           }
+          const int n = 16 * lh + k;
+          dprev = tbuf[((li + 1 + n) & 31) * 33 + n];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (have_prev) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const bool lo = li + 16 * lh + k >= 31;
-          s_lo += lo ? dv[k] : 0.f;
-          s_hi += lo ? 0.f : dv[k];
-        }
+        const bool lo = li + 16 * lh + 15 >= 31;
+        s_lo += lo ? dprev : 0.f;
+        s_hi += lo ? 0.f : dprev;
         finish_prev(s_lo, s_hi);
       }
+      // this step's P tile goes to the LDS tile now (it is read during the next chain); at
+      // the end of a block the same LDS space first transposes the next block's rows
+      if (nt == nt_count - 1 && j + 1 < nb && TD_FIR_ABL != 4) transpose_block(nxt, cur);
+      // C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * lh
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accp[r] = acc[r];
+      for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+      __builtin_amdgcn_wave_barrier();
       p_rel0 = rel0;
       p_nt = nt;
       have_prev = true;
     }
-    // the P tile of this block's last step now lives in accp (registers): the LDS tile
-    // is free for the transposition of the next block
-    if (j + 1 < nb && TD_FIR_ABL != 4) transpose_block(nxt, cur);
   }
-  // drain: the last tile
+  // drain: the last tile (already in the LDS tile)
   if (have_prev) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      tbuf[((k & 3) + 8 * (k >> 2) + 4 * lh) * 33 + li] = accp[k];
-    __builtin_amdgcn_wave_barrier();
     float s_lo = 0.f, s_hi = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -982,11 +992,11 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const bool mfma_ok = c <= 64 && vec4 && lds_for(dq_max) <= 64 * 1024;
   if (mfma_ok) {
-    // strip length: one wave per resident slot -- the kernel holds 2 waves per SIMD =
-    // 8 per CU (register-limited), so total / (256 CUs * 8) frames per wave runs the
-    // whole input in ONE round (a second, partly filled round costs as much as a full
-    // one); a multiple of 32, in [128, 4096]
-    int64_t strip = td_round_up(td_ceil_div(total, 256 * 8), 32);
+    // strip length: one wave per resident slot -- the kernel holds kFirWavesPerCu waves per CU
+    // (register / LDS limited), so total / (256 CUs * that) frames per wave runs the whole
+    // input in ONE round (a second, partly filled round costs as much as a full one); a
+    // multiple of 32, in [128, 4096]
+    int64_t strip = td_round_up(td_ceil_div(total, 256 * kFirWavesPerCu), 32);
     if (strip < 128) strip = 128;
     if (strip > 4096) strip = 4096;
     std::vector<FileDesc> files(num_files);
