@@ -149,7 +149,8 @@ def main():
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
   ap.add_argument('--solve-cus', type=int, default=32,
                   help='CUs set aside for the solve stream of the pipeline (0 = no CU masks)')
-  ap.add_argument('--pipeline', action='store_true', help='pipeline the fits also when N > 1')
+  ap.add_argument('--force-dist', action='store_true',
+                  help='run the N > 1 code path (RCCL all-reduce of the statistics) on one rank')
   ap.add_argument('--serial', action='store_true',
                   help='one stream, fits back to back (no accumulate/solve overlap)')
   args = ap.parse_args()
@@ -161,9 +162,17 @@ def main():
   if world != args.gpus and world > 1:
     raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
   torch.cuda.set_device(local_rank)
-  if world > 1:
+  dist_on = world > 1 or args.force_dist      # --force-dist: the N > 1 code path on one rank
+  if dist_on:
     import torch.distributed as dist
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if world == 1:
+      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+      os.environ.setdefault('MASTER_PORT', '29544')
+      os.environ['TD_ALLREDUCE_ALWAYS'] = '1'
+      dist.init_process_group('nccl', rank=0, world_size=1,
+                              device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
   from telluride_decoding_amd import device, distributed
   h = device.default_handle()
@@ -174,13 +183,11 @@ def main():
 
   def barrier():
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
       dist.barrier()
     torch.cuda.synchronize()
 
-  # N > 1: the plain one-stream path (the pipelined one is exercised on one GPU only so far)
-  if args.serial or (world > 1 and not args.pipeline):
-    args.serial = True
+  if args.serial:
     st = device.LagStats(C, PRE, POST, d=D, handle=h)
     h_prof = h
 
@@ -189,7 +196,7 @@ def main():
       for _ in range(k):
         st.reset()
         st.accumulate(x, None, y, offs)
-        if world > 1:
+        if dist_on:
           distributed.allreduce_stats(st, plan, rank)
         out = st.ridge_solve(lam)
       return out
@@ -197,7 +204,8 @@ def main():
     from telluride_decoding_amd import pipeline
     pipe = pipeline.FitPipeline(
         C, PRE, POST, d=D, solve_cus=args.solve_cus,
-        allreduce=(lambda s: distributed.allreduce_stats(s, plan, rank)) if world > 1 else None)
+        allreduce=(lambda s: distributed.allreduce_stats(
+            s, plan, rank, total_frames=sum(plan.file_lengths))) if dist_on else None)
     h_prof = pipe.h_acc
 
     def run(k):
@@ -217,7 +225,7 @@ def main():
   elapsed = time.perf_counter() - t0
   launches, kernel_ms, kernel_samples = h_prof.profile_read()
   h_prof.profile_enable(False)
-  if world > 1:
+  if dist_on:
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -279,10 +287,12 @@ def main():
       line['cpu_baseline'] = cpu_baseline(eeg, env)
     if world == 1 and not args.no_decode:
       line['decode'] = decode_leg(h, device)
-    print(json.dumps(line))
-  if world > 1:
+  if dist_on:
     dist.barrier()
     dist.destroy_process_group()
+  if rank == 0:
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)     # the last line of output (RCCL prints a banner on teardown)
 
 
 if __name__ == '__main__':

@@ -151,6 +151,10 @@ int td_stats_pack(td_handle* h, const td_stats* s, double* buf_dev,
                   int64_t total_file_slots, int64_t file_slot);
 int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev,
                     int64_t total_file_slots);
+/* The same without the device-to-host read of the frame count (which synchronises the
+ * stream): the caller states the total number of frames of all ranks. */
+int td_stats_unpack_known(td_handle* h, td_stats* s, const double* buf_dev,
+                          int64_t total_file_slots, int64_t total_frames);
 
 /* Dense moment matrices (float64, device), expanded from the compact lag
  * statistics with exact file-edge corrections.  k1 = c1*(pre1+1+post1),

@@ -68,6 +68,7 @@ SIGNATURES = {
     'td_stats_packed_len': [_vp, _vp, _i64, _pi64],
     'td_stats_pack': [_vp, _vp, _vp, _i64, _i64],
     'td_stats_unpack': [_vp, _vp, _vp, _i64],
+    'td_stats_unpack_known': [_vp, _vp, _vp, _i64, _i64],
     'td_stats_moments': [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'td_ridge_solve': [_vp, _vp, _pd, _i, _vp, _vp],
     'td_spd_solve': [_vp, _vp, _vp, _i, _i, _i],

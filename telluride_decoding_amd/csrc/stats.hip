@@ -632,7 +632,8 @@ int td_stats_pack(td_handle* h, const td_stats* s, double* buf_dev, int64_t tota
   return TD_OK;
 }
 
-int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev, int64_t total_file_slots) {
+int td_stats_unpack_known(td_handle* h, td_stats* s, const double* buf_dev, int64_t total_file_slots,
+                          int64_t total_frames) {
   if (!h || !s || !buf_dev) return td_fail(h, TD_ERR_INVALID, "td_stats_unpack: NULL");
   TD_TRY(ensure_window_capacity(h, s, total_file_slots));
   TD_HIP(h, hipMemcpyAsync(s->g, buf_dev, sizeof(double) * s->g_len, hipMemcpyDeviceToDevice,
@@ -649,11 +650,19 @@ int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev, int64_t to
     TD_HIP(h, hipGetLastError());
   }
   s->n_files = total_file_slots;
-  double nd = 0.0;
-  TD_HIP(h, hipMemcpyAsync(&nd, s->g + s->off_n, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  TD_HIP(h, hipStreamSynchronize(h->stream));
-  s->frames = (int64_t)(nd + 0.5);
+  if (total_frames >= 0) {
+    s->frames = total_frames;
+  } else {
+    double nd = 0.0;
+    TD_HIP(h, hipMemcpyAsync(&nd, s->g + s->off_n, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+    s->frames = (int64_t)(nd + 0.5);
+  }
   return TD_OK;
+}
+
+int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev, int64_t total_file_slots) {
+  return td_stats_unpack_known(h, s, buf_dev, total_file_slots, -1);
 }
 
 int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev,

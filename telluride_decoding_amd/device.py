@@ -197,9 +197,12 @@ class LagStats(object):
                                           int(total_file_slots), int(file_slot)))
     return buf
 
-  def unpack(self, buf, total_file_slots):
-    self.h.check(self.h.lib.td_stats_unpack(self.h.ptr, self.ptr, _ptr(buf),
-                                            int(total_file_slots)))
+  def unpack(self, buf, total_file_slots, total_frames=None):
+    """total_frames (frames of all ranks, if the caller knows them) avoids a device-to-host
+    read that synchronises the stream."""
+    self.h.check(self.h.lib.td_stats_unpack_known(
+        self.h.ptr, self.ptr, _ptr(buf), int(total_file_slots),
+        -1 if total_frames is None else int(total_frames)))
 
   def moments(self, want_xtx=True, want_xty=True, want_cca=False):
     """Dense float64 device matrices (see td_stats_moments)."""

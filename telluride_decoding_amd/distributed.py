@@ -11,6 +11,8 @@ is the concatenation -- no second collective is needed.
 The reference has no communication layer at all (process-level fan-out only,
 doc/DecodingCodelab.md:354-381); this module is new.
 """
+import os
+
 import numpy as np
 
 
@@ -59,16 +61,20 @@ def allreduce_packed(buf, group=None):
   """Sum a packed statistics buffer over ranks, in place (RCCL on GPU tensors,
   gloo on CPU tensors in the tests)."""
   dist = _dist()
-  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+  if dist.is_available() and dist.is_initialized() and (
+      dist.get_world_size(group) > 1 or os.environ.get('TD_ALLREDUCE_ALWAYS')):
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
   return buf
 
 
-def allreduce_stats(stats, plan, rank, group=None):
-  """Every rank ends with the statistics of all files (one all-reduce)."""
+def allreduce_stats(stats, plan, rank, group=None, total_frames=None):
+  """Every rank ends with the statistics of all files (one all-reduce).  total_frames: the
+  frames of all ranks if known on the host (no dropped remainders / offsets: the sum of the
+  file lengths) -- spares the unpack a stream synchronisation, which matters when fits are
+  pipelined."""
   buf = stats.pack(plan.total_files, plan.slot_of(rank))
   allreduce_packed(buf, group)
-  stats.unpack(buf, plan.total_files)
+  stats.unpack(buf, plan.total_files, total_frames)
   return stats
 
 

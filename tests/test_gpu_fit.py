@@ -449,3 +449,42 @@ def test_accumulate_in_two_parts_equals_one_call(dev):
   m1, m2 = one.moments(), two.moments()
   np.testing.assert_array_equal(m1['xtx'].cpu().numpy(), m2['xtx'].cpu().numpy())
   np.testing.assert_array_equal(m1['xty'].cpu().numpy(), m2['xty'].cpu().numpy())
+
+
+def test_single_rank_rccl_allreduce_round_trip(dev):
+  """The multi-GPU exchange on real RCCL with a one-rank group: pack -> all-reduce (nccl) ->
+  unpack leaves the statistics unchanged and the fit identical; the >1-rank protocol itself is
+  covered by the two-process gloo test on CPU."""
+  import os
+  import torch
+  import torch.distributed as dist
+  from telluride_decoding_amd import distributed
+  created = False
+  if not dist.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ['TD_ALLREDUCE_ALWAYS'] = '1'        # call RCCL although the group has one rank
+    dist.init_process_group('nccl', rank=0, world_size=1,
+                            device_id=torch.device('cuda', torch.cuda.current_device()))
+    created = True
+  try:
+    rng = np.random.default_rng(41)
+    h = dev.default_handle()
+    lens = [900, 1100, 700]
+    x = h.to_device(rng.standard_normal((sum(lens), 16)).astype(np.float32))
+    y = h.to_device(rng.standard_normal((sum(lens), 1)).astype(np.float32))
+    offs = np.concatenate(([0], np.cumsum(lens)))
+    st = dev.LagStats(16, 1, 6, d=1)
+    st.accumulate(x, None, y, offs)
+    w0, b0 = st.ridge_solve([0.1])
+    m0 = st.moments()['xtx'].clone()
+    plan = distributed.ShardPlan(lens, 1)
+    distributed.allreduce_stats(st, plan, 0)
+    assert st.counts() == (sum(lens), 3)
+    np.testing.assert_array_equal(st.moments()['xtx'].cpu().numpy(), m0.cpu().numpy())
+    w1, b1 = st.ridge_solve([0.1])
+    np.testing.assert_array_equal(w1.cpu().numpy(), w0.cpu().numpy())
+    np.testing.assert_array_equal(b1.cpu().numpy(), b0.cpu().numpy())
+  finally:
+    if created:
+      dist.destroy_process_group()
