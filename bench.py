@@ -291,8 +291,12 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
   if rank == 0:
+    # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer until exit: flush it
+    # first so that the JSON line is the last line of output
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
-    print(json.dumps(line), flush=True)     # the last line of output (RCCL prints a banner on teardown)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':
