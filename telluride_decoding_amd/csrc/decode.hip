@@ -1129,8 +1129,11 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
   TD_REQUIRE(h, dims > 0 && dims <= kFirMaxD, "td_cca_transform: dims must be in [1, %d]", kFirMaxD);
   TD_REQUIRE(h, ldout >= 2 * dims, "td_cca_transform: ldout too small");
   const int k1 = c1 * (pre1 + 1 + post1), k2 = c2 * (pre2 + 1 + post2);
-  float* bias = nullptr;
-  TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&bias), sizeof(float) * 2 * dims));
+  // the centring folded into a bias: stream-ordered scratch in the solver workspace arena
+  // (launch_fir uses td_scratch for its tables)
+  void* ws = nullptr;
+  TD_TRY(td_workspace(h, sizeof(float) * 2 * dims, &ws));
+  float* bias = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(neg_mean_rot_kernel, dim3((unsigned)dims), dim3(kThreads), 0, h->stream,
                      mean1_dev, rot1_dev, k1, dims, bias);
   hipLaunchKernelGGL(neg_mean_rot_kernel, dim3((unsigned)dims), dim3(kThreads), 0, h->stream,
@@ -1141,8 +1144,6 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
     rc = launch_fir(h, x2_dev, ldx2, file_offsets_host, num_files, c2, pre2, post2, rot2_dev,
                     bias + dims, dims, out_dev + dims, ldout,
                     input_offset < 0 ? -input_offset : 0);
-  hipStreamSynchronize(h->stream);
-  hipFree(bias);
   return rc;
 }
 
