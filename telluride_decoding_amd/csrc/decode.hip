@@ -123,10 +123,6 @@ __device__ __forceinline__ int find_file(const FileDesc* __restrict__ files, int
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef TD_FIR_ABL
-#define TD_FIR_ABL 0   // development ablations: 1 no global loads, 2 no diagonal sums, 3 no MFMA, 4 no transposition
-#endif
-
 // Column order of P: q-major, every output's L lags padded to whole tiles of 32
 // (tpq tiles per output), so one 32x32 tile belongs to ONE output q and 32
 // consecutive lags.  (Scattering the accumulator registers into the output ring
@@ -288,7 +284,7 @@ __global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
 
   for (int j = 0; j < nb; ++j) {
     const long long row0 = rb + 32LL * j;
-    if (j + 1 < nb && TD_FIR_ABL != 1) load_block(row0 + 32, nxt);
+    if (j + 1 < nb) load_block(row0 + 32, nxt);
     const int rel0 = (int)(row0 - ts) + pre;      // strip-relative output frame of (row 0, lag 0)
     for (int nt = 0; nt < nt_count; ++nt) {
       f32x16 acc;
@@ -307,9 +303,8 @@ __global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
         if (m + 3 < NCH * 32) wv[(m + 3) & 3] = wb[(m + 3) * 64];
         const float4 av = cur[m >> 5][(m & 31) >> 2];
         const float a = (m & 3) == 0 ? av.x : (m & 3) == 1 ? av.y : (m & 3) == 2 ? av.z : av.w;
-        if (TD_FIR_ABL != 3) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[m & 3], acc, 0, 0, 0);
-        else acc[m & 15] += a * wv[m & 3];
-        if (have_prev && m % (2 * NCH) == 0 && TD_FIR_ABL != 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[m & 3], acc, 0, 0, 0);
+        if (have_prev && m % (2 * NCH) == 0) {
           // one diagonal read of the previous P tile (already in the LDS tile) per two MFMAs
           const int k = m / (2 * NCH);         // 0..15
           if (k > 0) {
@@ -330,7 +325,7 @@ __global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
       }
       // this step's P tile goes to the LDS tile now (it is read during the next chain); at
       // the end of a block the same LDS space first transposes the next block's rows
-      if (nt == nt_count - 1 && j + 1 < nb && TD_FIR_ABL != 4) transpose_block(nxt, cur);
+      if (nt == nt_count - 1 && j + 1 < nb) transpose_block(nxt, cur);
       // C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * lh
 #pragma unroll
       for (int r = 0; r < 16; ++r) tbuf[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
