@@ -130,6 +130,34 @@ __device__ __forceinline__ float4 load_row4(const RowWindow& rw, int r, bool row
   return v;
 }
 
+// The same load in two halves: the raw (clamped, always in bounds) load, and the masking of
+// what it returned.  A select on a loaded value makes the compiler wait for the load where the
+// select stands, so a kernel that wants the load in flight across its matrix phase masks at the
+// LDS store instead (load_row4 above masks in place).
+template <bool kVec4>
+__device__ __forceinline__ float4 load_row4_raw(const RowWindow& rw, int r, int c4) {
+  const int rc = max(rw.lo, min(r, rw.hi));
+  const float* p = rw.base + rc * rw.ld;
+  float4 v;
+  if (kVec4) {
+    v = *reinterpret_cast<const float4*>(p + (c4 <= rw.last ? c4 : 0));
+  } else {
+    const int last = rw.last;
+    v.x = p[min(c4, last)]; v.y = p[min(c4 + 1, last)];
+    v.z = p[min(c4 + 2, last)]; v.w = p[min(c4 + 3, last)];
+  }
+  return v;
+}
+
+__device__ __forceinline__ float4 mask_row4(const RowWindow& rw, int r, bool row_ok, int c4, float4 v) {
+  const bool ok = row_ok && r >= rw.lo && r <= rw.hi;
+  v.x = (ok && c4 + 0 <= rw.last) ? v.x : 0.f;
+  v.y = (ok && c4 + 1 <= rw.last) ? v.y : 0.f;
+  v.z = (ok && c4 + 2 <= rw.last) ? v.z : 0.f;
+  v.w = (ok && c4 + 3 <= rw.last) ? v.w : 0.f;
+  return v;
+}
+
 template <bool kUnified, int kTileT, int kNPF, bool kVec4>
 __device__ __forceinline__ void prefetch_tile(const LagParams& p, const LagWork& w, long long ut,
                                               int e0, int rows, int cat, int cbt, int tid,
@@ -435,6 +463,311 @@ __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       slab[((size_t)e_idx * p.ca_pad + i) * p.cb_pad + cbt * 64 + j] = acc[m][i];
+  }
+}
+
+// ---- CCA without context: every moment in ONE pass ---------------------------------------
+// With no lags on either input (cca.py:272-369 on raw streams; BASELINE config C3) the whole
+// set of CCA moments is the Gram matrix of z = [x (<= 64 ch) | x2 (<= 31 ch) | 1]: x^T x,
+// x2^T x2, x^T x2 and, through the ones column, both column sums.  The lag kernels would read
+// the inputs five times and spend 7/8 of their matrix work on lags nobody asked for.  Here z
+// is cut into kG groups of 16 columns (4 of x, 1-2 of [x2 | 1]); a workgroup stages 128-row
+// tiles of z and its four waves take every fourth row quad each, accumulating the kG (kG+1)/2
+// upper 16x16 blocks with v_mfma_f32_16x16x4_f32 -- one register per group is both the A and
+// the B operand (z^T z), and the narrow x2 group costs a quarter of what a 32-wide tile
+// would.  HBM floor 46 us at C3, matrix work ~50 us; the five-pass path took 0.79 ms.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GramParams {
+  const float* x; const float* x2;
+  long long ldx, ldx2;
+  int c1, c2;
+  const LagWork* works;   // a_* = x stream, b_* = x2 stream
+  int n_work;
+  float* partial;         // [n_work][pairs][16][16]
+};
+
+// LDS row stride: 16 kG + (0 or 16) floats so that the four rows an operand read touches
+// fall into four different 16-bank groups (stride = 16 or 48 mod 64).
+__host__ __device__ constexpr int gram_ld(int kG) { return (16 * kG) % 32 == 16 ? 16 * kG : 16 * kG + 16; }
+
+// Eight waves per workgroup, two roles: waves 4-7 (producers) load 64-row tiles of z into
+// registers two tiles ahead, mask them and store them into one of two LDS buffers; waves 0-3
+// (consumers) do nothing but operand reads and MFMAs on the other buffer.  One barrier per
+// tile.  With the roles in one wave (load, MFMA, mask + store in turn) the matrix pipe sat idle
+// through every store phase: 92 us against 49 us for the memory side alone and 70 us for the
+// matrix side alone.
+constexpr int kGramTile = 64;
+constexpr int kGramThreads = 512;
+
+// Producer thread map (ptid = 0..255) of one 64-row tile: x part (columns 0..63) float4 column
+// (ptid & 15), rows (ptid >> 4) + 16 i; [x2 | 1] part row ptid >> 2, float4 columns
+// (ptid & 3) + 4 q for q < kG - 4; its last column holds the ones.
+//
+// The producers share their SIMDs' issue slots with the consumers' MFMAs, so every vector
+// instruction they spend shows up as matrix-pipe idle time.  GramLane holds what does not
+// change from tile to tile (element offsets inside a tile, channel masks); a tile that lies
+// wholly inside its file and its slab (all but the last of a slab, normally) is loaded and
+// stored with those alone, the others go through the clamping / masking row windows.
+template <int kG>
+struct GramLane {
+  int off[kG];      // element offset of each float4 from the tile's first row
+  unsigned keep;    // bit q: the channels of float4 q exist
+};
+
+template <int kG>
+__device__ __forceinline__ GramLane<kG> gram_lane(const GramParams& p, int ptid) {
+  GramLane<kG> g;
+  const int c4 = (ptid & 15) * 4, r0 = ptid >> 4, r2 = ptid >> 2;
+  g.keep = c4 < p.c1 ? 15u : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g.off[i] = (r0 + 16 * i) * (int)p.ldx + (c4 < p.c1 ? c4 : 0);
+#pragma unroll
+  for (int q = 0; q < kG - 4; ++q) {
+    const int cq = 4 * ((ptid & 3) + 4 * q);
+    if (cq < p.c2) g.keep |= 16u << q;
+    g.off[4 + q] = r2 * (int)p.ldx2 + (cq < p.c2 ? cq : 0);
+  }
+  return g;
+}
+
+__device__ __forceinline__ bool gram_interior(const LagWork& w, long long ut) {
+  const long long end = ut + kGramTile;
+  return ut >= 0 && end <= w.u_end && end <= w.a_valid && end <= w.b_valid;
+}
+
+template <bool kVec4, int kG>
+__device__ __forceinline__ void gram_prefetch(const GramParams& p, const LagWork& w, long long ut,
+                                              int ptid, const GramLane<kG>& g, float4 (&pf)[kG]) {
+  if (kVec4 && gram_interior(w, ut)) {
+    const float* xb = p.x + (w.a_row0 + ut) * p.ldx;      // wave-uniform bases
+    const float* yb = p.x2 + (w.b_row0 + ut) * p.ldx2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const float4*>(xb + g.off[i]);
+#pragma unroll
+    for (int q = 4; q < kG; ++q) pf[q] = *reinterpret_cast<const float4*>(yb + g.off[q]);
+    return;
+  }
+  const RowWindow rx = row_window(p.x, p.ldx, w.a_row0, ut, w.a_valid, 0, p.c1);
+  const RowWindow ry = row_window(p.x2, p.ldx2, w.b_row0, ut, w.b_valid, 0, p.c2);
+  const int c4 = (ptid & 15) * 4, r0 = ptid >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pf[i] = load_row4_raw<kVec4>(rx, r0 + 16 * i, c4);
+  const int r2 = ptid >> 2;
+#pragma unroll
+  for (int q = 0; q < kG - 4; ++q) pf[4 + q] = load_row4_raw<kVec4>(ry, r2, 4 * ((ptid & 3) + 4 * q));
+}
+
+// Masks what gram_prefetch loaded for the tile at ut (rows beyond u_end or outside the file,
+// channels beyond c1 / c2) and stores it.
+template <bool kVec4, int kG>
+__device__ __forceinline__ void gram_store(float* buf, const GramParams& p, const LagWork& w,
+                                           long long ut, int ptid, const GramLane<kG>& g,
+                                           const float4 (&pf)[kG]) {
+  constexpr int kLd = gram_ld(kG);
+  const int c4 = (ptid & 15) * 4, r0 = ptid >> 4, r2 = ptid >> 2;
+  if (kVec4 && gram_interior(w, ut)) {
+    // (component-wise selects: a select between float4 structs makes the compiler keep them
+    // in scratch memory)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool k = (g.keep & 1u) != 0;
+      float4 v = pf[i];
+      v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+      *reinterpret_cast<float4*>(buf + (r0 + 16 * i) * kLd + c4) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < kG - 4; ++q) {
+      const int cq = 4 * ((ptid & 3) + 4 * q);
+      const bool k = (g.keep >> (4 + q) & 1u) != 0;
+      float4 v = pf[4 + q];
+      v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+      if (cq + 3 == 16 * (kG - 4) - 1) v.w = 1.f;                   // the ones column
+      *reinterpret_cast<float4*>(buf + r2 * kLd + 64 + cq) = v;
+    }
+    return;
+  }
+  const RowWindow rx = row_window(p.x, p.ldx, w.a_row0, ut, w.a_valid, 0, p.c1);
+  const RowWindow ry = row_window(p.x2, p.ldx2, w.b_row0, ut, w.b_valid, 0, p.c2);
+  const long long left = w.u_end - ut;
+  const int lim = (int)(left < kGramTile ? left : kGramTile);   // rows of [ut, u_end) in this tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<float4*>(buf + (r0 + 16 * i) * kLd + c4) =
+        mask_row4(rx, r0 + 16 * i, r0 + 16 * i < lim, c4, pf[i]);
+#pragma unroll
+  for (int q = 0; q < kG - 4; ++q) {
+    const int cq = 4 * ((ptid & 3) + 4 * q);
+    float4 v = mask_row4(ry, r2, r2 < lim, cq, pf[4 + q]);
+    if (cq + 3 == 16 * (kG - 4) - 1) v.w = (r2 < lim) ? 1.f : 0.f;   // the ones column
+    *reinterpret_cast<float4*>(buf + r2 * kLd + 64 + cq) = v;
+  }
+}
+
+template <bool kVec4, int kG>
+__global__ __launch_bounds__(kGramThreads, 4) void gram_mfma_kernel(GramParams p) {
+  constexpr int kLd = gram_ld(kG), kPairs = kG * (kG + 1) / 2, kBuf = kGramTile * kLd;
+  static_assert(kBuf >= kPairs * 256, "cross-wave reduction reuses the tile buffers");
+  __shared__ __attribute__((aligned(16))) float lds[2 * kBuf];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const LagWork w = p.works[blockIdx.x];
+  const int n_tiles = (int)((w.u_end - w.u_begin + kGramTile - 1) / kGramTile);
+  // The two roles are two code paths (whole waves take one or the other) that execute the same
+  // number of barriers: n_tiles + 4.  Keeping them apart keeps the accumulators out of the
+  // producers' register budget and the prefetch registers out of the consumers'.
+  //
+  // Step t: consumers multiply tile t out of buffer t & 1; producers store tile t + 1 (loaded
+  // two steps ago) into the other buffer and start loading tile t + 3 into the freed registers.
+  if (wave >= 4) {
+    const int ptid = tid & 255;
+    float4 pfa[kG], pfb[kG];     // tiles 0, 2, 4 ... travel in pfa, tiles 1, 3, 5 ... in pfb
+    const GramLane<kG> g = gram_lane<kG>(p, ptid);
+    gram_prefetch<kVec4, kG>(p, w, w.u_begin, ptid, g, pfa);
+    if (n_tiles > 1) gram_prefetch<kVec4, kG>(p, w, w.u_begin + kGramTile, ptid, g, pfb);
+    gram_store<kVec4, kG>(lds, p, w, w.u_begin, ptid, g, pfa);
+    if (n_tiles > 2) gram_prefetch<kVec4, kG>(p, w, w.u_begin + 2 * kGramTile, ptid, g, pfa);
+    __syncthreads();
+#define TD_GRAM_PRODUCE(T, PF)                                                                 \
+  {                                                                                            \
+    const int t_ = (T);                                                                        \
+    if (t_ + 1 < n_tiles) {                                                                    \
+      gram_store<kVec4, kG>(lds + ((t_ + 1) & 1) * kBuf, p, w,                                 \
+                            w.u_begin + (long long)(t_ + 1) * kGramTile, ptid, g, PF);         \
+      if (t_ + 3 < n_tiles)                                                                    \
+        gram_prefetch<kVec4, kG>(p, w, w.u_begin + (long long)(t_ + 3) * kGramTile, ptid, g, PF); \
+    }                                                                                          \
+    __syncthreads();                                                                           \
+  }
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+      TD_GRAM_PRODUCE(t, pfb)
+      TD_GRAM_PRODUCE(t + 1, pfa)
+    }
+    if (t < n_tiles) TD_GRAM_PRODUCE(t, pfb)
+#undef TD_GRAM_PRODUCE
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
+  f32x4 acc[kPairs];
+#pragma unroll
+  for (int q = 0; q < kPairs; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, lk = lane >> 4;
+  const float* zp = lds + (4 * wave + lk) * kLd + li;   // row quads wave, wave + 4, ... of a tile
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    const float* zt = zp + (t & 1) * kBuf;
+    float z[4][kG];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int g = 0; g < kG; ++g) z[k][g] = zt[k * 16 * kLd + 16 * g];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int q = 0;
+#pragma unroll
+      for (int gi = 0; gi < kG; ++gi)
+#pragma unroll
+        for (int gj = gi; gj < kG; ++gj, ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[k][gi], z[k][gj], acc[q], 0, 0, 0);
+    }
+    // This path never stores to the tile buffers, and the compiler then feels free to sink LDS
+    // reads below the barrier that orders them against the producers' next store (seen with a
+    // variant that read one tile ahead).  An empty asm that "uses" the registers right before
+    // the barrier pins every read above it.
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int g = 0; g < kG; ++g) asm volatile("" ::"v"(z[k][g]));
+    __syncthreads();
+  }
+  // the four consumer waves' partial blocks are summed through the (now free) buffers: waves
+  // 2, 3 -> waves 0, 1, then wave 1 -> wave 0.  C/D map: col = lane & 15, row = 4 (lane >> 4) + r.
+  float* mine = lds + (wave & 1) * kBuf + (4 * lk) * 16 + li;
+  if (wave >= 2) {
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[q * 256 + r * 16] = acc[q][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] += mine[q * 256 + r * 16];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[q * 256 + r * 16] = acc[q][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float* other = mine + kBuf;
+    float* slab = p.partial + (size_t)blockIdx.x * kPairs * 256 + (4 * lk) * 16 + li;
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[q * 256 + r * 16] = acc[q][r] + other[q * 256 + r * 16];
+  }
+}
+
+// Sums the partial blocks in float64 (fixed order) and adds them into the statistics.  Block t
+// is the t-th pair (gi <= gj) of 16-column groups of z in row-major order; element (i, j) of
+// the Gram matrix goes to both triangles of its destination.
+__global__ __launch_bounds__(1024) void gram_reduce_kernel(const float* __restrict__ partial, int n_slabs,
+                                                           int n_groups, int c1, int c2,
+                                                           double* __restrict__ fxx,
+                                                           double* __restrict__ fyy,
+                                                           double* __restrict__ gxy,
+                                                           double* __restrict__ sx,
+                                                           double* __restrict__ sx2) {
+  __shared__ double part[16][64];
+  const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + ol;               // 0 .. pairs * 256 - 1
+  const size_t stride = (size_t)n_groups * (n_groups + 1) / 2 * 256;
+  double s0 = 0.0, s1 = 0.0;
+  int wk = q;
+  for (; wk + 16 < n_slabs; wk += 32) {
+    s0 += (double)partial[(size_t)wk * stride + o];
+    s1 += (double)partial[(size_t)(wk + 16) * stride + o];
+  }
+  if (wk < n_slabs) s0 += (double)partial[(size_t)wk * stride + o];
+  part[q][ol] = s0 + s1;
+  __syncthreads();
+  if (q != 0) return;
+  double v = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v += part[k][ol];
+  int t = o >> 8, gi = 0;
+  while (t >= n_groups - gi) { t -= n_groups - gi; ++gi; }
+  const int gj = gi + t;
+  const int i = gi * 16 + ((o >> 4) & 15), j = gj * 16 + (o & 15);   // columns of z
+  const int ones = 16 * n_groups - 1;
+  if (i > j) return;                                 // diagonal blocks hold both triangles
+  if (j < 64) {                                      // x^T x
+    if (j < c1) {
+      fxx[(size_t)i * c1 + j] += v;
+      if (i != j) fxx[(size_t)j * c1 + i] += v;
+    }
+  } else if (i < 64) {                               // x^T [x2 | 1]
+    if (i < c1) {
+      if (j - 64 < c2) gxy[(size_t)i * c2 + (j - 64)] += v;
+      else if (j == ones) sx[i] += v;
+    }
+  } else {                                           // [x2 | 1]^T [x2 | 1]
+    const int a = i - 64, b = j - 64;
+    if (b < c2) {
+      fyy[(size_t)a * c2 + b] += v;
+      if (a != b) fyy[(size_t)b * c2 + a] += v;
+    } else if (j == ones && a < c2) {
+      sx2[a] += v;
+    }
   }
 }
 
@@ -958,6 +1291,51 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
   TD_HIP(h, hipGetLastError());
   hipLaunchKernelGGL(colsum_file_reduce_kernel, dim3((unsigned)n_segs, (unsigned)p.n_cbt), dim3(1024), 0,
                      h->stream, csum, p.cb_pad, cb, d_seg, colsum_seg_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+// No-lag CCA moments in one pass (gram_mfma_kernel).  segs: a_* = x stream, b_* = x2 stream,
+// rows [u_begin, u_end) of both.  All outputs are accumulated into.  *handled = false (nothing
+// done) when the shape does not fit the 64 + 31 + 1 column layout.
+int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, int64_t ldx2, int c2,
+            const std::vector<LagSeg>& segs, double* fxx, double* fyy, double* gxy, double* sx,
+            double* sx2, bool* handled) {
+  *handled = false;
+  if (c1 > 64 || c2 > 31 || c1 <= 0 || c2 <= 0) return TD_OK;
+  *handled = true;
+  long long total = 0;
+  for (const LagSeg& sg : segs) total += (sg.u_end > sg.u_begin) ? sg.u_end - sg.u_begin : 0;
+  if (total == 0) return TD_OK;
+  // slabs of whole 64-row tiles, at most 2048 rows (f32 chains of 512 row quads per wave),
+  // whole rounds of 512 resident workgroups
+  const int slots = 512;   // two 512-thread workgroups per CU
+  long long slab = td_round_up(td_ceil_div(total, slots * td_ceil_div(total, (long long)slots * 2048)),
+                               kGramTile);
+  std::vector<LagWork> works = split_work(segs, slab);
+  GramParams p;
+  p.x = x; p.x2 = x2; p.ldx = ldx; p.ldx2 = ldx2; p.c1 = c1; p.c2 = c2;
+  p.n_work = (int)works.size();
+  const size_t table_bytes = td_round_up(works.size() * sizeof(LagWork), 256);
+  void* scratch = nullptr;
+  const int n_groups = c2 <= 15 ? 5 : 6;
+  const size_t pair_floats = (size_t)n_groups * (n_groups + 1) / 2 * 256;
+  TD_TRY(td_scratch(h, table_bytes + works.size() * pair_floats * sizeof(float), &scratch));
+  TD_TRY(td_upload_async(h, works.data(), works.size() * sizeof(LagWork), scratch));
+  p.works = reinterpret_cast<const LagWork*>(scratch);
+  p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + table_bytes);
+  const bool vec4 = (ldx % 4 == 0) && (c1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                    (ldx2 % 4 == 0) && (c2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x2) & 15) == 0);
+  const dim3 grid((unsigned)works.size()), block(kGramThreads);
+#define TD_GRAM(V, G) hipLaunchKernelGGL((gram_mfma_kernel<V, G>), grid, block, 0, h->stream, p)
+  if (vec4) {
+    if (n_groups == 5) TD_GRAM(true, 5); else TD_GRAM(true, 6);
+  } else {
+    if (n_groups == 5) TD_GRAM(false, 5); else TD_GRAM(false, 6);
+  }
+#undef TD_GRAM
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)(pair_floats / 64)), dim3(1024), 0, h->stream,
+                     p.partial, (int)works.size(), n_groups, c1, c2, fxx, fyy, gxy, sx, sx2);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

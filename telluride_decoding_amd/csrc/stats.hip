@@ -489,6 +489,9 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
   // after the MAIN call of the same files
   const int64_t first_slot = do_main ? s->n_files : s->n_files - num_files;
   TD_REQUIRE(h, first_slot >= 0, "td_stats_accumulate_parts: TARGETS before MAIN");
+  // CCA without context on either input: every moment is one Gram matrix of [x | x2 | 1]
+  // (td_gram), done by MAIN; TARGETS then has nothing left to add.
+  const bool one_pass = s->c2 > 0 && s->d == 0 && s->l1 == 1 && s->l2 == 1 && s->c1 <= 64 && s->c2 <= 31;
 
   if (do_main) {
     // Boundary windows of the new files (also feed the all-ones rows below).
@@ -512,9 +515,17 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
       TD_HIP(h, hipGetLastError());
     }
     // F'xx: lagged auto-covariance of x (the MFMA kernel), and the CCA auto / cross moments.
-    TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
-                     s->g + s->off_fxx, true));
-    if (s->c2) {
+    if (one_pass) {
+      bool handled = false;
+      TD_TRY(td_gram(h, x_dev, ldx, s->c1, x2_dev, ldx2, s->c2, sxy, s->g + s->off_fxx,
+                     s->g + s->off_fyy, s->g + s->off_gxy, s->g + s->off_gxo, s->g + s->off_gyo,
+                     &handled));
+      TD_REQUIRE(h, handled, "td_gram refused a shape the one-pass test accepted");
+    } else {
+      TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
+                       s->g + s->off_fxx, true));
+    }
+    if (s->c2 && !one_pass) {
       TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
                        s->g + s->off_fyy, true));
       TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x2_dev, ldx2, s->c2, sxy,
@@ -527,7 +538,7 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
     TD_TRY(td_upload_async(h, &nd, sizeof(double), s->g + s->off_n));
   }
 
-  if (do_targets) {
+  if (do_targets && !one_pass) {
     // [y | 1]^T x~ for every signed lag: Xty and the lagged column sums.  Per-file column
     // sums of x live in the solver workspace arena (td_scratch is used by the kernels' own
     // tables and partial slabs).

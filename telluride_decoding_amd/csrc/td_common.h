@@ -116,6 +116,11 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
                       int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
                       double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled);
 
+// CCA moments without context in one pass over z = [x | x2 | 1] (lagcov.hip); accumulates.
+int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, int64_t ldx2, int c2,
+            const std::vector<LagSeg>& segs, double* fxx, double* fyy, double* gxy, double* sx,
+            double* sx2, bool* handled);
+
 // Column sums in float64 of rows [r0, r1) per segment (lagcov.hip).
 int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vector<LagSeg>& segs,
               double* out_dev, bool accumulate);
