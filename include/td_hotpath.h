@@ -181,6 +181,23 @@ int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_
  * rhs_dev [batch, n, nrhs] float64 (overwritten with the solution). */
 int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, int batch);
 
+/* General square solve (np.linalg.solve, brain_model.py:477) for the one branch whose matrix
+ * may be indefinite: a negative Ledoit-Wolf shrinkage.  Float64 LU with partial pivoting on
+ * the device; a_dev [n, n] is destroyed, rhs_dev [n, nrhs] is overwritten with the solution.
+ * TD_ERR_SINGULAR on a zero pivot column. */
+int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs);
+
+/* Ledoit-Wolf moment of the automatic-shrinkage branch (lamb == -1, use_ridge False):
+ * np.sum(sum_x2tx2) of brain_model.py:440-443, i.e. the sum over all lagged rows r of
+ * (sum_k (X[r,k] - mean_b[k])^2)^2 with mean_b the running column mean after the minibatch
+ * that holds r (:441).  The stream is the files' lagged rows (context pre/post, the
+ * input_offset / rows_used conventions of td_stats_accumulate) cut into minibatches of
+ * batch_rows; a shorter last minibatch is allowed.  result_dev: one float64 on the device,
+ * overwritten. */
+int td_shrinkage_moment(td_handle* h, const float* x_dev, int64_t ldx, int c, int pre, int post,
+                        const int64_t* file_offsets_host, int num_files, int input_offset,
+                        const int64_t* rows_used_host, int64_t batch_rows, double* result_dev);
+
 /* ------------------------------------------------------------------ A3' / A4 forward
  * Linear model forward X.W + b on the lagged view of x, never materialised
  * (Keras Dense in brain_model.py:335-341, 376).  out_dev [rows, d] float32. */

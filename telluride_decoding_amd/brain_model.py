@@ -74,9 +74,10 @@ def _dataset_stats(dataset, want_y=True, want_x2=False, handle=None):
   return st
 
 
-def _iterable_stats(batches, key2=None, handle=None):
+def _iterable_stats(batches, key2=None, handle=None, keep=None):
   """LagStats of a generic iterable of already-lagged (dict, y) minibatches:
-  each minibatch is a context-free 'file' of K feature channels."""
+  each minibatch is a context-free 'file' of K feature channels.  `keep`: a list that
+  receives the device copies of input_1 (the Ledoit-Wolf moment needs a second pass)."""
   h = handle or device.default_handle()
   st = None
   n_batches = 0
@@ -89,6 +90,8 @@ def _iterable_stats(batches, key2=None, handle=None):
       st = device.LagStats(int(x.shape[1]), 0, 0, int(x2.shape[1]) if key2 else 0, 0, 0,
                            int(yd.shape[1]) if yd is not None else 0, handle=h)
     st.accumulate(x, x2, yd)
+    if keep is not None:
+      keep.append(x)
     n_batches += 1
     last_rows = int(x.shape[0])
   return st, n_batches, last_rows
@@ -107,18 +110,32 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
   if not _is_dataset(dataset) and not hasattr(dataset, '__iter__'):
     raise TypeError('dataset input to calculate_linear_regressor_parameters_from_database '
                     'must be a tf.data.Dataset object')
-  if lamb == -1 and not use_ridge:
-    raise NotImplementedError('Ledoit-Wolf automatic shrinkage (lamb=-1) is not on the HIP '
-                              'path yet (SURVEY.md 8f, row F2)')
-  if not use_ridge and (lamb > 1 or lamb < 0):
+  ledoit_wolf = lamb == -1 and not use_ridge
+  if not use_ridge and not ledoit_wolf and (lamb > 1 or lamb < 0):
     raise ValueError('Regularization lambda must be between 0 and 1, not %g.' % lamb)
   h = device.default_handle()
+  x2_moment = None     # np.sum(sum_x2tx2), brain_model.py:440-443 (Ledoit-Wolf only)
   if _is_dataset(dataset):
     st = _dataset_stats(dataset, handle=h)
+    if ledoit_wolf:
+      x, _, _, offs = dataset.device_arrays(h)
+      x2_moment = device.shrinkage_moment(x, offs, dataset.pre, dataset.post, dataset.batch_size,
+                                          input_offset=dataset.input_offset,
+                                          rows_used=dataset.rows_used(), handle=h)
   else:
-    st, _, _ = _iterable_stats(dataset, handle=h)
+    kept = [] if ledoit_wolf else None
+    st, _, _ = _iterable_stats(dataset, handle=h, keep=kept)
     if st is None:
       raise ValueError('No minibatches in dataset')
+    if ledoit_wolf:
+      # already-lagged minibatches: one context-free stream of K channels, cut where the
+      # caller cut it (equal minibatches, a shorter last one allowed)
+      import torch
+      rows = [int(t.shape[0]) for t in kept]
+      if any(r != rows[0] for r in rows[:-1]) or rows[-1] > rows[0]:
+        raise ValueError('Ledoit-Wolf shrinkage needs minibatches of equal size')
+      xs = torch.cat(kept).contiguous()
+      x2_moment = device.shrinkage_moment(xs, [0, int(xs.shape[0])], 0, 0, rows[0], handle=h)
   frames, _ = st.counts()
   k = st.k1
   if use_ridge and use_offset:
@@ -148,13 +165,26 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
     mean_x = (sum_x / frames).reshape(1, -1)
     cov_x_zc = xtx - mean_x.t() @ mean_x          # sum minus mean outer (sic, :450)
     mu = float(cov_x_zc.diagonal().sum() / n)
-    shrinkage = lamb
+    if ledoit_wolf:                               # :457-465
+      delta_ = cov_x_zc.clone()
+      delta_.diagonal().sub_(mu)
+      delta = float((delta_ ** 2).sum()) / n
+      beta_ = 1. / (n * frames) * (x2_moment / frames - float((cov_x_zc ** 2).sum()))
+      shrinkage = min(beta_, delta) / delta
+    else:
+      shrinkage = lamb
     cov_x = (1 - shrinkage) * cov_x
     cov_x.diagonal().add_(shrinkage * mu)
   a = cov_x.clone().contiguous()
   rhs = cov_xy.clone().contiguous()
-  h.check(h.lib.td_spd_solve(h.ptr, ctypes.c_void_p(a.data_ptr()),
-                             ctypes.c_void_p(rhs.data_ptr()), n, int(rhs.shape[1]), 1))
+  if ledoit_wolf:
+    # a negative estimated shrinkage (the reference's golden case has one) makes the matrix
+    # indefinite: LU like np.linalg.solve (:477), not the ridge path's Cholesky
+    h.check(h.lib.td_general_solve(h.ptr, ctypes.c_void_p(a.data_ptr()),
+                                   ctypes.c_void_p(rhs.data_ptr()), n, int(rhs.shape[1])))
+  else:
+    h.check(h.lib.td_spd_solve(h.ptr, ctypes.c_void_p(a.data_ptr()),
+                               ctypes.c_void_p(rhs.data_ptr()), n, int(rhs.shape[1]), 1))
   sol = rhs.cpu().numpy().astype(np.float32)
   cov_x_np = cov_x.cpu().numpy().astype(np.float32)
   cov_xy_np = cov_xy.cpu().numpy().astype(np.float32)

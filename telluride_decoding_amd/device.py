@@ -291,6 +291,30 @@ def window_layout(trial_offsets, width, hop):
   return wo, int(total.value)
 
 
+def general_solve(a, rhs, handle=None):
+  """np.linalg.solve(a, rhs) in float64 on the device (LU, partial pivoting): a [n, n] and
+  rhs [n, nrhs] float64 device tensors; returns the solution, inputs untouched."""
+  h = handle or default_handle()
+  a = a.clone().contiguous()
+  x = rhs.clone().contiguous()
+  h.check(h.lib.td_general_solve(h.ptr, _ptr(a), _ptr(x), int(a.shape[0]), int(x.shape[1])))
+  return x
+
+
+def shrinkage_moment(x, file_offsets, pre, post, batch_rows, input_offset=0, rows_used=None,
+                     handle=None):
+  """np.sum(sum_x2tx2) of the reference's Ledoit-Wolf branch (brain_model.py:440-443) for the
+  lagged rows of `x` [rows, C] cut into minibatches of `batch_rows`: a Python float."""
+  h = handle or default_handle()
+  out = h.zeros((1,), 'float64')
+  offs, offs_p = _lib.i64_array(file_offsets)
+  used, used_p = (_lib.i64_array(rows_used) if rows_used is not None else (None, None))
+  h.check(h.lib.td_shrinkage_moment(h.ptr, _ptr(x), x.stride(0), int(x.shape[1]), int(pre),
+                                    int(post), offs_p, len(offs) - 1, int(input_offset), used_p,
+                                    int(batch_rows), _ptr(out)))
+  return float(out.cpu()[0])
+
+
 def window_sums(a, b, trial_offsets, width, hop, handle=None):
   """Five float64 sums per window and column: [n_windows, cols, 5]."""
   h = handle or default_handle()

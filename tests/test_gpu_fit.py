@@ -498,3 +498,104 @@ def test_single_rank_rccl_allreduce_round_trip(dev):
   finally:
     if created:
       dist.destroy_process_group()
+
+
+def _lw_moment_numpy(batches):
+  """np.sum(sum_x2tx2) exactly as brain_model.py:429-443 accumulates it (float64)."""
+  sum_x, n, tot = 0.0, 0, 0.0
+  for x in batches:
+    x = np.asarray(x, np.float64)
+    n += x.shape[0]
+    sum_x = sum_x + x.sum(axis=0, keepdims=True)
+    x2 = (x - sum_x / n) ** 2
+    tot += float((x2.sum(axis=1) ** 2).sum())      # = np.sum(x2.T @ x2)
+  return tot
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('c,pre,post,off,lens,batch', [
+    (5, 2, 3, 0, (700, 333, 1021), 100),
+    (16, 0, 7, 2, (900, 0, 901), 64),
+    (64, 0, 31, 0, (3000, 2500), 500),
+    (3, 1, 1, -3, (640, 129, 7), 50),
+    (70, 0, 0, 0, (1000,), 300),           # shorter last minibatch (1000 = 3 * 300 + 100)
+])
+def test_shrinkage_moment_matches_reference_accumulation(dev, c, pre, post, off, lens, batch):
+  """Row F2: the Ledoit-Wolf moment of brain_model.py:440-443 (running mean including the
+  current minibatch) from the raw recordings, against the literal minibatch loop."""
+  rng = np.random.default_rng(99 + c)
+  files = [(rng.standard_normal((n, c)) + 0.7).astype(np.float32) for n in lens]
+  streams = []
+  for x in files:
+    a = np.zeros((x.shape[0], 1), np.float32)
+    xl, _, _, _ = o_lag.window_streams(x, a, a, a, pre=pre, post=post, input_offset=off)
+    streams.append(xl)
+  stream = np.concatenate(streams)
+  drop = batch != 300
+  total = (stream.shape[0] // batch) * batch if drop else stream.shape[0]
+  want = _lw_moment_numpy([stream[i:i + batch] for i in range(0, total, batch)])
+  h = dev.default_handle()
+  xd = h.to_device(np.concatenate(files))
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  used = None
+  if drop:
+    used, left = [], total
+    for s in streams:
+      used.append(min(left, s.shape[0]))
+      left -= used[-1]
+  got = dev.shrinkage_moment(xd, offs, pre, post, batch, input_offset=off, rows_used=used, handle=h)
+  assert abs(got - want) <= 2e-6 * abs(want)
+
+
+@pytest.mark.gpu
+def test_ledoit_wolf_regression_matches_reference_golden(dev):
+  """lamb = -1, use_ridge = False against the output of the reference itself (g2_ridge.npz,
+  'shrink_lw') and, on a lagged case, against the oracle in float64."""
+  from telluride_decoding_amd import brain_data, brain_model
+  g = golden('g2_ridge')
+  bd = brain_data.TestBrainData('eeg', 'env', 100.0, final_batch_size=100)
+  for i in range(3):
+    bd.add_file(g['c1_eeg%d' % i], g['c1_env%d' % i][:, 0:1])
+  w, b, cx, _, sh = brain_model.calculate_linear_regressor_parameters_from_dataset(
+      bd.create_dataset('train'), lamb=-1, use_ridge=False)
+  assert abs(sh - float(g['shrink_lw_shrinkage'])) < 1e-3 * abs(float(g['shrink_lw_shrinkage']))
+  np.testing.assert_allclose(w, g['shrink_lw_w'], rtol=1e-3, atol=2e-5)
+  np.testing.assert_allclose(cx, g['shrink_lw_cov_x'], rtol=1e-4, atol=1e-4)
+  # generic-iterable entry point (already lagged minibatches), float64 oracle
+  rng = np.random.default_rng(5)
+  files = []
+  for n in (1500, 801):
+    x = rng.standard_normal((n, 6)).astype(np.float32)
+    y = (x[:, :1] * 0.5 + rng.standard_normal((n, 1)) * 0.1).astype(np.float32)
+    files.append((x, y, y, np.zeros((n, 1), np.float32)))
+  batches = list(o_lag.minibatches(files, 100, pre=1, post=2))
+  f64 = [({'input_1': bx['input_1'].astype(np.float64)}, by.astype(np.float64)) for bx, by in batches]
+  w0, b0, _, _, sh0 = o_reg.linear_regressor_from_batches(f64, lamb=-1, use_ridge=False)
+  w1, b1, _, _, sh1 = brain_model.calculate_linear_regressor_parameters_from_dataset(
+      batches, lamb=-1, use_ridge=False)
+  assert abs(sh1 - sh0) < 1e-4 * abs(sh0)
+  np.testing.assert_allclose(w1, w0, rtol=1e-3, atol=2e-5)
+  np.testing.assert_allclose(b1, b0, rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,nrhs', [(1, 1), (5, 2), (70, 1), (300, 3)])
+def test_general_solve_indefinite_and_singular(dev, n, nrhs):
+  """td_general_solve = np.linalg.solve (brain_model.py:477) for the branch whose matrix can be
+  indefinite; a singular matrix raises like NumPy does."""
+  import torch
+  rng = np.random.default_rng(n)
+  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  eig = np.linspace(-3.0, 5.0, n) if n > 1 else np.array([-2.0])
+  a = (q * eig) @ q.T + 1e-3 * rng.standard_normal((n, n))      # indefinite, not symmetric
+  b = rng.standard_normal((n, nrhs))
+  h = dev.default_handle()
+  got = dev.general_solve(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), handle=h)
+  want = np.linalg.solve(a, b)
+  np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-9, atol=1e-10)
+  if n > 1:
+    a[:, 1] = 0.0                                  # an exactly zero pivot column
+    with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
+      np.linalg.solve(a, b)
+    with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
+      dev.general_solve(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), handle=h)
