@@ -1,12 +1,12 @@
 """Runs only the hot kernels a few times (for rocprofv3 kernel-trace / PMC passes):
-   python tools/prof_kernels.py [fit] [decode]"""
+   python tools/prof_kernels.py [fit] [cca] [decode]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from telluride_decoding_amd import device
 
-what = sys.argv[1:] or ['fit', 'decode']
+what = sys.argv[1:] or ['fit', 'cca', 'decode']
 h = device.default_handle()
 torch.manual_seed(0)
 if 'fit' in what:
@@ -17,6 +17,16 @@ if 'fit' in what:
   for rep in range(3):
     st.reset(); st.accumulate(x, None, y, offs)
   w, b = st.ridge_solve([0.1])
+  torch.cuda.synchronize()
+if 'cca' in what:
+  # C3: 64-ch EEG vs 8-band envelope, 1e6 samples, no context: one-pass Gram + transform
+  n = 1000000
+  x = torch.randn(n, 64, device='cuda'); x2 = torch.randn(n, 8, device='cuda')
+  st = device.LagStats(64, 0, 0, 8, 0, 0, 0)
+  offs = np.array([0, n], np.int64)
+  for rep in range(3):
+    st.reset(); st.accumulate(x, x2, None, offs)
+  m = st.moments(want_cca=True)
   torch.cuda.synchronize()
 if 'decode' in what:
   trials, t, c = 200, 6000, 64
