@@ -79,6 +79,35 @@ int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst)
   return TD_OK;
 }
 
+int td_table_upload(td_handle* h, const void* host, size_t bytes, const void** dev) {
+  *dev = nullptr;
+  if (bytes == 0) return TD_OK;
+  td_handle::TableSlot* lru = &h->tables[0];
+  for (auto& slot : h->tables) {
+    if (slot.host.size() == bytes && memcmp(slot.host.data(), host, bytes) == 0) {
+      slot.stamp = ++h->table_clock;
+      *dev = slot.dev;
+      return TD_OK;
+    }
+    if (slot.stamp < lru->stamp) lru = &slot;
+  }
+  if (lru->cap < bytes) {
+    // (hipFree waits for the device: kernels still reading the old block finish first)
+    if (lru->dev) TD_HIP(h, hipFree(lru->dev));
+    lru->dev = nullptr; lru->cap = 0; lru->host.clear();
+    const size_t want = td_round_up(bytes * 2 < 4096 ? 4096 : bytes * 2, 256);
+    TD_HIP(h, hipMalloc(&lru->dev, want));
+    lru->cap = want;
+  }
+  // overwriting a block that earlier kernels of this stream read is safe in stream order
+  lru->host.clear();                       // not a valid cache entry if the upload fails
+  TD_TRY(td_upload_async(h, host, bytes, lru->dev));
+  lru->host.assign(reinterpret_cast<const char*>(host), reinterpret_cast<const char*>(host) + bytes);
+  lru->stamp = ++h->table_clock;
+  *dev = lru->dev;
+  return TD_OK;
+}
+
 int td_profile_mark(td_handle* h, bool start, double samples) {
   if (!h->profile) return TD_OK;
   if (h->prof_used == h->prof_events.size()) {
@@ -165,6 +194,8 @@ int td_destroy(td_handle* h) {
     if (slot.p) hipHostFree(slot.p);
     if (slot.ev) hipEventDestroy(slot.ev);
   }
+  for (auto& slot : h->tables)
+    if (slot.dev) hipFree(slot.dev);
   if (h->dev_flag) hipFree(h->dev_flag);
   if (h->ev_start) hipEventDestroy(h->ev_start);
   if (h->ev_stop) hipEventDestroy(h->ev_stop);

@@ -517,31 +517,73 @@ __global__ __launch_bounds__(kThreads) void window_sums_kernel(
 // ---- two-stage window sums: block partials, then windows from blocks ---------
 // Overlapping windows share frames (width / hop = 10 at C4): with g = gcd(width,
 // hop) every window is a run of width / g whole blocks of g frames, so the frames
-// are read ONCE into per-block float64 partial sums (one wave per block, lane-
-// strided accumulation + fixed shuffle tree: bitwise reproducible) and a window
-// is the sum of its blocks in ascending order.
+// are read ONCE into per-block float64 partial sums and a window is the sum of its
+// blocks in ascending order.  A block belongs to 16 lanes (4 blocks per wave): lane-
+// strided accumulation, then a fixed 4-step shuffle tree -- bitwise reproducible, and the
+// same order in both kernels below (the fused decode is tested bit-for-bit against the
+// unfused chain).  One wave per block spent most of its time in 6-step float64 shuffle
+// trees for 2 rounds of loads (22 us at C4; 16 lanes per block: 8 us).
+constexpr int kBlockLanes = 16;
+
+__device__ __forceinline__ double group16_sum(double v) {
+#pragma unroll
+  for (int off = kBlockLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(kThreads) void block_sums_kernel(
     const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
     int cols, int b_cols, const FileDesc* __restrict__ trials, int n_trials, long long n_blocks,
     int g, double* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const long long blk = blockIdx.x * (long long)(kThreads / 64) + (threadIdx.x >> 6);
-  if (blk >= n_blocks) return;
-  const FileDesc tr = trials[find_file(trials, n_trials, blk)];
-  const long long r0 = tr.row0 + (blk - tr.first) * g;
+  const int sub = threadIdx.x & (kBlockLanes - 1);
+  const long long blk = blockIdx.x * (long long)(kThreads / kBlockLanes) + threadIdx.x / kBlockLanes;
+  const bool live = blk < n_blocks;                 // dead groups stay for the shuffles
+  const long long bq = live ? blk : n_blocks - 1;
+  const FileDesc tr = trials[find_file(trials, n_trials, bq)];
+  const long long r0 = tr.row0 + (bq - tr.first) * g;
   for (int col = 0; col < cols; ++col) {
     const int bc = col % b_cols;
     double s[5] = {0, 0, 0, 0, 0};
-    for (int r = lane; r < g; r += 64) {
+    for (int r = sub; r < g; r += kBlockLanes) {
       const double av = (double)a[(r0 + r) * lda + col];
       const double bv = (double)b[(r0 + r) * ldb + bc];
       s[0] += av; s[1] += bv; s[2] += av * av; s[3] += bv * bv; s[4] += av * bv;
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-      const double v = wave_sum(s[k]);
-      if (lane == 0) out[(blk * cols + col) * 5 + k] = v;
+      const double v = group16_sum(s[k]);
+      if (sub == 0 && live) out[(blk * cols + col) * 5 + k] = v;
     }
+  }
+}
+
+// The fused decode's shape: two truth columns (the speakers' envelopes) against ONE shared
+// prediction column -- every frame is loaded once and 8 sums instead of 10 go through the tree.
+__global__ __launch_bounds__(kThreads) void block_sums_pair_kernel(
+    const float* __restrict__ a, long long lda, const float* __restrict__ b,
+    const FileDesc* __restrict__ trials, int n_trials, long long n_blocks, int g,
+    double* __restrict__ out) {
+  const int sub = threadIdx.x & (kBlockLanes - 1);
+  const long long blk = blockIdx.x * (long long)(kThreads / kBlockLanes) + threadIdx.x / kBlockLanes;
+  const bool live = blk < n_blocks;
+  const long long bq = live ? blk : n_blocks - 1;
+  const FileDesc tr = trials[find_file(trials, n_trials, bq)];
+  const long long r0 = tr.row0 + (bq - tr.first) * g;
+  double sa0 = 0, sa1 = 0, sb = 0, qa0 = 0, qa1 = 0, qb = 0, p0 = 0, p1 = 0;
+  for (int r = sub; r < g; r += kBlockLanes) {
+    const double a0 = (double)a[(r0 + r) * lda], a1 = (double)a[(r0 + r) * lda + 1];
+    const double bv = (double)b[r0 + r];
+    sa0 += a0; sa1 += a1; sb += bv;
+    qa0 += a0 * a0; qa1 += a1 * a1; qb += bv * bv;
+    p0 += a0 * bv; p1 += a1 * bv;
+  }
+  sa0 = group16_sum(sa0); sa1 = group16_sum(sa1); sb = group16_sum(sb);
+  qa0 = group16_sum(qa0); qa1 = group16_sum(qa1); qb = group16_sum(qb);
+  p0 = group16_sum(p0); p1 = group16_sum(p1);
+  if (sub == 0 && live) {
+    double* o = out + blk * 10;
+    o[0] = sa0; o[1] = sb; o[2] = qa0; o[3] = qb; o[4] = p0;
+    o[5] = sa1; o[6] = sb; o[7] = qa1; o[8] = qb; o[9] = p1;
   }
 }
 
@@ -937,23 +979,11 @@ int fill_score_params(td_handle* h, ScoreParams* sp, int cols, const double* mea
   return TD_OK;
 }
 
-// Upper bound of the device table launch_fir needs (per-file descriptors for the
-// matrix-core kernel, per-tile ones for the VALU fallback).
-size_t fir_table_bytes(const int64_t* offs, int num_files, int64_t shift) {
-  size_t tiles = 0;
-  for (int f = 0; f < num_files; ++f) {
-    const int64_t n = offs[f + 1] - offs[f] - shift;
-    if (n > 0) tiles += (size_t)td_ceil_div(n, kThreads);
-  }
-  const size_t a = (size_t)num_files * sizeof(FileDesc), b = tiles * sizeof(FirTile);
-  return td_round_up((int64_t)((a > b ? a : b) + 256), 256);
-}
-
-// table_dev: optional caller-provided device block of fir_table_bytes() bytes (so
-// that a caller holding other td_scratch data is not disturbed); NULL = td_scratch.
+// The per-file descriptor table goes through the handle's content-cached table slots
+// (td_table_upload): no td_scratch use, and no upload at all when the layout repeats.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
                int c, int pre, int post, const float* w, const float* bias, int d, float* out,
-               int64_t ldout, int64_t shift = 0, void* table_dev = nullptr) {
+               int64_t ldout, int64_t shift = 0) {
   // `shift` leading rows of every file are dropped from this input stream BEFORE
   // context is added (brain_data.py:466-475); output row offs[f] + t is frame t of
   // the shifted stream, i.e. the index of the zipped streams.
@@ -964,11 +994,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     if (n > 0) total += n;
   }
   if (total == 0) return TD_OK;
-  if (!table_dev) {
-    void* scratch = nullptr;
-    TD_TRY(td_scratch(h, fir_table_bytes(offs, num_files, shift), &scratch));
-    table_dev = scratch;
-  }
+  const void* table_dev = nullptr;
 
   // ---- matrix-core path: C <= 64 and the weights (MFMA order, each output's lags padded
   // to whole 32-column tiles) + per-wave output rings fit 64 KB of LDS; outputs go in
@@ -1004,7 +1030,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       files[f].first = n_strips;
       if (n > 0) n_strips += td_ceil_div(n, strip);
     }
-    TD_TRY(td_upload_async(h, files.data(), files.size() * sizeof(FileDesc), table_dev));
+    TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(FileDesc), &table_dev));
     const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
     const unsigned blocks = (unsigned)td_ceil_div(n_strips, kThreads / 64);
     for (int q0 = 0; q0 < d; q0 += dq_max) {
@@ -1041,7 +1067,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       files[f].first = n_strips;
       if (n > 0) n_strips += td_ceil_div(n, strip);
     }
-    TD_TRY(td_upload_async(h, files.data(), files.size() * sizeof(FileDesc), table_dev));
+    TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(FileDesc), &table_dev));
     const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
     const unsigned blocks = (unsigned)td_ceil_div(n_strips, waves);
     for (int q0 = 0; q0 < d; q0 += dqv) {
@@ -1072,7 +1098,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     }
   }
   if (tiles.empty()) return TD_OK;
-  TD_TRY(td_upload_async(h, tiles.data(), tiles.size() * sizeof(FirTile), table_dev));
+  TD_TRY(td_table_upload(h, tiles.data(), tiles.size() * sizeof(FirTile), &table_dev));
   const FirTile* dt = reinterpret_cast<const FirTile*>(table_dev);
   for (int q0 = 0; q0 < d;) {
     const int left = d - q0;
@@ -1177,7 +1203,7 @@ int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b
     double* bsums = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + 2 * tb);
     TD_TRY(td_upload_async(h, blk_tab.data(), sizeof(FileDesc) * num_trials, d_blk));
     TD_TRY(td_upload_async(h, win_tab.data(), sizeof(FileDesc) * num_trials, d_win));
-    hipLaunchKernelGGL(block_sums_kernel, dim3((unsigned)td_ceil_div(n_blocks, kThreads / 64)),
+    hipLaunchKernelGGL(block_sums_kernel, dim3((unsigned)td_ceil_div(n_blocks, kThreads / kBlockLanes)),
                        dim3(kThreads), 0, h->stream, a_dev, (long long)lda, b_dev, (long long)ldb,
                        cols, cols, d_blk, num_trials, (long long)n_blocks, g, bsums);
     const long long outs = (long long)n_win * cols * 5;
@@ -1376,8 +1402,8 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
     hipFree(pred);
     return rc;
   }
-  // Three launches, one scratch block, one small upload (per-trial descriptors),
-  // no allocation and no host synchronisation:
+  // Three launches, one scratch block, per-trial descriptors from the table cache (uploaded
+  // only when the trial layout changes), no allocation and no host synchronisation:
   //   FIR prediction (matrix cores) -> block partial sums of (envelope_spk, prediction)
   //   -> window scores of both speakers + winner-take-all.
   std::vector<FileDesc> tabs, win_tab;
@@ -1385,24 +1411,25 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
   build_block_tables(trial_offsets_host, num_trials, width, hop, g, &tabs, &win_tab, &n_blocks,
                      &nwin);
   tabs.insert(tabs.end(), win_tab.begin(), win_tab.end());
-  const size_t s_fir = fir_table_bytes(trial_offsets_host, num_trials, 0);
-  const size_t s_tab = td_round_up(sizeof(FileDesc) * tabs.size(), 256);
   const size_t s_pred = td_round_up(sizeof(float) * rows, 256);
   void* scratch = nullptr;
-  TD_TRY(td_scratch(h, s_fir + s_tab + s_pred + sizeof(double) * n_blocks * 10 + 256, &scratch));
+  TD_TRY(td_scratch(h, s_pred + sizeof(double) * n_blocks * 10 + 256, &scratch));
   char* base = reinterpret_cast<char*>(scratch);
-  FileDesc* d_blk = reinterpret_cast<FileDesc*>(base + s_fir);
-  FileDesc* d_win = d_blk + num_trials;
-  float* pred = reinterpret_cast<float*>(base + s_fir + s_tab);
-  double* bsums = reinterpret_cast<double*>(base + s_fir + s_tab + s_pred);
+  float* pred = reinterpret_cast<float*>(base);
+  double* bsums = reinterpret_cast<double*>(base + s_pred);
+  // both descriptor tables first, so that no copy sits between the kernels
+  const void* tab_dev = nullptr;
+  if (nwin > 0) TD_TRY(td_table_upload(h, tabs.data(), sizeof(FileDesc) * tabs.size(), &tab_dev));
+  const FileDesc* d_blk = reinterpret_cast<const FileDesc*>(tab_dev);
+  const FileDesc* d_win = d_blk + num_trials;
   TD_TRY(launch_fir(h, eeg_dev, ldx, trial_offsets_host, num_trials, c, pre, post, w_dev, b_dev, 1,
-                    pred, 1, 0, base));
+                    pred, 1, 0));
   if (nwin == 0) return TD_OK;
-  TD_TRY(td_upload_async(h, tabs.data(), sizeof(FileDesc) * tabs.size(), d_blk));
   // a = envelope of speaker spk (the "truth" stream), b = the shared prediction
-  hipLaunchKernelGGL(block_sums_kernel, dim3((unsigned)td_ceil_div(n_blocks, kThreads / 64)),
-                     dim3(kThreads), 0, h->stream, env_dev, (long long)ldenv, pred, 1LL, 2, 1, d_blk,
-                     num_trials, (long long)n_blocks, g, bsums);
+  hipLaunchKernelGGL(block_sums_pair_kernel,
+                     dim3((unsigned)td_ceil_div(n_blocks, kThreads / kBlockLanes)), dim3(kThreads), 0,
+                     h->stream, env_dev, (long long)ldenv, pred, d_blk, num_trials,
+                     (long long)n_blocks, g, bsums);
   FusedCorr fc;
   for (int spk = 0; spk < 2; ++spk) {
     fc.mean_a[spk] = corr_host[3 * spk];

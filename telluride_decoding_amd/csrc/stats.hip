@@ -497,20 +497,18 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
     // Boundary windows of the new files (also feed the all-ones rows below).
     TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
     {
-      void* scratch = nullptr;
       const size_t bytes = sizeof(WinJob) * num_files;
-      TD_TRY(td_scratch(h, 2 * td_round_up(bytes, 256), &scratch));
-      WinJob* d1 = reinterpret_cast<WinJob*>(scratch);
-      WinJob* d2 = reinterpret_cast<WinJob*>(reinterpret_cast<char*>(scratch) + td_round_up(bytes, 256));
-      TD_TRY(td_upload_async(h, j1.data(), bytes, d1));
+      const void* d1 = nullptr;
+      const void* d2 = nullptr;
+      TD_TRY(td_table_upload(h, j1.data(), bytes, &d1));
       hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)num_files, 2), dim3(256), 0,
-                         h->stream, x_dev, (long long)ldx, s->c1, s->hw, d1, s->win1,
-                         (long long)first_slot);
+                         h->stream, x_dev, (long long)ldx, s->c1, s->hw,
+                         reinterpret_cast<const WinJob*>(d1), s->win1, (long long)first_slot);
       if (s->c2) {
-        TD_TRY(td_upload_async(h, j2.data(), bytes, d2));
+        TD_TRY(td_table_upload(h, j2.data(), bytes, &d2));
         hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)num_files, 2), dim3(256), 0,
-                           h->stream, x2_dev, (long long)ldx2, s->c2, s->hw, d2, s->win2,
-                           (long long)first_slot);
+                           h->stream, x2_dev, (long long)ldx2, s->c2, s->hw,
+                           reinterpret_cast<const WinJob*>(d2), s->win2, (long long)first_slot);
       }
       TD_HIP(h, hipGetLastError());
     }

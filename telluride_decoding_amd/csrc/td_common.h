@@ -37,6 +37,19 @@ struct td_handle {
   static constexpr int kPinSlots = 16;
   PinSlot pin[kPinSlots];
   int pin_next = 0;
+  // Small parameter tables (per-file / per-trial descriptors, work lists) by content: a
+  // serving loop presents the same layout call after call, so the table of the previous call
+  // is usually still on the device and the upload (a copy engine packet plus the idle gap
+  // around it: ~9 us of a 146 us decode step) can be skipped.
+  struct TableSlot {
+    void* dev = nullptr;
+    size_t cap = 0;
+    std::vector<char> host;   // what dev holds (or will, in stream order)
+    uint64_t stamp = 0;
+  };
+  static constexpr int kTableSlots = 8;
+  TableSlot tables[kTableSlots];
+  uint64_t table_clock = 0;
   int* dev_flag = nullptr;  // device int used for "not positive definite" reports
   // Optional per-kernel hipEvent timing of the dominant kernel (td_profile_*):
   // event pairs recorded on h->stream around every lagcov MFMA launch.
@@ -82,6 +95,10 @@ int td_workspace(td_handle* h, size_t bytes, void** out);
 // Stream-ordered upload of a small host block (work tables, parameters) through
 // the pinned ring; the host block may be reused as soon as this returns.
 int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst);
+
+// Device copy of a small host table, cached by content (td_handle::TableSlot): *dev is valid, in
+// stream order, until kTableSlots other tables have been asked for.
+int td_table_upload(td_handle* h, const void* host, size_t bytes, const void** dev);
 
 static inline int64_t td_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t td_round_up(int64_t a, int64_t b) { return td_ceil_div(a, b) * b; }

@@ -89,6 +89,11 @@ class Handle(object):
     torch = _torch()
     return torch.zeros(shape, dtype=getattr(torch, dtype), device=self.device)
 
+  def empty(self, shape, dtype='float32'):
+    """Uninitialised device tensor: for outputs a kernel writes completely."""
+    torch = _torch()
+    return torch.empty(shape, dtype=getattr(torch, dtype), device=self.device)
+
   def __del__(self):
     try:
       if getattr(self, 'ptr', None):
@@ -416,8 +421,9 @@ def decode_fused(eeg, env, trial_offsets, w, b, pre, post, width, hop, corr, han
   """corr = [mean_truth, mean_pred, power] for speaker 1 then speaker 2."""
   h = handle or default_handle()
   _, total = window_layout(trial_offsets, width, hop)
-  scores = h.zeros((total, 2), 'float64')
-  decisions = h.zeros((total,), 'uint8')
+  # (every element is written by decode_finalize_kernel: no zero-fill launches)
+  scores = h.empty((total, 2), 'float64')
+  decisions = h.empty((total,), 'uint8')
   offs, offs_p = _lib.i64_array(trial_offsets)
   cr, cr_p = _lib.f64_array(np.asarray(corr, np.float64).reshape(-1))
   h.check(h.lib.td_decode_fused(h.ptr, _ptr(eeg), eeg.stride(0), int(eeg.shape[1]), pre, post,
