@@ -924,15 +924,19 @@ int64_t gcd64(int64_t a, int64_t b) {
   return a;
 }
 
-// Block size for the two-stage window sums: the largest divisor of gcd(width,
-// hop) that is <= 4096 (a block is summed by one wave), or 0 if the only usable
-// divisors are tiny / the windows would span too many blocks (then the
-// one-workgroup-per-window kernel is used).
+// Block size for the two-stage window sums: a divisor of gcd(width, hop) -- the largest one
+// <= 256 (a block is summed by 16 lanes: <= 16 frames per lane, and non-overlapping windows,
+// e.g. minibatch metrics with hop = width = 1000, still give thousands of blocks to spread over
+// the chip), else the largest <= 4096 -- or 0 if the only usable divisors are tiny / the
+// windows would span too many blocks (then the one-workgroup-per-window kernel is used).
 int window_block_size(int width, int hop) {
   const int64_t g = gcd64(width, hop);
   int best = 0;
-  for (int64_t dv = g < 4096 ? g : 4096; dv >= 32; --dv)
+  for (int64_t dv = g < 256 ? g : 256; dv >= 32; --dv)
     if (g % dv == 0) { best = (int)dv; break; }
+  if (best == 0)
+    for (int64_t dv = g < 4096 ? g : 4096; dv >= 32; --dv)
+      if (g % dv == 0) { best = (int)dv; break; }
   if (best == 0 || width / best > 4096) return 0;
   return best;
 }

@@ -38,11 +38,6 @@ def calculate_stats(values):
   return float(np.mean(values)), float(np.std(values))
 
 
-def _file_dataset(files, i, proto):
-  return brain_data.Dataset([files[i]], proto.batch_size, proto.pre, proto.post, proto.pre2,
-                            proto.post2, proto.input_offset)
-
-
 def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, world_size=1,
                                    group=None):
   """dataset: brain_data.Dataset whose files are the jackknife units (subjects).
@@ -50,44 +45,79 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   Returns an OrderedDict {lambda: (mean, std)} of the held-out
   pearson_correlation_first, like reference regression.py:411-420, plus the raw
   [Lambda, F] matrix under the key 'all_runs'.
+
+  The recordings are uploaded once; per-file statistics, fold solves and the held-out
+  evaluation all work on slices of that one device copy.  A fold's 20 lambdas are evaluated
+  together: their weight vectors are the output columns of ONE FIR prediction of the held-out
+  file, and one window-sums launch gives the per-minibatch Pearson correlation of every column
+  (Keras `evaluate` = the unweighted mean over minibatches, reference brain_model.py:206-253).
   """
+  import torch
   lambdas = parse_regularization_values() if regularization_list is None else list(regularization_list)
-  files = dataset.files
-  n_files = len(files)
+  n_files = len(dataset.files)
   if n_files < 2:
     raise ValueError('Need at least two files for a jackknife test.')
   h = device.default_handle()
-  plan = distributed.ShardPlan([f[0].shape[0] for f in files], world_size)
+  x, _, y, offs = dataset.device_arrays(h)
+  off, bsz = dataset.input_offset, dataset.batch_size
+  dy = max(-off, 0)
+  lengths = dataset.file_lengths()
+  # a held-out / single file is its own dataset: batch(drop_remainder=True) per file
+  used = [(max(n - abs(off), 0) // bsz) * bsz for n in lengths]
+  plan = distributed.ShardPlan(lengths, world_size)
+
+  def new_stats():
+    return device.LagStats(dataset.c1, dataset.pre, dataset.post, 0, 0, 0, dataset.d, handle=h)
+
   # 1. per-file statistics of this rank's files
   per_file = {}
   for i in plan.files_of(rank):
-    per_file[i] = brain_model._dataset_stats(_file_dataset(files, i, dataset), handle=h)
+    st = new_stats()
+    lo, hi = int(offs[i]), int(offs[i + 1])
+    st.accumulate(x[lo:hi], None, y[lo:hi], [0, hi - lo], input_offset=off, rows_used=[used[i]])
+    per_file[i] = st
   # 2. make every file's statistics available on every rank: one all-reduce of
   #    [file][packed] with each rank filling only its own rows.
-  proto = next(iter(per_file.values())) if per_file else brain_model._dataset_stats(
-      _file_dataset(files, 0, dataset), handle=h)
+  proto = next(iter(per_file.values())) if per_file else new_stats()
   plen = proto.packed_len(1)
-  import torch
   table = torch.zeros((n_files, plen), dtype=torch.float64, device=h.device)
   for i, st in per_file.items():
     table[i] = st.pack(1, 0)
   distributed.allreduce_packed(table, group)
   stats = []
   for i in range(n_files):
+    if i in per_file and world_size == 1:
+      stats.append(per_file[i])
+      continue
     st = proto.like()
     st.unpack(table[i].contiguous(), 1)
     stats.append(st)
   # 3-4. folds of this rank
   my_folds = distributed.split_round_robin(list(range(n_files)), rank, world_size)
-  rows = np.zeros((len(my_folds), len(lambdas)))
-  for j, f in enumerate(my_folds):
-    train = proto.like().combine([stats[g] for g in range(n_files) if g != f])
-    w, b = train.ridge_solve(lambdas)
-    test = _file_dataset(files, f, dataset)
-    model = brain_model.BrainModelLinearRegression(test)
-    for li in range(len(lambdas)):
-      model.set_weights([w[li].cpu().numpy(), b[li].cpu().numpy()])
-      rows[j, li] = model.evaluate(test)['pearson_correlation_first']
+  n_lam, d = len(lambdas), dataset.d
+  scores = []
+  train = proto.like()
+  for f in my_folds:
+    train.combine([stats[g] for g in range(n_files) if g != f])
+    w, b = train.ridge_solve(lambdas)                    # [Lambda, K, D], [Lambda, D]
+    u = used[f]
+    if u == 0:
+      scores.append(torch.full((n_lam,), float('nan'), dtype=torch.float64, device=h.device))
+      continue
+    k = int(w.shape[1])
+    w_all = w.permute(1, 0, 2).reshape(k, n_lam * d).contiguous()
+    xf = x[int(offs[f]):int(offs[f + 1])]
+    pred = device.predict_fir(xf, [0, int(xf.shape[0])], w_all, b.reshape(-1).contiguous(),
+                              dataset.pre, dataset.post, handle=h, input_offset=off)
+    p0 = pred[:u, ::d].contiguous()                      # first output of every lambda
+    y0 = y[int(offs[f]) + dy:int(offs[f]) + dy + u, 0:1].expand(u, n_lam).contiguous()
+    r = []
+    for c0 in range(0, n_lam, 16):                       # the window kernels take <= 16 columns
+      sums = device.window_sums(y0[:, c0:c0 + 16].contiguous(), p0[:, c0:c0 + 16].contiguous(),
+                                [0, u], bsz, bsz, handle=h)
+      r.append(device.window_scores(sums, bsz, mode=1, handle=h))   # [minibatches, <= 16]
+    scores.append(torch.cat(r, dim=1).mean(dim=0))
+  rows = (torch.stack(scores).cpu().numpy() if scores else np.zeros((0, n_lam)))
   # 5. gather
   all_folds = distributed.gather_rows(rows, n_files, my_folds, group)     # [F, Lambda]
   results = collections.OrderedDict()

@@ -1,0 +1,18 @@
+"""End-to-end wall time of BASELINE config C5 on one GPU: regression.jackknife_over_regularizations,
+32 subjects x 31 250 samples x 64 ch, 32 lags, 20 lambdas (640 fits + 640 held-out evaluations)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from telluride_decoding_amd import brain_data, regression, synth
+n_subj, n, c = 32, 31250, 64
+trials = synth.make_trials(5, n_subj, n, c)
+files = [(eeg, env, env[:, 0:1].astype(np.float32), att) for eeg, env, att in trials]
+ds = brain_data.Dataset(files, 1000, pre_context=0, post_context=31)
+lams = list(np.logspace(-6, 3, 20))
+for rep in range(2):
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  res = regression.jackknife_over_regularizations(ds, lams)
+  torch.cuda.synchronize(); t1 = time.perf_counter()
+  print('C5 LOSO x lambda sweep end to end: %.3f s (%d fits)' % (t1 - t0, n_subj * len(lams)))
+best = max((v[0], k) for k, v in res.items() if k != 'all_runs')
+print('best lambda %.3g mean r %.4f' % (best[1], best[0]))
