@@ -204,8 +204,8 @@ def main():
     from telluride_decoding_amd import pipeline
     pipe = pipeline.FitPipeline(
         C, PRE, POST, d=D, solve_cus=args.solve_cus,
-        allreduce=(lambda s: distributed.allreduce_stats(
-            s, plan, rank, total_frames=sum(plan.file_lengths))) if dist_on else None)
+        allreduce=(lambda s, hs: distributed.allreduce_stats(
+            s, plan, rank, total_frames=sum(plan.file_lengths), handle=hs)) if dist_on else None)
     h_prof = pipe.h_acc
 
     def run(k):

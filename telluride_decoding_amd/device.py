@@ -196,17 +196,20 @@ class LagStats(object):
                                                 ctypes.byref(n)))
     return int(n.value)
 
-  def pack(self, total_file_slots, file_slot):
-    buf = self.h.empty((self.packed_len(total_file_slots),), 'float64')
-    self.h.check(self.h.lib.td_stats_pack(self.h.ptr, self.ptr, _ptr(buf),
-                                          int(total_file_slots), int(file_slot)))
+  def pack(self, total_file_slots, file_slot, handle=None):
+    """handle: the handle (= stream) to queue the kernel on, if not the statistics' own."""
+    h = handle or self.h
+    buf = h.empty((self.packed_len(total_file_slots),), 'float64')
+    h.check(h.lib.td_stats_pack(h.ptr, self.ptr, _ptr(buf), int(total_file_slots),
+                                int(file_slot)))
     return buf
 
-  def unpack(self, buf, total_file_slots, total_frames=None):
+  def unpack(self, buf, total_file_slots, total_frames=None, handle=None):
     """total_frames (frames of all ranks, if the caller knows them) avoids a device-to-host
     read that synchronises the stream."""
-    self.h.check(self.h.lib.td_stats_unpack_known(
-        self.h.ptr, self.ptr, _ptr(buf), int(total_file_slots),
+    h = handle or self.h
+    h.check(h.lib.td_stats_unpack_known(
+        h.ptr, self.ptr, _ptr(buf), int(total_file_slots),
         -1 if total_frames is None else int(total_frames)))
 
   def moments(self, want_xtx=True, want_xty=True, want_cca=False):

@@ -67,14 +67,16 @@ def allreduce_packed(buf, group=None):
   return buf
 
 
-def allreduce_stats(stats, plan, rank, group=None, total_frames=None):
+def allreduce_stats(stats, plan, rank, group=None, total_frames=None, handle=None):
   """Every rank ends with the statistics of all files (one all-reduce).  total_frames: the
   frames of all ranks if known on the host (no dropped remainders / offsets: the sum of the
   file lengths) -- spares the unpack a stream synchronisation, which matters when fits are
-  pipelined."""
-  buf = stats.pack(plan.total_files, plan.slot_of(rank))
+  pipelined.  handle: queue pack / unpack on that handle's stream (the caller has made it
+  torch's current stream, which is where the collective is ordered) instead of the
+  statistics' own."""
+  buf = stats.pack(plan.total_files, plan.slot_of(rank), handle=handle)
   allreduce_packed(buf, group)
-  stats.unpack(buf, plan.total_files, total_frames)
+  stats.unpack(buf, plan.total_files, total_frames, handle=handle)
   return stats
 
 

@@ -58,12 +58,17 @@ class FitPipeline(object):
     self.ev_solved = [None, None]
     self.pending = None          # (buffer index, lambdas) of the fit whose solve is outstanding
     self.count = 0
-    self.allreduce = allreduce   # optional callable(stats) run on the accumulate stream
+    self.allreduce = allreduce   # optional callable(stats, handle), run on the SOLVE stream
 
   def _solve(self, buf, lambdas, args, kw):
     torch = self.torch
     with torch.cuda.stream(self.s_solve):
       self.s_solve.wait_event(self.ev_acc[buf])
+      # The exchange of a multi-GPU fit belongs to this stream: the solve needs it, the next
+      # accumulate (other statistics buffer) does not -- on the accumulate stream the
+      # collective's latency and the ranks' skew would sit in front of every accumulate.
+      if self.allreduce is not None:
+        self.allreduce(self.stats[buf], self.h_solve)
       # (running the targets part of the accumulate -- LagStats.accumulate(parts=2) -- on this
       # stream was tried: it is throughput-bound and 4x slower on the solve stream's 32 CUs)
       w, b = self.stats[buf].ridge_solve(lambdas, handle=self.h_solve)   # blocks the host
@@ -82,8 +87,6 @@ class FitPipeline(object):
       st = self.stats[buf]
       st.reset()
       st.accumulate(x, None, y, file_offsets, **kw)
-      if self.allreduce is not None:
-        self.allreduce(st)
       self.ev_acc[buf].record(self.s_acc)
     out = None
     if self.pending is not None:

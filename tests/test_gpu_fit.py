@@ -495,6 +495,23 @@ def test_single_rank_rccl_allreduce_round_trip(dev):
     w1, b1 = st.ridge_solve([0.1])
     np.testing.assert_array_equal(w1.cpu().numpy(), w0.cpu().numpy())
     np.testing.assert_array_equal(b1.cpu().numpy(), b0.cpu().numpy())
+    # the pipelined form bench.py runs at N > 1: the exchange of fit i rides on the solve
+    # stream (its own handle) while accumulate i + 1 runs; every fit equals the serial one
+    from telluride_decoding_amd import pipeline
+    pipe = pipeline.FitPipeline(
+        16, 1, 6, d=1,
+        allreduce=lambda s, hs: distributed.allreduce_stats(s, plan, 0, total_frames=sum(lens),
+                                                            handle=hs))
+    outs = []
+    for _ in range(4):
+      r = pipe.submit(x, y, offs, [0.1])
+      if r is not None:
+        outs.append(r)
+    outs.append(pipe.flush())
+    assert len(outs) == 4
+    for w2, b2 in outs:
+      np.testing.assert_array_equal(w2.cpu().numpy(), w0.cpu().numpy())
+      np.testing.assert_array_equal(b2.cpu().numpy(), b0.cpu().numpy())
   finally:
     if created:
       dist.destroy_process_group()
