@@ -902,6 +902,164 @@ __global__ __launch_bounds__(kThreads) void lagcov_wave_kernel(LagParams p, doub
   }
 }
 
+// The same moments on the matrix cores (one target column, at most 32 lags).  As a product,
+// G[m][j] = sum_v A[m][v] B[v][j] with A[m][v] = y[v - e_min - m] (a Toeplitz matrix of the
+// strip's targets, zero outside [u_begin, u_end)) and B[v][j] = x~[v][j]: M = lag, K = time,
+// N = channel.  The B operand of v_mfma_f32_32x32x2_f32 wants lane (n = lane & 31, k = lane >> 5)
+// to hold B[2 kk + k][n]: with n -> channels 2n (tile 0) and 2n + 1 (tile 1) that is ONE
+// coalesced float2 load per lane straight from global memory -- two 256-byte rows per wave
+// instruction, no LDS for x at all -- and the A operand is one broadcast-friendly LDS read of the
+// staged targets.  The lane-per-channel kernel above spends 32 FMAs per row and lane (VALU-bound,
+// 123 us at C2); here a row costs one MFMA per 32 channels and the kernel runs at the speed of
+// its loads.  The sums drift (y correlates with x), so the MFMA accumulators are short chains:
+// every 32 rows they are added into a second float32 set (16 additions per strip: blocked
+// summation, ~1e-7 relative) that goes to float64 once per strip -- float64 accumulators in
+// registers cost 64 VGPRs and a third of the occupancy the loads need.
+constexpr int kTgtPrefetch = 16;     // steps (row pairs) of x in flight per wave
+constexpr int kTgtBody = 16;         // steps per flush (= the prefetch ring: static slots)
+constexpr int kTgtStrip = 4 * kWaveStrip;   // rows of one WORKGROUP's strip
+
+// The four waves of a workgroup share one strip of up to kTgtStrip rows and take its 32-row
+// bodies in turn (wave w: bodies w, w + 4, ...): the workgroup reads one contiguous window of
+// memory (512 concurrent streams on the chip instead of 2048 -- with a strip per wave the loads
+// came back after ~5 us and the kernel sat at 3.5 TB/s) while every wave still owns a private
+// slab (index 4 * strip + wave), so nothing is combined across waves here.
+template <bool kVec2>
+__global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams p,
+                                                                       double* __restrict__ part64,
+                                                                       double* __restrict__ csum,
+                                                                       double* __restrict__ ysum) {
+  constexpr int E = 32, P = kTgtPrefetch, kPad = 32, kRowsBody = 2 * kTgtBody;
+  constexpr int kBodiesMax = (kTgtStrip + E - 1 + kRowsBody - 1) / kRowsBody;
+  __shared__ float ya[kPad + kBodiesMax * kRowsBody];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cbt = (int)(blockIdx.x % p.n_cbt);
+  const int wi = (int)(blockIdx.x / p.n_cbt);          // strip; p.n_work counts the SLABS (4 per strip)
+  const LagWork w = p.works[wi];
+  const int len = (int)(w.u_end - w.u_begin);
+  const int n_rows = len + E - 1;                                  // rows of x that meet a target
+  const int n_body = (n_rows + kRowsBody - 1) / kRowsBody;
+  const int slab_i = wi * 4 + wave;
+
+  // targets of the strip behind kPad zeros (lag m pairs stream row r with target r - m),
+  // zero outside [u_begin, u_end) and beyond the stream
+  for (int t = tid; t < kPad + n_body * kRowsBody; t += kThreads) {
+    const int tt = t - kPad;
+    const long long u = w.u_begin + tt;
+    const bool ok = tt >= 0 && tt < len && u >= 0 && u < w.a_valid;
+    ya[t] = ok ? p.a[(w.a_row0 + (ok ? u : 0)) * p.lda] : 0.f;
+  }
+  __syncthreads();
+  if (cbt == 0 && ysum) {
+    // the strip's column sum of y lands in wave 0's slot, the other waves' slots are zero
+    double sy = 0.0;
+    if (wave == 0)
+      for (int t = lane; t < len; t += 64) sy += (double)ya[kPad + t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sy += __shfl_down(sy, off, 64);
+    if (lane == 0) ysum[slab_i] = sy;
+  }
+
+  const int n = lane & 31, g = lane >> 5;
+  const int c0 = cbt * 64 + 2 * n;                    // this lane's channels: c0 (tile 0), c0 + 1
+  const bool ok0 = c0 < p.cb, ok1 = c0 + 1 < p.cb;
+  const int off0 = ok0 ? c0 : 0, off1 = ok1 ? c0 + 1 : off0;
+  const long long vs = w.u_begin + p.e_min;           // first streamed row
+  // (32-bit offsets from the strip's first row: the strip spans < 4096 rows)
+  const long long v_first = vs < 0 ? 0 : (vs < w.b_valid ? vs : (w.b_valid > 0 ? w.b_valid - 1 : 0));
+  const float* strip = p.b + (w.b_row0 + v_first) * p.ldb;
+  const int r_lo = (int)(v_first - vs);                                   // stream row of v_first
+  const long long last = w.b_valid - 1 - vs;                              // stream row of the last valid row
+  const int r_hi = last < r_lo ? r_lo : (last > (1 << 20) ? (1 << 20) : (int)last);
+  const int ldb32 = (int)p.ldb;
+  // unconditional loads from a clamped row; the row's validity is a 0/1 factor at use
+  auto load_pair = [&](int r, float& x0, float& x1) {
+    const int rc = min(max(r, r_lo), r_hi) - r_lo;
+    const float* rowp = strip + rc * ldb32;
+    if (kVec2) {
+      const float2 v = *reinterpret_cast<const float2*>(rowp + off0);
+      x0 = v.x; x1 = v.y;
+    } else {
+      x0 = rowp[off0]; x1 = rowp[off1];
+    }
+  };
+  f32x16 acc0, acc1, big0, big1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; big0[r] = 0.f; big1[r] = 0.f; }
+  double cs0 = 0.0, cs1 = 0.0;        // column sums of x over [u_begin, u_end): float64 per body
+  float xr[P][2];
+#pragma unroll
+  for (int k = 0; k < P; ++k) load_pair((wave * kTgtBody + k) * 2 + g, xr[k][0], xr[k][1]);
+  const int t_lo = -p.e_min, t_hi = len - p.e_min;    // rows of [u_begin, u_end) in stream time
+  const float* yp = ya + kPad + g - n;                // A operand of step kk: yp[2 kk]
+
+  // A body (16 steps = 32 rows) whose rows, and the rows of the wave's NEXT body (4 bodies on)
+  // that it prefetches, all exist and all lie in [u_begin, u_end) needs no masks and no clamping
+  // -- every vector instruction spent on them is taken from the MFMAs' issue slots.
+#define TD_TGT_BODY(FAST)                                                                      \
+  {                                                                                            \
+    float c0s = 0.f, c1s = 0.f;                                                                \
+    const float* bp = strip + (((b + 4) * kTgtBody) * 2 + g - r_lo) * ldb32 + off0;            \
+    _Pragma("unroll") for (int s = 0; s < kTgtBody; ++s) {                                     \
+      const int r = (b * kTgtBody + s) * 2 + g;                                                \
+      float x0 = xr[s % P][0], x1 = xr[s % P][1];                                              \
+      if (FAST) {                                                                              \
+        c0s += x0; c1s += x1;                                                                  \
+      } else {                                                                                 \
+        const float m = (r >= r_lo && (long long)r <= last) ? 1.f : 0.f;                       \
+        x0 *= m; x1 *= m;                                                                      \
+        const float in = (r >= t_lo && r < t_hi) ? 1.f : 0.f;                                  \
+        c0s = fmaf(in, x0, c0s); c1s = fmaf(in, x1, c1s);                                      \
+      }                                                                                        \
+      const float a = yp[(b * kTgtBody + s) * 2];                                              \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x0, acc0, 0, 0, 0);                       \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);                       \
+      /* the slot is free once the MFMAs have read it: refill it for the wave's next body */   \
+      if (FAST) {                                                                              \
+        if (kVec2) {                                                                           \
+          const float2 v = *reinterpret_cast<const float2*>(bp + s * 2 * ldb32);               \
+          xr[s % P][0] = v.x; xr[s % P][1] = v.y;                                              \
+        } else {                                                                               \
+          xr[s % P][0] = bp[s * 2 * ldb32]; xr[s % P][1] = bp[s * 2 * ldb32 + off1 - off0];    \
+        }                                                                                      \
+      } else {                                                                                 \
+        load_pair(r + 8 * kTgtBody, xr[s % P][0], xr[s % P][1]);                               \
+      }                                                                                        \
+    }                                                                                          \
+    cs0 += (double)c0s;                                                                        \
+    cs1 += (double)c1s;                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                           \
+      big0[r] += acc0[r]; acc0[r] = 0.f;                                                       \
+      big1[r] += acc1[r]; acc1[r] = 0.f;                                                       \
+    }                                                                                          \
+  }
+  for (int b = wave; b < n_body; b += 4) {
+    const int first = b * kRowsBody, end = first + kRowsBody;            // rows [first, end)
+    const bool fast = first >= r_lo && (long long)(end + 4 * kRowsBody - 1) <= last &&
+                      first >= t_lo && end <= t_hi;                      // incl. the prefetched body
+    if (fast) TD_TGT_BODY(true) else TD_TGT_BODY(false)
+  }
+#undef TD_TGT_BODY
+  // C/D map: col = lane & 31 (channel pair n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (lag)
+  double* slab = part64 + (size_t)slab_i * p.e_pad * p.ca_pad * p.cb_pad;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int k = (r & 3) + 8 * (r >> 2) + 4 * g;
+    if (k < p.e_count) {
+      slab[(size_t)k * p.ca_pad * p.cb_pad + c0] = (double)big0[r];
+      slab[(size_t)k * p.ca_pad * p.cb_pad + c0 + 1] = (double)big1[r];
+    }
+  }
+  // the two row parities of a channel sit in lanes n and n + 32
+  cs0 += __shfl_xor(cs0, 32, 64);
+  cs1 += __shfl_xor(cs1, 32, 64);
+  if (g == 0) {
+    csum[(size_t)slab_i * p.cb_pad + c0] = cs0;
+    csum[(size_t)slab_i * p.cb_pad + c0 + 1] = cs1;
+  }
+}
+
 // per-file float64 column sums from the per-strip float32 ones: out[f][j] (+)= sum over the
 // strips of file f
 // (one workgroup of 1024 threads per file and 64-channel tile: 16 strip-strided partial sums
@@ -1232,23 +1390,28 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
   *handled = true;
   if (segs.empty()) return TD_OK;
   const int n_segs = (int)segs.size();
-  // strips of kWaveStrip rows; every segment gets at least one (possibly empty) strip so
-  // that the per-segment column sums are defined
+  // Strips.  Without targets (column sums only: lagcov_wave_kernel) a strip is kWaveStrip rows
+  // and one wave; with targets (lagcov_targets_mfma_kernel) a strip is kTgtStrip rows and one
+  // WORKGROUP whose four waves each fill their own slab.  Every segment gets at least one
+  // (possibly empty) strip so that the per-segment column sums are defined.  seg_work0 counts
+  // slabs.
+  const int ni = d > 0 ? 1 : 0;     // one target column per launch
+  const int slabs_per_strip = ni > 0 ? 4 : 1;
   std::vector<LagWork> works;
   std::vector<int> seg_work0(n_segs + 1, 0);
   for (int f = 0; f < n_segs; ++f) {
-    seg_work0[f] = (int)works.size();
+    seg_work0[f] = (int)works.size() * slabs_per_strip;
     std::vector<LagSeg> one(1, segs[f]);
-    std::vector<LagWork> ws = split_work(one, kWaveStrip);
+    std::vector<LagWork> ws = split_work(one, ni > 0 ? kTgtStrip : kWaveStrip);
     works.insert(works.end(), ws.begin(), ws.end());
   }
-  seg_work0[n_segs] = (int)works.size();
-  const int n_work = (int)works.size();
+  seg_work0[n_segs] = (int)works.size() * slabs_per_strip;
+  const int n_strips = (int)works.size();
+  const int n_work = n_strips * slabs_per_strip;     // slabs
   if (n_work == 0) {
     TD_HIP(h, hipMemsetAsync(colsum_seg_dev, 0, sizeof(double) * n_segs * cb, h->stream));
     return TD_OK;
   }
-  const int ni = d > 0 ? 1 : 0;     // one target column per launch (float64 sums: 2 VGPRs per lag)
   LagParams p;
   p.a = y; p.b = b; p.lda = ldy; p.ldb = ldb; p.ca = d; p.cb = cb; p.a_ones = 0;
   p.e_min = e_min; p.e_count = e_count;
@@ -1284,8 +1447,14 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
       LagParams pi = p;
       pi.a = y + i;
       pi.ca = 1;
-      hipLaunchKernelGGL((lagcov_wave_kernel<32, 1>), dim3(blocks), dim3(kThreads), 0, h->stream, pi,
-                         part64, csum, ysum);
+      const bool vec2 = (ldb % 2 == 0) && (cb % 2 == 0) && ((reinterpret_cast<uintptr_t>(b) & 7) == 0);
+      const dim3 grid((unsigned)(n_strips * p.n_cbt));
+      if (vec2)
+        hipLaunchKernelGGL((lagcov_targets_mfma_kernel<true>), grid, dim3(kThreads), 0, h->stream,
+                           pi, part64, csum, ysum);
+      else
+        hipLaunchKernelGGL((lagcov_targets_mfma_kernel<false>), grid, dim3(kThreads), 0, h->stream,
+                           pi, part64, csum, ysum);
       launch_lagcov_reduce<double>(h, part64, n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, 1, cb,
                                    g_dev + (size_t)i * cb, true, d + 1);
       if (sy_dev)
