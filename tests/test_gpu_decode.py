@@ -465,3 +465,23 @@ def test_decoder_streaming_api_and_persistence(dev, tmp_path):
     infer_decoder.create_decoder('mystery')
   assert isinstance(infer_decoder.create_decoder('my_linear_model'), infer_decoder.LinearRegressionDecoder)
   assert isinstance(infer_decoder.create_decoder('CCA'), infer_decoder.CCADecoder)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,width,hop', [(120000, 120000, 120000), (65000, 32000, 16000)])
+def test_long_window_sums_match_float64(dev, rows, width, hop):
+  """Whole-recording windows (the global statistics of infer_decoder.py:288-310): thousands of
+  blocks per window go through the wave-per-output reduction."""
+  rng = np.random.default_rng(rows)
+  a = (rng.standard_normal((rows, 3)) + 0.3).astype(np.float32)
+  b = (0.5 * a + rng.standard_normal((rows, 3))).astype(np.float32)
+  h = dev.default_handle()
+  got = dev.window_sums(h.to_device(a), h.to_device(b), [0, rows], width, hop, handle=h).cpu().numpy()
+  n_win = (rows - width) // hop + 1
+  assert got.shape == (n_win, 3, 5)
+  a64, b64 = a.astype(np.float64), b.astype(np.float64)
+  for w in range(n_win):
+    s = slice(w * hop, w * hop + width)
+    want = np.stack([a64[s].sum(0), b64[s].sum(0), (a64[s] ** 2).sum(0), (b64[s] ** 2).sum(0),
+                     (a64[s] * b64[s]).sum(0)], axis=1)
+    np.testing.assert_allclose(got[w], want, rtol=1e-12, atol=1e-9)
