@@ -1001,6 +1001,85 @@ int fill_score_params(td_handle* h, ScoreParams* sp, int cols, const double* mea
   return TD_OK;
 }
 
+// ---- no context: a plain projection out = x . W + b (CCA transform, cca.py:157-161) -----------
+// With one lag the FIR kernels above still build 32 "lag" columns per output and keep one (627 us
+// for the C3 transform, 12x its HBM floor).  Here the outputs ARE the 32 columns of one MFMA
+// tile: out[row][q] = sum_c x[row][c] W[c][q], M = row, K = channel, N = output.  Lane
+// (i = lane & 31, g = lane >> 5) owns row i of a 32-row tile and the channel half
+// [g Kh, g Kh + Kh): it reads them as Kh / 4 float4s -- whole cache lines per lane, no LDS, no
+// transposition (the order of k inside an MFMA chain is free, so "k = g" may mean channel
+// g Kh + kk at step kk) -- and holds the matching W rows in Kh registers for its output column.
+constexpr int kProjWavesPerCu = 12;
+
+template <int kKh>   // channels per lane half: 4, 8, 16 or 32 (c <= 2 kKh)
+__global__ __launch_bounds__(kThreads, 3) void project_mfma_kernel(
+    const float* __restrict__ x, long long ldx, const FileDesc* __restrict__ files, int n_files,
+    long long n_strips, int strip, int c, const float* __restrict__ w, const float* __restrict__ bias,
+    int d, float* __restrict__ out, long long ldout) {
+  const int lane = threadIdx.x & 63;
+  const long long sid = blockIdx.x * (long long)(kThreads / 64) + (threadIdx.x >> 6);
+  if (sid >= n_strips) return;
+  const FileDesc fd = files[find_file(files, n_files, sid)];
+  const long long t0 = (sid - fd.first) * strip;               // first frame of the strip
+  const int rows = (int)((fd.nrows - t0) < strip ? (fd.nrows - t0) : strip);
+  const int i = lane & 31, g = lane >> 5;
+  // this lane's W rows for output column q = i: channel g kKh + kk at MFMA step kk
+  float bw[kKh];
+#pragma unroll
+  for (int kk = 0; kk < kKh; ++kk) {
+    const int ch = g * kKh + kk;
+    bw[kk] = (ch < c && i < d) ? w[(size_t)ch * d + i] : 0.f;
+  }
+  const float bq = (bias && i < d) ? bias[i] : 0.f;
+  // float4 q of the lane's half; halves that stick out of a narrow input re-read the last
+  // float4 of the row (their W rows are zero)
+  int off4[kKh / 4];
+#pragma unroll
+  for (int q = 0; q < kKh / 4; ++q) {
+    const int ch = g * kKh + 4 * q;
+    off4[q] = ch + 4 <= c ? ch : c - 4;
+  }
+  const float* xs = x + (fd.row0 + t0) * ldx;
+  auto row_offset = [&](int tile) {
+    int r = tile * 32 + i;
+    r = r < rows ? r : rows - 1;                                // clamped: the row is not stored
+    return r * (int)ldx;                                        // (a strip is < 2^31 elements)
+  };
+  const int n_tiles = (rows + 31) / 32;
+  // ONE register set: a float4 is refilled with the next tile's data as soon as its four MFMAs
+  // have read it, so the loads of tile t + 1 fly under the rest of tile t and its stores
+  // (80 registers in all: 4 waves per SIMD, 128 KB in flight per CU)
+  float4 a[kKh / 4];
+  int ro = row_offset(0);
+#pragma unroll
+  for (int q = 0; q < kKh / 4; ++q) a[q] = *reinterpret_cast<const float4*>(xs + ro + off4[q]);
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const bool more = tile + 1 < n_tiles;
+    ro = row_offset(more ? tile + 1 : tile);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < kKh / 4; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bw[4 * q + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bw[4 * q + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bw[4 * q + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bw[4 * q + 3], acc, 0, 0, 0);
+      if (more) a[q] = *reinterpret_cast<const float4*>(xs + ro + off4[q]);
+    }
+    // C/D map: col = lane & 31 (output), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (i < d) {
+      float* op = out + (fd.out0 + t0 + tile * 32) * ldout;     // wave-uniform base, 32-bit offsets
+      const int ldo = (int)ldout;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (tile * 32 + row < rows) op[row * ldo + i] = acc[r] + bq;
+      }
+    }
+  }
+}
+
 // The per-file descriptor table goes through the handle's content-cached table slots
 // (td_table_upload): no td_scratch use, and no upload at all when the layout repeats.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
@@ -1034,6 +1113,31 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   // (16-byte aligned rows of at most 64 channels; everything else takes the lane-per-channel path)
   const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const bool mfma_ok = c <= 64 && vec4 && lds_for(dq_max) <= 64 * 1024;
+  if (nl == 1 && c >= 4 && c <= 64 && vec4 && d <= 32) {
+    // no context: one MFMA tile holds all outputs (project_mfma_kernel)
+    int64_t strip = td_round_up(td_ceil_div(total, 256 * kProjWavesPerCu), 64);
+    if (strip < 128) strip = 128;
+    std::vector<FileDesc> files(num_files);
+    long long n_strips = 0;
+    for (int f = 0; f < num_files; ++f) {
+      const int64_t n = offs[f + 1] - offs[f] - shift;
+      files[f].row0 = offs[f] + shift;
+      files[f].nrows = n > 0 ? n : 0;
+      files[f].out0 = offs[f];
+      files[f].first = n_strips;
+      if (n > 0) n_strips += td_ceil_div(n, strip);
+    }
+    TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(FileDesc), &table_dev));
+    const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
+    const dim3 grid((unsigned)td_ceil_div(n_strips, kThreads / 64)), block(kThreads);
+#define TD_PROJ(KH)                                                                            \
+  hipLaunchKernelGGL((project_mfma_kernel<KH>), grid, block, 0, h->stream, x, (long long)ldx, df, \
+                     num_files, n_strips, (int)strip, c, w, bias, d, out, (long long)ldout)
+    if (c <= 8) TD_PROJ(4); else if (c <= 16) TD_PROJ(8); else if (c <= 32) TD_PROJ(16); else TD_PROJ(32);
+#undef TD_PROJ
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
   if (mfma_ok) {
     // strip length: one wave per resident slot -- the kernel holds kFirWavesPerCu waves per CU
     // (register / LDS limited), so total / (256 CUs * that) frames per wave runs the whole
