@@ -20,7 +20,9 @@ The JSON line also carries
                 hipEvents on the stream it runs on (td_profile_*),
   cpu_baseline  the NumPy restatement of the reference algorithm (oracle/) timed
                 on this host on a bounded slice of the same workload (rank 0, N=1),
-  decode        windows/s of the two-speaker decode (config C4), informational.
+  decode        windows/s of the two-speaker decode (config C4), informational,
+  cca, loso     configs C3 (CCA accumulate + transform) and C5 (LOSO x lambda sweep on one
+                GPU), informational (N = 1; --no-extra skips them).
 """
 import argparse
 import json
@@ -134,9 +136,72 @@ def decode_leg(h, device):
       'windows': n_win, 'ms': dt * 1e3, 'windows_per_s': n_win / dt,
       'algorithmic_bytes': int(n) * 4 * (C + 2),
       'hbm_gbps_algorithmic': n * 4 * (C + 2) / dt / 1e9,
+      'roofline': {'bound': 'hbm', 'achieved': n * 4 * (C + 2) / dt / 1e9, 'peak': 8000.0,
+                   'unit': 'GB/s', 'frac': n * 4 * (C + 2) / dt / 8e12},
       'wta_accuracy_clear_windows': acc,
       'cpu_baseline_windows_per_s': cpu_win / cpu_dt,
       'cpu_sample': 'oracle on 4 trials (%d windows), %d cores' % (cpu_win, os.cpu_count()),
+  }
+
+
+def cca_leg(h, device, eeg):
+  """Config C3: 64-ch EEG vs an 8-band envelope, 1e6 samples, no context: the moments of the CCA
+  fit (one-pass Gram kernel) and the transform of both streams onto 5 components."""
+  import torch
+  n = eeg.shape[0]
+  rng = np.random.default_rng(3)
+  bands = (eeg[:, :8] * 0.5 + rng.standard_normal((n, 8))).astype(np.float32)
+  x, x2 = h.to_device(eeg), h.to_device(bands)
+  offs = np.array([0, n], np.int64)
+  st = device.LagStats(C, 0, 0, 8, 0, 0, 0, handle=h)
+  mean1 = torch.zeros(C, device=x.device); mean2 = torch.zeros(8, device=x.device)
+  rot1 = torch.randn(C, 5, device=x.device); rot2 = torch.randn(8, 5, device=x.device)
+
+  def timed(fn, reps=10):
+    fn(); h.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    h.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+  def acc():
+    st.reset()
+    st.accumulate(x, x2, None, offs)
+
+  t_acc = timed(acc)
+  t_tr = timed(lambda: device.cca_transform(x, x2, offs, mean1, rot1, mean2, rot2, 0, 0, 0, 0,
+                                            handle=h))
+  return {
+      'workload': 'C3: CCA, 64-ch EEG vs 8-band envelope, 1e6 samples, no context, 5 components',
+      'accumulate_ms': t_acc * 1e3, 'transform_ms': t_tr * 1e3,
+      'accumulate_hbm_gbps_algorithmic': n * 4 * 72 / t_acc / 1e9,
+      'transform_hbm_gbps_algorithmic': n * 4 * (72 + 10) / t_tr / 1e9,
+      'note': 'the 64x64 / 8x8 eig + SVD stage runs on the host (LAPACK) like the reference',
+  }
+
+
+def loso_leg(eeg, env):
+  """Config C5 on one GPU: 32 subjects x 31 250 samples, 20 lambdas, leave-one-subject-out:
+  regression.jackknife_over_regularizations end to end (640 fits + 640 held-out evaluations)."""
+  from telluride_decoding_amd import brain_data, regression
+  n_subj, n = 32, 31250
+  att = np.zeros((n, 1), np.float32)
+  files = [(eeg[i * n:(i + 1) * n], env[i * n:(i + 1) * n], env[i * n:(i + 1) * n], att)
+           for i in range(n_subj)]
+  ds = brain_data.Dataset(files, 1000, pre_context=PRE, post_context=POST)
+  lams = list(np.logspace(-6, 3, 20))
+  best = None
+  for _ in range(2):
+    t0 = time.perf_counter()
+    res = regression.jackknife_over_regularizations(ds, lams)
+    dt = time.perf_counter() - t0
+    best = dt if best is None else min(best, dt)
+  top = max((v[0], k) for k, v in res.items() if k != 'all_runs')
+  return {
+      'workload': 'C5: LOSO x 20 lambdas, 32 subjects x 31 250 samples x 64 ch, 32 lags, one GPU',
+      'seconds': best, 'fits': n_subj * len(lams), 'fits_per_s': n_subj * len(lams) / best,
+      'best_lambda': float(top[1]), 'best_mean_r': float(top[0]),
   }
 
 
@@ -147,6 +212,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--no-decode', action='store_true', help='skip the informational decode leg')
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
+  ap.add_argument('--no-extra', action='store_true', help='skip the C3 / C5 legs')
   ap.add_argument('--solve-cus', type=int, default=32,
                   help='CUs set aside for the solve stream of the pipeline (0 = no CU masks)')
   ap.add_argument('--force-dist', action='store_true',
@@ -287,6 +353,9 @@ def main():
       line['cpu_baseline'] = cpu_baseline(eeg, env)
     if world == 1 and not args.no_decode:
       line['decode'] = decode_leg(h, device)
+    if world == 1 and not args.no_extra:
+      line['cca'] = cca_leg(h, device, eeg)
+      line['loso'] = loso_leg(eeg, env)
   if dist_on:
     dist.barrier()
     dist.destroy_process_group()
