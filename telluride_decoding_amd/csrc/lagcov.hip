@@ -911,19 +911,65 @@ __global__ __launch_bounds__(kThreads) void lagcov_wave_kernel(LagParams p, doub
 // instruction, no LDS for x at all -- and the A operand is one broadcast-friendly LDS read of the
 // staged targets.  The lane-per-channel kernel above spends 32 FMAs per row and lane (VALU-bound,
 // 123 us at C2); here a row costs one MFMA per 32 channels and the kernel runs at the speed of
-// its loads.  The sums drift (y correlates with x), so the MFMA accumulators are short chains:
-// every 32 rows they are added into a second float32 set (16 additions per strip: blocked
-// summation, ~1e-7 relative) that goes to float64 once per strip -- float64 accumulators in
-// registers cost 64 VGPRs and a third of the occupancy the loads need.
+// its loads.  The sums drift (y correlates with x), so the MFMA accumulators are 32-row chains
+// flushed into float64 sums (64 VGPRs).  The pipelined loop does only the bodies that need no
+// masks and no address clamping (all but the first / last one or two of a strip); the others
+// follow in a plain load-then-multiply tail.  (With both forms inside one unrolled loop the
+// register allocation of the rare form cost the common one its float64 accumulators.)
 constexpr int kTgtPrefetch = 16;     // steps (row pairs) of x in flight per wave
 constexpr int kTgtBody = 16;         // steps per flush (= the prefetch ring: static slots)
 constexpr int kTgtStrip = 4 * kWaveStrip;   // rows of one WORKGROUP's strip
 
+// Geometry of a wave's share of a strip, the same in both kernels.
+struct TgtStrip {
+  const float* strip;   // first valid streamed row of x
+  int len, n_body;      // targets in the strip; 32-row bodies of streamed rows
+  int r_lo, r_hi;       // stream rows of the first / last valid row of x (clamped)
+  long long last;       // stream row of the last valid row (may be < 0 or huge)
+  int t_lo, t_hi;       // stream rows of [u_begin, u_end)
+  int ldb32;
+};
+
+__device__ __forceinline__ TgtStrip tgt_strip(const LagParams& p, const LagWork& w) {
+  constexpr int E = 32, kRowsBody = 2 * kTgtBody;
+  TgtStrip t;
+  t.len = (int)(w.u_end - w.u_begin);
+  t.n_body = (t.len + E - 1 + kRowsBody - 1) / kRowsBody;
+  const long long vs = w.u_begin + p.e_min;           // first streamed row
+  const long long v_first = vs < 0 ? 0 : (vs < w.b_valid ? vs : (w.b_valid > 0 ? w.b_valid - 1 : 0));
+  t.strip = p.b + (w.b_row0 + v_first) * p.ldb;
+  t.r_lo = (int)(v_first - vs);
+  t.last = w.b_valid - 1 - vs;
+  t.r_hi = t.last < t.r_lo ? t.r_lo : (t.last > (1 << 20) ? (1 << 20) : (int)t.last);
+  t.t_lo = -p.e_min;
+  t.t_hi = t.len - p.e_min;
+  t.ldb32 = (int)p.ldb;
+  return t;
+}
+
+// Body b (rows [32 b, 32 b + 32)) and the body the wave prefetches under it (4 bodies on) lie
+// wholly inside the file and inside [u_begin, u_end): no masks, no clamping.
+__device__ __forceinline__ bool tgt_body_fast(const TgtStrip& t, int b) {
+  const int first = b * 2 * kTgtBody, end = first + 2 * kTgtBody;
+  return first >= t.r_lo && (long long)(end + 8 * kTgtBody - 1) <= t.last && first >= t.t_lo &&
+         end <= t.t_hi;
+}
+
+// Targets of the strip behind kPad zeros (lag m pairs stream row r with target r - m), zero
+// outside [u_begin, u_end) and beyond the stream.
+__device__ __forceinline__ void tgt_stage_targets(const LagParams& p, const LagWork& w, int len,
+                                                  int n_body, int kPad, float* ya, int tid) {
+  for (int t = tid; t < kPad + n_body * 2 * kTgtBody; t += kThreads) {
+    const int tt = t - kPad;
+    const long long u = w.u_begin + tt;
+    const bool ok = tt >= 0 && tt < len && u >= 0 && u < w.a_valid;
+    ya[t] = ok ? p.a[(w.a_row0 + (ok ? u : 0)) * p.lda] : 0.f;
+  }
+}
+
 // The four waves of a workgroup share one strip of up to kTgtStrip rows and take its 32-row
-// bodies in turn (wave w: bodies w, w + 4, ...): the workgroup reads one contiguous window of
-// memory (512 concurrent streams on the chip instead of 2048 -- with a strip per wave the loads
-// came back after ~5 us and the kernel sat at 3.5 TB/s) while every wave still owns a private
-// slab (index 4 * strip + wave), so nothing is combined across waves here.
+// bodies in turn (wave w: bodies w, w + 4, ...); every wave owns a private slab (index
+// 4 * strip + wave), so nothing is combined across waves here.
 template <bool kVec2>
 __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams p,
                                                                        double* __restrict__ part64,
@@ -937,25 +983,15 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   const int cbt = (int)(blockIdx.x % p.n_cbt);
   const int wi = (int)(blockIdx.x / p.n_cbt);          // strip; p.n_work counts the SLABS (4 per strip)
   const LagWork w = p.works[wi];
-  const int len = (int)(w.u_end - w.u_begin);
-  const int n_rows = len + E - 1;                                  // rows of x that meet a target
-  const int n_body = (n_rows + kRowsBody - 1) / kRowsBody;
+  const TgtStrip ts = tgt_strip(p, w);
   const int slab_i = wi * 4 + wave;
-
-  // targets of the strip behind kPad zeros (lag m pairs stream row r with target r - m),
-  // zero outside [u_begin, u_end) and beyond the stream
-  for (int t = tid; t < kPad + n_body * kRowsBody; t += kThreads) {
-    const int tt = t - kPad;
-    const long long u = w.u_begin + tt;
-    const bool ok = tt >= 0 && tt < len && u >= 0 && u < w.a_valid;
-    ya[t] = ok ? p.a[(w.a_row0 + (ok ? u : 0)) * p.lda] : 0.f;
-  }
+  tgt_stage_targets(p, w, ts.len, ts.n_body, kPad, ya, tid);
   __syncthreads();
   if (cbt == 0 && ysum) {
     // the strip's column sum of y lands in wave 0's slot, the other waves' slots are zero
     double sy = 0.0;
     if (wave == 0)
-      for (int t = lane; t < len; t += 64) sy += (double)ya[kPad + t];
+      for (int t = lane; t < ts.len; t += 64) sy += (double)ya[kPad + t];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sy += __shfl_down(sy, off, 64);
     if (lane == 0) ysum[slab_i] = sy;
@@ -965,90 +1001,102 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   const int c0 = cbt * 64 + 2 * n;                    // this lane's channels: c0 (tile 0), c0 + 1
   const bool ok0 = c0 < p.cb, ok1 = c0 + 1 < p.cb;
   const int off0 = ok0 ? c0 : 0, off1 = ok1 ? c0 + 1 : off0;
-  const long long vs = w.u_begin + p.e_min;           // first streamed row
-  // (32-bit offsets from the strip's first row: the strip spans < 4096 rows)
-  const long long v_first = vs < 0 ? 0 : (vs < w.b_valid ? vs : (w.b_valid > 0 ? w.b_valid - 1 : 0));
-  const float* strip = p.b + (w.b_row0 + v_first) * p.ldb;
-  const int r_lo = (int)(v_first - vs);                                   // stream row of v_first
-  const long long last = w.b_valid - 1 - vs;                              // stream row of the last valid row
-  const int r_hi = last < r_lo ? r_lo : (last > (1 << 20) ? (1 << 20) : (int)last);
-  const int ldb32 = (int)p.ldb;
-  // unconditional loads from a clamped row; the row's validity is a 0/1 factor at use
-  auto load_pair = [&](int r, float& x0, float& x1) {
-    const int rc = min(max(r, r_lo), r_hi) - r_lo;
-    const float* rowp = strip + rc * ldb32;
-    if (kVec2) {
-      const float2 v = *reinterpret_cast<const float2*>(rowp + off0);
-      x0 = v.x; x1 = v.y;
-    } else {
-      x0 = rowp[off0]; x1 = rowp[off1];
-    }
-  };
-  f32x16 acc0, acc1, big0, big1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; big0[r] = 0.f; big1[r] = 0.f; }
-  double cs0 = 0.0, cs1 = 0.0;        // column sums of x over [u_begin, u_end): float64 per body
-  float xr[P][2];
-#pragma unroll
-  for (int k = 0; k < P; ++k) load_pair((wave * kTgtBody + k) * 2 + g, xr[k][0], xr[k][1]);
-  const int t_lo = -p.e_min, t_hi = len - p.e_min;    // rows of [u_begin, u_end) in stream time
-  const float* yp = ya + kPad + g - n;                // A operand of step kk: yp[2 kk]
+  // this wave's fast bodies: b0, b0 + 4, ... (fast bodies are a contiguous run of the strip)
+  int b0 = wave, nb = 0;
+  while (b0 < ts.n_body && !tgt_body_fast(ts, b0)) b0 += 4;
+  for (int b = b0; b < ts.n_body && tgt_body_fast(ts, b); b += 4) ++nb;
 
-  // A body (16 steps = 32 rows) whose rows, and the rows of the wave's NEXT body (4 bodies on)
-  // that it prefetches, all exist and all lie in [u_begin, u_end) needs no masks and no clamping
-  // -- every vector instruction spent on them is taken from the MFMAs' issue slots.
-#define TD_TGT_BODY(FAST)                                                                      \
-  {                                                                                            \
-    float c0s = 0.f, c1s = 0.f;                                                                \
-    const float* bp = strip + (((b + 4) * kTgtBody) * 2 + g - r_lo) * ldb32 + off0;            \
-    _Pragma("unroll") for (int s = 0; s < kTgtBody; ++s) {                                     \
-      const int r = (b * kTgtBody + s) * 2 + g;                                                \
-      float x0 = xr[s % P][0], x1 = xr[s % P][1];                                              \
-      if (FAST) {                                                                              \
-        c0s += x0; c1s += x1;                                                                  \
-      } else {                                                                                 \
-        const float m = (r >= r_lo && (long long)r <= last) ? 1.f : 0.f;                       \
-        x0 *= m; x1 *= m;                                                                      \
-        const float in = (r >= t_lo && r < t_hi) ? 1.f : 0.f;                                  \
-        c0s = fmaf(in, x0, c0s); c1s = fmaf(in, x1, c1s);                                      \
-      }                                                                                        \
-      const float a = yp[(b * kTgtBody + s) * 2];                                              \
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x0, acc0, 0, 0, 0);                       \
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);                       \
-      /* the slot is free once the MFMAs have read it: refill it for the wave's next body */   \
-      if (FAST) {                                                                              \
-        if (kVec2) {                                                                           \
-          const float2 v = *reinterpret_cast<const float2*>(bp + s * 2 * ldb32);               \
-          xr[s % P][0] = v.x; xr[s % P][1] = v.y;                                              \
-        } else {                                                                               \
-          xr[s % P][0] = bp[s * 2 * ldb32]; xr[s % P][1] = bp[s * 2 * ldb32 + off1 - off0];    \
-        }                                                                                      \
-      } else {                                                                                 \
-        load_pair(r + 8 * kTgtBody, xr[s % P][0], xr[s % P][1]);                               \
-      }                                                                                        \
-    }                                                                                          \
-    cs0 += (double)c0s;                                                                        \
-    cs1 += (double)c1s;                                                                        \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                           \
-      big0[r] += acc0[r]; acc0[r] = 0.f;                                                       \
-      big1[r] += acc1[r]; acc1[r] = 0.f;                                                       \
-    }                                                                                          \
+  f32x16 acc0, acc1;
+  double big0[16], big1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; big0[r] = 0.0; big1[r] = 0.0; }
+  double cs0 = 0.0, cs1 = 0.0;        // column sums of x over [u_begin, u_end)
+  const float* yp = ya + kPad + g - n;                // A operand of step kk: yp[2 kk]
+  if (nb > 0) {
+    float xr[P][2];
+    auto load_step = [&](const float* bp, int s, float& x0, float& x1) {
+      if (kVec2) {
+        const float2 v = *reinterpret_cast<const float2*>(bp + s * 2 * ts.ldb32);
+        x0 = v.x; x1 = v.y;
+      } else {
+        x0 = bp[s * 2 * ts.ldb32]; x1 = bp[s * 2 * ts.ldb32 + off1 - off0];
+      }
+    };
+    {
+      const float* bp = ts.strip + (b0 * kRowsBody + g - ts.r_lo) * ts.ldb32 + off0;
+#pragma unroll
+      for (int k = 0; k < P; ++k) load_step(bp, k, xr[k][0], xr[k][1]);
+    }
+    for (int it = 0; it < nb; ++it) {
+      const int b = b0 + 4 * it;
+      // the wave's next body (always readable: tgt_body_fast covers it)
+      const float* bp = ts.strip + ((b + 4) * kRowsBody + g - ts.r_lo) * ts.ldb32 + off0;
+      float c0s = 0.f, c1s = 0.f;
+#pragma unroll
+      for (int s = 0; s < kTgtBody; ++s) {
+        const float x0 = xr[s % P][0], x1 = xr[s % P][1];
+        c0s += x0; c1s += x1;
+        const float a = yp[(b * kTgtBody + s) * 2];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);
+        // the slot is free once the MFMAs have read it: refill it for the wave's next body
+        load_step(bp, s, xr[s % P][0], xr[s % P][1]);
+      }
+      cs0 += (double)c0s;
+      cs1 += (double)c1s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        big0[r] += (double)acc0[r]; acc0[r] = 0.f;
+        big1[r] += (double)acc1[r]; acc1[r] = 0.f;
+      }
+    }
   }
-  for (int b = wave; b < n_body; b += 4) {
-    const int first = b * kRowsBody, end = first + kRowsBody;            // rows [first, end)
-    const bool fast = first >= r_lo && (long long)(end + 4 * kRowsBody - 1) <= last &&
-                      first >= t_lo && end <= t_hi;                      // incl. the prefetched body
-    if (fast) TD_TGT_BODY(true) else TD_TGT_BODY(false)
+  // The bodies left out above (first / last of a strip: rows outside the file or outside
+  // [u_begin, u_end), or a prefetch that would run past the file): clamped loads, 0/1 masks,
+  // all loads of a body first and then its MFMAs -- a few percent of the rows.
+  for (int b = wave; b < ts.n_body; b += 4) {
+    if (tgt_body_fast(ts, b)) continue;
+    float c0s = 0.f, c1s = 0.f;
+    float xe[kTgtBody][2];
+#pragma unroll
+    for (int s = 0; s < kTgtBody; ++s) {
+      const int r = (b * kTgtBody + s) * 2 + g;
+      const int rc = min(max(r, ts.r_lo), ts.r_hi) - ts.r_lo;
+      const float* rowp = ts.strip + rc * ts.ldb32;
+      if (kVec2) {
+        const float2 v = *reinterpret_cast<const float2*>(rowp + off0);
+        xe[s][0] = v.x; xe[s][1] = v.y;
+      } else {
+        xe[s][0] = rowp[off0]; xe[s][1] = rowp[off1];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kTgtBody; ++s) {
+      const int r = (b * kTgtBody + s) * 2 + g;
+      const float m = (r >= ts.r_lo && (long long)r <= ts.last) ? 1.f : 0.f;
+      const float x0 = xe[s][0] * m, x1 = xe[s][1] * m;
+      const float in = (r >= ts.t_lo && r < ts.t_hi) ? 1.f : 0.f;
+      c0s = fmaf(in, x0, c0s); c1s = fmaf(in, x1, c1s);
+      const float a = yp[(b * kTgtBody + s) * 2];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);
+    }
+    cs0 += (double)c0s;
+    cs1 += (double)c1s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      big0[r] += (double)acc0[r]; acc0[r] = 0.f;
+      big1[r] += (double)acc1[r]; acc1[r] = 0.f;
+    }
   }
-#undef TD_TGT_BODY
   // C/D map: col = lane & 31 (channel pair n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (lag)
   double* slab = part64 + (size_t)slab_i * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int k = (r & 3) + 8 * (r >> 2) + 4 * g;
     if (k < p.e_count) {
-      slab[(size_t)k * p.ca_pad * p.cb_pad + c0] = (double)big0[r];
-      slab[(size_t)k * p.ca_pad * p.cb_pad + c0 + 1] = (double)big1[r];
+      slab[(size_t)k * p.ca_pad * p.cb_pad + c0] = big0[r];
+      slab[(size_t)k * p.ca_pad * p.cb_pad + c0 + 1] = big1[r];
     }
   }
   // the two row parities of a channel sit in lanes n and n + 32
