@@ -213,6 +213,8 @@ def main():
   ap.add_argument('--no-decode', action='store_true', help='skip the informational decode leg')
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
   ap.add_argument('--no-extra', action='store_true', help='skip the C3 / C5 legs')
+  ap.add_argument('--targets-on-acc', action='store_true',
+                  help='keep the y^T x part of the accumulate on the accumulate stream')
   ap.add_argument('--solve-cus', type=int, default=32,
                   help='CUs set aside for the solve stream of the pipeline (0 = no CU masks)')
   ap.add_argument('--force-dist', action='store_true',
@@ -269,7 +271,7 @@ def main():
   else:
     from telluride_decoding_amd import pipeline
     pipe = pipeline.FitPipeline(
-        C, PRE, POST, d=D, solve_cus=args.solve_cus,
+        C, PRE, POST, d=D, solve_cus=args.solve_cus, targets_on_solve=not args.targets_on_acc,
         allreduce=(lambda s, hs: distributed.allreduce_stats(
             s, plan, rank, total_frames=sum(plan.file_lengths), handle=hs)) if dist_on else None)
     h_prof = pipe.h_acc

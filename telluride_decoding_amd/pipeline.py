@@ -16,7 +16,7 @@ from telluride_decoding_amd import device
 class FitPipeline(object):
   """submit() queues accumulate(i) and returns the solution of fit i - 1."""
 
-  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32):
+  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32, targets_on_solve=True):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -59,18 +59,25 @@ class FitPipeline(object):
     self.pending = None          # (buffer index, lambdas) of the fit whose solve is outstanding
     self.count = 0
     self.allreduce = allreduce   # optional callable(stats, handle), run on the SOLVE stream
+    self.targets_on_solve = targets_on_solve
 
   def _solve(self, buf, lambdas, args, kw):
     torch = self.torch
     with torch.cuda.stream(self.s_solve):
       self.s_solve.wait_event(self.ev_acc[buf])
+      # The y^T x part of the accumulate (LagStats.accumulate(parts=2)) also rides here: it is
+      # HBM-bound (the MFMA targets kernel), the solve stream has ~0.6 ms of slack per fit, and
+      # every microsecond taken off the accumulate stream is throughput (2.72 -> 2.65 ms per
+      # fit).  With the earlier VALU-bound targets kernel the same move cost more on this
+      # stream's 32 CUs than it saved.
+      if self.targets_on_solve:
+        x, _, y, offs = args
+        self.stats[buf].accumulate(x, None, y, offs, parts=2, handle=self.h_solve, **kw)
       # The exchange of a multi-GPU fit belongs to this stream: the solve needs it, the next
       # accumulate (other statistics buffer) does not -- on the accumulate stream the
       # collective's latency and the ranks' skew would sit in front of every accumulate.
       if self.allreduce is not None:
         self.allreduce(self.stats[buf], self.h_solve)
-      # (running the targets part of the accumulate -- LagStats.accumulate(parts=2) -- on this
-      # stream was tried: it is throughput-bound and 4x slower on the solve stream's 32 CUs)
       w, b = self.stats[buf].ridge_solve(lambdas, handle=self.h_solve)   # blocks the host
       ev = torch.cuda.Event()
       ev.record(self.s_solve)
@@ -86,7 +93,7 @@ class FitPipeline(object):
         self.s_acc.wait_event(self.ev_solved[buf])
       st = self.stats[buf]
       st.reset()
-      st.accumulate(x, None, y, file_offsets, **kw)
+      st.accumulate(x, None, y, file_offsets, parts=1 if self.targets_on_solve else 3, **kw)
       self.ev_acc[buf].record(self.s_acc)
     out = None
     if self.pending is not None:

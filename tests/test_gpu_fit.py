@@ -280,19 +280,21 @@ def test_pipelined_fits_equal_serial_fits(dev):
     st.accumulate(x, None, y, offs)
     w, b = st.ridge_solve([0.1, 1.0])
     want.append((w.cpu().numpy(), b.cpu().numpy()))
-  pipe = pipeline.FitPipeline(c, pre, post, d=1)
-  got = []
-  for x, y in data:
-    r = pipe.submit(x, y, offs, [0.1, 1.0])
-    if r is not None:
-      got.append(r)
-  got.append(pipe.flush())
-  assert pipe.flush() is None
-  torch.cuda.synchronize()
-  assert len(got) == len(want)
-  for (w, b), (w0, b0) in zip(got, want):
-    np.testing.assert_array_equal(w.cpu().numpy(), w0)
-    np.testing.assert_array_equal(b.cpu().numpy(), b0)
+  # both placements of the y^T x part: on the solve stream (default) and on the accumulate stream
+  for on_solve in (True, False):
+    pipe = pipeline.FitPipeline(c, pre, post, d=1, targets_on_solve=on_solve)
+    got = []
+    for x, y in data:
+      r = pipe.submit(x, y, offs, [0.1, 1.0])
+      if r is not None:
+        got.append(r)
+    got.append(pipe.flush())
+    assert pipe.flush() is None
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for (w, b), (w0, b0) in zip(got, want):
+      np.testing.assert_array_equal(w.cpu().numpy(), w0)
+      np.testing.assert_array_equal(b.cpu().numpy(), b0)
 
 
 def _lag_block_f64(torch, x, offs, a, b, rows_used=None):
