@@ -69,7 +69,8 @@ class FitPipeline(object):
       # HBM-bound (the MFMA targets kernel), the solve stream has ~0.6 ms of slack per fit, and
       # every microsecond taken off the accumulate stream is throughput (2.72 -> 2.65 ms per
       # fit).  With the earlier VALU-bound targets kernel the same move cost more on this
-      # stream's 32 CUs than it saved.
+      # stream's 32 CUs than it saved, and moving the float64 reduction of the accumulate
+      # kernel's partial slabs (268 MB) over as well overloads this stream: 2.85 ms.
       if self.targets_on_solve:
         x, _, y, offs = args
         self.stats[buf].accumulate(x, None, y, offs, parts=2, handle=self.h_solve, **kw)
