@@ -8,10 +8,10 @@ out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 # 1. the bench command itself (pipelined, the default) and its serial variant
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o t -- python3 bench.py --steps 20 --warmup 3 > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o t -- python3 bench.py --steps 20 --warmup 3 --no-extra > $out/bench.log 2>&1
 python3 tools/prof_summary.py $out/bench > $out/${tag}_bench_kernel_stats.txt
 cp $(ls $out/bench/*/t_kernel_stats.csv $out/bench/t_kernel_stats.csv 2>/dev/null | head -1) $out/${tag}_bench_rocprofv3_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -o t -- python3 bench.py --steps 20 --warmup 3 --serial --no-cpu > $out/serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -o t -- python3 bench.py --steps 20 --warmup 3 --serial --no-cpu --no-extra > $out/serial.log 2>&1
 python3 tools/prof_summary.py $out/serial > $out/${tag}_bench_serial_kernel_stats.txt
 # 2. the hot kernels alone, whole chip: trace, then PMC in separate passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/hot -o t -- python3 tools/prof_kernels.py > $out/hot.log 2>&1
