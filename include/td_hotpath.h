@@ -175,6 +175,14 @@ int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev
  * TD_ERR_SINGULAR when cov_x is not positive definite. */
 int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
                    float* w_dev, float* b_dev);
+/* The same without waiting for the device.  *singular_flag_host points at a pinned host int
+ * owned by the handle (a ring of 8: read it before the 8th later call) that becomes 0, or 1 if
+ * some cov_x was not positive definite (w_dev / b_dev are then meaningless), once the work queued
+ * by this call has completed -- wait for an event recorded after the call, then read it.  For
+ * callers that pipeline fits: a host that waits for every solve cannot queue the next fit's
+ * work in time (pipeline.FitPipeline). */
+int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
+                         float* w_dev, float* b_dev, const int** singular_flag_host);
 
 /* Generic SPD solve used by the above and by the shrinkage branch
  * (brain_model.py:456-477): a_dev [batch, n, n] float64 (destroyed),

@@ -197,6 +197,8 @@ int td_destroy(td_handle* h) {
   for (auto& slot : h->tables)
     if (slot.dev) hipFree(slot.dev);
   if (h->dev_flag) hipFree(h->dev_flag);
+  if (h->dev_flags) hipFree(h->dev_flags);
+  if (h->host_flags) hipHostFree(h->host_flags);
   if (h->ev_start) hipEventDestroy(h->ev_start);
   if (h->ev_stop) hipEventDestroy(h->ev_stop);
   if (h->own_stream) hipStreamDestroy(h->own_stream);

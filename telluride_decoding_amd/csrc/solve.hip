@@ -538,14 +538,16 @@ __global__ __launch_bounds__(256) void diag_tol_kernel(const double* __restrict_
 
 // Core: a [batch][n][n] (n a multiple of 64), rt [batch][kMaxRhs][n]; solution in sol.
 int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
-                     double* linv_dev, double* tol_dev, int n, int nrhs, int batch) {
-  TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
+                     double* linv_dev, double* tol_dev, int n, int nrhs, int batch,
+                     int* flag_dev = nullptr) {
+  if (!flag_dev) flag_dev = h->dev_flag;      // (a caller's flag outlives the next solve)
+  TD_HIP(h, hipMemsetAsync(flag_dev, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(diag_tol_kernel, dim3((unsigned)batch), dim3(256), 0, h->stream, a_dev, n,
                      tol_dev);
   const int nblk = n / NB;
   CholParams p;
   p.a = a_dev; p.rt = rt_dev; p.linv = linv_dev; p.sol = sol_dev; p.tol = tol_dev;
-  p.n = n; p.nrhs = nrhs; p.nblk = nblk; p.flag = h->dev_flag;
+  p.n = n; p.nrhs = nrhs; p.nblk = nblk; p.flag = flag_dev;
   p.k = 0;
   hipLaunchKernelGGL(chol_diag_kernel, dim3(1, (unsigned)batch), dim3(256), 0, h->stream, p);
   for (int k = 0; k < nblk; ++k) {
@@ -684,8 +686,10 @@ int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, 
   return spd_check_flag(h);
 }
 
-int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
-                   float* w_dev, float* b_dev) {
+// flag_dev == NULL: synchronous (the status reports a singular system); else the caller's device
+// int receives 0 / 1 in stream order and nothing waits for the device.
+static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
+                            float* w_dev, float* b_dev, int* flag_dev) {
   if (!h || !s || !lambdas_host || !w_dev || !b_dev)
     return td_fail(h, TD_ERR_INVALID, "td_ridge_solve: NULL argument");
   int k1 = 0, d = 0;
@@ -713,11 +717,35 @@ int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_
                      0LL, n, np, inv, w.lams, w.a);
   hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)n_lambda), dim3(256), 0, h->stream, xty, 0LL,
                      n, d, np, inv, w.rt);
-  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, d, n_lambda));
+  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, d, n_lambda, flag_dev));
   hipLaunchKernelGGL(ridge_emit_kernel, dim3(256), dim3(256), 0, h->stream, w.sol, k1, d, np,
                      n_lambda, w_dev, b_dev);
   TD_HIP(h, hipGetLastError());
-  return spd_check_flag(h);
+  return flag_dev ? TD_OK : spd_check_flag(h);
+}
+
+int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
+                   float* w_dev, float* b_dev) {
+  return ridge_solve_impl(h, s, lambdas_host, n_lambda, w_dev, b_dev, nullptr);
+}
+
+int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
+                         float* w_dev, float* b_dev, const int** singular_flag_host) {
+  if (!h || !singular_flag_host)
+    return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_async: NULL argument");
+  *singular_flag_host = nullptr;
+  if (!h->dev_flags) {
+    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flags), sizeof(int) * td_handle::kAsyncFlags));
+    TD_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags),
+                            sizeof(int) * td_handle::kAsyncFlags, hipHostMallocDefault));
+  }
+  const int slot = h->async_next;
+  h->async_next = (h->async_next + 1) % td_handle::kAsyncFlags;
+  TD_TRY(ridge_solve_impl(h, s, lambdas_host, n_lambda, w_dev, b_dev, h->dev_flags + slot));
+  TD_HIP(h, hipMemcpyAsync(h->host_flags + slot, h->dev_flags + slot, sizeof(int),
+                           hipMemcpyDeviceToHost, h->stream));
+  *singular_flag_host = h->host_flags + slot;
+  return TD_OK;
 }
 
 }  // extern "C"

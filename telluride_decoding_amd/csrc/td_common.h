@@ -51,6 +51,11 @@ struct td_handle {
   TableSlot tables[kTableSlots];
   uint64_t table_clock = 0;
   int* dev_flag = nullptr;  // device int used for "not positive definite" reports
+  // asynchronous solves: rings of device flags and of pinned host ints they are copied to
+  static constexpr int kAsyncFlags = 8;
+  int* dev_flags = nullptr;
+  int* host_flags = nullptr;
+  int async_next = 0;
   // Optional per-kernel hipEvent timing of the dominant kernel (td_profile_*):
   // event pairs recorded on h->stream around every lagcov MFMA launch.
   bool profile = false;

@@ -239,6 +239,19 @@ class LagStats(object):
     h.check(h.lib.td_ridge_solve(h.ptr, self.ptr, lam_p, len(lam), _ptr(w), _ptr(b)))
     return w, b
 
+  def ridge_solve_async(self, lambdas, handle=None):
+    """ridge_solve without waiting for the device: returns (W, b, flag) where flag() reads the
+    singular-system flag (1 = some system was not positive definite) from the handle's pinned
+    host ring -- call it only after waiting for an event recorded behind this call."""
+    h = handle or self.h
+    lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
+    w = h.empty((len(lam), self.k1, self.d), 'float32')
+    b = h.empty((len(lam), self.d), 'float32')
+    ptr = ctypes.POINTER(ctypes.c_int)()
+    h.check(h.lib.td_ridge_solve_async(h.ptr, self.ptr, lam_p, len(lam), _ptr(w), _ptr(b),
+                                       ctypes.byref(ptr)))
+    return w, b, (lambda: int(ptr[0]))
+
   def __del__(self):
     try:
       if getattr(self, 'ptr', None):

@@ -260,7 +260,8 @@ def test_c2_shape_fit_against_float64_oracle(dev):
 @pytest.mark.gpu
 def test_pipelined_fits_equal_serial_fits(dev):
   """pipeline.FitPipeline (accumulate of fit i+1 under the solve of fit i, two streams,
-  double-buffered statistics) returns, fit by fit, exactly what back-to-back fits return."""
+  double-buffered statistics, results handed out two submits later) returns, fit by fit,
+  exactly what back-to-back fits return; a singular fit raises when its result is due."""
   import torch
   from telluride_decoding_amd import pipeline
   rng = np.random.default_rng(21)
@@ -280,6 +281,17 @@ def test_pipelined_fits_equal_serial_fits(dev):
     st.accumulate(x, None, y, offs)
     w, b = st.ridge_solve([0.1, 1.0])
     want.append((w.cpu().numpy(), b.cpu().numpy()))
+  # a singular fit (all-zero recording, lambda = 0) is reported when its result is due
+  pipe = pipeline.FitPipeline(c, pre, post, d=1)
+  zx = torch.zeros(n, c, device='cuda'); zy = torch.zeros(n, 1, device='cuda')
+  assert pipe.submit(zx, zy, offs, [0.0]) is None
+  assert pipe.submit(data[0][0], data[0][1], offs, [0.1, 1.0]) is None
+  with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
+    pipe.submit(data[1][0], data[1][1], offs, [0.1, 1.0])        # hands out fit 0
+  rest = pipe.flush()
+  assert len(rest) == 2
+  np.testing.assert_array_equal(rest[0][0].cpu().numpy(), want[0][0])
+  del pipe
   # both placements of the y^T x part: on the solve stream (default) and on the accumulate stream
   for on_solve in (True, False):
     pipe = pipeline.FitPipeline(c, pre, post, d=1, targets_on_solve=on_solve)
@@ -288,8 +300,8 @@ def test_pipelined_fits_equal_serial_fits(dev):
       r = pipe.submit(x, y, offs, [0.1, 1.0])
       if r is not None:
         got.append(r)
-    got.append(pipe.flush())
-    assert pipe.flush() is None
+    got.extend(pipe.flush())
+    assert pipe.flush() == []
     torch.cuda.synchronize()
     assert len(got) == len(want)
     for (w, b), (w0, b0) in zip(got, want):
@@ -509,7 +521,7 @@ def test_single_rank_rccl_allreduce_round_trip(dev):
       r = pipe.submit(x, y, offs, [0.1])
       if r is not None:
         outs.append(r)
-    outs.append(pipe.flush())
+    outs.extend(pipe.flush())
     assert len(outs) == 4
     for w2, b2 in outs:
       np.testing.assert_array_equal(w2.cpu().numpy(), w0.cpu().numpy())
