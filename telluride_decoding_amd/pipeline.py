@@ -23,7 +23,7 @@ class FitPipeline(object):
   other blocking stream and serialises the two stages (measured: 3.44 ms instead of 2.68).
   """
 
-  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32, targets_on_solve=True):
+  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32, targets_on_solve=True, buffers=3):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -60,9 +60,11 @@ class FitPipeline(object):
       self.h_acc = device.Handle()
     with torch.cuda.stream(self.s_solve):
       self.h_solve = device.Handle()
-    self.stats = [device.LagStats(c, pre, post, d=d, handle=self.h_acc) for _ in range(2)]
-    self.ev_acc = [torch.cuda.Event() for _ in range(2)]
-    self.ev_solved = [None, None]
+    # three statistics buffers: with two, accumulate i + 2 has to wait for solve i, and the two
+    # stages (2.55 and 2.5 ms) end up waiting for each other's jitter
+    self.stats = [device.LagStats(c, pre, post, d=d, handle=self.h_acc) for _ in range(buffers)]
+    self.ev_acc = [torch.cuda.Event() for _ in range(buffers)]
+    self.ev_solved = [None] * buffers
     self.pending = None          # (buffer index, lambdas) of the fit whose solve is not queued yet
     self._results = []           # queued solves: (w, b, flag reader, event)
     self.count = 0
@@ -105,7 +107,7 @@ class FitPipeline(object):
 
   def submit(self, x, y, file_offsets, lambdas, **kw):
     torch = self.torch
-    buf = self.count % 2
+    buf = self.count % len(self.stats)
     self.count += 1
     with torch.cuda.stream(self.s_acc):
       if self.ev_solved[buf] is not None:
