@@ -97,9 +97,26 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   n_lam, d = len(lambdas), dataset.d
   scores = []
   train = proto.like()
+  # The solves are queued without waiting for their singular-system flags (the host would
+  # otherwise stop after every fold and the device idle while it queues the next one); a flag
+  # is read a few folds later, before its slot in the handle's ring of 8 is reused.
+  outstanding = []
+
+  def check(keep):
+    while len(outstanding) > keep:
+      ev, flag, fold = outstanding.pop(0)
+      ev.synchronize()
+      if flag():
+        raise np.linalg.LinAlgError('Singular matrix: covariance is not positive definite '
+                                    '(fold %d)' % fold)
+
   for f in my_folds:
     train.combine([stats[g] for g in range(n_files) if g != f])
-    w, b = train.ridge_solve(lambdas)                    # [Lambda, K, D], [Lambda, D]
+    w, b, flag = train.ridge_solve_async(lambdas)        # [Lambda, K, D], [Lambda, D]
+    ev = torch.cuda.Event()
+    ev.record()
+    outstanding.append((ev, flag, f))
+    check(keep=4)
     u = used[f]
     if u == 0:
       scores.append(torch.full((n_lam,), float('nan'), dtype=torch.float64, device=h.device))
@@ -117,6 +134,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
                                 [0, u], bsz, bsz, handle=h)
       r.append(device.window_scores(sums, bsz, mode=1, handle=h))   # [minibatches, <= 16]
     scores.append(torch.cat(r, dim=1).mean(dim=0))
+  check(keep=0)
   rows = (torch.stack(scores).cpu().numpy() if scores else np.zeros((0, n_lam)))
   # 5. gather
   all_folds = distributed.gather_rows(rows, n_files, my_folds, group)     # [F, Lambda]
