@@ -226,6 +226,36 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
                      const float* mean2_dev, const float* rot2_dev, int dims,
                      float* out_dev, int64_t ldout);
 
+/* ------------------------------------------------------------------ A4 dense stage
+ * CCA rotations from the accumulated moments, entirely on the device in float64
+ * (cca.calculate_cca_parameters_from_dataset, cca.py:337-367): means, the reference's
+ * covariance normalisation  cov = S / denom - mean^T mean  with
+ * denom = num_mini_batches * n_row - 1 (:339-343, n_row = rows of the LAST minibatch),
+ * + regularization * I on both auto-covariances, symmetric eigen-decompositions
+ * (np.linalg.eig at :345-346), eigenvalues <= eps_eig dropped (:349-355), whitening
+ * K11 / K22 (:357-360), svd(K11 cov_xy K22) (:361-363) and the rotations (:365-367).
+ *   rot_x_dev [k1, dim], rot_y_dev [k2, dim], mean_x_dev [k1], mean_y_dev [k2], e_dev [dim]:
+ *   float32 on the device, the dtype the reference returns for float32 inputs.
+ *   dim <= min(k1, k2) (the caller clips, as the reference's slicing does).
+ *   info_host (may be NULL) receives the Jacobi sweep counts {eig xx, eig yy, svd}.
+ * Singular vectors are defined up to a joint sign of (rot_x[:, i], rot_y[:, i]). */
+int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization, double eps_eig,
+                 int dim, float* rot_x_dev, float* rot_y_dev, float* mean_x_dev, float* mean_y_dev,
+                 float* e_dev, int* info_host);
+
+/* The two float64 decompositions td_cca_solve is built from, for callers that bring their
+ * own covariance matrices (np.linalg.eig on a symmetric matrix, np.linalg.svd).
+ * td_sym_eigh: a_dev [n, n] symmetric (left untouched) -> vals_dev [n] (unsorted, as
+ * np.linalg.eig leaves them), vecs_dev [n, n] with the eigenvectors as columns.  Cyclic Jacobi
+ * (n <= 64: one workgroup in LDS; larger: block Jacobi with MFMA updates); *sweeps (may be
+ * NULL) = outer sweeps used.
+ * td_jacobi_svd: t_dev [m, n] -> the dim largest singular values s_dev [dim] (descending) with
+ * u_dev [dim, m] and v_dev [dim, n] (singular vectors as ROWS), one-sided Jacobi. */
+int td_sym_eigh(td_handle* h, const double* a_dev, int n, double* vals_dev, double* vecs_dev,
+                int* sweeps);
+int td_jacobi_svd(td_handle* h, const double* t_dev, int m, int n, int dim, double* u_dev,
+                  double* s_dev, double* v_dev, int* sweeps);
+
 /* ------------------------------------------------------------------ A5 / A6 / A7
  * Five running sums per window and column, in float64:
  *   out_dev[w][col] = {sum a, sum b, sum a^2, sum b^2, sum a*b}

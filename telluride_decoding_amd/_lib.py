@@ -78,6 +78,9 @@ SIGNATURES = {
     'td_predict_fir': [_vp, _vp, _i64, _pi64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64],
     'td_cca_transform': [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i, _i, _pi64, _i, _i,
                          _vp, _vp, _vp, _vp, _i, _vp, _i64],
+    'td_cca_solve': [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i)],
+    'td_sym_eigh': [_vp, _vp, _i, _vp, _vp, _c.POINTER(_i)],
+    'td_jacobi_svd': [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _c.POINTER(_i)],
     'td_window_count': [_pi64, _i, _i, _i, _pi64, _pi64],
     'td_window_sums': [_vp, _vp, _i64, _vp, _i64, _i, _pi64, _i, _i, _i, _vp],
     'td_window_scores': [_vp, _vp, _i64, _i, _i, _i, _i, _pd, _pd, _pd, _vp],

@@ -5,11 +5,11 @@ _second]` (cca.py:39-78), `calculate_cca_parameters_from_dataset` (:272-369),
 `BrainCcaLayer.call` (:150-161) and `BrainModelCCA` (:169-244).  The TF-graph
 deep-CCA loss (`cca_loss`, :372-443) is out of scope.
 
-Split of work: the accumulate over all frames (cov_xx, cov_yy, cov_xy, sums --
-the cost that made one model "~1 hour on my workstation" in the codelab) and the
-transform run in HIP kernels; the K x K eigen/SVD stage is a small dense,
-latency-bound problem and is done with LAPACK in float64 on the host from the
-device-reduced moments (DESIGN.md "CCA dense stage").
+Everything runs in HIP kernels behind the C-ABI: the accumulate over all frames
+(cov_xx, cov_yy, cov_xy, sums -- the cost that made one model "~1 hour on my
+workstation" in the codelab), the K x K dense stage (covariance normalisation,
+two symmetric eigen-decompositions, whitening, SVD: td_cca_solve, float64 Jacobi
+on the device) and the transform.
 """
 import numpy as np
 
@@ -34,22 +34,6 @@ def cca_pearson_correlation_first(x, y):
 
 def cca_pearson_correlation_second(x, y):
   return cca_pearson_correlation(x, y)[1]
-
-
-def _dense_stage(cov_xx, cov_yy, cov_xy, dim, eps_eig):
-  """cca.py:345-367 on the reduced moment matrices (float64, host LAPACK)."""
-  x_vals, x_vecs = np.linalg.eig(cov_xx)
-  y_vals, y_vecs = np.linalg.eig(cov_yy)
-  idx1 = np.where(x_vals > eps_eig)[0]
-  x_vals, x_vecs = x_vals[idx1], x_vecs[:, idx1]
-  idx2 = np.where(y_vals > eps_eig)[0]
-  y_vals, y_vecs = y_vals[idx2], y_vecs[:, idx2]
-  k11 = (x_vecs @ np.diag(np.reciprocal(np.sqrt(x_vals)))) @ x_vecs.T
-  k22 = (y_vecs @ np.diag(np.reciprocal(np.sqrt(y_vals)))) @ y_vecs.T
-  t = (k11 @ cov_xy) @ k22
-  u, e, v = np.linalg.svd(t, full_matrices=False)
-  v = v.T
-  return k11 @ u[:, 0:dim], k22 @ v[:, 0:dim], e[0:dim]
 
 
 def calculate_cca_parameters_from_dataset(dataset, dim, regularization=0.1,
@@ -92,24 +76,13 @@ def calculate_cca_parameters_from_dataset(dataset, dim, regularization=0.1,
     if not num_mini_batches:
       raise ValueError('No minibatches in dataset, can\'t compute CCA model.')
   total_frames, _ = st.counts()
-  m = st.moments(want_xtx=True, want_xty=False, want_cca=True)
-  k1, k2 = st.k1, st.k2
-  xtx = m['xtx'].cpu().numpy()
-  s_xx = xtx[:k1, :k1]
-  sum_x = xtx[k1:k1 + 1, :k1]
-  s_yy = m['x2tx2'].cpu().numpy()
-  s_xy = m['xtx2'].cpu().numpy()
-  sum_y = m['sum_x2'].cpu().numpy().reshape(1, -1)
-  mean_x = sum_x / total_frames
-  mean_y = sum_y / total_frames
-  denom = num_mini_batches * n_row - 1
-  cov_xx = s_xx / denom - mean_x.T @ mean_x + regularization * np.eye(k1)
-  cov_yy = s_yy / denom - mean_y.T @ mean_y + regularization * np.eye(k2)
-  cov_xy = s_xy / denom - mean_x.T @ mean_y
-  rot_x, rot_y, e = _dense_stage(cov_xx, cov_yy, cov_xy, dim, eps_eig)
-  f32 = np.float32
-  return (np.real(rot_x).astype(f32), np.real(rot_y).astype(f32), mean_x.astype(f32),
-          mean_y.astype(f32), np.real(e).astype(f32))
+  if not total_frames:
+    raise ValueError('No minibatches in dataset, can\'t compute CCA model.')
+  # u[:, 0:dim] of the reference slices to what exists
+  dim_eff = max(1, min(int(dim), st.k1, st.k2))
+  rot_x, rot_y, mean_x, mean_y, e, _ = st.cca_solve(num_mini_batches * n_row - 1, regularization,
+                                                    dim_eff, eps_eig, handle=h)
+  return tuple(t.cpu().numpy() for t in (rot_x, rot_y, mean_x, mean_y, e))
 
 
 class BrainModelCCA(object):

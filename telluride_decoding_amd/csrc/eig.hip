@@ -1,0 +1,795 @@
+// A4 dense stage -- CCA rotations from the reduced moments, on the device in float64.
+//
+// Reference: cca.calculate_cca_parameters_from_dataset, cca.py:337-367:
+//   mean = sum / total_frames                                  (:337-338)
+//   cov  = S / (num_mini_batches * n_row - 1) - mean^T mean    (:339-343, the reference's own
+//          normalisation, reproduced as is) + regularization * I on the two auto-covariances
+//   eig(cov_xx), eig(cov_yy); eigenvalues <= eps_eig dropped   (:345-355)
+//   K11 = V diag(lambda^-1/2) V^T, K22 likewise                (:357-360)
+//   T = K11 cov_xy K22 ; u, e, v = svd(T)                      (:361-363)
+//   rot_x = K11 u[:, :dim] ; rot_y = K22 v[:, :dim] ; e[:dim]  (:365-367)
+// The reference calls the general np.linalg.eig on symmetric matrices; the symmetric solver
+// below returns the same decomposition (K11 / K22 do not depend on the eigenvalue order).
+//
+// Building blocks, all float64:
+//   gemm_kernel        C = alpha op(A) op(B), 64x64 tiles on v_mfma_f64_16x16x4_f64
+//   jacobi64_kernel    cyclic two-sided Jacobi of a symmetric 64x64 matrix held in LDS
+//                      (32 disjoint rotations per round, round-robin ordering); solves small
+//                      problems directly and is the sub-problem solver of
+//   block Jacobi       n > 64: 32-column blocks, a round = n/64 disjoint block pairs; per round
+//                      (1) every pair's 64x64 sub-problem is diagonalised in LDS -> J_pq,
+//                      (2) A <- A J and V <- V J on the pair's columns, (3) A <- J^T A on its
+//                      rows, both as 64^3 MFMA GEMMs.  Pairs whose sub-problem needed no
+//                      rotation are skipped.  Converged when a whole sweep rotates nothing.
+//   one-sided Jacobi   SVD of T: the columns of the narrower side are orthogonalised in
+//                      pairs (a workgroup per pair and round), singular values = column norms.
+// Rotation criterion |a_pq| > 1e-15 sqrt|a_pp a_qq| (relative: small eigenvalues of the
+// positive definite covariances keep their relative accuracy, which K = V lambda^-1/2 V^T
+// needs).  Small dense and latency-bound: reported as time, not against a roofline.
+#include <algorithm>
+
+#include "td_common.h"
+
+int td_stats_dims(const td_stats* s, int* k1, int* k2, int64_t* frames);
+
+namespace {
+
+constexpr int NB = 64;
+constexpr int LS = NB + 2;    // LDS row stride in doubles
+constexpr int HB = 32;        // block-Jacobi block width (a pair = one 64x64 sub-problem)
+constexpr double kRotTol = 1e-15;
+constexpr int kMaxOuterSweeps = 40;
+constexpr int kMaxInnerSweeps = 12;
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// acc += As . Bs^T (64x64x64) on the float64 matrix cores; wave w owns the 32x32 quadrant
+// (w >> 1, w & 1).  Operand lane map: A[i = lane & 15][k = lane >> 4]; C/D: col = lane & 15,
+// row = (lane >> 4) + 4 * reg.
+__device__ __forceinline__ void mma_nt_64(const double* __restrict__ as,
+                                          const double* __restrict__ bs, int wave, int lane,
+                                          f64x4 (&acc)[2][2]) {
+  const int li = lane & 15, lk = lane >> 4;
+  const double* ap = as + ((wave >> 1) * 32 + li) * LS + lk;
+  const double* bp = bs + ((wave & 1) * 32 + li) * LS + lk;
+#pragma unroll 4
+  for (int s = 0; s < NB / 4; ++s) {
+    const double a0 = ap[4 * s], a1 = ap[16 * LS + 4 * s];
+    const double b0 = bp[4 * s], b1 = bp[16 * LS + 4 * s];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void zero_acc(f64x4 (&acc)[2][2]) {
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.0;
+}
+__device__ __forceinline__ int acc_row(int wave, int lane, int m, int r) {
+  return (wave >> 1) * 32 + 16 * m + (lane >> 4) + 4 * r;
+}
+__device__ __forceinline__ int acc_col(int wave, int lane, int n) {
+  return (wave & 1) * 32 + 16 * n + (lane & 15);
+}
+
+// lds[r][k] = X[r0 + r][k0 + k], zero outside [0, rows) x [0, ks).  `trans` = X is stored
+// transposed (element (r, k) at src[k * ld + r]); either way the global reads are coalesced.
+__device__ __forceinline__ void load_operand(double* lds, const double* __restrict__ src, int ld,
+                                             bool trans, int r0, int k0, int rows, int ks, int tid) {
+  const int f = tid & 63, s0 = tid >> 6;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int s = s0 + 4 * i;
+    const int r = trans ? f : s, k = trans ? s : f;
+    const int gr = r0 + r, gk = k0 + k;
+    double v = 0.0;
+    if (gr < rows && gk < ks) v = trans ? src[(size_t)gk * ld + gr] : src[(size_t)gr * ld + gk];
+    lds[r * LS + k] = v;
+  }
+}
+
+// ---- general product -------------------------------------------------------------------
+// C[m x n] = alpha * op(A)[m x k] * op(B)[k x n].  ta: A is stored [k x m]; tb: B is stored
+// [n x k].  Row-major with leading dimensions.
+struct GemmParams {
+  const double* a; const double* b; double* c;
+  int m, n, k, lda, ldb, ldc, ta, tb;
+  double alpha;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  __shared__ double as[NB * LS];
+  __shared__ double bs[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * NB, n0 = blockIdx.x * NB;
+  f64x4 acc[2][2];
+  zero_acc(acc);
+  for (int k0 = 0; k0 < p.k; k0 += NB) {
+    load_operand(as, p.a, p.lda, p.ta != 0, m0, k0, p.m, p.k, tid);
+    // the B operand of the NT product is X[n][k] = op(B)[k][n]: stored as is when B is [n x k]
+    load_operand(bs, p.b, p.ldb, p.tb == 0, n0, k0, p.n, p.k, tid);
+    __syncthreads();
+    mma_nt_64(as, bs, wave, lane, acc);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + acc_row(wave, lane, m, r), col = n0 + acc_col(wave, lane, n);
+        if (row < p.m && col < p.n) p.c[(size_t)row * p.ldc + col] = p.alpha * acc[m][n][r];
+      }
+}
+
+int gemm(td_handle* h, const double* a, int lda, bool ta, const double* b, int ldb, bool tb,
+         double* c, int ldc, int m, int n, int k, double alpha = 1.0) {
+  if (m <= 0 || n <= 0) return TD_OK;
+  GemmParams p;
+  p.a = a; p.b = b; p.c = c; p.m = m; p.n = n; p.k = k;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ta = ta; p.tb = tb; p.alpha = alpha;
+  hipLaunchKernelGGL(gemm_kernel, dim3((unsigned)td_ceil_div(n, NB), (unsigned)td_ceil_div(m, NB)),
+                     dim3(256), 0, h->stream, p);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+// ---- round-robin pairing ---------------------------------------------------------------------
+// `players` even; round r in [0, players - 1): pair 0 = (r, players - 1), pair k >= 1 =
+// ((r + k) mod (players - 1), (r - k) mod (players - 1)); returned with p < q.
+__device__ __forceinline__ void rr_pair(int players, int round, int k, int* p, int* q) {
+  const int m = players - 1;
+  int a, b;
+  if (k == 0) { a = round; b = m; }
+  else { a = (round + k) % m; b = (round + m - k) % m; }
+  *p = a < b ? a : b;
+  *q = a < b ? b : a;
+}
+
+// ---- 64x64 symmetric Jacobi in LDS ---------------------------------------------------------------
+struct JacParams {
+  double* a;           // direct: [n][lda]; block mode: padded [np][np]
+  int lda, n;
+  int direct;          // 1: whole (n <= 64) problem; 0: block pair `blockIdx.x` of `round`
+  int nblocks, round;  // block mode: number of 32-wide blocks, round of the outer ordering
+  double* jout;        // block mode: [pairs][64][64] rotation J; direct: V [n][n]
+  double* vals;        // direct: eigenvalues [n]
+  int* skip;           // block mode: [pairs] 1 = J is the identity (no rotation needed)
+  unsigned int* rotations;  // += rotations applied (convergence test of the outer sweep)
+  int max_sweeps;
+};
+
+__global__ __launch_bounds__(256) void jacobi64_kernel(JacParams P) {
+  __shared__ double S[NB * LS];
+  __shared__ double J[NB * LS];
+  __shared__ double cs[32], sn[32];
+  __shared__ int pp[32], qq[32];
+  __shared__ int nrot, total;
+  const int tid = threadIdx.x;
+  int bp = 0, bq = 0;
+  if (!P.direct) rr_pair(P.nblocks, P.round, blockIdx.x, &bp, &bq);
+  // ---- load
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    double v = 0.0;
+    if (P.direct) {
+      if (r < P.n && c < P.n) v = P.a[(size_t)r * P.lda + c];
+    } else {
+      const int gr = (r < HB ? bp : bq) * HB + (r & (HB - 1));
+      const int gc = (c < HB ? bp : bq) * HB + (c & (HB - 1));
+      v = P.a[(size_t)gr * P.lda + gc];
+    }
+    S[r * LS + c] = v;
+    J[r * LS + c] = (r == c) ? 1.0 : 0.0;
+  }
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int sweep = 0; sweep < P.max_sweeps; ++sweep) {
+    if (tid == 0) nrot = 0;
+    for (int round = 0; round < NB - 1; ++round) {
+      __syncthreads();
+      if (tid < 32) {
+        int p, q;
+        rr_pair(NB, round, tid, &p, &q);
+        const double app = S[p * LS + p], aqq = S[q * LS + q], apq = S[p * LS + q];
+        double c = 1.0, s = 0.0;
+        const double mag = fabs(apq);
+        if (mag > 1e-290 && mag > kRotTol * sqrt(fabs(app * aqq))) {
+          const double tau = (aqq - app) / (2.0 * apq);
+          const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          c = 1.0 / sqrt(1.0 + t * t);
+          s = t * c;
+          atomicAdd(&nrot, 1);
+        }
+        cs[tid] = c; sn[tid] = s; pp[tid] = p; qq[tid] = q;
+      }
+      __syncthreads();
+      {  // columns p, q of S and J:  [x_p x_q] <- [c x_p - s x_q, s x_p + c x_q]
+        const int k = tid & 31;
+        const int p = pp[k], q = qq[k];
+        const double c = cs[k], s = sn[k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = (tid >> 5) + 8 * i;
+          const double sp = S[row * LS + p], sq = S[row * LS + q];
+          S[row * LS + p] = c * sp - s * sq;
+          S[row * LS + q] = s * sp + c * sq;
+          const double jp = J[row * LS + p], jq = J[row * LS + q];
+          J[row * LS + p] = c * jp - s * jq;
+          J[row * LS + q] = s * jp + c * jq;
+        }
+      }
+      __syncthreads();
+      {  // rows p, q of S
+        const int col = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = (tid >> 6) + 4 * i;
+          const int p = pp[k], q = qq[k];
+          const double c = cs[k], s = sn[k];
+          const double sp = S[p * LS + col], sq = S[q * LS + col];
+          S[p * LS + col] = c * sp - s * sq;
+          S[q * LS + col] = s * sp + c * sq;
+        }
+      }
+    }
+    __syncthreads();
+    const int done = nrot;
+    if (tid == 0) total += done;
+    __syncthreads();
+    if (done == 0) break;
+  }
+  // ---- publish
+  if (P.direct) {
+    for (int idx = tid; idx < P.n * P.n; idx += 256) {
+      const int r = idx / P.n, c = idx % P.n;
+      P.jout[idx] = J[r * LS + c];
+    }
+    if (tid < P.n) P.vals[tid] = S[tid * LS + tid];
+    if (tid == 0 && total) atomicAdd(P.rotations, (unsigned int)total);
+  } else {
+    double* jo = P.jout + (size_t)blockIdx.x * NB * NB;
+    for (int idx = tid; idx < NB * NB; idx += 256) jo[idx] = J[(idx >> 6) * LS + (idx & 63)];
+    if (tid == 0) {
+      P.skip[blockIdx.x] = total == 0;
+      if (total) atomicAdd(P.rotations, (unsigned int)total);
+    }
+  }
+}
+
+// ---- block-Jacobi updates -------------------------------------------------------------------
+struct BlockUpd {
+  double* a; double* v; int np, nblocks, round;
+  const double* j; const int* skip;
+};
+
+// rows [64 t, 64 t + 64), the pair's 64 columns:  X <- X J   (blockIdx.z: 0 = A, 1 = V)
+__global__ __launch_bounds__(256) void block_cols_kernel(BlockUpd P) {
+  const int pair = blockIdx.y;
+  if (P.skip[pair]) return;
+  __shared__ double xs[NB * LS];
+  __shared__ double js[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bp, bq;
+  rr_pair(P.nblocks, P.round, pair, &bp, &bq);
+  double* mat = (blockIdx.z ? P.v : P.a) + (size_t)blockIdx.x * NB * P.np;
+  const double* jg = P.j + (size_t)pair * NB * NB;
+  {
+    const int c = tid & 63;
+    const int gc = (c < HB ? bp : bq) * HB + (c & (HB - 1));
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = (tid >> 6) + 4 * i;
+      xs[r * LS + c] = mat[(size_t)r * P.np + gc];          // As[m][k] = X[m][k]
+      js[c * LS + r] = jg[r * NB + c];                      // Bs[n][k] = J[k][n]
+    }
+  }
+  __syncthreads();
+  f64x4 acc[2][2];
+  zero_acc(acc);
+  mma_nt_64(xs, js, wave, lane, acc);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = acc_row(wave, lane, m, r), c = acc_col(wave, lane, n);
+        const int gc = (c < HB ? bp : bq) * HB + (c & (HB - 1));
+        mat[(size_t)row * P.np + gc] = acc[m][n][r];
+      }
+}
+
+// the pair's 64 rows, columns [64 t, 64 t + 64):  Y <- J^T Y
+__global__ __launch_bounds__(256) void block_rows_kernel(BlockUpd P) {
+  const int pair = blockIdx.y;
+  if (P.skip[pair]) return;
+  __shared__ double js[NB * LS];
+  __shared__ double ys[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bp, bq;
+  rr_pair(P.nblocks, P.round, pair, &bp, &bq);
+  const double* jg = P.j + (size_t)pair * NB * NB;
+  double* mat = P.a + (size_t)blockIdx.x * NB;
+  {
+    const int c = tid & 63;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = (tid >> 6) + 4 * i;
+      const int gr = (r < HB ? bp : bq) * HB + (r & (HB - 1));
+      js[c * LS + r] = jg[r * NB + c];                      // As[m][k] = J[k][m]
+      ys[c * LS + r] = mat[(size_t)gr * P.np + c];          // Bs[n][k] = Y[k][n]
+    }
+  }
+  __syncthreads();
+  f64x4 acc[2][2];
+  zero_acc(acc);
+  mma_nt_64(js, ys, wave, lane, acc);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = acc_row(wave, lane, m, r), c = acc_col(wave, lane, n);
+        const int gr = (row < HB ? bp : bq) * HB + (row & (HB - 1));
+        mat[(size_t)gr * P.np + c] = acc[m][n][r];
+      }
+}
+
+// dst [np][np] = src [n][n] (ld lds) zero padded; v = identity
+__global__ void pad_sym_kernel(const double* __restrict__ src, int lds_, int n, int np,
+                               double* __restrict__ dst, double* __restrict__ v) {
+  const long long total = (long long)np * np;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / np), c = (int)(i % np);
+    dst[i] = (r < n && c < n) ? src[(size_t)r * lds_ + c] : 0.0;
+    v[i] = (r == c) ? 1.0 : 0.0;
+  }
+}
+
+// vals[i] = a[i][i]; vecs [n][n] = v [np][np] top-left
+__global__ void unpad_eig_kernel(const double* __restrict__ a, const double* __restrict__ v, int n,
+                                 int np, double* __restrict__ vals, double* __restrict__ vecs) {
+  const long long total = (long long)n * n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    vecs[i] = v[(size_t)r * np + c];
+    if (r == 0) vals[c] = a[(size_t)c * np + c];
+  }
+}
+
+inline int grid_for(long long n) {
+  long long b = td_ceil_div(n, 256);
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// Eigen-decomposition of the symmetric a [n][lda] (left untouched): vals [n], vecs [n][n] with the
+// eigenvectors as COLUMNS.  ws: eig_ws_bytes(n) bytes of device workspace.
+size_t eig_ws_bytes(int n) {
+  if (n <= NB) return 256;
+  const size_t np = td_round_up(n, NB);
+  const size_t pairs = np / NB;
+  return sizeof(double) * (2 * np * np + pairs * NB * NB) + sizeof(int) * td_round_up(pairs, 64) + 256;
+}
+
+int sym_eig(td_handle* h, const double* a, int lda, int n, double* vals, double* vecs, void* ws,
+            int* sweeps_out) {
+  unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
+  JacParams P;
+  P.rotations = counter;
+  if (sweeps_out) *sweeps_out = 0;
+  if (n <= NB) {
+    TD_HIP(h, hipMemsetAsync(counter, 0, sizeof(unsigned int), h->stream));
+    P.a = const_cast<double*>(a); P.lda = lda; P.n = n; P.direct = 1;
+    P.nblocks = 0; P.round = 0; P.jout = vecs; P.vals = vals; P.skip = nullptr;
+    P.max_sweeps = kMaxOuterSweeps;
+    hipLaunchKernelGGL(jacobi64_kernel, dim3(1), dim3(256), 0, h->stream, P);
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
+  const int np = (int)td_round_up(n, NB);
+  const int nblocks = np / HB, pairs = nblocks / 2;
+  char* w = reinterpret_cast<char*>(ws) + 256;
+  double* ap = reinterpret_cast<double*>(w);   w += sizeof(double) * (size_t)np * np;
+  double* vp = reinterpret_cast<double*>(w);   w += sizeof(double) * (size_t)np * np;
+  double* jm = reinterpret_cast<double*>(w);   w += sizeof(double) * (size_t)pairs * NB * NB;
+  int* skip = reinterpret_cast<int*>(w);
+  hipLaunchKernelGGL(pad_sym_kernel, dim3(grid_for((long long)np * np)), dim3(256), 0, h->stream, a,
+                     lda, n, np, ap, vp);
+  P.a = ap; P.lda = np; P.n = np; P.direct = 0; P.nblocks = nblocks; P.jout = jm; P.vals = nullptr;
+  P.skip = skip; P.max_sweeps = kMaxInnerSweeps;
+  BlockUpd U;
+  U.a = ap; U.v = vp; U.np = np; U.nblocks = nblocks; U.j = jm; U.skip = skip;
+  int sweep = 0;
+  for (; sweep < kMaxOuterSweeps; ++sweep) {
+    TD_HIP(h, hipMemsetAsync(counter, 0, sizeof(unsigned int), h->stream));
+    for (int round = 0; round < nblocks - 1; ++round) {
+      P.round = U.round = round;
+      hipLaunchKernelGGL(jacobi64_kernel, dim3((unsigned)pairs), dim3(256), 0, h->stream, P);
+      hipLaunchKernelGGL(block_cols_kernel, dim3((unsigned)(np / NB), (unsigned)pairs, 2), dim3(256),
+                         0, h->stream, U);
+      hipLaunchKernelGGL(block_rows_kernel, dim3((unsigned)(np / NB), (unsigned)pairs), dim3(256), 0,
+                         h->stream, U);
+    }
+    TD_HIP(h, hipGetLastError());
+    unsigned int rotated = 0;
+    TD_HIP(h, hipMemcpyAsync(&rotated, counter, sizeof(unsigned int), hipMemcpyDeviceToHost,
+                             h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+    if (rotated == 0) break;
+  }
+  if (sweeps_out) *sweeps_out = sweep + 1;
+  hipLaunchKernelGGL(unpad_eig_kernel, dim3(grid_for((long long)n * n)), dim3(256), 0, h->stream, ap,
+                     vp, n, np, vals, vecs);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+// ---- one-sided Jacobi SVD ---------------------------------------------------------------------
+// g [k][ldg]: the k vectors (length m) to orthogonalise; vt [k][k] accumulates the rotations
+// (starts as the identity).  One workgroup per pair of the round.
+struct SvdParams {
+  double* g; double* vt; int k, kp, m, ldg, round;
+  unsigned int* rotations;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();                      // `red` may still be read from the previous call
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void svd_round_kernel(SvdParams P) {
+  __shared__ double red[4];
+  __shared__ double rot[2];
+  int i, j;
+  rr_pair(P.kp, P.round, blockIdx.x, &i, &j);
+  if (j >= P.k) return;                 // bye (odd k)
+  const int tid = threadIdx.x;
+  double* gi = P.g + (size_t)i * P.ldg;
+  double* gj = P.g + (size_t)j * P.ldg;
+  double al = 0.0, be = 0.0, ga = 0.0;
+  for (int t = tid; t < P.m; t += 256) {
+    const double x = gi[t], y = gj[t];
+    al += x * x; be += y * y; ga += x * y;
+  }
+  al = block_sum(al, red, tid);
+  be = block_sum(be, red, tid);
+  ga = block_sum(ga, red, tid);
+  if (tid == 0) {
+    double c = 1.0, s = 0.0;
+    const double mag = fabs(ga);
+    if (mag > 1e-290 && mag > kRotTol * sqrt(al * be)) {
+      const double tau = (be - al) / (2.0 * ga);
+      const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+      c = 1.0 / sqrt(1.0 + t * t);
+      s = t * c;
+      atomicAdd(P.rotations, 1u);
+    }
+    rot[0] = c; rot[1] = s;
+  }
+  __syncthreads();
+  const double c = rot[0], s = rot[1];
+  if (s == 0.0) return;
+  for (int t = tid; t < P.m; t += 256) {
+    const double x = gi[t], y = gj[t];
+    gi[t] = c * x - s * y;
+    gj[t] = s * x + c * y;
+  }
+  double* vi = P.vt + (size_t)i * P.k;
+  double* vj = P.vt + (size_t)j * P.k;
+  for (int t = tid; t < P.k; t += 256) {
+    const double x = vi[t], y = vj[t];
+    vi[t] = c * x - s * y;
+    vj[t] = s * x + c * y;
+  }
+}
+
+__global__ void identity_kernel(double* __restrict__ v, int k) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k * k; i += gridDim.x * blockDim.x)
+    v[i] = (i / k == i % k) ? 1.0 : 0.0;
+}
+
+// norms[i] = |g_i|
+__global__ __launch_bounds__(256) void svd_norms_kernel(const double* __restrict__ g, int ldg, int m,
+                                                        double* __restrict__ norms) {
+  __shared__ double red[4];
+  const double* gi = g + (size_t)blockIdx.x * ldg;
+  double al = 0.0;
+  for (int t = threadIdx.x; t < m; t += 256) al += gi[t] * gi[t];
+  al = block_sum(al, red, threadIdx.x);
+  if (threadIdx.x == 0) norms[blockIdx.x] = sqrt(al);
+}
+
+// The `dim` largest singular values in descending order (ties: lower index first) with their
+// vectors: gn [dim][m] = g_i / sigma_i, vn [dim][k] = vt_i.  One workgroup per output.
+__global__ __launch_bounds__(256) void svd_extract_kernel(const double* __restrict__ g, int ldg,
+                                                          const double* __restrict__ vt,
+                                                          const double* __restrict__ norms, int k,
+                                                          int m, double* __restrict__ sig,
+                                                          double* __restrict__ gn,
+                                                          double* __restrict__ vn) {
+  __shared__ int pick;
+  const int want = blockIdx.x;
+  if (threadIdx.x == 0) pick = -1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += 256) {
+    const double si = norms[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const double sj = norms[j];
+      rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+    }
+    if (rank == want) pick = i;
+  }
+  __syncthreads();
+  const int i = pick;
+  const double s = norms[i];
+  const double inv = s > 0.0 ? 1.0 / s : 0.0;
+  if (threadIdx.x == 0) sig[want] = s;
+  for (int t = threadIdx.x; t < m; t += 256) gn[(size_t)want * m + t] = g[(size_t)i * ldg + t] * inv;
+  for (int t = threadIdx.x; t < k; t += 256) vn[(size_t)want * k + t] = vt[(size_t)i * k + t];
+}
+
+size_t svd_ws_bytes(int k) { return sizeof(double) * ((size_t)k * k + k) + 256; }
+
+// g [k][ldg] (overwritten), k <= m: top `dim` singular triplets as rows sig [dim], gn [dim][m]
+// (unit vectors along the g side), vn [dim][k] (rotation side).
+int jacobi_svd(td_handle* h, double* g, int ldg, int k, int m, int dim, double* sig, double* gn,
+               double* vn, void* ws, int* sweeps_out) {
+  unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
+  double* vt = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + 256);
+  double* norms = vt + (size_t)k * k;
+  hipLaunchKernelGGL(identity_kernel, dim3(grid_for((long long)k * k)), dim3(256), 0, h->stream, vt, k);
+  SvdParams P;
+  P.g = g; P.vt = vt; P.k = k; P.kp = k + (k & 1); P.m = m; P.ldg = ldg; P.rotations = counter;
+  int sweep = 0;
+  if (k > 1) {
+    for (; sweep < kMaxOuterSweeps; ++sweep) {
+      TD_HIP(h, hipMemsetAsync(counter, 0, sizeof(unsigned int), h->stream));
+      for (int round = 0; round < P.kp - 1; ++round) {
+        P.round = round;
+        hipLaunchKernelGGL(svd_round_kernel, dim3((unsigned)(P.kp / 2)), dim3(256), 0, h->stream, P);
+      }
+      TD_HIP(h, hipGetLastError());
+      unsigned int rotated = 0;
+      TD_HIP(h, hipMemcpyAsync(&rotated, counter, sizeof(unsigned int), hipMemcpyDeviceToHost,
+                               h->stream));
+      TD_HIP(h, hipStreamSynchronize(h->stream));
+      if (rotated == 0) break;
+    }
+  }
+  if (sweeps_out) *sweeps_out = sweep + 1;
+  hipLaunchKernelGGL(svd_norms_kernel, dim3((unsigned)k), dim3(256), 0, h->stream, g, ldg, m, norms);
+  hipLaunchKernelGGL(svd_extract_kernel, dim3((unsigned)dim), dim3(256), 0, h->stream, g, ldg, vt,
+                     norms, k, m, sig, gn, vn);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+// ---- CCA glue -------------------------------------------------------------------------
+// out[i][j] = s[i][j] * inv_denom - (sa[i] inv_frames)(sb[j] inv_frames) + (i == j ? reg : 0)
+__global__ void cov_kernel(const double* __restrict__ s, int ld, int na, int nb_,
+                           const double* __restrict__ sa, const double* __restrict__ sb,
+                           double inv_denom, double inv_frames, double reg,
+                           double* __restrict__ out) {
+  const long long total = (long long)na * nb_;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / nb_), c = (int)(i % nb_);
+    out[i] = s[(size_t)r * ld + c] * inv_denom - (sa[r] * inv_frames) * (sb[c] * inv_frames) +
+             (r == c ? reg : 0.0);
+  }
+}
+
+// w[r][c] = v[r][c] * f(vals[c]),  f = lambda^-1/4 for lambda > eps, else 0:  K = W W^T
+__global__ void whiten_scale_kernel(const double* __restrict__ v, const double* __restrict__ vals,
+                                    int n, double eps, double* __restrict__ w) {
+  const long long total = (long long)n * n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const double lam = vals[i % n];
+    w[i] = lam > eps ? v[i] / sqrt(sqrt(lam)) : 0.0;
+  }
+}
+
+__global__ void scale_to_f32_kernel(const double* __restrict__ src, double scale, long long n,
+                                    float* __restrict__ dst) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = (float)(src[i] * scale);
+}
+
+// dst [cols][rows] float32 = src [rows][cols]^T  (rot = (K u)^T computed as rows)
+__global__ void transpose_to_f32_kernel(const double* __restrict__ src, int rows, int cols,
+                                        float* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
+    const int r = i / cols, c = i % cols;
+    dst[(size_t)c * rows + r] = (float)src[i];
+  }
+}
+
+// dst [cols][rows] = src [rows][cols]^T
+__global__ void transpose_kernel(const double* __restrict__ src, int rows, int cols,
+                                 double* __restrict__ dst) {
+  const long long total = (long long)rows * cols;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(size_t)c * rows + r] = src[i];
+  }
+}
+
+struct Carver {
+  char* p;
+  explicit Carver(void* base) : p(reinterpret_cast<char*>(base)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* r = reinterpret_cast<T*>(p);
+    p += td_round_up((int64_t)(sizeof(T) * count), 256);
+    return r;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int td_sym_eigh(td_handle* h, const double* a_dev, int n, double* vals_dev, double* vecs_dev,
+                int* sweeps) {
+  if (!h || !a_dev || !vals_dev || !vecs_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_sym_eigh: NULL argument");
+  TD_REQUIRE(h, n > 0, "td_sym_eigh: empty matrix");
+  void* ws = nullptr;
+  TD_TRY(td_workspace(h, eig_ws_bytes(n), &ws));
+  TD_TRY(sym_eig(h, a_dev, n, n, vals_dev, vecs_dev, ws, sweeps));
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  return TD_OK;
+}
+
+int td_jacobi_svd(td_handle* h, const double* t_dev, int m, int n, int dim, double* u_dev,
+                  double* s_dev, double* v_dev, int* sweeps) {
+  if (!h || !t_dev || !u_dev || !s_dev || !v_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_jacobi_svd: NULL argument");
+  TD_REQUIRE(h, m > 0 && n > 0, "td_jacobi_svd: empty matrix");
+  TD_REQUIRE(h, dim > 0 && dim <= std::min(m, n), "td_jacobi_svd: dim must be in [1, min(m, n)]");
+  // orthogonalise the vectors of the narrower side: g = T^T (n <= m) or T (m < n)
+  const bool cols = n <= m;
+  const int k = cols ? n : m, len = cols ? m : n;
+  Carver dry(nullptr);
+  dry.take<char>(svd_ws_bytes(k));
+  dry.take<double>((size_t)k * len);
+  void* base = nullptr;
+  TD_TRY(td_workspace(h, (size_t)(dry.p - (char*)nullptr), &base));
+  Carver cv(base);
+  void* ws = cv.take<char>(svd_ws_bytes(k));
+  double* g = cv.take<double>((size_t)k * len);
+  if (cols)
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)m * n)), dim3(256), 0, h->stream,
+                       t_dev, m, n, g);
+  else
+    TD_HIP(h, hipMemcpyAsync(g, t_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice,
+                             h->stream));
+  TD_TRY(jacobi_svd(h, g, len, k, len, dim, s_dev, cols ? u_dev : v_dev, cols ? v_dev : u_dev, ws,
+                    sweeps));
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  return TD_OK;
+}
+
+int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization, double eps_eig,
+                 int dim, float* rot_x_dev, float* rot_y_dev, float* mean_x_dev, float* mean_y_dev,
+                 float* e_dev, int* info_host) {
+  if (!h || !s || !rot_x_dev || !rot_y_dev || !mean_x_dev || !mean_y_dev || !e_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_cca_solve: NULL argument");
+  int k1 = 0, k2 = 0;
+  int64_t frames = 0;
+  td_stats_dims(s, &k1, &k2, &frames);
+  TD_REQUIRE(h, k2 > 0, "td_cca_solve: statistics were created without input_2");
+  if (frames <= 0) return td_fail(h, TD_ERR_STATE, "td_cca_solve: no data accumulated");
+  TD_REQUIRE(h, regularization >= 0.0, "regularization lambda must be >= 0");
+  TD_REQUIRE(h, denom != 0.0, "td_cca_solve: zero covariance denominator");
+  TD_REQUIRE(h, dim > 0 && dim <= std::min(k1, k2), "td_cca_solve: dim must be in [1, %d], not %d",
+             std::min(k1, k2), dim);
+  const bool cols = k2 <= k1;                 // side whose vectors the SVD orthogonalises
+  const int k = cols ? k2 : k1, len = cols ? k1 : k2;
+  const size_t n1 = (size_t)k1 + 1;
+  struct Ws {
+    double *xtx, *x2tx2, *xtx2, *sum2, *cxx, *cyy, *cxy, *vals1, *vecs1, *vals2, *vecs2, *m1, *g,
+        *sig, *gn, *vn, *rt;
+    void *eig, *svd;
+  } w;
+  auto carve = [&](void* base) {
+    Carver cv(base);
+    w.xtx = cv.take<double>(n1 * n1);
+    w.x2tx2 = cv.take<double>((size_t)k2 * k2);
+    w.xtx2 = cv.take<double>((size_t)k1 * k2);
+    w.sum2 = cv.take<double>(k2);
+    w.cxx = cv.take<double>((size_t)k1 * k1);
+    w.cyy = cv.take<double>((size_t)k2 * k2);
+    w.cxy = cv.take<double>((size_t)k1 * k2);
+    w.vals1 = cv.take<double>(k1);
+    w.vecs1 = cv.take<double>((size_t)k1 * k1);
+    w.vals2 = cv.take<double>(k2);
+    w.vecs2 = cv.take<double>((size_t)k2 * k2);
+    w.m1 = cv.take<double>((size_t)k1 * k2);
+    w.g = cv.take<double>((size_t)k1 * k2);
+    w.sig = cv.take<double>(dim);
+    w.gn = cv.take<double>((size_t)dim * len);
+    w.vn = cv.take<double>((size_t)dim * k);
+    w.rt = cv.take<double>((size_t)dim * std::max(k1, k2));
+    w.eig = cv.take<char>(eig_ws_bytes(std::max(k1, k2)));
+    w.svd = cv.take<char>(svd_ws_bytes(k));
+    return (size_t)(cv.p - reinterpret_cast<char*>(base));
+  };
+  void* base = nullptr;
+  TD_TRY(td_workspace(h, carve(nullptr), &base));
+  carve(base);
+  TD_TRY(td_stats_moments(h, s, w.xtx, nullptr, w.x2tx2, w.xtx2, w.sum2));
+  const double inv_d = 1.0 / denom, inv_f = 1.0 / (double)frames;
+  const double* sum1 = w.xtx + (size_t)k1 * n1;        // the ones row of sum_xtx = column sums
+  hipLaunchKernelGGL(cov_kernel, dim3(grid_for((long long)k1 * k1)), dim3(256), 0, h->stream, w.xtx,
+                     (int)n1, k1, k1, sum1, sum1, inv_d, inv_f, regularization, w.cxx);
+  hipLaunchKernelGGL(cov_kernel, dim3(grid_for((long long)k2 * k2)), dim3(256), 0, h->stream, w.x2tx2,
+                     k2, k2, k2, w.sum2, w.sum2, inv_d, inv_f, regularization, w.cyy);
+  // (the regularisation only goes on the auto-covariances: reg = 0 here)
+  hipLaunchKernelGGL(cov_kernel, dim3(grid_for((long long)k1 * k2)), dim3(256), 0, h->stream, w.xtx2,
+                     k2, k1, k2, sum1, w.sum2, inv_d, inv_f, 0.0, w.cxy);
+  hipLaunchKernelGGL(scale_to_f32_kernel, dim3(grid_for(k1)), dim3(256), 0, h->stream, sum1, inv_f,
+                     (long long)k1, mean_x_dev);
+  hipLaunchKernelGGL(scale_to_f32_kernel, dim3(grid_for(k2)), dim3(256), 0, h->stream, w.sum2, inv_f,
+                     (long long)k2, mean_y_dev);
+  TD_HIP(h, hipGetLastError());
+  int sweeps[3] = {0, 0, 0};
+  // K11 = V f(lambda) V^T = W W^T (W into the cxx buffer, K11 into the vecs1 buffer)
+  TD_TRY(sym_eig(h, w.cxx, k1, k1, w.vals1, w.vecs1, w.eig, &sweeps[0]));
+  hipLaunchKernelGGL(whiten_scale_kernel, dim3(grid_for((long long)k1 * k1)), dim3(256), 0, h->stream,
+                     w.vecs1, w.vals1, k1, eps_eig, w.cxx);
+  double* k11 = w.vecs1;
+  TD_TRY(gemm(h, w.cxx, k1, false, w.cxx, k1, true, k11, k1, k1, k1, k1));
+  TD_TRY(sym_eig(h, w.cyy, k2, k2, w.vals2, w.vecs2, w.eig, &sweeps[1]));
+  hipLaunchKernelGGL(whiten_scale_kernel, dim3(grid_for((long long)k2 * k2)), dim3(256), 0, h->stream,
+                     w.vecs2, w.vals2, k2, eps_eig, w.cyy);
+  double* k22 = w.vecs2;
+  TD_TRY(gemm(h, w.cyy, k2, false, w.cyy, k2, true, k22, k2, k2, k2, k2));
+  // T = K11 cov_xy K22, laid out with the vectors to orthogonalise as rows
+  if (cols) {   // g = T^T [k2][k1] = K22 (cov_xy^T K11)
+    TD_TRY(gemm(h, w.cxy, k2, true, k11, k1, false, w.m1, k1, k2, k1, k1));
+    TD_TRY(gemm(h, k22, k2, false, w.m1, k1, false, w.g, k1, k2, k1, k2));
+  } else {      // g = T [k1][k2] = K11 (cov_xy K22)
+    TD_TRY(gemm(h, w.cxy, k2, false, k22, k2, false, w.m1, k2, k1, k2, k2));
+    TD_TRY(gemm(h, k11, k1, false, w.m1, k2, false, w.g, k2, k1, k2, k1));
+  }
+  TD_TRY(jacobi_svd(h, w.g, len, k, len, dim, w.sig, w.gn, w.vn, w.svd, &sweeps[2]));
+  const double* u_rows = cols ? w.gn : w.vn;   // [dim][k1]
+  const double* v_rows = cols ? w.vn : w.gn;   // [dim][k2]
+  // rot_x^T [dim][k1] = u^T K11 (K11 symmetric), rot_y^T = v^T K22
+  TD_TRY(gemm(h, u_rows, k1, false, k11, k1, false, w.rt, k1, dim, k1, k1));
+  hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(grid_for((long long)dim * k1)), dim3(256), 0,
+                     h->stream, w.rt, dim, k1, rot_x_dev);
+  TD_TRY(gemm(h, v_rows, k2, false, k22, k2, false, w.rt, k2, dim, k2, k2));
+  hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(grid_for((long long)dim * k2)), dim3(256), 0,
+                     h->stream, w.rt, dim, k2, rot_y_dev);
+  hipLaunchKernelGGL(scale_to_f32_kernel, dim3(1), dim3(256), 0, h->stream, w.sig, 1.0, (long long)dim,
+                     e_dev);
+  TD_HIP(h, hipGetLastError());
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  if (info_host) { info_host[0] = sweeps[0]; info_host[1] = sweeps[1]; info_host[2] = sweeps[2]; }
+  return TD_OK;
+}
+
+}  // extern "C"

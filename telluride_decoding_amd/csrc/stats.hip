@@ -358,6 +358,14 @@ int td_stats_layout(const td_stats* s, int* k1, int* d, int64_t* frames) {
   return TD_OK;
 }
 
+// Used by eig.hip.
+int td_stats_dims(const td_stats* s, int* k1, int* k2, int64_t* frames) {
+  *k1 = s->k1;
+  *k2 = s->k2;
+  *frames = s->frames;
+  return TD_OK;
+}
+
 extern "C" {
 
 int td_stats_create(td_handle* h, int c1, int pre1, int post1, int c2, int pre2, int post2,

@@ -252,6 +252,22 @@ class LagStats(object):
                                        ctypes.byref(ptr)))
     return w, b, (lambda: int(ptr[0]))
 
+  def cca_solve(self, denom, regularization, dim, eps_eig=1e-12, handle=None):
+    """CCA dense stage on the device (td_cca_solve; reference cca.py:337-367): returns float32
+    device tensors (rot_x [k1, dim], rot_y [k2, dim], mean_x [1, k1], mean_y [1, k2], e [dim])
+    and the Jacobi sweep counts (eig xx, eig yy, svd)."""
+    h = handle or self.h
+    rot_x = h.empty((self.k1, dim), 'float32')
+    rot_y = h.empty((self.k2, dim), 'float32')
+    mean_x = h.empty((1, self.k1), 'float32')
+    mean_y = h.empty((1, self.k2), 'float32')
+    e = h.empty((dim,), 'float32')
+    info = (ctypes.c_int * 4)()
+    h.check(h.lib.td_cca_solve(h.ptr, self.ptr, float(denom), float(regularization),
+                               float(eps_eig), int(dim), _ptr(rot_x), _ptr(rot_y), _ptr(mean_x),
+                               _ptr(mean_y), _ptr(e), info))
+    return rot_x, rot_y, mean_x, mean_y, e, tuple(info[:3])
+
   def __del__(self):
     try:
       if getattr(self, 'ptr', None):
@@ -320,6 +336,34 @@ def general_solve(a, rhs, handle=None):
   x = rhs.clone().contiguous()
   h.check(h.lib.td_general_solve(h.ptr, _ptr(a), _ptr(x), int(a.shape[0]), int(x.shape[1])))
   return x
+
+
+def sym_eigh(a, handle=None):
+  """Eigen-decomposition of a symmetric float64 device matrix (td_sym_eigh): (vals [n]
+  unsorted, vecs [n, n] with the eigenvectors as columns, outer sweeps)."""
+  h = handle or default_handle()
+  a = a.contiguous()
+  n = int(a.shape[0])
+  vals = h.empty((n,), 'float64')
+  vecs = h.empty((n, n), 'float64')
+  sweeps = ctypes.c_int(0)
+  h.check(h.lib.td_sym_eigh(h.ptr, _ptr(a), n, _ptr(vals), _ptr(vecs), ctypes.byref(sweeps)))
+  return vals, vecs, int(sweeps.value)
+
+
+def jacobi_svd(t, dim, handle=None):
+  """The `dim` largest singular triplets of a float64 device matrix t [m, n] (td_jacobi_svd):
+  (u [dim, m], s [dim] descending, v [dim, n]) with the singular vectors as rows, sweeps."""
+  h = handle or default_handle()
+  t = t.contiguous()
+  m, n = int(t.shape[0]), int(t.shape[1])
+  u = h.empty((dim, m), 'float64')
+  sv = h.empty((dim,), 'float64')
+  v = h.empty((dim, n), 'float64')
+  sweeps = ctypes.c_int(0)
+  h.check(h.lib.td_jacobi_svd(h.ptr, _ptr(t), m, n, int(dim), _ptr(u), _ptr(sv), _ptr(v),
+                              ctypes.byref(sweeps)))
+  return u, sv, v, int(sweeps.value)
 
 
 def shrinkage_moment(x, file_offsets, pre, post, batch_rows, input_offset=0, rows_used=None,

@@ -1,0 +1,206 @@
+"""GPU parity tests of the CCA dense stage (row A4: td_cca_solve, td_sym_eigh,
+td_jacobi_svd) against NumPy/LAPACK in float64, the oracle restatement of
+cca.py:337-367 and the golden fixtures generated from the reference itself.
+"""
+import numpy as np
+import pytest
+
+from oracle import cca as o_cca
+from oracle import lag as o_lag
+from tests.conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+  from telluride_decoding_amd import device
+  return device
+
+
+def _check_eig(dev, a, tol=2e-13):
+  h = dev.default_handle()
+  n = a.shape[0]
+  vals, vecs, sweeps = dev.sym_eigh(h.to_device(a, np.float64))
+  vals, vecs = vals.cpu().numpy(), vecs.cpu().numpy()
+  scale = max(np.max(np.abs(a)), 1e-300)
+  # A V = V diag(vals), V orthogonal, same spectrum as LAPACK's symmetric solver
+  assert np.max(np.abs(a @ vecs - vecs * vals)) < tol * n * scale
+  assert np.max(np.abs(vecs.T @ vecs - np.eye(n))) < tol * n
+  np.testing.assert_allclose(np.sort(vals), np.linalg.eigvalsh(a), rtol=0, atol=tol * n * scale)
+  return vals, vecs, sweeps
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 31, 64, 65, 130, 300, 577])
+def test_sym_eigh_matches_lapack(dev, n):
+  """Direct LDS Jacobi (n <= 64) and block Jacobi with MFMA updates (n > 64)."""
+  rng = np.random.default_rng(n)
+  b = rng.standard_normal((n, n + 3))
+  _check_eig(dev, b @ b.T / n + 0.01 * np.eye(n))            # positive definite (a covariance)
+  s = rng.standard_normal((n, n))
+  _check_eig(dev, (s + s.T) * 3.0)                           # indefinite
+  if n > 4:
+    low = rng.standard_normal((n, n // 2))
+    vals, _, _ = _check_eig(dev, low @ low.T)                # rank deficient: n - n//2 zeros
+    assert np.sum(np.abs(vals) < 1e-10 * np.max(vals)) == n - n // 2
+
+
+def test_sym_eigh_keeps_small_eigenvalues_relatively_accurate(dev):
+  """The whitening K = V lambda^-1/2 V^T is dominated by the small eigenvalues: on a graded
+  positive definite matrix (condition 1e14, 1e6 after diagonal scaling) they keep their
+  RELATIVE accuracy (the rotation criterion is relative to sqrt(a_pp a_qq)), so K A K = I
+  holds to 1e-7 where an absolutely accurate solver leaves errors of order one."""
+  rng = np.random.default_rng(3)
+  n = 96
+  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  a = (q * np.logspace(0, -6, n)) @ q.T
+  d = np.logspace(0, -4, n)
+  a = d[:, None] * a * d[None, :]
+  a = (a + a.T) / 2
+  h = dev.default_handle()
+  vals, vecs, _ = dev.sym_eigh(h.to_device(a, np.float64))
+  vals, v = vals.cpu().numpy(), vecs.cpu().numpy()
+  assert np.all(vals > 0)
+  kmat = (v / np.sqrt(vals)) @ v.T
+  assert np.max(np.abs(kmat @ a @ kmat - np.eye(n))) < 1e-7
+
+
+@pytest.mark.parametrize('m,n,dim', [(64, 8, 8), (8, 64, 5), (300, 31, 31), (5, 5, 5), (1, 3, 1),
+                                     (3, 1, 1), (700, 130, 10), (40, 10, 3), (9, 9, 2)])
+def test_jacobi_svd_matches_lapack(dev, m, n, dim):
+  rng = np.random.default_rng(m * 1000 + n)
+  t = rng.standard_normal((m, n)) * np.logspace(0, -6, n)[None, :]
+  h = dev.default_handle()
+  u, s, v, _ = dev.jacobi_svd(h.to_device(t, np.float64), dim)
+  u, s, v = u.cpu().numpy(), s.cpu().numpy(), v.cpu().numpy()
+  uu, ss, vv = np.linalg.svd(t, full_matrices=False)
+  np.testing.assert_allclose(s, ss[:dim], rtol=1e-11, atol=1e-14 * ss[0])
+  for i in range(dim):
+    sign = np.sign(u[i] @ uu[:, i])
+    assert abs(abs(u[i] @ uu[:, i]) - 1) < 1e-9
+    assert abs(sign * (v[i] @ vv[i]) - 1) < 1e-9       # the pair shares its sign
+  # T v_i = s_i u_i
+  np.testing.assert_allclose(t @ v.T, u.T * s, atol=1e-12 * ss[0] * max(m, n))
+
+
+def _aligned(a, b, ra, rb):
+  """Joint per-component sign of (rot_x[:, i], rot_y[:, i]) fixed against the reference."""
+  sign = np.sign(np.sum(a * ra, axis=0) + np.sum(b * rb, axis=0))
+  sign[sign == 0] = 1
+  return a * sign, b * sign
+
+
+@pytest.mark.parametrize('name', ['t42', 'r10', 'r0'])
+def test_cca_solve_matches_reference_golden(dev, name):
+  """td_cca_solve against the reference's own output (reg = 0.1 / 10 / 0), ALL components."""
+  from telluride_decoding_amd import brain_data, cca
+  g = golden('g4_cca')
+  dim, batch = (int(v) for v in g[name + '_cfg'])
+  bd = brain_data.TestBrainData('input_1', 'input_2', 100.0, final_batch_size=batch)
+  bd.preserve_test_data(g['x1'], np.ones((g['x1'].shape[0], 1), np.float32), g['x2'])
+  ds = bd.create_dataset('program_test', temporal_context=False)
+  a, b, mx, my, e = cca.calculate_cca_parameters_from_dataset(
+      ds, dim, regularization=float(g[name + '_reg']), mini_batch_count=1000)
+  assert a.dtype == np.float32 and a.shape == g[name + '_rot_x'].shape
+  assert b.shape == g[name + '_rot_y'].shape and mx.shape == (1, 3) and my.shape == (1, 5)
+  np.testing.assert_allclose(e, g[name + '_e'], rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(mx, g[name + '_mean_x'], atol=1e-6)
+  np.testing.assert_allclose(my, g[name + '_mean_y'], atol=1e-6)
+  a, b = _aligned(a, b, g[name + '_rot_x'], g[name + '_rot_y'])
+  # the reference computes in float32 (eig / svd of float32 matrices): its own rounding is
+  # ~1e-6 / gap of the singular values
+  scale_a, scale_b = np.max(np.abs(g[name + '_rot_x'])), np.max(np.abs(g[name + '_rot_y']))
+  np.testing.assert_allclose(a, g[name + '_rot_x'], atol=3e-4 * scale_a)
+  np.testing.assert_allclose(b, g[name + '_rot_y'], atol=3e-4 * scale_b)
+  # ... and against the same algorithm in float64 (the oracle), tightly
+  batches = [({'input_1': g['x1'][s:s + batch].astype(np.float64),
+               'input_2': g['x2'][s:s + batch].astype(np.float64)}, None)
+             for s in range(0, g['x1'].shape[0] - batch + 1, batch)]
+  ra, rb, _, _, re = o_cca.cca_parameters_from_batches(batches, dim,
+                                                       regularization=float(g[name + '_reg']))
+  np.testing.assert_allclose(e, re, rtol=2e-6, atol=1e-7)
+  a, b = _aligned(a, b, ra, rb)
+  np.testing.assert_allclose(a, ra, atol=2e-6 * np.max(np.abs(ra)) / max(re.min(), 1e-2))
+  np.testing.assert_allclose(b, rb, atol=2e-6 * np.max(np.abs(rb)) / max(re.min(), 1e-2))
+
+
+def test_cca_solve_lagged_golden_all_components(dev):
+  from telluride_decoding_amd import brain_data, cca
+  g = golden('g4_cca')
+  pre, post, pre2, post2, batch, dim = (int(v) for v in g['lag_cfg'])
+  bd = brain_data.TestBrainData('eeg', 'env', 100.0, pre_context=pre, post_context=post,
+                                in2_fields='env', in2_pre_context=pre2, in2_post_context=post2,
+                                final_batch_size=batch)
+  for i in range(2):
+    bd.add_file(g['lag_eeg%d' % i], g['lag_env%d' % i][:, 0:1], g['lag_env%d' % i])
+  ds = bd.create_dataset('train')
+  a, b, mx, my, e = cca.calculate_cca_parameters_from_dataset(ds, dim, regularization=0.1,
+                                                              mini_batch_count=0)
+  np.testing.assert_allclose(e, g['lag_e'], rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(mx, g['lag_mean_x'], atol=1e-5)
+  np.testing.assert_allclose(my, g['lag_mean_y'], atol=1e-5)
+  a, b = _aligned(a, b, g['lag_rot_x'], g['lag_rot_y'])
+  np.testing.assert_allclose(a, g['lag_rot_x'], atol=2e-3 * np.max(np.abs(g['lag_rot_x'])))
+  np.testing.assert_allclose(b, g['lag_rot_y'], atol=2e-3 * np.max(np.abs(g['lag_rot_y'])))
+  # float64 oracle on the materialised lag matrices
+  files = [(g['lag_eeg%d' % i].astype(np.float64), g['lag_env%d' % i].astype(np.float64),
+            g['lag_env%d' % i][:, 0:1].astype(np.float64), np.zeros((3000, 1))) for i in range(2)]
+  ra, rb, _, _, re = o_cca.cca_parameters_from_batches(
+      o_lag.minibatches(files, batch, pre=pre, post=post, pre2=pre2, post2=post2), dim,
+      regularization=0.1, mini_batch_count=0)
+  np.testing.assert_allclose(e, re, rtol=3e-6)
+  a, b = _aligned(a, b, ra, rb)
+  np.testing.assert_allclose(a, ra, atol=1e-5 * np.max(np.abs(ra)))
+  np.testing.assert_allclose(b, rb, atol=1e-5 * np.max(np.abs(rb)))
+
+
+def _numpy_dense_stage(cxx, cyy, cxy, dim, eps=1e-12):
+  """cca.py:345-367 with the symmetric LAPACK solver, float64."""
+  def whiten(c):
+    lam, v = np.linalg.eigh(c)
+    keep = lam > eps
+    return (v[:, keep] / np.sqrt(lam[keep])) @ v[:, keep].T
+  k11, k22 = whiten(cxx), whiten(cyy)
+  u, e, vt = np.linalg.svd(k11 @ cxy @ k22, full_matrices=False)
+  return k11 @ u[:, :dim], k22 @ vt.T[:, :dim], e[:dim]
+
+
+@pytest.mark.parametrize('c1,l1,c2,l2,n,reg', [
+    (64, 1, 8, 1, 20000, 0.1),        # C3 shape
+    (23, 9, 1, 31, 6000, 0.1),        # block Jacobi (207 x 207), narrow second view
+    (69, 37, 1, 31, 6000, 0.1),       # the codelab shape: K1 = 2553, K2 = 31
+    (6, 3, 40, 3, 3000, 0.0),         # K1 < K2 (rows of T are orthogonalised), reg = 0
+])
+def test_cca_solve_matches_float64_lapack(dev, c1, l1, c2, l2, n, reg):
+  """Moments -> rotations on the device vs the same dense stage through LAPACK's symmetric
+  solvers, from the device's own float64 moment matrices (isolates td_cca_solve)."""
+  rng = np.random.default_rng(c1 * 7 + c2)
+  h = dev.default_handle()
+  src = rng.standard_normal((n, 4)).astype(np.float32)
+  x = (src @ rng.standard_normal((4, c1)) + rng.standard_normal((n, c1))).astype(np.float32)
+  x2 = (src @ rng.standard_normal((4, c2)) + 0.5 * rng.standard_normal((n, c2))).astype(np.float32)
+  if reg == 0.0:
+    x[:, -1] = x[:, 0]                 # exactly collinear: the eigenvalue filter must act
+  st = dev.LagStats(c1, 0, l1 - 1, c2, 0, l2 - 1)
+  st.accumulate(h.to_device(x), h.to_device(x2), None, [0, n])
+  k1, k2 = c1 * l1, c2 * l2
+  dim = min(5, k1, k2)
+  denom = n - 1
+  ra, rb, mx, my, e, sweeps = st.cca_solve(denom, reg, dim)
+  m = st.moments(want_xtx=True, want_xty=False, want_cca=True)
+  xtx = m['xtx'].cpu().numpy()
+  sx = xtx[k1:, :k1] / n
+  sy = m['sum_x2'].cpu().numpy().reshape(1, -1) / n
+  cxx = xtx[:k1, :k1] / denom - sx.T @ sx + reg * np.eye(k1)
+  cyy = m['x2tx2'].cpu().numpy() / denom - sy.T @ sy + reg * np.eye(k2)
+  cxy = m['xtx2'].cpu().numpy() / denom - sx.T @ sy
+  wa, wb, we = _numpy_dense_stage(cxx, cyy, cxy, dim)
+  print('K1 %d K2 %d: Jacobi sweeps (eig xx, eig yy, svd) = %s' % (k1, k2, sweeps))
+  np.testing.assert_allclose(e.cpu().numpy(), we, rtol=2e-6, atol=1e-7)
+  a, b = _aligned(ra.cpu().numpy().astype(np.float64), rb.cpu().numpy().astype(np.float64), wa, wb)
+  gap = np.min(np.abs(np.diff(np.concatenate((we, [0.0]))))) if dim > 1 else 1.0
+  tol = 2e-6 / max(gap, 1e-3)          # float32 outputs; vectors of close singular values mix
+  np.testing.assert_allclose(a, wa, atol=tol * np.max(np.abs(wa)))
+  np.testing.assert_allclose(b, wb, atol=tol * np.max(np.abs(wb)))
+  np.testing.assert_allclose(mx.cpu().numpy(), sx, atol=1e-6)
+  np.testing.assert_allclose(my.cpu().numpy(), sy, atol=1e-6)
