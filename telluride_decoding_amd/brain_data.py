@@ -169,6 +169,44 @@ class Dataset(object):
       yield ({'input_1': _t(xs[s]), 'input_2': _t(x2b), 'attended_speaker': _t(atts[s])},
              _t(yb))
 
+  def resolved(self):
+    """The dataset the device fast paths work on.  Without `mixup_batch` that is the dataset
+    itself.  With it (the null-hypothesis baseline of brain_data.py:376-382: input_2 and the
+    output are shuffled, independently, inside every minibatch of the final stream) the
+    shuffles are applied once on the host -- same seeded permutations as iteration -- and
+    returned as a plain dataset: input_1 keeps its raw recordings and context, input_2 is
+    materialised WITH its context (the shuffle acts on lagged rows) as a context-free stream,
+    and the permuted rows sit where the offset / zip / drop-remainder conventions of the
+    kernels expect them."""
+    if not self.mixup_batch:
+      return self
+    if getattr(self, '_resolved', None) is not None:
+      return self._resolved
+    off = self.input_offset
+    skip = -off if off < 0 else 0                 # leading rows of input_2 / output dropped
+    z = self.zipped_lengths()
+    x2_parts, y_parts = [], []
+    for (x, x2, y, a), n in zip(self.files, z):
+      x2_parts.append(lag_view(x2[skip:], self.pre2, self.post2)[:n])
+      y_parts.append(y[skip:skip + n])
+    x2s, ys = np.concatenate(x2_parts), np.concatenate(y_parts)
+    rng = np.random.default_rng(self.mixup_seed)
+    for b in range(self.num_batches()):
+      s = slice(b * self.batch_size, (b + 1) * self.batch_size)
+      x2s[s] = x2s[s][rng.permutation(self.batch_size)]
+      ys[s] = ys[s][rng.permutation(self.batch_size)]
+    files, pos = [], 0
+    for (x, x2, y, a), n in zip(self.files, z):
+      x2n = np.zeros((x2.shape[0], x2s.shape[1]), x2s.dtype)
+      yn = np.zeros_like(y)
+      x2n[skip:skip + n] = x2s[pos:pos + n]
+      yn[skip:skip + n] = ys[pos:pos + n]
+      pos += n
+      files.append((x, x2n, yn, a))
+    self._resolved = Dataset(files, self.batch_size, self.pre, self.post, 0, 0, off,
+                             mixup_batch=False, max_batches=self.max_batches)
+    return self._resolved
+
   # -- device fast path --------------------------------------------------------
   def device_arrays(self, handle):
     """(x, x2, y, attention) device tensors of the concatenated files + offsets."""
@@ -267,7 +305,15 @@ class TestBrainData(BrainData):
     if not getattr(self, '_files', None):
       raise ValueError('Must call preserve_test_data before create_dataset.')
     ctx = temporal_context
-    return Dataset(self._files, self.final_batch_size,
+    files = self._files
+    if ctx and (self.in1_pre_context or self.in1_post_context or self.in2_pre_context or
+                self.in2_post_context or self.input_offset):
+      # brain_data.py:487-499: context (and the input_offset shift) is added per INITIAL batch
+      # of `initial_batch_size` frames, so a longer recording behaves like several files
+      step = int(self.initial_batch_size)
+      files = [tuple(a[s:s + step] for a in f) for f in files
+               for s in range(0, max(f[0].shape[0], 1), step)]
+    return Dataset(files, self.final_batch_size,
                    self.in1_pre_context if ctx else 0, self.in1_post_context if ctx else 0,
                    self.in2_pre_context if ctx else 0, self.in2_post_context if ctx else 0,
                    self.input_offset if ctx else 0, mixup_batch=mixup_batch)

@@ -41,15 +41,15 @@ def pearson_correlation(x, y):
   if xd.shape[-1] != yd.shape[-1]:
     raise AssertionError('x (%s) and y (%s) do not have the same final dimensionality' %
                          (tuple(xd.shape), tuple(yd.shape)))
-  if xd.shape[1] > 16:
-    raise ValueError('pearson_correlation supports up to 16 columns')
   rows = int(xd.shape[0])
   sums = device.window_sums(xd, yd, [0, rows], rows, rows, handle=h)
   r = device.window_scores(sums, rows, mode=1, handle=h).cpu().numpy()[0]
   s = sums.cpu().numpy()[0]
-  var_a = s[:, 2] - s[:, 0] ** 2 / rows
-  var_b = s[:, 3] - s[:, 1] ** 2 / rows
-  if np.prod(var_a) <= 0 or np.prod(var_b) <= 0:
+  # the zero rule as the kernel applies it (a constant column leaves a rounding residue of
+  # either sign in the raw float64 sums: within 32 eps of the sum of squares counts as zero)
+  tiny = 32 * np.finfo(np.float64).eps
+  if (np.any(s[:, 2] - s[:, 0] ** 2 / rows <= tiny * s[:, 2]) or
+      np.any(s[:, 3] - s[:, 1] ** 2 / rows <= tiny * s[:, 3])):
     return np.zeros((rows, xd.shape[1]), np.float32)
   return r.astype(np.float32 if str(xd.dtype) == 'torch.float32' else np.float64)
 
@@ -65,6 +65,7 @@ def pearson_correlation_second(x, y):
 def _dataset_stats(dataset, want_y=True, want_x2=False, handle=None):
   """LagStats of a Dataset via the raw-array fast path."""
   h = handle or device.default_handle()
+  dataset = dataset.resolved()       # mixup_batch: the shuffled streams (brain_data.py:376-382)
   x, x2, y, offs = dataset.device_arrays(h)
   st = device.LagStats(dataset.c1, dataset.pre, dataset.post,
                        dataset.c2 if want_x2 else 0, dataset.pre2, dataset.post2,
@@ -72,6 +73,25 @@ def _dataset_stats(dataset, want_y=True, want_x2=False, handle=None):
   st.accumulate(x, x2 if want_x2 else None, y if want_y else None, offs,
                 input_offset=dataset.input_offset, rows_used=dataset.rows_used())
   return st
+
+
+def zipped_rows(dataset, h, output, per_frame):
+  """The rows of the final (zipped, drop-remainder) stream of a Dataset, concatenated over
+  its files, as contiguous device tensors: `output` = the dataset's output tensor (its rows
+  are shifted by a negative input_offset, brain_data.py:466-475), `per_frame` = a tensor whose
+  row file_offsets[f] + t already is frame t of file f (predictions, transforms).  Either
+  may be None."""
+  import torch
+  offs = dataset.device_arrays(h)[3]
+  used = dataset.rows_used()
+  dy = max(-dataset.input_offset, 0)
+  cat = lambda parts: torch.cat(parts).contiguous() if parts else None
+  y_all = p_all = None
+  if output is not None:
+    y_all = cat([output[offs[i] + dy:offs[i] + dy + u] for i, u in enumerate(used)])
+  if per_frame is not None:
+    p_all = cat([per_frame[offs[i]:offs[i] + u] for i, u in enumerate(used)])
+  return y_all, p_all
 
 
 def _iterable_stats(batches, key2=None, handle=None, keep=None):
@@ -142,52 +162,50 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
     w, b = st.ridge_solve([lamb])
     w_np, b_np = w.cpu().numpy()[0], b.cpu().numpy()
     m = st.moments()
-    cov_x = (m['xtx'] / frames)
-    cov_x.diagonal().add_(lamb)
-    return (w_np, b_np.reshape(1, -1), cov_x.cpu().numpy().astype(np.float32),
-            (m['xty'] / frames).cpu().numpy().astype(np.float32), lamb)
-  # Remaining branches share the device moments and the generic SPD solve.
-  import ctypes
+    cov_x = m['xtx'].cpu().numpy() / frames
+    cov_x[np.diag_indices(k + 1)] += lamb
+    return (w_np, b_np.reshape(1, -1), cov_x.astype(np.float32),
+            (m['xty'].cpu().numpy() / frames).astype(np.float32), lamb)
+  # Remaining (rare) branches: the dense float64 moments come from the device, the O(n^2)
+  # shrinkage algebra of brain_model.py:447-476 is host NumPy, the solve is td_spd_solve /
+  # td_general_solve on the device.
   m = st.moments()
   n = k + 1 if use_offset else k
-  xtx = m['xtx'][:n, :n].contiguous()
-  xty = m['xty'][:n].contiguous()
+  xtx_full = m['xtx'].cpu().numpy()
+  xtx = np.ascontiguousarray(xtx_full[:n, :n])
+  xty = np.ascontiguousarray(m['xty'].cpu().numpy()[:n])
   cov_x = xtx / frames
   cov_xy = xty / frames
   if use_ridge:
-    cov_x.diagonal().add_(lamb)
+    cov_x[np.diag_indices(n)] += lamb
     shrinkage = lamb
   else:
-    # Blankertz shrinkage, brain_model.py:449-476 (mean_x is the column-sum row).
-    sum_x = m['xtx'][k, :n] if use_offset else None
-    if sum_x is None:
-      raise NotImplementedError('shrinkage without an offset column is not supported')
-    mean_x = (sum_x / frames).reshape(1, -1)
-    cov_x_zc = xtx - mean_x.t() @ mean_x          # sum minus mean outer (sic, :450)
-    mu = float(cov_x_zc.diagonal().sum() / n)
+    # Blankertz shrinkage, brain_model.py:449-476.  sum_x is the column-sum row of the moments
+    # (with use_offset it includes the ones column's own sum, the frame count).
+    mean_x = (xtx_full[k:k + 1, :n] / frames)
+    cov_x_zc = xtx - mean_x.T @ mean_x            # sum minus mean outer (sic, :450)
+    mu = float(np.trace(cov_x_zc) / n)
     if ledoit_wolf:                               # :457-465
-      delta_ = cov_x_zc.clone()
-      delta_.diagonal().sub_(mu)
+      delta_ = cov_x_zc.copy()
+      delta_[np.diag_indices(n)] -= mu
       delta = float((delta_ ** 2).sum()) / n
       beta_ = 1. / (n * frames) * (x2_moment / frames - float((cov_x_zc ** 2).sum()))
       shrinkage = min(beta_, delta) / delta
     else:
       shrinkage = lamb
     cov_x = (1 - shrinkage) * cov_x
-    cov_x.diagonal().add_(shrinkage * mu)
-  a = cov_x.clone().contiguous()
-  rhs = cov_xy.clone().contiguous()
+    cov_x[np.diag_indices(n)] += shrinkage * mu
+  a = h.to_device(cov_x, np.float64)
+  rhs = h.to_device(cov_xy, np.float64)
   if ledoit_wolf:
     # a negative estimated shrinkage (the reference's golden case has one) makes the matrix
     # indefinite: LU like np.linalg.solve (:477), not the ridge path's Cholesky
-    h.check(h.lib.td_general_solve(h.ptr, ctypes.c_void_p(a.data_ptr()),
-                                   ctypes.c_void_p(rhs.data_ptr()), n, int(rhs.shape[1])))
+    rhs = device.general_solve(a, rhs, handle=h)
   else:
-    h.check(h.lib.td_spd_solve(h.ptr, ctypes.c_void_p(a.data_ptr()),
-                               ctypes.c_void_p(rhs.data_ptr()), n, int(rhs.shape[1]), 1))
+    rhs = device.spd_solve(a, rhs, handle=h)
   sol = rhs.cpu().numpy().astype(np.float32)
-  cov_x_np = cov_x.cpu().numpy().astype(np.float32)
-  cov_xy_np = cov_xy.cpu().numpy().astype(np.float32)
+  cov_x_np = cov_x.astype(np.float32)
+  cov_xy_np = cov_xy.astype(np.float32)
   if use_offset:
     return sol[:-1], sol[-1:], cov_x_np, cov_xy_np, shrinkage
   return sol, np.zeros((1,)), cov_x_np, cov_xy_np, shrinkage
@@ -260,7 +278,7 @@ class BrainModelLinearRegression(object):
     """Predictions for every frame of every file, on the device: [rows, D]."""
     h = handle or device.default_handle()
     w, b = self._device_weights(h)
-    x, _, _, offs = dataset.device_arrays(h)
+    x, _, _, offs = dataset.device_arrays(h)       # (input_1 is never shuffled by mixup_batch)
     # row offs[f] + t of the result is frame t of file f's zipped streams
     return device.predict_fir(x, offs, w, b, dataset.pre, dataset.post, handle=h,
                               input_offset=dataset.input_offset)
@@ -278,18 +296,13 @@ class BrainModelLinearRegression(object):
     if not _is_dataset(dataset):
       raise TypeError('BrainModel.evaluate must be called with tf.data.Dataset object.')
     h = device.default_handle()
+    dataset = dataset.resolved()     # mixup_batch: evaluate against the shuffled output
     pred = self.predict_device(dataset, handle=h)
     _, _, y, offs = dataset.device_arrays(h)
-    used = dataset.rows_used()
-    dy = max(-dataset.input_offset, 0)
     bsz = dataset.batch_size
     # Minibatches run across file boundaries in the reference; gather the zipped
     # stream once (device copies), then window it with hop = width = batch.
-    import torch
-    p_parts = [pred[offs[i]:offs[i] + u] for i, u in enumerate(used)]
-    y_parts = [y[offs[i] + dy:offs[i] + dy + u] for i, u in enumerate(used)]
-    p_all = torch.cat(p_parts).contiguous()
-    y_all = torch.cat(y_parts).contiguous()
+    y_all, p_all = zipped_rows(dataset, h, y, pred)
     rows = int(p_all.shape[0])
     if rows == 0:
       return {'loss': float('nan'), 'pearson_correlation_first': float('nan')}

@@ -143,6 +143,7 @@ class BrainModelCCA(object):
   def transform_device(self, dataset, handle=None):
     h = handle or device.default_handle()
     m1, r1, m2, r2 = self._device_params(h)
+    dataset = dataset.resolved()     # mixup_batch: input_2 shuffled inside every minibatch
     x, x2, _, offs = dataset.device_arrays(h)
     return device.cca_transform(x, x2, offs, m1, r1, m2, r2, dataset.pre, dataset.post,
                                 dataset.pre2, dataset.post2, handle=h,
@@ -160,6 +161,7 @@ class BrainModelCCA(object):
     del kwargs
     import torch
     h = device.default_handle()
+    dataset = dataset.resolved()
     out = self.transform_device(dataset, handle=h)
     _, _, _, offs = dataset.device_arrays(h)
     used = dataset.rows_used()

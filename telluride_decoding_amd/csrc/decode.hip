@@ -680,10 +680,20 @@ __global__ __launch_bounds__(kThreads) void window_means_kernel(
   if (tid == 0) out[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)width;
 }
 
+// Per-column statistics live in a device table (td_table_upload: cached by content), so the
+// number of columns is unlimited (the reference has no limit either, brain_model.py:34-79).
 struct ScoreParams {
-  double mean_a[16], mean_b[16], power[16], lda_w[16];
+  const double* mean_a; const double* mean_b; const double* power; const double* lda_w;  // [cols]
   double lda_slope, lda_intercept;
 };
+
+// "Constant column" test of the Pearson zero rule (brain_model.py:72-79: all zeros if the
+// centred sum of squares of ANY column is <= 0).  The reference centres in float32, where a
+// constant column gives exactly 0; from raw float64 sums the same column leaves a rounding
+// residue of either sign, so anything within 32 eps of the raw sum of squares counts as zero.
+__device__ __forceinline__ bool no_variance(double var, double sum_sq) {
+  return var <= 32.0 * 2.220446049250313e-16 * sum_sq;
+}
 
 // mode 0: mean over the window of (a-ma)(b-mb)/power per column, reduced across
 // columns; mode 1: per-window Pearson per column with the reference's "any
@@ -707,13 +717,12 @@ __global__ void window_scores_kernel(const double* __restrict__ sums, long long 
     }
     scores[w] = acc / (double)(c_hi - c_lo);
   } else {
-    double prod_a = 1.0, prod_b = 1.0;
+    bool zero = false;
     for (int c = 0; c < cols; ++c) {
       const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
-      prod_a *= s[c * 5 + 2] - sa * sa / n;
-      prod_b *= s[c * 5 + 3] - sb * sb / n;
+      zero = zero || no_variance(s[c * 5 + 2] - sa * sa / n, s[c * 5 + 2]) ||
+             no_variance(s[c * 5 + 3] - sb * sb / n, s[c * 5 + 3]);
     }
-    const bool zero = (prod_a <= 0.0) || (prod_b <= 0.0);
     for (int c = 0; c < cols; ++c) {
       const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
       const double va = s[c * 5 + 2] - sa * sa / n, vb = s[c * 5 + 3] - sb * sb / n;
@@ -988,14 +997,18 @@ void build_block_tables(const int64_t* trial_offsets, int num_trials, int width,
 int fill_score_params(td_handle* h, ScoreParams* sp, int cols, const double* mean_a,
                       const double* mean_b, const double* power, const double* lda_w,
                       double slope, double intercept) {
-  TD_REQUIRE(h, cols >= 1 && cols <= 16, "cols must be in [1, 16], not %d", cols);
-  memset(sp, 0, sizeof(*sp));
+  TD_REQUIRE(h, cols >= 1, "cols must be >= 1, not %d", cols);
+  std::vector<double> t((size_t)4 * cols);
   for (int c = 0; c < cols; ++c) {
-    sp->mean_a[c] = mean_a ? mean_a[c] : 0.0;
-    sp->mean_b[c] = mean_b ? mean_b[c] : 0.0;
-    sp->power[c] = power ? power[c] : 1.0;
-    sp->lda_w[c] = lda_w ? lda_w[c] : 0.0;
+    t[c] = mean_a ? mean_a[c] : 0.0;
+    t[cols + c] = mean_b ? mean_b[c] : 0.0;
+    t[2 * cols + c] = power ? power[c] : 1.0;
+    t[3 * cols + c] = lda_w ? lda_w[c] : 0.0;
   }
+  const void* dev = nullptr;
+  TD_TRY(td_table_upload(h, t.data(), sizeof(double) * t.size(), &dev));
+  const double* d = reinterpret_cast<const double*>(dev);
+  sp->mean_a = d; sp->mean_b = d + cols; sp->power = d + 2 * cols; sp->lda_w = d + 3 * cols;
   sp->lda_slope = slope;
   sp->lda_intercept = intercept;
   return TD_OK;
@@ -1384,8 +1397,9 @@ int td_window_scores(td_handle* h, const double* sums_dev, int64_t total_windows
   TD_REQUIRE(h, mode == 1 || (reduction >= 0 && reduction <= 2),
              "Unknown reduction technique: %d", reduction);
   TD_REQUIRE(h, mode == 1 || reduction != 1 || cols >= 2, "reduction 'second' needs >= 2 columns");
-  ScoreParams sp;
-  TD_TRY(fill_score_params(h, &sp, cols, mean_a_host, mean_b_host, power_host, nullptr, 1.0, 0.0));
+  ScoreParams sp = {nullptr, nullptr, nullptr, nullptr, 1.0, 0.0};
+  if (mode == 0)      // (the Pearson mode uses no per-column statistics)
+    TD_TRY(fill_score_params(h, &sp, cols, mean_a_host, mean_b_host, power_host, nullptr, 1.0, 0.0));
   if (total_windows <= 0) return TD_OK;
   hipLaunchKernelGGL(window_scores_kernel, dim3((unsigned)td_ceil_div(total_windows, 256)),
                      dim3(256), 0, h->stream, sums_dev, (long long)total_windows, cols, width, mode,

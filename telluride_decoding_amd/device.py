@@ -366,6 +366,16 @@ def jacobi_svd(t, dim, handle=None):
   return u, sv, v, int(sweeps.value)
 
 
+def spd_solve(a, rhs, handle=None):
+  """Solution of a x = rhs for a symmetric positive definite float64 device matrix a [n, n]
+  and rhs [n, nrhs] (td_spd_solve, blocked Cholesky); inputs untouched."""
+  h = handle or default_handle()
+  a = a.clone().contiguous()
+  x = rhs.clone().contiguous()
+  h.check(h.lib.td_spd_solve(h.ptr, _ptr(a), _ptr(x), int(a.shape[0]), int(x.shape[1]), 1))
+  return x
+
+
 def shrinkage_moment(x, file_offsets, pre, post, batch_rows, input_offset=0, rows_used=None,
                      handle=None):
   """np.sum(sum_x2tx2) of the reference's Ledoit-Wolf branch (brain_model.py:440-443) for the

@@ -180,29 +180,56 @@ class Decoder(object):
     out = device.frame_scores(xd, yd, 'all', mx, my, pw, handle=h)
     return out.cpu().numpy()
 
+  # -- whole-dataset decode ---------------------------------------------------------
+  def _decode_dataset_device(self, data, h):
+    """Subclass hook: (r1, r2, labels) of a brain_data.Dataset computed on the device in one
+    pass when the decoding model is one of this package's estimators; None otherwise."""
+    del data, h
+    return None
+
+  def _decode_dataset(self, data):
+    """The two decoded streams of a whole dataset as [frames, dims] float32 device tensors,
+    plus the attention labels (host).  The reference walks a dataset minibatch by minibatch
+    and decodes it again in every pass (four model passes in `train`); here every minibatch
+    goes through the model ONCE, and the correlator / scoring kernels then see the whole
+    stream in one launch.  None for a dataset without minibatches."""
+    h = device.default_handle()
+    fast = self._decode_dataset_device(data, h)
+    if fast is not None:
+      return fast
+    r1s, r2s, labels = [], [], []
+    for input_dict, output in data:
+      r1, r2 = self.decode_one(input_dict, output)
+      r1, r2 = np.asarray(r1), np.asarray(r2)
+      r1s.append(r1.reshape(r1.shape[0], -1))
+      r2s.append(r2.reshape(r2.shape[0], -1))
+      if 'attended_speaker' in input_dict:
+        labels.append(_host(input_dict['attended_speaker']))
+    if not r1s or sum(r.shape[0] for r in r1s) == 0:
+      return None
+    return (h.to_device(np.concatenate(r1s)), h.to_device(np.concatenate(r2s)),
+            np.concatenate(labels) if labels else None)
+
   # -- training (reference :330-400) ------------------------------------------
   def train(self, data0, data1, window_size=0):
+    """Correlation statistics over both datasets (class 0 = mixed-up / unattended first, then
+    class 1 = matched / attended), per-frame correlations with those statistics, LDA between
+    the two classes; returns d'."""
     for name, data in (('data0', data0), ('data1', data1)):
       if not isinstance(data, brain_data.Dataset) and not hasattr(data, '__iter__'):
         raise TypeError('Must feed training routine %s with a tf.data.Dataset not a %s.' %
                         (name, type(data)))
-    for data in (data0, data1):
-      for input_dict, output in data:
-        r1, r2 = self.decode_one(input_dict, output)
-        self.add_data_correlator(r1, r2)
-    stores = []
-    for data in (data0, data1):
-      store = result_store.NumpyStore()
-      for input_dict, output in data:
-        r1, r2 = self.decode_one(input_dict, output)
-        store.add_data(self.compute_correlation(r1, r2))
-      stores.append(store.all_data)
-    if stores[0] is None or stores[0].shape[0] == 0:
-      raise ValueError('No data for class 0')
-    if stores[1] is None or stores[1].shape[0] == 0:
-      raise ValueError('No data for class 1')
-    return self.compute_lda_model(average_data(stores[0], window_size),
-                                  average_data(stores[1], window_size))
+    decoded = [self._decode_dataset(data) for data in (data0, data1)]
+    for streams in decoded:
+      if streams is not None:
+        self.add_data_correlator(streams[0], streams[1])
+    correlations = [None if streams is None else self.compute_correlation(streams[0], streams[1])
+                    for streams in decoded]
+    for label, c in enumerate(correlations):
+      if c is None or c.shape[0] == 0:
+        raise ValueError('No data for class %d' % label)
+    return self.compute_lda_model(average_data(correlations[0], window_size),
+                                  average_data(correlations[1], window_size))
 
   def decode_one(self, input_dict, ground_truth):
     raise NotImplementedError('Must be implemented by a subclass.')
@@ -213,8 +240,8 @@ class Decoder(object):
     if self._reduction == 'lda':
       if self._lda is None or self._lda.coef_array is None:
         raise ValueError('Must compute the LDA model before reducing data.')
-      kw = dict(lda_w=np.real(self._lda.coef_array[:, 0]), lda_slope=self._lda._slope,
-                lda_intercept=self._lda._intercept)
+      kw = dict(lda_w=np.real(self._lda.coef_array[:, 0]), lda_slope=self._lda.slope,
+                lda_intercept=self._lda.intercept)
     return kw
 
   def infer_one(self, input_dict, output):
@@ -222,33 +249,41 @@ class Decoder(object):
     reduction 'all')."""
     r1, r2 = self.decode_one(input_dict, output)
     h = device.default_handle()
-    xd, yd = brain_model._as_2d_device(h, r1), brain_model._as_2d_device(h, r2)
-    cols = int(xd.shape[1])
+    return self._score_streams(brain_model._as_2d_device(h, r1), brain_model._as_2d_device(h, r2))
+
+  def _score_streams(self, r1, r2):
+    """Per-frame reduced score of two decoded streams (device tensors): host [frames] float64
+    ([frames, dims] for reduction 'all')."""
+    h = device.default_handle()
+    cols = int(r1.shape[1])
     if self._reduction == 'second' and cols < 2:
       raise IndexError('index 1 is out of bounds for axis 1 with size %d' % cols)
     mx, my, pw = self._stat_vectors(cols)
-    out = device.frame_scores(xd, yd, self._reduction, mx, my, pw, handle=h,
-                              **self._reduce_kwargs())
-    return out.cpu().numpy()
+    return device.frame_scores(r1, r2, self._reduction, mx, my, pw, handle=h,
+                               **self._reduce_kwargs()).cpu().numpy()
 
   def test_all(self, exp_data):
-    predictions = result_store.NumpyStore(name='test_all predictions')
-    labels = result_store.NumpyStore(name='test_all labels')
-    for input_dict, output in exp_data:
-      predictions.add_data(self.infer_one(input_dict, output))
-      labels.add_data(_host(input_dict['attended_speaker']))
-    return predictions.all_data, labels.all_data
+    """(scores [frames, 1 or dims], attention labels [frames, 1]) of a whole dataset
+    (reference :457-482), scored in one launch."""
+    streams = self._decode_dataset(exp_data)
+    if streams is None:
+      return None, None
+    scores = self._score_streams(streams[0], streams[1])
+    if scores.ndim == 1:
+      scores = scores.reshape(-1, 1)      # NumpyStore keeps vectors as columns
+    return scores, streams[2]
 
   def test_by_window(self, dataset, window_size):
-    """Generator of (scores, labels) windows, step = window_size // 2."""
+    """Generator of (scores, labels) windows of `window_size` frames every
+    window_size // 2 (reference :484-504; full windows only)."""
+    scores, labels = self.test_all(dataset)
+    if scores is None:
+      return
     storage = result_store.TwoResultStore(window_width=window_size,
                                           window_step=window_size // 2)
-    for input_dict, output in dataset:
-      storage.add_data(np.reshape(self.infer_one(input_dict, output), (-1, 1))
-                       if self._reduction != 'all' else self.infer_one(input_dict, output),
-                       _host(input_dict['attended_speaker']))
-      for r1, r2 in storage.next_window():
-        yield r1, r2
+    storage.add_data(scores, labels)
+    for r1, r2 in storage.next_window():
+      yield r1, r2
 
   # -- LDA (reference :506-550) -------------------------------------------------
   def compute_lda_model(self, d1, d2):
@@ -303,6 +338,18 @@ class LinearRegressionDecoder(Decoder):
     predictions = self._decoding_model(input_dict)
     return _host(ground_truth), _host(predictions)
 
+  def _decode_dataset_device(self, data, h):
+    model = self._decoding_model
+    if not (isinstance(data, brain_data.Dataset) and
+            isinstance(model, brain_model.BrainModelLinearRegression)):
+      return None
+    ds = data.resolved()
+    if ds.num_batches() == 0:
+      return None
+    pred = model.predict_device(ds, handle=h)
+    truth, pred = brain_model.zipped_rows(ds, h, ds.device_arrays(h)[2], pred)
+    return truth, pred, ds.attention_host()
+
 
 class CCADecoder(Decoder):
   """The two halves of the CCA model's output (reference :607-632)."""
@@ -312,6 +359,18 @@ class CCADecoder(Decoder):
     predictions = _host(self._decoding_model(input_dict))
     dims = predictions.shape[1] // 2
     return predictions[:, :dims], predictions[:, dims:]
+
+  def _decode_dataset_device(self, data, h):
+    model = self._decoding_model
+    if not (isinstance(data, brain_data.Dataset) and hasattr(model, 'transform_device')):
+      return None
+    ds = data.resolved()
+    if ds.num_batches() == 0:
+      return None
+    out = model.transform_device(ds, handle=h)
+    _, out = brain_model.zipped_rows(ds, h, None, out)
+    dims = int(out.shape[1]) // 2
+    return out[:, :dims].contiguous(), out[:, dims:].contiguous(), ds.attention_host()
 
 
 def create_decoder(model_tag, reduction='lda', model=None):

@@ -1,12 +1,22 @@
-"""(Scaled) linear discriminant analysis -- SURVEY.md 8f row F1 ("next").
+"""(Scaled) linear discriminant analysis -- SURVEY.md 8f row F1.
 
-Same interface as reference scaled_lda.py (`LinearDiscriminantAnalysis`
-:36-246, `ScaledLinearDiscriminantAnalysis` :249-355, `LdaParamsTuple` :30-32).
-The model is d x d with d <= ~10 (CCA dimensions), so the eigen problem is done
-with LAPACK on the host; the scatter matrices are float64 sums over the frames.
-Only the first output dimension is contractually stable: with two classes the
-between-class scatter has rank one and every further eigenvalue is rounding
-noise (the reference sorts them by that noise).
+Public surface of reference scaled_lda.py: `LdaParamsTuple` (:30-32),
+`LinearDiscriminantAnalysis` (:36-246) and `ScaledLinearDiscriminantAnalysis`
+(:249-355) with the same method names, argument meaning, return shapes and error
+messages, written from that behaviour:
+
+  * the discriminant axes are the eigenvectors of  S_w^-1 S_b  ordered by the
+    magnitude of their eigenvalues; the model keeps the first two (or the 1 x 1
+    identity for one-dimensional data);
+  * the scaled variant adds the affine map that sends the two class means, seen
+    along the first axis, to y0 and y1.
+
+The scatter matrices come from per-class moment sums (count, sum, x^T x) in
+float64 instead of a Python loop over the rows:
+  S_w = sum_c (X_c^T X_c - n_c m_c m_c^T),  S_b = sum_c n_c (m_c - m)(m_c - m)^T.
+The model is d x d with d <= ~10 (the CCA dimensions), so this is host NumPy.
+With two classes S_b has rank one: only the first axis is meaningful, every
+further eigenvalue is rounding noise (in the reference too).
 """
 import collections
 
@@ -16,18 +26,52 @@ LdaParamsTuple = collections.namedtuple(
     'LdaParamsTuple', ['w_real', 'w_imag', 'labels', 'mean_vectors', 'slope', 'intercept'])
 
 
+def _columns(data):
+  """Vectors become single-column matrices."""
+  data = np.asarray(data)
+  return data.reshape(-1, 1) if data.ndim == 1 else data
+
+
+def _class_moments(x, y):
+  """Sorted labels with (count, mean) per class, and the two scatter matrices."""
+  x = np.asarray(x, dtype=np.float64)
+  labels = sorted(set(np.asarray(y).tolist()))
+  grand_mean = x.mean(axis=0)
+  dims = x.shape[1]
+  within = np.zeros((dims, dims))
+  between = np.zeros((dims, dims))
+  means = []
+  for label in labels:
+    members = x[np.asarray(y) == label]
+    count = members.shape[0]
+    mean = members.sum(axis=0) / count
+    means.append(mean)
+    within += members.T @ members - count * np.outer(mean, mean)
+    shift = mean - grand_mean
+    between += count * np.outer(shift, shift)
+  return labels, means, within, between
+
+
+def _ranked_axes(within, between):
+  """(|eigenvalue|, eigenvector) of S_w^-1 S_b, largest magnitude first."""
+  values, vectors = np.linalg.eig(np.linalg.inv(within) @ between)
+  order = sorted(range(len(values)), key=lambda i: np.abs(values[i]), reverse=True)
+  return [np.abs(values[i]) for i in order], [vectors[:, i] for i in order]
+
+
 class LinearDiscriminantAnalysis(object):
+  """Two-axis LDA projection."""
 
   def __init__(self):
-    self._eigen_pairs = []
+    self._clear()
+
+  def _clear(self):
+    self._w = None                 # [dims, 2] (complex when np.linalg.eig says so) or [[1]]
     self._labels = []
     self._mean_vectors = []
-    self._w = None
+    self._strengths = []           # |eigenvalues|, descending
 
-  @property
-  def mean_vectors(self):
-    return self._mean_vectors
-
+  # ---- state -------------------------------------------------------------------
   @property
   def coef_array(self):
     return self._w
@@ -37,65 +81,60 @@ class LinearDiscriminantAnalysis(object):
     return self._labels
 
   @property
+  def mean_vectors(self):
+    return self._mean_vectors
+
+  def _export(self, slope=None, intercept=None):
+    w = self._w
+    return LdaParamsTuple(None if w is None else np.real(w), None if w is None else np.imag(w),
+                          self._labels, self._mean_vectors, slope, intercept)
+
+  def _import(self, values):
+    if values.w_real is None:
+      self._w = None
+    else:
+      self._w = np.asarray(values.w_real) + 1j * np.asarray(values.w_imag)
+    self._labels = np.asarray(values.labels)
+    self._mean_vectors = np.asarray(values.mean_vectors)
+
+  @property
   def model_parameters(self):
-    return LdaParamsTuple(np.real(self._w), np.imag(self._w), self._labels,
-                          self._mean_vectors, None, None)
+    return self._export()
 
   @model_parameters.setter
   def model_parameters(self, values):
-    self._set_parameters(values)
-
-  def _set_parameters(self, values):
-    if values.w_real is not None:
-      self._w = np.array(values.w_real) + 1j * np.array(values.w_imag)
-    else:
-      self._w = None
-    self._labels = np.array(values.labels)
-    self._mean_vectors = np.array(values.mean_vectors)
+    self._import(values)
 
   @classmethod
   def from_fitted_data(cls, x, y):
-    obj = cls()
-    obj.fit(x, y)
-    return obj
+    model = cls()
+    model.fit(x, y)
+    return model
 
   def expand_dims(self, data):
-    if data.ndim == 1:
-      data = np.reshape(data, (-1, 1))
-    return data
+    return _columns(data)
 
+  # ---- estimation ------------------------------------------------------------------
   def fit(self, x, y):
-    x = self.expand_dims(np.asarray(x))
-    y = np.asarray(y)
-    self._labels = sorted(set(y))
-    self._mean_vectors = [np.mean(x[y == label], axis=0) for label in self._labels]
-    d = x.shape[1]
-    scatter_within = np.zeros((d, d))
-    scatter_between = np.zeros((d, d))
-    overall = np.mean(x, axis=0).reshape(d, 1)
-    for label, mean in zip(self._labels, self._mean_vectors):
-      rows = x[y == label]
-      centred = rows - mean
-      scatter_within += centred.T @ centred        # scaled_lda.py:141-148
-      dm = mean.reshape(d, 1) - overall
-      scatter_between += rows.shape[0] * dm @ dm.T  # :165-173
-    vals, vecs = np.linalg.eig(np.linalg.inv(scatter_within).dot(scatter_between))
-    pairs = [(np.abs(vals[i]), vecs[:, i]) for i in range(len(vals))]
-    self._eigen_pairs = sorted(pairs, key=lambda k: k[0], reverse=True)
-    if len(self._eigen_pairs) > 1:
-      self._w = np.hstack((self._eigen_pairs[0][1].reshape(d, 1),
-                           self._eigen_pairs[1][1].reshape(d, 1)))
+    x = _columns(x)
+    self._labels, self._mean_vectors, within, between = _class_moments(x, y)
+    self._strengths, axes = _ranked_axes(within, between)
+    if len(axes) < 2:
+      self._w = np.ones((1, 1))
     else:
-      self._w = np.array([[1, ], ])
+      self._w = np.stack(axes[:2], axis=1)
 
-  def transform(self, x):
+  def _project(self, x):
     if self._w is None:
       raise ValueError('Must fit the model before transforming.')
-    x = self.expand_dims(np.asarray(x))
-    if np.ndim(x) != 2 or self._w.shape[0] != x.shape[1]:
+    x = _columns(x)
+    if x.ndim != 2 or x.shape[1] != self._w.shape[0]:
       raise TypeError('Inconsistent training and transform sizes. %s vs %s' %
                       (x.shape, self._w.shape))
-    return np.real(x.dot(self._w))
+    return np.real(x @ self._w)
+
+  def transform(self, x):
+    return self._project(x)
 
   def fit_transform(self, x, y):
     self.fit(x, y)
@@ -104,57 +143,59 @@ class LinearDiscriminantAnalysis(object):
   def explained_variance_ratio(self):
     if self._w is None:
       raise ValueError('Must fit the model before transforming.')
-    vals = np.array([v for v, _ in self._eigen_pairs])
-    return vals / np.sum(vals)
+    strengths = np.asarray(self._strengths)
+    return strengths / strengths.sum()
 
 
 class ScaledLinearDiscriminantAnalysis(LinearDiscriminantAnalysis):
-  """LDA whose first axis maps the two class means to 0 and 1."""
+  """LDA followed by the affine map that puts the class means at y0 and y1."""
 
   def __init__(self):
-    self._slope = 1
-    self._intercept = 0
     super(ScaledLinearDiscriminantAnalysis, self).__init__()
+    self._slope, self._intercept = 1, 0
+
+  @property
+  def slope(self):
+    return self._slope
+
+  @property
+  def intercept(self):
+    return self._intercept
 
   @property
   def model_parameters(self):
-    return LdaParamsTuple(np.real(self._w), np.imag(self._w), self._labels,
-                          self._mean_vectors, self._slope, self._intercept)
+    return self._export(self._slope, self._intercept)
 
   @model_parameters.setter
   def model_parameters(self, values):
-    self._set_parameters(values)
-
-  def _set_parameters(self, values):
-    values = LdaParamsTuple(*values)
-    super(ScaledLinearDiscriminantAnalysis, self)._set_parameters(values)
-    self._slope = values.slope
-    self._intercept = values.intercept
+    values = LdaParamsTuple(*values)          # also accepts the JSON round trip's plain list
+    self._import(values)
+    self._slope, self._intercept = values.slope, values.intercept
 
   def fit(self, x, y, y0=0, y1=1):
-    x = self.expand_dims(np.asarray(x))
     super(ScaledLinearDiscriminantAnalysis, self).fit(x, y)
-    if len(self.labels) != 2:
+    if len(self._labels) != 2:
       raise ValueError('Scaled LDA can only be done on two-class data.')
-    # The class means go through the CURRENT scaled transform (slope 1,
-    # intercept 0 on a fresh object), as in the reference (:315-316).
-    x0 = self.transform(np.reshape(self.mean_vectors[0], (1, -1)))[0, 0]
-    x1 = self.transform(np.reshape(self.mean_vectors[1], (1, -1)))[0, 0]
-    if x0 == x1:
-      raise ValueError('X0 and X1 in Scaled LDA are identical (%g and %g)' % (x0, x1))
-    self._slope = (y0 - y1) / (x0 - x1)
-    self._intercept = y0 - self._slope * x0
+    # where the class means land along the first axis, through the CURRENT affine map
+    # (slope 1 / intercept 0 on a fresh object; a refit composes with the previous map, as
+    # the reference's does, scaled_lda.py:315-316)
+    landed = self.transform(np.stack(self._mean_vectors))[:, 0]
+    if landed[0] == landed[1]:
+      raise ValueError('X0 and X1 in Scaled LDA are identical (%g and %g)' %
+                       (landed[0], landed[1]))
+    self._slope = (y0 - y1) / (landed[0] - landed[1])
+    self._intercept = y0 - self._slope * landed[0]
 
   def fit_two_classes(self, class0, class1):
-    class0 = np.asarray(class0)
-    class1 = np.asarray(class1)
-    if class0.ndim * class1.ndim != 1 and class0.shape[1] != class1.shape[1]:
+    class0, class1 = np.asarray(class0), np.asarray(class1)
+    both_vectors = class0.ndim == 1 and class1.ndim == 1
+    if not both_vectors and class0.shape[1] != class1.shape[1]:
       raise ValueError('Class 0 and Class1 must have the same number of dimensions '
                        '(%s vs %s).' % (class0.shape, class1.shape))
-    x = np.concatenate((class0, class1), axis=0)
-    y = np.concatenate((np.ones(class0.shape[0]) * 0, np.ones(class0.shape[0]) * 1))
-    self.fit(x, y)
+    # label vector as the reference builds it (scaled_lda.py:340-341): BOTH halves are sized
+    # by class 0, so unequal class sizes fail in the fit exactly as they do there
+    labels = np.repeat([0.0, 1.0], class0.shape[0])
+    self.fit(np.concatenate((class0, class1), axis=0), labels)
 
   def transform(self, x):
-    x_lda = super(ScaledLinearDiscriminantAnalysis, self).transform(x)
-    return np.real(self._slope * x_lda + self._intercept)
+    return np.real(self._slope * self._project(x) + self._intercept)

@@ -408,6 +408,81 @@ def g9_end_to_end():
   save('g9_end_to_end', **out)
 
 
+# ----------------------------------------------------------------- G10 Decoder.train
+def g10_data():
+  """The data of test/infer_decoder_test.py:86-148 with fixed seeds: uniform intensities,
+  eeg = (attended intensity - 0.5) * 2, 200-frame minibatches (infer_decoder.py:696), the
+  null-hypothesis copy with input_2 and the output shuffled inside every minibatch
+  (brain_data.py:376-382; the two permutations are stored)."""
+  rng = np.random.default_rng(10)
+  n, dims, batch = 1000, 4, 200
+  out = {}
+  for name, switch in (('train', False), ('test', True)):
+    i1 = rng.random((n, dims)).astype(np.float32)
+    i2 = rng.random((n, dims)).astype(np.float32)
+    flag = np.zeros((n, 1), np.float32)
+    if switch:
+      flag[n // 2:] = 1
+    eeg = np.where(flag > 0.5, (i2 - 0.5) * 2.0, (i1 - 0.5) * 2.0).astype(np.float32)
+    out.update({name + '_eeg': eeg, name + '_i1': i1, name + '_i2': i2, name + '_flag': flag})
+  out['mix_perm_x2'] = np.stack([rng.permutation(batch) for _ in range(n // batch)])
+  out['mix_perm_y'] = np.stack([rng.permutation(batch) for _ in range(n // batch)])
+  out['cfg'] = np.array([n, dims, batch], np.int64)
+  return out
+
+
+def g10_datasets(d):
+  n, _, batch = (int(v) for v in d['cfg'])
+  def batches(eeg, i1, flag, perm_x2=None, perm_y=None):
+    items = []
+    for k, s in enumerate(range(0, n, batch)):
+      x2 = i1[s:s + batch]
+      y = i1[s:s + batch]
+      if perm_x2 is not None:
+        x2, y = x2[perm_x2[k]], y[perm_y[k]]
+      items.append(({'input_1': eeg[s:s + batch], 'input_2': x2,
+                     'attended_speaker': flag[s:s + batch]}, y))
+    return items
+  train = batches(d['train_eeg'], d['train_i1'], d['train_flag'])
+  mixed = batches(d['train_eeg'], d['train_i1'], d['train_flag'], d['mix_perm_x2'],
+                  d['mix_perm_y'])
+  test = batches(d['test_eeg'], d['test_i1'], d['test_flag'])
+  return train, mixed, test
+
+
+def g10_decoder_train():
+  """Decoder.train / test_all / test_by_window of the reference (infer_decoder.py:330-400,
+  457-504) on the data of its own tests (test/infer_decoder_test.py:269-335, 371-404)."""
+  out = g10_data()
+  train, mixed, test = (tf.data.Dataset(b) for b in g10_datasets(out))
+  linear = lambda d: tf._t(np.asarray(d['input_1']) / 2.0 + 0.5)          # _linear_model :46-58
+  cca2 = lambda d: tf._t(np.concatenate((np.asarray(d['input_1'])[:, 0:2],
+                                         np.asarray(d['input_2'])[:, 0:2]), axis=1))  # :61-74
+  for tag, make in (('linear', lambda r: ref_id.LinearRegressionDecoder(linear, reduction=r)),
+                    ('cca', lambda r: ref_id.CCADecoder(cca2, reduction=r))):
+    for red in ('lda', 'first', 'mean', 'mean-squared'):
+      for win in (1, 100):
+        dec = make(red)
+        dprime = dec.train(mixed, train, window_size=win)
+        k = '%s_%s_w%d_' % (tag, red.replace('-', '_'), win)
+        cp, lp = dec.correlation_params, dec.lda_params
+        out[k + 'dprime'] = np.array(dprime)
+        for f in cp._fields:
+          out[k + 'cp_' + f] = np.asarray(getattr(cp, f))
+        out[k + 'lda_w'] = np.asarray(lp.w_real)
+        out[k + 'lda_slope'] = np.asarray(lp.slope)
+        out[k + 'lda_intercept'] = np.asarray(lp.intercept)
+        out[k + 'lda_means'] = np.asarray(lp.mean_vectors)
+        speaker, labels = dec.test_all(test)
+        out[k + 'speaker'] = speaker
+        out[k + 'labels'] = labels
+        if win == 1:
+          wins = list(dec.test_by_window(test, 101))
+          out[k + 'win_scores'] = np.stack([w[0] for w in wins])
+          out[k + 'win_labels'] = np.stack([w[1] for w in wins])
+  save('g10_decoder_train', **out)
+
+
 if __name__ == '__main__':
   g1_lag()
   g2_ridge()
@@ -418,3 +493,4 @@ if __name__ == '__main__':
   g7_decoders()
   g8_lda()
   g9_end_to_end()
+  g10_decoder_train()

@@ -1,0 +1,256 @@
+"""GPU parity tests of row F1: Decoder.train / test_all / test_by_window against golden G10
+(the reference's own Decoder run on the data of test/infer_decoder_test.py), the batched
+device fast paths against the minibatch-streaming path, and the null-hypothesis (mixup_batch)
+datasets on every device path.
+"""
+import numpy as np
+import pytest
+
+from oracle import lag as o_lag
+from oracle import pearson as o_p
+from oracle import regression as o_reg
+from tests.conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+TAGS = ('linear', 'cca')
+REDUCTIONS = ('lda', 'first', 'mean', 'mean-squared')
+
+
+def _g10_batches(g):
+  n, _, batch = (int(v) for v in g['cfg'])
+
+  def batches(eeg, i1, flag, perm_x2=None, perm_y=None):
+    items = []
+    for k, s in enumerate(range(0, n, batch)):
+      x2, y = i1[s:s + batch], i1[s:s + batch]
+      if perm_x2 is not None:
+        x2, y = x2[perm_x2[k]], y[perm_y[k]]
+      items.append(({'input_1': eeg[s:s + batch], 'input_2': x2,
+                     'attended_speaker': flag[s:s + batch]}, y))
+    return items
+  train = batches(g['train_eeg'], g['train_i1'], g['train_flag'])
+  mixed = batches(g['train_eeg'], g['train_i1'], g['train_flag'], g['mix_perm_x2'],
+                  g['mix_perm_y'])
+  test = batches(g['test_eeg'], g['test_i1'], g['test_flag'])
+  return train, mixed, test
+
+
+def _linear_model(d):                   # test/infer_decoder_test.py:46-58
+  return np.asarray(d['input_1']) / 2.0 + 0.5
+
+
+def _cca_model(d):                      # :61-74
+  return np.concatenate((np.asarray(d['input_1'])[:, 0:2], np.asarray(d['input_2'])[:, 0:2]),
+                        axis=1)
+
+
+def _make(tag, reduction):
+  from telluride_decoding_amd import infer_decoder
+  if tag == 'linear':
+    return infer_decoder.LinearRegressionDecoder(_linear_model, reduction=reduction)
+  return infer_decoder.CCADecoder(_cca_model, reduction=reduction)
+
+
+def _check_against_golden(dec, dprime, g, k, test, win):
+  # the reference accumulates its statistics in float32; tolerances are float32-level
+  np.testing.assert_allclose(dprime, g[k + 'dprime'], rtol=2e-5)
+  cp = dec.correlation_params
+  assert cp.count == int(g[k + 'cp_count'])
+  for f in ('sum_x', 'sum_y', 'sum_x2', 'sum_y2', 'mean_x', 'mean_y', 'power'):
+    np.testing.assert_allclose(getattr(cp, f), g[k + 'cp_' + f], rtol=2e-5, err_msg=f)
+  lp = dec.lda_params
+  # the first discriminant is sign-ambiguous on its own; slope * w and the intercept are not
+  np.testing.assert_allclose(lp.slope * np.asarray(lp.w_real)[:, 0],
+                             g[k + 'lda_slope'] * g[k + 'lda_w'][:, 0], rtol=2e-4, atol=1e-6)
+  np.testing.assert_allclose(lp.intercept, g[k + 'lda_intercept'], rtol=2e-4, atol=1e-6)
+  np.testing.assert_allclose(np.asarray(lp.mean_vectors), g[k + 'lda_means'], rtol=1e-4, atol=1e-6)
+  speaker, labels = dec.test_all(test)
+  assert speaker.shape == g[k + 'speaker'].shape and labels.shape == g[k + 'labels'].shape
+  np.testing.assert_allclose(speaker, g[k + 'speaker'], rtol=2e-4, atol=2e-5)
+  np.testing.assert_array_equal(labels, g[k + 'labels'])
+  if win == 1:
+    wins = list(dec.test_by_window(test, 101))
+    assert len(wins) == g[k + 'win_scores'].shape[0]
+    for (r, l), wr, wl in zip(wins, g[k + 'win_scores'], g[k + 'win_labels']):
+      assert r.shape == (101, 1) and l.shape == (101, 1)     # test_one_window, :329-335
+      np.testing.assert_allclose(r, wr, rtol=2e-4, atol=2e-5)
+      np.testing.assert_array_equal(l, wl)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+@pytest.mark.parametrize('reduction', REDUCTIONS)
+@pytest.mark.parametrize('win', [1, 100])
+def test_train_and_inference_match_reference_golden(tag, reduction, win):
+  """Product Decoder.train -> d', correlation parameters, LDA parameters, test_all,
+  test_by_window on (dict, y) minibatches, against the reference's own run (G10)."""
+  g = golden('g10_decoder_train')
+  train, mixed, test = _g10_batches(g)
+  dec = _make(tag, reduction)
+  dprime = dec.train(mixed, train, window_size=win)
+  k = '%s_%s_w%d_' % (tag, reduction.replace('-', '_'), win)
+  _check_against_golden(dec, dprime, g, k, test, win)
+  # behaviour the reference's tests pin (test/infer_decoder_test.py:269-335, 371-404)
+  speaker, labels = dec.test_all(test)
+  assert np.mean(speaker[labels == 0]) > 0.5 > np.mean(speaker[labels == 1])
+  if reduction != 'mean-squared':         # test_training_and_inference, :399-402
+    n = speaker.shape[0]
+    assert np.mean(speaker[:n // 2]) > 0.9 and np.mean(speaker[n // 2:]) < 0.1
+  dec.decoding_model_params = dec.decoding_model_params
+
+
+def test_train_without_data_raises():
+  from telluride_decoding_amd import infer_decoder
+  g = golden('g10_decoder_train')
+  _, mixed, _ = _g10_batches(g)
+  dec = infer_decoder.LinearRegressionDecoder(_linear_model)
+  with pytest.raises(ValueError, match='No data for class 0'):      # :337-348
+    dec.train([], mixed)
+  with pytest.raises(ValueError, match='No data for class 1'):
+    dec.train(mixed, [])
+  with pytest.raises(TypeError, match='Must feed training routine data0'):
+    dec.train(3, mixed)
+
+
+def test_train_device_fast_path_matches_golden_and_streaming():
+  """brain_data.Dataset + BrainModelLinearRegression: the whole dataset is decoded on the device
+  (FIR kernel), no minibatch loop -- same numbers as the golden and as the streaming path."""
+  from telluride_decoding_amd import brain_data, brain_model, infer_decoder
+  g = golden('g10_decoder_train')
+  n, dims, batch = (int(v) for v in g['cfg'])
+  train_b, mixed_b, test_b = _g10_batches(g)
+
+  def dataset(items):
+    cat = lambda f: np.concatenate([f(it) for it in items])
+    return brain_data.Dataset([(cat(lambda it: it[0]['input_1']), cat(lambda it: it[0]['input_2']),
+                                cat(lambda it: it[1]), cat(lambda it: it[0]['attended_speaker']))],
+                              batch)
+  train, mixed, test = dataset(train_b), dataset(mixed_b), dataset(test_b)
+  model = brain_model.BrainModelLinearRegression(train)
+  model.set_weights([0.5 * np.eye(dims, dtype=np.float32), 0.5 * np.ones(dims, np.float32)])
+  for reduction in ('lda', 'mean-squared'):
+    dec = infer_decoder.LinearRegressionDecoder(model, reduction=reduction)
+    dprime = dec.train(mixed, train, window_size=1)
+    _check_against_golden(dec, dprime, g, 'linear_%s_w1_' % reduction.replace('-', '_'), test, 1)
+  # the null-hypothesis dataset built by the Dataset itself (mixup_batch=True): the device
+  # path sees the same shuffles as iteration
+  mix_ds = brain_data.Dataset(train.files, batch, mixup_batch=True, mixup_seed=5)
+  fast = infer_decoder.LinearRegressionDecoder(model, reduction='lda')
+  d_fast = fast.train(mix_ds, train)
+  slow = infer_decoder.LinearRegressionDecoder(_linear_model, reduction='lda')
+  d_slow = slow.train(list(mix_ds), list(train))
+  np.testing.assert_allclose(d_fast, d_slow, rtol=1e-6)
+  np.testing.assert_allclose(fast.correlation_params.power, slow.correlation_params.power,
+                             rtol=1e-6)
+  assert abs(d_fast - float(g['linear_lda_w1_dprime'])) < 0.5     # another shuffle, same regime
+
+
+def test_mixup_batch_is_honoured_by_every_device_path():
+  """fit / evaluate / CCA on a mixup_batch dataset use the shuffled streams
+  (brain_data.py:376-382), with context, several files, an input offset and a dropped tail."""
+  from telluride_decoding_amd import brain_data, brain_model, cca
+  from oracle import cca as o_cca
+  rng = np.random.default_rng(77)
+  files = []
+  for n in (530, 410, 777):
+    x = rng.standard_normal((n, 6)).astype(np.float32)
+    x2 = (x[:, :3] + 0.3 * rng.standard_normal((n, 3))).astype(np.float32)
+    y = (x[:, :1] * 2 - x[:, 1:2] + 0.1 * rng.standard_normal((n, 1))).astype(np.float32)
+    files.append((x, x2, y, np.zeros((n, 1), np.float32)))
+  for off in (0, 2, -3):
+    ds = brain_data.Dataset(files, 100, 1, 2, 1, 1, off, mixup_batch=True, mixup_seed=9)
+    plain = brain_data.Dataset(files, 100, 1, 2, 1, 1, off)
+    batches = [({k: np.asarray(v, np.float64) for k, v in f.items()}, np.asarray(y, np.float64))
+               for f, y in ds]
+    # ridge fit
+    w, b, _, _, _ = brain_model.calculate_linear_regressor_parameters_from_dataset(ds, lamb=0.1)
+    w64, b64, _, _, _ = o_reg.linear_regressor_from_batches(batches, lamb=0.1)
+    np.testing.assert_allclose(w, w64, atol=2e-6)
+    np.testing.assert_allclose(b, b64, atol=2e-6)
+    wp, _, _, _, _ = brain_model.calculate_linear_regressor_parameters_from_dataset(plain, lamb=0.1)
+    assert np.max(np.abs(wp - w)) > 0.1            # the matched fit is a different model
+    # evaluate: per-minibatch Pearson / mse against the SHUFFLED output
+    model = brain_model.BrainModelLinearRegression(plain, regularization_lambda=0.1)
+    model.fit(plain)
+    ev = model.evaluate(ds)
+    wm, bm = model.w_estimate.astype(np.float64), model.b_estimate.astype(np.float64)
+    rs = [o_p.pearson_correlation(y, f['input_1'] @ wm + bm)[0] for f, y in batches]
+    mse = [np.mean((y - (f['input_1'] @ wm + bm)) ** 2) for f, y in batches]
+    assert abs(ev['pearson_correlation_first'] - np.mean(rs)) < 2e-6
+    assert abs(ev['loss'] - np.mean(mse)) < 1e-5 * max(1.0, np.mean(mse))
+    assert model.evaluate(plain)['pearson_correlation_first'] > 0.9 and abs(np.mean(rs)) < 0.3
+    # CCA fit on the shuffled input_2
+    ra, rb, mx, my, e = cca.calculate_cca_parameters_from_dataset(ds, 2, regularization=0.1,
+                                                                  mini_batch_count=0)
+    oa, ob, _, _, oe = o_cca.cca_parameters_from_batches(batches, 2, regularization=0.1,
+                                                         mini_batch_count=0)
+    np.testing.assert_allclose(e, oe, rtol=1e-5, atol=1e-7)
+
+
+def test_pearson_wide_and_constant_columns():
+  """No 16-column limit (the reference has none, brain_model.py:34-79); a constant non-zero
+  column zeroes the whole result although its raw-sum variance is a rounding residue."""
+  from telluride_decoding_amd import brain_model
+  rng = np.random.default_rng(12)
+  x = rng.standard_normal((500, 40)).astype(np.float32)
+  y = (0.5 * x + rng.standard_normal((500, 40))).astype(np.float32)
+  r = brain_model.pearson_correlation(x, y)
+  np.testing.assert_allclose(r, o_p.pearson_correlation(x.astype(np.float64), y.astype(np.float64)),
+                             atol=2e-6)
+  for const in (0.1, -3.7, 1e-6, 12345.678):
+    xc = x[:, :5].copy()
+    xc[:, 2] = np.float32(const)
+    z = brain_model.pearson_correlation(xc, y[:, :5])
+    assert z.shape == (500, 5) and not z.any(), const
+    z = brain_model.pearson_correlation(y[:, :5], xc)
+    assert not z.any(), const
+
+
+def test_initial_batch_size_splits_context():
+  """brain_data.py:487-499: context (and the offset shift) is added per initial batch, so a
+  recording longer than `initial_batch_size` behaves like several files."""
+  from telluride_decoding_amd import brain_data, brain_model
+  rng = np.random.default_rng(5)
+  n = 1000
+  x = rng.standard_normal((n, 4)).astype(np.float32)
+  y = (x[:, :1] + 0.1 * rng.standard_normal((n, 1))).astype(np.float32)
+  bd = brain_data.TestBrainData('x', 'y', 100, pre_context=2, post_context=3, final_batch_size=100,
+                                initial_batch_size=300)
+  bd.preserve_test_data(x, y)
+  ds = bd.create_dataset('train')
+  assert ds.file_lengths() == [300, 300, 300, 100]
+  w, b, _, _, _ = brain_model.calculate_linear_regressor_parameters_from_dataset(ds, lamb=0.01)
+  chunks = [(x[s:s + 300].astype(np.float64), np.zeros((len(x[s:s + 300]), 1)),
+             y[s:s + 300].astype(np.float64), np.zeros((len(x[s:s + 300]), 1)))
+            for s in range(0, n, 300)]
+  w64, b64, _, _, _ = o_reg.linear_regressor_from_batches(
+      o_lag.minibatches(chunks, 100, pre=2, post=3), lamb=0.01)
+  np.testing.assert_allclose(w, w64, atol=3e-6)
+  whole = [(x.astype(np.float64), np.zeros((n, 1)), y.astype(np.float64), np.zeros((n, 1)))]
+  ww, _, _, _, _ = o_reg.linear_regressor_from_batches(
+      o_lag.minibatches(whole, 100, pre=2, post=3), lamb=0.01)
+  assert np.max(np.abs(ww - w64)) > 1e-4             # the chunk edges matter
+
+
+@pytest.mark.parametrize('use_ridge,lamb', [(False, 0.3), (True, 0.1), (False, -1)])
+def test_regression_without_offset_column(use_ridge, lamb):
+  """use_offset=False (no ones column, brain_model.py:434-436) for ridge, Blankertz shrinkage
+  and Ledoit-Wolf, against the oracle restatement."""
+  from telluride_decoding_amd import brain_data, brain_model
+  rng = np.random.default_rng(31)
+  n = 2000
+  x = (rng.standard_normal((n, 5)) + 0.5).astype(np.float32)
+  y = (x @ rng.standard_normal((5, 2)) + 0.2 * rng.standard_normal((n, 2)) + 1.0).astype(np.float32)
+  ds = brain_data.Dataset([(x, np.zeros((n, 1), np.float32), y, np.zeros((n, 1), np.float32))],
+                          100, 1, 1)
+  w, b, cov_x, cov_xy, shrink = brain_model.calculate_linear_regressor_parameters_from_dataset(
+      ds, lamb=lamb, use_offset=False, use_ridge=use_ridge)
+  files = [(x.astype(np.float64), np.zeros((n, 1)), y.astype(np.float64), np.zeros((n, 1)))]
+  w64, b64, cx, cxy, sh = o_reg.linear_regressor_from_batches(
+      o_lag.minibatches(files, 100, pre=1, post=1), lamb=lamb, use_offset=False,
+      use_ridge=use_ridge)
+  assert w.shape == w64.shape == (15, 2) and b.shape == (1,)
+  np.testing.assert_allclose(shrink, sh, rtol=1e-5, atol=1e-9)
+  np.testing.assert_allclose(w, w64, rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(cov_x, cx, rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(cov_xy, cxy, rtol=1e-4, atol=1e-5)

@@ -9,6 +9,7 @@ import pytest
 
 from oracle import lag as o_lag
 from oracle import regression as o_reg
+from tests import parity_log
 from tests.conftest import golden
 
 pytestmark = pytest.mark.gpu
@@ -134,6 +135,9 @@ def test_accumulate_is_additive_and_packable(dev):
   assert merged.counts() == whole.counts()
 
 
+# cases whose reference (float32) output is further than 3e-6 from the same algorithm in float64
+# (|ref32 - ref64| in profiles/r02_parity.json): more lags on low-pass data, lambda = 0
+ILL_CONDITIONED_C1 = ('c1_pre2post2', 'c1_lam0', 'c1_offp2', 'c1_offm3', 'c1_post3')
 C1_CASES = ['c1_nolag', 'c1_post3', 'c1_pre2post2', 'c1_lam0', 'c1_lam10', 'c1_offp2', 'c1_offm3']
 
 
@@ -174,12 +178,18 @@ def test_ridge_matches_reference_golden(dev, name):
   d_gpu_32 = max(np.max(np.abs(w - w32)), np.max(np.abs(b - b32))) / scale
   print('%s: |gpu-ref64| %.2e  |ref32-ref64| %.2e  |gpu-ref32| %.2e' %
         (name, d_gpu_64, d_32_64, d_gpu_32))
-  # north_star tolerance (1e-5 relative) against exact arithmetic; for an
-  # ill-conditioned case (lambda = 0) the bar is the reference's own distance.
-  assert d_gpu_64 < max(1e-5, d_32_64)
-  # ... and never further from the reference than 1e-5 plus the reference's own
-  # distance from exact arithmetic.
-  assert d_gpu_32 < 1e-5 + 1.01 * d_32_64
+  parity_log.record('ridge_golden_' + name, gpu_ref64=d_gpu_64, ref32_ref64=d_32_64,
+                    gpu_ref32=d_gpu_32, strict=bool(d_gpu_32 < 1e-5))
+  # north_star: TRF weights within 1e-5 relative of the reference's float32 output.  STRICT for
+  # every case, except the named ones where the reference's own float32 rounding (its distance
+  # from the same algorithm in float64) is itself above 3e-6 -- there the bar is 1e-5 against
+  # exact arithmetic and 1e-5 + the reference's own error against the reference.
+  assert d_gpu_64 < 1e-5
+  if d_32_64 < 3e-6 or name not in ILL_CONDITIONED_C1:
+    assert d_gpu_32 < 1e-5
+  else:
+    assert d_32_64 > 3e-6
+    assert d_gpu_32 < 1e-5 + 1.01 * d_32_64
 
 
 def test_ridge_lambda_batch_and_spd_failure(dev):
@@ -249,12 +259,56 @@ def test_c2_shape_fit_against_float64_oracle(dev):
   d_gpu_32 = np.linalg.norm(w - w32) / norm
   print('C2 shape, 60k samples: |gpu-ref64| %.2e  |ref32-ref64| %.2e  |gpu-ref32| %.2e' %
         (d_gpu_64, d_32_64, d_gpu_32))
-  # K = 2049 on 60k low-pass samples is far worse conditioned than the full 1e6
-  # workload; the bar is 1e-5 or the reference's own distance from exact
-  # arithmetic, whichever is larger (DESIGN.md "Parity").
-  assert d_gpu_64 < max(1e-5, d_32_64)
+  parity_log.record('ridge_c2_shape_60k_lowpass', gpu_ref64=d_gpu_64, ref32_ref64=d_32_64,
+                    gpu_ref32=d_gpu_32, strict=bool(d_gpu_32 < 1e-5))
+  # K = 2049 on 60k LOW-PASS samples is ill-conditioned (the reference's own float32 output is
+  # ~1e-4 from exact arithmetic): the bar is 1e-5 against exact arithmetic and the reference's
+  # own distance against the reference.  The well-conditioned strict case is the next test.
+  assert d_gpu_64 < 1e-5
+  assert d_32_64 > 3e-6
   assert d_gpu_32 < 1e-5 + 1.01 * d_32_64
   assert abs(float(b.cpu().numpy()[0, 0]) - sol[-1, 0]) < 1e-5 * max(1.0, np.max(np.abs(sol)))
+
+
+def test_c2_shape_fit_strict_against_float32_reference(dev):
+  """SURVEY 7 "Hard parts": the pass/fail number on a well-conditioned synthetic -- C2 shape
+  (64 ch x 32 lags, K = 2049) on 200k samples of white-ish EEG, lambda = 0.1 -- is the STRICT
+  north_star bound |gpu - ref32| < 1e-5 relative against the reference's float32 arithmetic
+  (materialised lag matrix, per-minibatch float32 x^T x, float32 solve)."""
+  rng = np.random.default_rng(2024)
+  n_files, n, c, post = 4, 50000, 64, 31
+  trf = (rng.standard_normal((post + 1, c)) * np.exp(-np.arange(post + 1) / 8.0)[:, None]).astype(np.float32)
+  files = []
+  for _ in range(n_files):
+    eeg = rng.standard_normal((n, c)).astype(np.float32)
+    lagged = o_lag.lag_matrix(eeg, 0, post)
+    env = (lagged @ trf.reshape(-1, 1) / 8.0 + 0.5 * rng.standard_normal((n, 1))).astype(np.float32)
+    files.append((eeg, env, env, np.zeros((n, 1), np.float32)))
+    del lagged
+  h = dev.default_handle()
+  st = dev.LagStats(c, 0, post, d=1)
+  st.accumulate(h.to_device(np.concatenate([f[0] for f in files])), None,
+                h.to_device(np.concatenate([f[2] for f in files])), np.arange(n_files + 1) * n)
+  w, b = st.ridge_solve([0.1])
+  w, b = w.cpu().numpy()[0].astype(np.float64), b.cpu().numpy().astype(np.float64)
+  # the reference's arithmetic in float32 and the same in float64, batch 1000
+  # (file lengths are multiples of the batch size: batching file by file = batching the stream)
+  def batches(dtype):
+    for f in files:
+      yield from o_lag.minibatches([tuple(a.astype(dtype) for a in f)], 1000, pre=0, post=post)
+  w32, b32, _, _, _ = o_reg.linear_regressor_from_batches(batches(np.float32), lamb=0.1)
+  assert w32.dtype == np.float32
+  w64, b64, _, _, _ = o_reg.linear_regressor_from_batches(batches(np.float64), lamb=0.1)
+  scale = np.max(np.abs(w64))
+  d_gpu_64 = max(np.max(np.abs(w - w64)), np.max(np.abs(b - b64))) / scale
+  d_32_64 = max(np.max(np.abs(w32 - w64)), np.max(np.abs(b32 - b64))) / scale
+  d_gpu_32 = max(np.max(np.abs(w - w32)), np.max(np.abs(b - b32))) / scale
+  print('C2 shape, 200k white samples: |gpu-ref64| %.2e  |ref32-ref64| %.2e  |gpu-ref32| %.2e' %
+        (d_gpu_64, d_32_64, d_gpu_32))
+  parity_log.record('ridge_c2_shape_200k_white', gpu_ref64=d_gpu_64, ref32_ref64=d_32_64,
+                    gpu_ref32=d_gpu_32, strict=bool(d_gpu_32 < 1e-5))
+  assert d_gpu_32 < 1e-5          # north_star, strict
+  assert d_gpu_64 < 1e-5
 
 
 @pytest.mark.gpu
