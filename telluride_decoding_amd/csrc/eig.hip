@@ -18,15 +18,17 @@
 //                      problems directly and is the sub-problem solver of
 //   block Jacobi       n > 64: 32-column blocks, a round = n/64 disjoint block pairs; per round
 //                      (1) every pair's 64x64 sub-problem is diagonalised in LDS -> J_pq,
-//                      (2) A <- A J and V <- V J on the pair's columns, (3) A <- J^T A on its
-//                      rows, both as 64^3 MFMA GEMMs.  Pairs whose sub-problem needed no
-//                      rotation are skipped.  Converged when a whole sweep rotates nothing.
+//                      (2) every 64x64 tile (pair I, pair J) of A <- J_I^T (tile J_J) in one
+//                      pass, (3) V <- V J on the pair's columns, all as 64^3 MFMA GEMMs.  Pairs
+//                      whose sub-problem needed no rotation are skipped.  Converged when a
+//                      whole sweep rotates nothing.
 //   one-sided Jacobi   SVD of T: the columns of the narrower side are orthogonalised in
 //                      pairs (a workgroup per pair and round), singular values = column norms.
 // Rotation criterion |a_pq| > 1e-15 sqrt|a_pp a_qq| (relative: small eigenvalues of the
 // positive definite covariances keep their relative accuracy, which K = V lambda^-1/2 V^T
 // needs).  Small dense and latency-bound: reported as time, not against a roofline.
 #include <algorithm>
+#include <cstdlib>
 
 #include "td_common.h"
 
@@ -39,7 +41,7 @@ constexpr int LS = NB + 2;    // LDS row stride in doubles
 constexpr int HB = 32;        // block-Jacobi block width (a pair = one 64x64 sub-problem)
 constexpr double kRotTol = 1e-15;
 constexpr int kMaxOuterSweeps = 40;
-constexpr int kMaxInnerSweeps = 12;
+constexpr int kMaxInnerSweeps = 1;
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -164,18 +166,56 @@ struct JacParams {
   int* skip;           // block mode: [pairs] 1 = J is the identity (no rotation needed)
   unsigned int* rotations;  // += rotations applied (convergence test of the outer sweep)
   int max_sweeps;
+  int cross_only;      // block mode: rotate only pairs (p in block I, q in block J): 32 rounds
 };
 
+// 1/sqrt(x) and 1/x to float64 accuracy from the hardware seeds (~2^-26) and two Newton steps:
+// the rotation parameters sit on the serial path of every round, and the correctly rounded
+// sqrt / divide sequences are several hundred cycles each.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
+// Jacobi rotation that annihilates a_pq:  t = b / (d + sign(d) hypot(d, b)),  d = a_qq - a_pp,
+// b = 2 a_pq  (the smaller root of t^2 + 2 (d / b) t - 1 = 0);  c = 1 / sqrt(1 + t^2), s = t c.
+// Rotates only if |a_pq| > kRotTol sqrt|a_pp a_qq| (compared as squares).
+__device__ __forceinline__ bool jacobi_rotation(double app, double aqq, double apq, double* c,
+                                                double* s) {
+  *c = 1.0; *s = 0.0;
+  const double mag2 = apq * apq;
+  if (!(mag2 > 1e-290 && mag2 > (kRotTol * kRotTol) * fabs(app * aqq))) return false;
+  const double d = aqq - app, b = 2.0 * apq;
+  const double x = d * d + b * b;
+  const double hyp = x * fast_rsqrt(x);
+  const double t = b * fast_rcp(d + copysign(hyp, d));
+  const double cc = fast_rsqrt(1.0 + t * t);
+  *c = cc; *s = t * cc;
+  return true;
+}
+
+// A round = up to 32 disjoint rotations (round-robin ordering) and two barriers: the rotation
+// parameters from the diagonal; barrier; S <- R^T S R in 2 x 2 blocks and J <- J R; barrier.
+// The kernel is bound by LDS traffic (S and J are rewritten every round).
 __global__ __launch_bounds__(256) void jacobi64_kernel(JacParams P) {
   __shared__ double S[NB * LS];
   __shared__ double J[NB * LS];
   __shared__ double cs[32], sn[32];
   __shared__ int pp[32], qq[32];
-  __shared__ int nrot, total;
+  __shared__ int nrot, total, need;
   const int tid = threadIdx.x;
   int bp = 0, bq = 0;
   if (!P.direct) rr_pair(P.nblocks, P.round, blockIdx.x, &bp, &bq);
   // ---- load
+  if (tid == 0) { total = 0; need = 0; }
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     double v = 0.0;
@@ -189,63 +229,84 @@ __global__ __launch_bounds__(256) void jacobi64_kernel(JacParams P) {
     S[r * LS + c] = v;
     J[r * LS + c] = (r == c) ? 1.0 : 0.0;
   }
-  if (tid == 0) total = 0;
   __syncthreads();
-  for (int sweep = 0; sweep < P.max_sweeps; ++sweep) {
-    if (tid == 0) nrot = 0;
-    for (int round = 0; round < NB - 1; ++round) {
-      __syncthreads();
-      if (tid < 32) {
-        int p, q;
-        rr_pair(NB, round, tid, &p, &q);
-        const double app = S[p * LS + p], aqq = S[q * LS + q], apq = S[p * LS + q];
-        double c = 1.0, s = 0.0;
-        const double mag = fabs(apq);
-        if (mag > 1e-290 && mag > kRotTol * sqrt(fabs(app * aqq))) {
-          const double tau = (aqq - app) / (2.0 * apq);
-          const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + t * t);
-          s = t * c;
-          atomicAdd(&nrot, 1);
-        }
-        cs[tid] = c; sn[tid] = s; pp[tid] = p; qq[tid] = q;
-      }
-      __syncthreads();
-      {  // columns p, q of S and J:  [x_p x_q] <- [c x_p - s x_q, s x_p + c x_q]
-        const int k = tid & 31;
-        const int p = pp[k], q = qq[k];
-        const double c = cs[k], s = sn[k];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int row = (tid >> 5) + 8 * i;
-          const double sp = S[row * LS + p], sq = S[row * LS + q];
-          S[row * LS + p] = c * sp - s * sq;
-          S[row * LS + q] = s * sp + c * sq;
-          const double jp = J[row * LS + p], jq = J[row * LS + q];
-          J[row * LS + p] = c * jp - s * jq;
-          J[row * LS + q] = s * jp + c * jq;
-        }
-      }
-      __syncthreads();
-      {  // rows p, q of S
-        const int col = tid & 63;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = (tid >> 6) + 4 * i;
-          const int p = pp[k], q = qq[k];
-          const double c = cs[k], s = sn[k];
-          const double sp = S[p * LS + col], sq = S[q * LS + col];
-          S[p * LS + col] = c * sp - s * sq;
-          S[q * LS + col] = s * sp + c * sq;
-        }
-      }
+  // ---- quick reject: nothing above the rotation threshold (most pairs of the late sweeps)
+  {
+    bool any = false;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      const double v = S[r * LS + c];
+      const double m2 = v * v;
+      any = any || (r < c && m2 > 1e-290 &&
+                    m2 > (kRotTol * kRotTol) * fabs(S[r * LS + r] * S[c * LS + c]));
     }
-    __syncthreads();
-    const int done = nrot;
-    if (tid == 0) total += done;
-    __syncthreads();
-    if (done == 0) break;
+    if (any) need = 1;       // benign race: every writer stores the same value
   }
+  __syncthreads();
+  if (need) {
+    // players of the round-robin: the whole 64 in block mode, n rounded up to even for a small
+    // direct problem (an 8 x 8 matrix takes 7 rounds of 4 rotations per sweep, not 63 of 32)
+    const int players = P.direct ? (P.n + (P.n & 1) < 2 ? 2 : P.n + (P.n & 1)) : NB;
+    const int npairs = players / 2;
+    const int rounds = P.cross_only ? HB : players - 1;
+    for (int sweep = 0; sweep < P.max_sweeps; ++sweep) {
+      if (tid == 0) nrot = 0;
+      for (int round = 0; round < rounds; ++round) {
+        __syncthreads();
+        if (tid < npairs) {     // rotation of pair tid from the current diagonal
+          int p, q;
+          if (P.cross_only) { p = tid; q = HB + ((tid + round) & (HB - 1)); }
+          else rr_pair(players, round, tid, &p, &q);
+          double c, s;
+          const bool rot = jacobi_rotation(S[p * LS + p], S[q * LS + q], S[p * LS + q], &c, &s);
+          cs[tid] = c; sn[tid] = s; pp[tid] = p; qq[tid] = q;
+          if (rot) atomicAdd(&nrot, 1);
+        }
+        __syncthreads();
+        // S <- R^T S R block by block: the 2 x 2 block (pair ki, pair kj) takes both its row
+        // and its column rotation in registers (one pass over S, no barrier between the two
+        // sides); J <- J R on the columns of pair k.
+        {
+          const int kj = tid & 31;
+          if (kj < npairs) {
+            const int pj = pp[kj], qj = qq[kj];
+            const double cj = cs[kj], sj = sn[kj];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int ki = (tid >> 5) + 8 * i;
+              if (ki < npairs) {
+                const int pi = pp[ki], qi = qq[ki];
+                const double ci = cs[ki], si = sn[ki];
+                const double a00 = S[pi * LS + pj], a01 = S[pi * LS + qj];
+                const double a10 = S[qi * LS + pj], a11 = S[qi * LS + qj];
+                // columns: [x_p x_q] <- [c x_p - s x_q, s x_p + c x_q]
+                const double b00 = cj * a00 - sj * a01, b01 = sj * a00 + cj * a01;
+                const double b10 = cj * a10 - sj * a11, b11 = sj * a10 + cj * a11;
+                // rows, the same with (ci, si)
+                S[pi * LS + pj] = ci * b00 - si * b10;
+                S[pi * LS + qj] = ci * b01 - si * b11;
+                S[qi * LS + pj] = si * b00 + ci * b10;
+                S[qi * LS + qj] = si * b01 + ci * b11;
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int row = (tid >> 5) + 8 * i;
+              const double jp = J[row * LS + pj], jq = J[row * LS + qj];
+              J[row * LS + pj] = cj * jp - sj * jq;
+              J[row * LS + qj] = sj * jp + cj * jq;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int done = nrot;
+      __syncthreads();
+      if (tid == 0) total += done;
+      if (done == 0) break;
+    }
+  }
+  __syncthreads();
   // ---- publish
   if (P.direct) {
     for (int idx = tid; idx < P.n * P.n; idx += 256) {
@@ -255,12 +316,13 @@ __global__ __launch_bounds__(256) void jacobi64_kernel(JacParams P) {
     if (tid < P.n) P.vals[tid] = S[tid * LS + tid];
     if (tid == 0 && total) atomicAdd(P.rotations, (unsigned int)total);
   } else {
-    double* jo = P.jout + (size_t)blockIdx.x * NB * NB;
-    for (int idx = tid; idx < NB * NB; idx += 256) jo[idx] = J[(idx >> 6) * LS + (idx & 63)];
     if (tid == 0) {
       P.skip[blockIdx.x] = total == 0;
       if (total) atomicAdd(P.rotations, (unsigned int)total);
     }
+    if (total == 0) return;
+    double* jo = P.jout + (size_t)blockIdx.x * NB * NB;
+    for (int idx = tid; idx < NB * NB; idx += 256) jo[idx] = J[(idx >> 6) * LS + (idx & 63)];
   }
 }
 
@@ -270,7 +332,75 @@ struct BlockUpd {
   const double* j; const int* skip;
 };
 
-// rows [64 t, 64 t + 64), the pair's 64 columns:  X <- X J   (blockIdx.z: 0 = A, 1 = V)
+// lds[r][c] (or its transpose) = J of `pair`, the identity if the pair rotated nothing
+__device__ __forceinline__ void load_rotation(double* lds, const double* __restrict__ jall,
+                                              const int* __restrict__ skip, int pair, bool transposed,
+                                              int tid) {
+  const bool ident = skip[pair] != 0;
+  const double* jg = jall + (size_t)pair * NB * NB;
+  const int c = tid & 63;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = (tid >> 6) + 4 * i;
+    const double v = ident ? (r == c ? 1.0 : 0.0) : jg[r * NB + c];
+    if (transposed) lds[c * LS + r] = v; else lds[r * LS + c] = v;
+  }
+}
+
+// Two-sided update of the tile (pair I rows, pair J columns) of A in one pass:
+//   T <- J_I^T (T J_J)      (A is read and written once per round instead of twice)
+__global__ __launch_bounds__(256) void block_tile_kernel(BlockUpd P) {
+  const int pi = blockIdx.y, pj = blockIdx.x;
+  if (P.skip[pi] && P.skip[pj]) return;
+  __shared__ double xs[NB * LS];
+  __shared__ double ys[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int ip, iq, jp, jq;
+  rr_pair(P.nblocks, P.round, pi, &ip, &iq);
+  rr_pair(P.nblocks, P.round, pj, &jp, &jq);
+  {
+    const int c = tid & 63;
+    const int gc = (c < HB ? jp : jq) * HB + (c & (HB - 1));
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = (tid >> 6) + 4 * i;
+      const int gr = (r < HB ? ip : iq) * HB + (r & (HB - 1));
+      xs[r * LS + c] = P.a[(size_t)gr * P.np + gc];        // As[m][k] = T[m][k]
+    }
+  }
+  load_rotation(ys, P.j, P.skip, pj, true, tid);            // Bs[n][k] = J_J[k][n]
+  __syncthreads();
+  f64x4 acc[2][2];
+  zero_acc(acc);
+  mma_nt_64(xs, ys, wave, lane, acc);                       // M = T J_J
+  __syncthreads();
+  // second product T'' = J_I^T M:  As[m][k] = J_I[k][m],  Bs[n][k] = M[k][n]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ys[acc_col(wave, lane, n) * LS + acc_row(wave, lane, m, r)] = acc[m][n][r];
+  load_rotation(xs, P.j, P.skip, pi, true, tid);
+  __syncthreads();
+  zero_acc(acc);
+  mma_nt_64(xs, ys, wave, lane, acc);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = acc_row(wave, lane, m, r), c = acc_col(wave, lane, n);
+        const int gr = (row < HB ? ip : iq) * HB + (row & (HB - 1));
+        const int gc = (c < HB ? jp : jq) * HB + (c & (HB - 1));
+        P.a[(size_t)gr * P.np + gc] = acc[m][n][r];
+      }
+}
+
+// rows [64 t, 64 t + 64) of V, the pair's 64 columns:  X <- X J
 __global__ __launch_bounds__(256) void block_cols_kernel(BlockUpd P) {
   const int pair = blockIdx.y;
   if (P.skip[pair]) return;
@@ -280,8 +410,7 @@ __global__ __launch_bounds__(256) void block_cols_kernel(BlockUpd P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bp, bq;
   rr_pair(P.nblocks, P.round, pair, &bp, &bq);
-  double* mat = (blockIdx.z ? P.v : P.a) + (size_t)blockIdx.x * NB * P.np;
-  const double* jg = P.j + (size_t)pair * NB * NB;
+  double* mat = P.v + (size_t)blockIdx.x * NB * P.np;
   {
     const int c = tid & 63;
     const int gc = (c < HB ? bp : bq) * HB + (c & (HB - 1));
@@ -289,9 +418,9 @@ __global__ __launch_bounds__(256) void block_cols_kernel(BlockUpd P) {
     for (int i = 0; i < 16; ++i) {
       const int r = (tid >> 6) + 4 * i;
       xs[r * LS + c] = mat[(size_t)r * P.np + gc];          // As[m][k] = X[m][k]
-      js[c * LS + r] = jg[r * NB + c];                      // Bs[n][k] = J[k][n]
     }
   }
+  load_rotation(js, P.j, P.skip, pair, true, tid);          // Bs[n][k] = J[k][n]
   __syncthreads();
   f64x4 acc[2][2];
   zero_acc(acc);
@@ -305,44 +434,6 @@ __global__ __launch_bounds__(256) void block_cols_kernel(BlockUpd P) {
         const int row = acc_row(wave, lane, m, r), c = acc_col(wave, lane, n);
         const int gc = (c < HB ? bp : bq) * HB + (c & (HB - 1));
         mat[(size_t)row * P.np + gc] = acc[m][n][r];
-      }
-}
-
-// the pair's 64 rows, columns [64 t, 64 t + 64):  Y <- J^T Y
-__global__ __launch_bounds__(256) void block_rows_kernel(BlockUpd P) {
-  const int pair = blockIdx.y;
-  if (P.skip[pair]) return;
-  __shared__ double js[NB * LS];
-  __shared__ double ys[NB * LS];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bp, bq;
-  rr_pair(P.nblocks, P.round, pair, &bp, &bq);
-  const double* jg = P.j + (size_t)pair * NB * NB;
-  double* mat = P.a + (size_t)blockIdx.x * NB;
-  {
-    const int c = tid & 63;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int r = (tid >> 6) + 4 * i;
-      const int gr = (r < HB ? bp : bq) * HB + (r & (HB - 1));
-      js[c * LS + r] = jg[r * NB + c];                      // As[m][k] = J[k][m]
-      ys[c * LS + r] = mat[(size_t)gr * P.np + c];          // Bs[n][k] = Y[k][n]
-    }
-  }
-  __syncthreads();
-  f64x4 acc[2][2];
-  zero_acc(acc);
-  mma_nt_64(js, ys, wave, lane, acc);
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = acc_row(wave, lane, m, r), c = acc_col(wave, lane, n);
-        const int gr = (row < HB ? bp : bq) * HB + (row & (HB - 1));
-        mat[(size_t)gr * P.np + c] = acc[m][n][r];
       }
 }
 
@@ -394,7 +485,7 @@ int sym_eig(td_handle* h, const double* a, int lda, int n, double* vals, double*
     TD_HIP(h, hipMemsetAsync(counter, 0, sizeof(unsigned int), h->stream));
     P.a = const_cast<double*>(a); P.lda = lda; P.n = n; P.direct = 1;
     P.nblocks = 0; P.round = 0; P.jout = vecs; P.vals = vals; P.skip = nullptr;
-    P.max_sweeps = kMaxOuterSweeps;
+    P.max_sweeps = kMaxOuterSweeps; P.cross_only = 0;
     hipLaunchKernelGGL(jacobi64_kernel, dim3(1), dim3(256), 0, h->stream, P);
     TD_HIP(h, hipGetLastError());
     return TD_OK;
@@ -409,7 +500,7 @@ int sym_eig(td_handle* h, const double* a, int lda, int n, double* vals, double*
   hipLaunchKernelGGL(pad_sym_kernel, dim3(grid_for((long long)np * np)), dim3(256), 0, h->stream, a,
                      lda, n, np, ap, vp);
   P.a = ap; P.lda = np; P.n = np; P.direct = 0; P.nblocks = nblocks; P.jout = jm; P.vals = nullptr;
-  P.skip = skip; P.max_sweeps = kMaxInnerSweeps;
+  P.skip = skip; P.max_sweeps = getenv("TD_EIG_INNER") ? atoi(getenv("TD_EIG_INNER")) : kMaxInnerSweeps;
   BlockUpd U;
   U.a = ap; U.v = vp; U.np = np; U.nblocks = nblocks; U.j = jm; U.skip = skip;
   int sweep = 0;
@@ -417,10 +508,15 @@ int sym_eig(td_handle* h, const double* a, int lda, int n, double* vals, double*
     TD_HIP(h, hipMemsetAsync(counter, 0, sizeof(unsigned int), h->stream));
     for (int round = 0; round < nblocks - 1; ++round) {
       P.round = U.round = round;
+      // pairs inside a 32-block are rotated once per sweep (round 0 pairs every block exactly
+      // once and runs the full 63-round ordering); the other rounds rotate the 32 x 32 cross
+      // pairs only.  One inner sweep per visit: full diagonalisation of the sub-problems did
+      // not reduce the number of outer sweeps (16 either way at n = 2553) and cost 3x the time.
+      P.cross_only = round > 0;
       hipLaunchKernelGGL(jacobi64_kernel, dim3((unsigned)pairs), dim3(256), 0, h->stream, P);
-      hipLaunchKernelGGL(block_cols_kernel, dim3((unsigned)(np / NB), (unsigned)pairs, 2), dim3(256),
-                         0, h->stream, U);
-      hipLaunchKernelGGL(block_rows_kernel, dim3((unsigned)(np / NB), (unsigned)pairs), dim3(256), 0,
+      hipLaunchKernelGGL(block_tile_kernel, dim3((unsigned)pairs, (unsigned)pairs), dim3(256), 0,
+                         h->stream, U);
+      hipLaunchKernelGGL(block_cols_kernel, dim3((unsigned)(np / NB), (unsigned)pairs), dim3(256), 0,
                          h->stream, U);
     }
     TD_HIP(h, hipGetLastError());
@@ -428,6 +524,7 @@ int sym_eig(td_handle* h, const double* a, int lda, int n, double* vals, double*
     TD_HIP(h, hipMemcpyAsync(&rotated, counter, sizeof(unsigned int), hipMemcpyDeviceToHost,
                              h->stream));
     TD_HIP(h, hipStreamSynchronize(h->stream));
+    if (getenv("TD_EIG_TRACE")) fprintf(stderr, "eig n=%d sweep %d: %u rotations\n", n, sweep, rotated);
     if (rotated == 0) break;
   }
   if (sweeps_out) *sweeps_out = sweep + 1;
@@ -546,6 +643,102 @@ __global__ __launch_bounds__(256) void svd_extract_kernel(const double* __restri
   for (int t = threadIdx.x; t < k; t += 256) vn[(size_t)want * k + t] = vt[(size_t)i * k + t];
 }
 
+
+// The whole one-sided Jacobi SVD in ONE workgroup when the vectors fit in LDS (C3: 8 vectors
+// of 64): a wave per pair, wave-shuffle dot products, rotations applied in LDS, then norms,
+// descending order and the `dim` leading triplets -- one launch instead of ~50 and no host
+// round trips for the convergence test.
+constexpr int kSmallSvdDoubles = 7000;     // g [k][m | 1] + vt [k][k | 1] + norms [k]
+
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void svd_small_kernel(const double* __restrict__ g, int ldg, int k,
+                                                        int m, int dim, int max_sweeps,
+                                                        double* __restrict__ sig,
+                                                        double* __restrict__ gn,
+                                                        double* __restrict__ vn,
+                                                        int* __restrict__ sweeps_out) {
+  extern __shared__ double lds[];
+  const int mp = m | 1, kq = k | 1, kp = k + (k & 1);
+  double* gs = lds;                  // [k][mp]
+  double* vs = gs + (size_t)k * mp;  // [k][kq]
+  double* norms = vs + (size_t)k * kq;
+  __shared__ int nrot;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int idx = tid; idx < k * m; idx += 256) gs[(idx / m) * mp + idx % m] = g[(size_t)(idx / m) * ldg + idx % m];
+  for (int idx = tid; idx < k * k; idx += 256) vs[(idx / k) * kq + idx % k] = (idx / k == idx % k) ? 1.0 : 0.0;
+  int sweep = 0;
+  for (; sweep < max_sweeps && k > 1; ++sweep) {
+    __syncthreads();
+    if (tid == 0) nrot = 0;
+    for (int round = 0; round < kp - 1; ++round) {
+      __syncthreads();
+      for (int pair = wave; pair < kp / 2; pair += 4) {
+        int i, j;
+        rr_pair(kp, round, pair, &i, &j);
+        if (j >= k) continue;
+        double* gi = gs + (size_t)i * mp;
+        double* gj = gs + (size_t)j * mp;
+        double al = 0.0, be = 0.0, ga = 0.0;
+        for (int t = lane; t < m; t += 64) {
+          const double x = gi[t], y = gj[t];
+          al += x * x; be += y * y; ga += x * y;
+        }
+        al = wave_sum64(al); be = wave_sum64(be); ga = wave_sum64(ga);
+        const double mag = fabs(ga);
+        if (!(mag > 1e-290 && mag > kRotTol * sqrt(al * be))) continue;
+        const double tau = (be - al) / (2.0 * ga);
+        const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        const double c = 1.0 / sqrt(1.0 + tt * tt), sn = tt * c;
+        for (int t = lane; t < m; t += 64) {
+          const double x = gi[t], y = gj[t];
+          gi[t] = c * x - sn * y;
+          gj[t] = sn * x + c * y;
+        }
+        double* vi = vs + (size_t)i * kq;
+        double* vj = vs + (size_t)j * kq;
+        for (int t = lane; t < k; t += 64) {
+          const double x = vi[t], y = vj[t];
+          vi[t] = c * x - sn * y;
+          vj[t] = sn * x + c * y;
+        }
+        if (lane == 0) atomicAdd(&nrot, 1);
+      }
+    }
+    __syncthreads();
+    const int done = nrot;
+    if (done == 0) { ++sweep; break; }
+  }
+  __syncthreads();
+  for (int i = wave; i < k; i += 4) {
+    double al = 0.0;
+    for (int t = lane; t < m; t += 64) al += gs[(size_t)i * mp + t] * gs[(size_t)i * mp + t];
+    al = wave_sum64(al);
+    if (lane == 0) norms[i] = sqrt(al);
+  }
+  __syncthreads();
+  for (int want = wave; want < dim; want += 4) {
+    int pick = 0;
+    for (int i = 0; i < k; ++i) {
+      const double si = norms[i];
+      int rank = 0;
+      for (int j = 0; j < k; ++j) rank += (norms[j] > si || (norms[j] == si && j < i)) ? 1 : 0;
+      if (rank == want) pick = i;
+    }
+    const double sv = norms[pick];
+    const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
+    if (lane == 0) sig[want] = sv;
+    for (int t = lane; t < m; t += 64) gn[(size_t)want * m + t] = gs[(size_t)pick * mp + t] * inv;
+    for (int t = lane; t < k; t += 64) vn[(size_t)want * k + t] = vs[(size_t)pick * kq + t];
+  }
+  if (tid == 0 && sweeps_out) *sweeps_out = sweep;
+}
+
 size_t svd_ws_bytes(int k) { return sizeof(double) * ((size_t)k * k + k) + 256; }
 
 // g [k][ldg] (overwritten), k <= m: top `dim` singular triplets as rows sig [dim], gn [dim][m]
@@ -555,6 +748,15 @@ int jacobi_svd(td_handle* h, double* g, int ldg, int k, int m, int dim, double* 
   unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
   double* vt = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + 256);
   double* norms = vt + (size_t)k * k;
+  const size_t small = (size_t)k * (m | 1) + (size_t)k * (k | 1) + k;
+  if (small <= (size_t)kSmallSvdDoubles) {
+    // (the sweep count stays on the device: no host round trip on this path)
+    hipLaunchKernelGGL(svd_small_kernel, dim3(1), dim3(256), sizeof(double) * small, h->stream, g,
+                       ldg, k, m, dim, kMaxOuterSweeps, sig, gn, vn, (int*)nullptr);
+    TD_HIP(h, hipGetLastError());
+    if (sweeps_out) *sweeps_out = 0;
+    return TD_OK;
+  }
   hipLaunchKernelGGL(identity_kernel, dim3(grid_for((long long)k * k)), dim3(256), 0, h->stream, vt, k);
   SvdParams P;
   P.g = g; P.vt = vt; P.k = k; P.kp = k + (k & 1); P.m = m; P.ldg = ldg; P.rotations = counter;

