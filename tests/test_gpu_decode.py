@@ -313,6 +313,72 @@ def test_decode_fused_equals_unfused_at_scale(dev):
   assert acc > 0.95, acc                              # reference floor: infer_test.py:171-176
 
 
+@pytest.mark.parametrize('width,hop,pre,post', [(1000, 100, 0, 31), (1000, 500, 0, 31), (400, 200, 3, 20),
+                                                (256, 64, 0, 7), (96, 32, 0, 40)])
+def test_decode_fused_matches_oracle(dev, width, hop, pre, post):
+  """td_decode_fused (FIR prediction -> block sums of both speakers -> window scores +
+  winner-take-all) against the ORACLE chain: dense forward on the
+  materialised lag matrix, per-frame global-statistics correlation
+  (infer_decoder.py:326-328), np.mean per window (infer.py:263-265), strict > (attention_
+  decoder.py:128-134).  24 distinct trials, half of them with an attention switch, of different
+  lengths (incl. one window exactly and none at all)."""
+  from telluride_decoding_amd import synth
+  h = dev.default_handle()
+  c = 64
+  lens = [6000, 5000, 3100, width, width - 1, 4321, 2048, 6000] * 3
+  rng = np.random.default_rng(width + hop)
+  h_att, h_unatt = synth.impulse_responses(rng, c)
+  trials = []
+  for i, n in enumerate(lens):
+    att = np.zeros((n,), np.float32)
+    if i % 2 == 1:
+      att[n // 2:] = 1.0
+    trials.append(synth.trial(rng, n, c, h_att, h_unatt, att))
+  eeg = np.concatenate([t[0] for t in trials])
+  env = np.concatenate([t[1] for t in trials])
+  att = np.concatenate([t[2] for t in trials])
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  attended = np.where(att > 0.5, env[:, 1:2], env[:, 0:1]).astype(np.float32)
+  st = dev.LagStats(c, pre, post, d=1)
+  xd, envd = h.to_device(eeg), h.to_device(env)
+  st.accumulate(xd, None, h.to_device(attended), offs)
+  w, b = st.ridge_solve([0.1])
+  w, b = w[0].contiguous(), b[0].contiguous()
+  wn, bn = w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+  # oracle: predictions per trial (context never crosses a trial), trained statistics over all
+  pred_o = [o_reg.dense_forward(o_lag.lag_matrix(t[0].astype(np.float64), pre, post), wn, bn)
+            for t in trials]
+  cors, corr = [], []
+  for spk in (0, 1):
+    cor = o_cor.Correlator()
+    cor.add(env[:, spk:spk + 1].astype(np.float64), np.concatenate(pred_o))
+    cors.append(cor)
+    corr += [float(cor.mean_x[0]), float(cor.mean_y[0]), float(cor.power[0])]
+  scores, decisions = dev.decode_fused(xd, envd, offs, w, b, pre, post, width, hop, corr, handle=h)
+  scores, decisions = scores.cpu().numpy(), decisions.cpu().numpy()
+  want = [[], []]
+  for t, p in zip(trials, pred_o):
+    for spk in (0, 1):
+      want[spk].append(o_cor.windowed_means(
+          cors[spk].correlate(t[1][:, spk:spk + 1].astype(np.float64), p), t[2], width, hop)[0])
+  want = [np.concatenate(v) for v in want]
+  assert scores.shape == (len(want[0]), 2) and len(want[0]) > 0
+  # float32 predictions on the device vs float64 in the oracle: 1e-5 relative (north_star)
+  tol = 1e-5 * max(np.max(np.abs(want[0])), np.max(np.abs(want[1])))
+  np.testing.assert_allclose(scores[:, 0], want[0], rtol=1e-5, atol=tol)
+  np.testing.assert_allclose(scores[:, 1], want[1], rtol=1e-5, atol=tol)
+  truth = o_att.wta_sequence(want[0], want[1])
+  margin = np.abs(want[0] - want[1])
+  flips = int(np.sum(decisions != truth))
+  print('fused decode W=%d hop=%d: %d windows, %d decision flips vs oracle, min margin %.2e' %
+        (width, hop, len(truth), flips, margin.min()))
+  parity_log.record('decode_fused_W%d_hop%d' % (width, hop), windows=len(truth), flips=flips,
+                    min_margin=float(margin.min()),
+                    max_score_err=float(max(np.max(np.abs(scores[:, 0] - want[0])),
+                                            np.max(np.abs(scores[:, 1] - want[1])))))
+  assert flips == 0                   # attended-speaker argmax bit-exact
+
+
 def test_pearson_functions(dev):
   from telluride_decoding_amd import brain_model, cca
   g = golden('g3_pearson')
