@@ -134,6 +134,25 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
                               int64_t ldy, const int64_t* file_offsets_host, int num_files,
                               int input_offset, const int64_t* rows_used_host, int parts);
 
+/* The same for callers that share ONE long recording between ranks by time range
+ * (third unit): the moments are sums over rows, so a call may sum only the rows
+ * [range_begin[f], range_end[f]) of file f's zipped stream.  A "file" here is the piece of the
+ * recording the caller holds: its range plus a read-only halo of pre + post rows on either
+ * side (clipped at the true ends), so that x~[u + lag] is real data at an interior cut and zero
+ * only beyond a true end of the recording (brain_data.py:448-454).  edge_flags[f]: bit 0 =
+ * the piece starts at the recording's first row, bit 1 = it ends at its last row -- only that
+ * piece contributes the head / tail boundary window (the edge corrections of the dense
+ * moments and the bias moments are linear in them, so the sum over ranks is exact).
+ * rows_used[f] counts rows of the PIECE (the tail piece applies drop_remainder).  Ranks map a
+ * shared recording to the same boundary slot of the packed all-reduce buffer.  NULL ranges =
+ * whole files, NULL flags = both ends: td_stats_accumulate_parts.  input_offset must be 0. */
+int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
+                               const float* x2_dev, int64_t ldx2, const float* y_dev,
+                               int64_t ldy, const int64_t* file_offsets_host, int num_files,
+                               int input_offset, const int64_t* rows_used_host,
+                               const int64_t* range_begin_host, const int64_t* range_end_host,
+                               const int* edge_flags_host, int parts);
+
 /* Frames summed so far (num_samples / total_frames) and number of files. */
 int td_stats_counts(td_handle* h, const td_stats* s, int64_t* frames, int64_t* files);
 

@@ -63,6 +63,8 @@ SIGNATURES = {
                             _pi64],
     'td_stats_accumulate_parts': [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _pi64, _i, _i,
                             _pi64, _i],
+    'td_stats_accumulate_ranges': [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _pi64, _i, _i,
+                                   _pi64, _pi64, _pi64, _c.POINTER(_i), _i],
     'td_stats_counts': [_vp, _vp, _pi64, _pi64],
     'td_stats_combine': [_vp, _vp, _c.POINTER(_vp), _i],
     'td_stats_packed_len': [_vp, _vp, _i64, _pi64],

@@ -43,6 +43,8 @@ namespace {
 
 struct WinJob {
   long long row0, valid, nprime;  // stream rows of this file; rows used
+  int head, tail;                 // which boundary windows this call owns (else they stay zero:
+                                  // another rank holds that end of the recording)
 };
 
 __global__ void gather_windows_kernel(const float* __restrict__ x, long long ld, int c, int hw,
@@ -52,10 +54,11 @@ __global__ void gather_windows_kernel(const float* __restrict__ x, long long ld,
   const int which = blockIdx.y;  // 0 head, 1 tail
   float* dst = win + ((first_slot + blockIdx.x) * 2 + which) * (long long)(2 * hw) * c;
   const long long base = which == 0 ? -hw : j.nprime - hw;
+  const bool own = which == 0 ? j.head != 0 : j.tail != 0;
   for (int idx = threadIdx.x; idx < 2 * hw * c; idx += blockDim.x) {
     const int r = idx / c, col = idx % c;
     const long long u = base + r;
-    dst[idx] = (u >= 0 && u < j.valid) ? x[(j.row0 + u) * ld + col] : 0.f;
+    dst[idx] = (own && u >= 0 && u < j.valid) ? x[(j.row0 + u) * ld + col] : 0.f;
   }
 }
 
@@ -441,7 +444,22 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
                               const float* x2_dev, int64_t ldx2, const float* y_dev, int64_t ldy,
                               const int64_t* file_offsets_host, int num_files, int input_offset,
                               const int64_t* rows_used_host, int parts) {
+  return td_stats_accumulate_ranges(h, s, x_dev, ldx, x2_dev, ldx2, y_dev, ldy, file_offsets_host,
+                                    num_files, input_offset, rows_used_host, nullptr, nullptr,
+                                    nullptr, parts);
+}
+
+int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
+                               const float* x2_dev, int64_t ldx2, const float* y_dev, int64_t ldy,
+                               const int64_t* file_offsets_host, int num_files, int input_offset,
+                               const int64_t* rows_used_host, const int64_t* range_begin_host,
+                               const int64_t* range_end_host, const int* edge_flags_host,
+                               int parts) {
   if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_accumulate: NULL argument");
+  TD_REQUIRE(h, (range_begin_host == nullptr) == (range_end_host == nullptr),
+             "td_stats_accumulate_ranges: give both range arrays or neither");
+  TD_REQUIRE(h, !range_begin_host || input_offset == 0,
+             "td_stats_accumulate_ranges: time ranges need input_offset = 0");
   TD_REQUIRE(h, parts >= 1 && parts <= 3, "td_stats_accumulate_parts: parts must be 1, 2 or 3");
   const bool do_main = (parts & TD_ACC_MAIN) != 0, do_targets = (parts & TD_ACC_TARGETS) != 0;
   TD_REQUIRE(h, x_dev && file_offsets_host && num_files >= 0, "td_stats_accumulate: NULL input");
@@ -472,25 +490,36 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
                  (long long)nz);
       np = rows_used_host[f];
     }
-    new_frames += np;
+    // the rows [ub, ue) of the file that THIS call sums (all of [0, N') by default): the sums
+    // are additive over disjoint row ranges, so ranks can share one long recording
+    int64_t ub = 0, ue = np;
+    if (range_begin_host) {
+      ub = range_begin_host[f]; ue = range_end_host[f];
+      TD_REQUIRE(h, ub >= 0 && ub <= ue && ue <= np, "range [%lld, %lld) of file %d outside [0, %lld]",
+                 (long long)ub, (long long)ue, f, (long long)np);
+    }
+    new_frames += ue - ub;
     LagSeg a;
     a.a_row0 = r0 + dx; a.a_valid = vx; a.b_row0 = r0 + dx; a.b_valid = vx;
-    a.u_begin = 0; a.u_end = np;
+    a.u_begin = ub; a.u_end = ue;
     sxx.push_back(a);
     LagSeg b;   // A = y stream, B = x
     b.a_row0 = r0 + dy; b.a_valid = vy; b.b_row0 = r0 + dx; b.b_valid = vx;
-    b.u_begin = 0; b.u_end = np;
+    b.u_begin = ub; b.u_end = ue;
     syx.push_back(b);
     LagSeg c;   // A = B = x2
     c.a_row0 = r0 + dy; c.a_valid = vy; c.b_row0 = r0 + dy; c.b_valid = vy;
-    c.u_begin = 0; c.u_end = np;
+    c.u_begin = ub; c.u_end = ue;
     syy.push_back(c);
     LagSeg e;   // A = x, B = x2
     e.a_row0 = r0 + dx; e.a_valid = vx; e.b_row0 = r0 + dy; e.b_valid = vy;
-    e.u_begin = 0; e.u_end = np;
+    e.u_begin = ub; e.u_end = ue;
     sxy.push_back(e);
+    const int flags = edge_flags_host ? edge_flags_host[f] : 3;
     j1[f].row0 = r0 + dx; j1[f].valid = vx; j1[f].nprime = np;
+    j1[f].head = flags & 1; j1[f].tail = flags & 2;
     j2[f].row0 = r0 + dy; j2[f].valid = vy; j2[f].nprime = np;
+    j2[f].head = flags & 1; j2[f].tail = flags & 2;
   }
 
   // window slot of the first new file: MAIN appends the files, a TARGETS-only call comes

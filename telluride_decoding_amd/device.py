@@ -50,6 +50,13 @@ class Handle(object):
   def synchronize(self):
     self.check(self.lib.td_synchronize(self.ptr))
 
+  def record_event(self):
+    """An event recorded on the stream this handle queues its work on (torch's current
+    stream); .synchronize() waits for everything queued before it."""
+    ev = _torch().cuda.Event()
+    ev.record()
+    return ev
+
   def timer_start(self):
     self.check(self.lib.td_timer_start(self.ptr))
 
@@ -152,11 +159,15 @@ class LagStats(object):
     self.h.check(self.h.lib.td_stats_reset(self.h.ptr, self.ptr))
 
   def accumulate(self, x, x2=None, y=None, file_offsets=None, input_offset=0,
-                 rows_used=None, parts=3, handle=None):
+                 rows_used=None, parts=3, handle=None, ranges=None, edges=None):
     """x [rows, c1], x2 [rows, c2] / y [rows, d]: device float32 tensors holding
     the files concatenated along time; file_offsets has F+1 row offsets.
     parts: 1 = covariances + windows + counters, 2 = targets / bias moments (after part 1 of
-    the same files, possibly on another handle's stream), 3 = both."""
+    the same files, possibly on another handle's stream), 3 = both.
+    ranges: per file (begin, end) rows of the file that this call sums, for ranks that share a
+    long recording by time range (each holds its range plus a halo of pre + post rows);
+    edges: per file bit 0 / bit 1 = the piece holds the recording's first / last row
+    (td_stats_accumulate_ranges)."""
     rows = int(x.shape[0])
     if file_offsets is None:
       file_offsets = [0, rows]
@@ -173,11 +184,28 @@ class LagStats(object):
       if t is not None and w and (str(t.dtype) != 'torch.float32' or not t.is_cuda):
         raise TypeError('%s must be a float32 device tensor' % name)
     h = handle or self.h
-    h.check(h.lib.td_stats_accumulate_parts(
+    if ranges is None and edges is None:
+      h.check(h.lib.td_stats_accumulate_parts(
+          h.ptr, self.ptr, _ptr(x), x.stride(0),
+          _ptr(x2 if self.c2 else None), x2.stride(0) if self.c2 else 0,
+          _ptr(y if self.d else None), y.stride(0) if self.d else 0,
+          offs_p, len(offs) - 1, int(input_offset), used_p, int(parts)))
+      return
+    nf = len(offs) - 1
+    rb_p = re_p = None
+    if ranges is not None:
+      rb, rb_p = _lib.i64_array([r[0] for r in ranges])
+      re, re_p = _lib.i64_array([r[1] for r in ranges])
+      if len(rb) != nf:
+        raise ValueError('ranges must have one (begin, end) pair per file')
+    fl = None
+    if edges is not None:
+      fl = (ctypes.c_int * nf)(*[int(e) for e in edges])
+    h.check(h.lib.td_stats_accumulate_ranges(
         h.ptr, self.ptr, _ptr(x), x.stride(0),
         _ptr(x2 if self.c2 else None), x2.stride(0) if self.c2 else 0,
         _ptr(y if self.d else None), y.stride(0) if self.d else 0,
-        offs_p, len(offs) - 1, int(input_offset), used_p, int(parts)))
+        offs_p, nf, int(input_offset), used_p, rb_p, re_p, fl, int(parts)))
 
   def counts(self):
     frames, files = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -57,6 +57,92 @@ class ShardPlan(object):
     return sum(self.file_lengths[f] for f in self.files_of(rank))
 
 
+class TimeShardPlan(object):
+  """Strong scaling of ONE fit: the concatenated recordings are cut into `world_size`
+  contiguous time ranges of (nearly) equal length, so a long recording is shared by several
+  ranks (third unit).  Rank r sums the rows of its range; of every recording
+  it touches it holds a PIECE = the range plus a read-only halo of `halo` rows on either side
+  (clipped at the recording's true ends), so lagged products across the cut see real data and
+  the zero extension happens only at true ends.  Boundary slots of the packed all-reduce
+  buffer are per recording: the ranks sharing one map it to the same slot, only the piece
+  that holds an end contributes that end's boundary window.
+
+  halo must be >= pre + post of every lagged input (device.LagStats.hw, which also covers the
+  boundary windows, is the safe choice)."""
+
+  def __init__(self, file_lengths, world_size, halo, batch_size=None):
+    self.file_lengths = [int(n) for n in file_lengths]
+    self.world_size = int(world_size)
+    self.halo = int(halo)
+    # rows that enter the fit: batch(drop_remainder=True) drops the tail of the LAST file
+    used = list(self.file_lengths)
+    if batch_size:
+      total = sum(used)
+      used[-1] -= total % int(batch_size)
+      if used[-1] < 0:
+        raise ValueError('the last recording is shorter than the dropped remainder')
+    self.rows_used = used
+    total = sum(used)
+    self.cuts = [(total * r) // self.world_size for r in range(self.world_size + 1)]
+    self.starts = np.concatenate(([0], np.cumsum(used))).astype(np.int64)   # in used rows
+
+  @property
+  def total_files(self):
+    return len(self.file_lengths)
+
+  @property
+  def total_frames(self):
+    return int(sum(self.rows_used))
+
+  def pieces_of(self, rank):
+    """[(file, piece_first, piece_last, range_begin, range_end, edge_flags, rows_used)]: the
+    piece is rows [piece_first, piece_last) of the recording; the range and rows_used are in
+    PIECE coordinates."""
+    lo, hi = self.cuts[rank], self.cuts[rank + 1]
+    out = []
+    for f, n in enumerate(self.file_lengths):
+      a = max(lo, int(self.starts[f])) - int(self.starts[f])
+      b = min(hi, int(self.starts[f + 1])) - int(self.starts[f])
+      if b <= a:
+        continue
+      first = max(a - self.halo, 0)
+      last = min(b + self.halo, n)
+      # an end's boundary window comes from the ONE piece whose range touches that end
+      flags = (1 if a == 0 else 0) | (2 if b == self.rows_used[f] else 0)
+      # the piece's N': the recording's rows_used seen from the piece (only the tail piece is
+      # ever cut by it; ranges never reach past it)
+      used = min(self.rows_used[f], last) - first
+      out.append((f, first, last, a - first, b - first, flags, used))
+    return out
+
+  def slot_of(self, rank):
+    pieces = self.pieces_of(rank)
+    return pieces[0][0] if pieces else 0
+
+  def frames_of(self, rank):
+    return self.cuts[rank + 1] - self.cuts[rank]
+
+
+def accumulate_time_shard(stats, plan, rank, arrays, handle=None, parts=3):
+  """Adds rank `rank`'s pieces to `stats`.  arrays(file, first, last) -> (x, x2, y) device
+  tensors holding rows [first, last) of that recording (x2 / y may be None)."""
+  pieces = plan.pieces_of(rank)
+  if not pieces:
+    return stats
+  import torch
+  xs, x2s, ys, offs = [], [], [], [0]
+  for f, first, last, _, _, _, _ in pieces:
+    x, x2, y = arrays(f, first, last)
+    xs.append(x); x2s.append(x2); ys.append(y)
+    offs.append(offs[-1] + last - first)
+  cat = lambda parts_: None if parts_[0] is None else (
+      parts_[0] if len(parts_) == 1 else torch.cat(parts_).contiguous())
+  stats.accumulate(cat(xs), cat(x2s), cat(ys), offs, rows_used=[p[6] for p in pieces],
+                   ranges=[(p[3], p[4]) for p in pieces], edges=[p[5] for p in pieces],
+                   handle=handle, parts=parts)
+  return stats
+
+
 def allreduce_packed(buf, group=None):
   """Sum a packed statistics buffer over ranks, in place (RCCL on GPU tensors,
   gloo on CPU tensors in the tests)."""

@@ -23,7 +23,8 @@ class FitPipeline(object):
   other blocking stream and serialises the two stages (measured: 3.44 ms instead of 2.68).
   """
 
-  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32, targets_on_solve=True, buffers=3):
+  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32, targets_on_solve=True, buffers=3,
+               solves=None):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -33,8 +34,17 @@ class FitPipeline(object):
     import ctypes
     import torch
     from telluride_decoding_amd import _lib
+    if buffers < 2:
+      # with one buffer submit(i + 1) would reset the statistics before solve(i) is even queued
+      raise ValueError('FitPipeline needs at least two statistics buffers, not %d' % buffers)
     self.torch = torch
     self._masked = []
+    # solves: optional callable(fit index) -> bool.  With several ranks sharing every fit
+    # (strong scaling) each fit is SOLVED by one rank only -- fit i by rank i mod N, say --
+    # while every rank takes part in its all-reduce: N redundant 1.2 ms solves per fit would
+    # cap the speed-up at the solve time.  submit() / flush() hand out None for fits this rank
+    # did not solve.
+    self.solves = solves
     lib = _lib.load()
     dev = torch.cuda.current_device()
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -71,7 +81,7 @@ class FitPipeline(object):
     self.allreduce = allreduce   # optional callable(stats, handle), run on the SOLVE stream
     self.targets_on_solve = targets_on_solve
 
-  def _solve(self, buf, lambdas, args, kw):
+  def _solve(self, buf, lambdas, args, kw, index=0):
     """Queues targets + exchange + solve of one fit on the solve stream; nothing waits."""
     torch = self.torch
     with torch.cuda.stream(self.s_solve):
@@ -91,7 +101,10 @@ class FitPipeline(object):
       if self.allreduce is not None:
         self.allreduce(self.stats[buf], self.h_solve)
       # (the singular-system flag follows the solve into the handle's pinned host ring)
-      w, b, flag = self.stats[buf].ridge_solve_async(lambdas, handle=self.h_solve)
+      if self.solves is None or self.solves(index):
+        w, b, flag = self.stats[buf].ridge_solve_async(lambdas, handle=self.h_solve)
+      else:
+        w = b = flag = None
       ev = torch.cuda.Event()
       ev.record(self.s_solve)
       self.ev_solved[buf] = ev
@@ -101,6 +114,8 @@ class FitPipeline(object):
     """Oldest queued solution, waited for and checked."""
     w, b, flag, ev = self._results.pop(0)
     ev.synchronize()
+    if flag is None:
+      return None
     if flag():
       raise np.linalg.LinAlgError('Singular matrix: covariance is not positive definite')
     return w, b
@@ -118,7 +133,7 @@ class FitPipeline(object):
       self.ev_acc[buf].record(self.s_acc)
     if self.pending is not None:
       self._solve(*self.pending)
-    self.pending = (buf, np.atleast_1d(lambdas), (x, None, y, file_offsets), kw)
+    self.pending = (buf, np.atleast_1d(lambdas), (x, None, y, file_offsets), kw, self.count - 1)
     return self._pop() if len(self._results) > 1 else None
 
   def flush(self):

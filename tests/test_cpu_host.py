@@ -192,38 +192,129 @@ def test_shard_plan_and_sweep_helpers():
   assert regression.calculate_stats([1.0, 3.0]) == (2.0, 1.0)
 
 
+def _loso_case():
+  """Five recordings whose lengths are NOT multiples of the batch size, two outputs."""
+  rng = np.random.default_rng(77)
+  files = []
+  for n in (1230, 1111, 987, 1300, 1045):
+    x = rng.standard_normal((n, 4)).astype(np.float32)
+    y = (x[:, :1] * 1.5 - np.roll(x[:, 1:2], 1, axis=0) + 0.5 * rng.standard_normal((n, 1)))
+    y = np.concatenate((y, rng.standard_normal((n, 1))), axis=1).astype(np.float32)
+    files.append((x, np.zeros((n, 1), np.float32), y, np.zeros((n, 1), np.float32)))
+  return files
+
+
+def _loso_refits(files, batch, pre, post, off, lambdas):
+  """The reference's loop (regression.py:151-242): for every held-out file and lambda refit
+  from scratch on the minibatched training stream, score the held-out file's minibatches."""
+  from oracle import pearson as o_p
+  from oracle import regression as o_reg
+  f64 = [tuple(a.astype(np.float64) for a in f) for f in files]
+  out = np.zeros((len(lambdas), len(files)))
+  for f in range(len(files)):
+    train = [f64[g] for g in range(len(files)) if g != f]
+    held = list(o_lag.minibatches([f64[f]], batch, pre=pre, post=post, input_offset=off))
+    for li, lam in enumerate(lambdas):
+      w, b, _, _, _ = o_reg.linear_regressor_from_batches(
+          o_lag.minibatches(train, batch, pre=pre, post=post, input_offset=off), lamb=lam)
+      r = [o_p.pearson_correlation(y, d['input_1'] @ w + b)[0] for d, y in held]
+      out[li, f] = np.mean(r)
+  return out
+
+
+@pytest.mark.parametrize('off', [0, 2, -3])
+def test_loso_sweep_batching_matches_refits_from_scratch(off):
+  """a fold's training stream is the CONCATENATION of its files cut into minibatches
+  with drop_remainder=True (brain_data.py:369-370) -- only the tail of the last training file
+  is lost, not every file's own remainder; the held-out file is its own stream.  The product's
+  sweep (the host orchestration, with the NumPy stand-in as device layer) against from-scratch
+  refits, file lengths not multiples of the batch size and a non-zero input_offset."""
+  from telluride_decoding_amd import brain_data, regression
+  from tests import host_device
+  files = _loso_case()
+  batch, pre, post, lambdas = 100, 1, 2, [1e-3, 0.1, 10.0]
+  ds = brain_data.Dataset(files, batch, pre, post, input_offset=off)
+  res = regression.jackknife_over_regularizations(ds, lambdas, device=host_device)
+  want = _loso_refits(files, batch, pre, post, off, lambdas)
+  np.testing.assert_allclose(res['all_runs'], want, rtol=0, atol=2e-6)
+  for li, lam in enumerate(lambdas):
+    assert abs(res[lam][0] - want[li].mean()) < 2e-6 and abs(res[lam][1] - want[li].std()) < 2e-6
+  # truncating every file to a batch multiple (what round 1 did) is a different model
+  short = [tuple(a[:(a.shape[0] - abs(off)) // batch * batch + abs(off)] for a in f) for f in files]
+  other = _loso_refits(short, batch, pre, post, off, lambdas)
+  assert np.max(np.abs(other - want)) > 1e-4
+
+
 _WORKER = r'''
 import os, sys
 import numpy as np
 import torch
 import torch.distributed as dist
 sys.path.insert(0, %(root)r)
-from telluride_decoding_amd import distributed
+from telluride_decoding_amd import brain_data, distributed, regression
+from tests import host_device
+from tests.test_cpu_host import _loso_case
 
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 dist.init_process_group('gloo')
-# The packed-statistics protocol: [additive part | one slot per file]; a rank
-# fills only its own slots, the all-reduce(sum) yields the concatenation.
-lengths = [300, 500, 200, 400, 100]
-plan = distributed.ShardPlan(lengths, world)
-g_len, per_slot = 7, 3
-rng = np.random.default_rng(100 + rank)
-additive = rng.standard_normal(g_len)
-buf = np.zeros(g_len + per_slot * plan.total_files)
-buf[:g_len] = additive
-for f in plan.files_of(rank):
-  buf[g_len + per_slot * f: g_len + per_slot * (f + 1)] = 1000 * rank + f
-t = torch.from_numpy(buf)
-distributed.allreduce_packed(t)
-want_add = sum(np.random.default_rng(100 + r).standard_normal(g_len) for r in range(world))
-np.testing.assert_allclose(t[:g_len].numpy(), want_add, rtol=1e-12)
-for r in range(world):
-  for f in plan.files_of(r):
-    np.testing.assert_array_equal(t[g_len + per_slot * f: g_len + per_slot * (f + 1)].numpy(),
-                                  np.full(per_slot, 1000 * r + f))
-folds = distributed.split_round_robin(list(range(5)), rank, world)
-full = distributed.gather_rows(np.array([[10.0 * f, f] for f in folds]).reshape(len(folds), 2), 5, folds)
-np.testing.assert_array_equal(full, [[10.0 * f, f] for f in range(5)])
+files = _loso_case()
+lens = [f[0].shape[0] for f in files]
+pre, post, batch = 1, 2, 100
+h = host_device.default_handle()
+
+def stats_of(idx):
+  st = host_device.LagStats(4, pre, post, d=2)
+  offs = np.concatenate(([0], np.cumsum([lens[i] for i in idx])))
+  st.accumulate(np.concatenate([files[i][0] for i in idx]), None,
+                np.concatenate([files[i][2] for i in idx]), offs)
+  return st
+
+whole = stats_of(range(len(files)))
+
+# (a) recordings dealt to ranks (distributed.ShardPlan): every rank accumulates its own files,
+#     ONE all-reduce of [additive statistics | one boundary slot per file], each rank filling
+#     only its own slots -- the product's allreduce_stats with the total frame count known.
+plan = distributed.ShardPlan(lens, world)
+mine = stats_of(plan.files_of(rank))
+assert mine.counts() == (plan.frames_of(rank), len(plan.files_of(rank)))
+distributed.allreduce_stats(mine, plan, rank, total_frames=sum(lens))
+np.testing.assert_allclose(mine.xtx, whole.xtx, rtol=1e-12)
+np.testing.assert_allclose(mine.xty, whole.xty, rtol=1e-12)
+assert mine.counts() == whole.counts()
+assert mine.slots == whole.slots              # the concatenation, in file order
+
+# (b) ONE long stream shared by time range (distributed.TimeShardPlan): piece = range + halo,
+#     edge windows from the piece whose range touches that end, recordings shared by two ranks
+#     land in the same slot.
+tplan = distributed.TimeShardPlan(lens, world, halo=pre + post + 1, batch_size=batch)
+shard = host_device.LagStats(4, pre, post, d=2)
+distributed.accumulate_time_shard(
+    shard, tplan, rank, lambda f, a, b: (h.to_device(files[f][0][a:b]), None,
+                                         h.to_device(files[f][2][a:b])))
+assert shard.counts()[0] == tplan.frames_of(rank)
+distributed.allreduce_stats(shard, tplan, rank, total_frames=tplan.total_frames)
+ref = host_device.LagStats(4, pre, post, d=2)
+ref.accumulate(np.concatenate([f[0] for f in files]), None, np.concatenate([f[2] for f in files]),
+               np.concatenate(([0], np.cumsum(lens))), rows_used=tplan.rows_used)
+np.testing.assert_allclose(shard.xtx, ref.xtx, rtol=1e-11, atol=1e-9)
+np.testing.assert_allclose(shard.xty, ref.xty, rtol=1e-11, atol=1e-9)
+assert shard.counts()[0] == sum(tplan.rows_used)
+# every recording's head and tail window was contributed exactly once, its rows add up
+np.testing.assert_array_equal(np.asarray(shard.slots)[:, :2], np.ones((len(lens), 2)))
+np.testing.assert_array_equal(np.asarray(shard.slots)[:, 2], tplan.rows_used)
+
+# (c) the leave-one-out x lambda sweep on two ranks (regression.py: table all-reduce, unpack of
+#     the other rank's rows, folds round-robin, gather_rows) equals the one-rank sweep.
+ds = brain_data.Dataset(files, batch, pre, post, input_offset=2)
+lams = [1e-3, 0.1, 10.0]
+two = regression.jackknife_over_regularizations(ds, lams, rank=rank, world_size=world,
+                                                device=host_device)
+solo = [dist.new_group([r]) for r in range(world)][rank]     # a group of this process alone
+one = regression.jackknife_over_regularizations(ds, lams, rank=0, world_size=1, group=solo,
+                                                device=host_device)
+np.testing.assert_allclose(two['all_runs'], one['all_runs'], rtol=0, atol=1e-9)
+for lam in lams:
+  np.testing.assert_allclose(two[lam], one[lam], rtol=0, atol=1e-9)
 dist.barrier()
 dist.destroy_process_group()
 print('rank %%d ok' %% rank)
@@ -231,6 +322,9 @@ print('rank %%d ok' %% rank)
 
 
 def test_two_process_gloo_allreduce_protocol(tmp_path):
+  """The product's multi-rank code paths under gloo with world_size 2: allreduce_stats over
+  file shards and over time-range shards (slot layout, total_frames, edge-window ownership)
+  and jackknife_over_regularizations(world_size=2), with the NumPy stand-in as device layer."""
   script = tmp_path / 'worker.py'
   script.write_text(_WORKER % {'root': ROOT})
   env = dict(os.environ)
