@@ -1,28 +1,42 @@
 """Benchmark of the linear auditory-attention-decoding hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One "step" = one complete ridge TRF fit of BASELINE.json's config[1] ("C2") on
-this rank's recordings: lagged-covariance accumulate (64 ch x 32 lags, never
-materialising the lag matrix) -> [N > 1: one RCCL all-reduce of the packed
-statistics] -> edge-exact expansion -> float64 Cholesky solve -> W, b.  Inputs are
-resident in HBM before the timed region.  Weak scaling: every GPU holds its own
-1e6 samples (10 recordings x 100 000 frames), `value` is the whole-job samples/s.
+One "step" = one complete ridge TRF fit of BASELINE.json's config[1] ("C2"): lagged-covariance
+accumulate (64 ch x 32 lags, never materialising the lag matrix) -> [N > 1: one RCCL all-reduce
+of the packed statistics] -> edge-exact expansion -> float64 Cholesky solve -> W, b.  Inputs
+are resident in HBM before the timed region.
 
-Consecutive fits are independent (the reference refits from scratch per fold /
-lambda / subject), so by default they are software-pipelined on two HIP streams
+  --scaling weak   (default) every GPU holds its own 1e6 samples (10 recordings x 100 000
+                   frames); `value` is the whole-job samples/s.
+  --scaling strong ONE 1e6-sample job (the same 10 recordings) is cut into N time ranges
+                   (distributed.TimeShardPlan: range + halo per rank, one all-reduce, fit i
+                   solved by rank i mod N); `value` is 1e6 x fits / time.  The JSON also
+                   carries the accumulate-only time per rank (north_star's strong-scaling
+                   target is on the covariance accumulate).
+At N > 1 the default (weak) run appends a short strong-scaling leg after the timed region
+(`"strong": {...}`), so one driver run per N measures both.
+
+Consecutive fits are independent (the reference refits from scratch per fold / lambda /
+subject), so by default they are software-pipelined on two HIP streams
 (pipeline.FitPipeline): the latency-bound solve of fit i runs underneath the
-throughput-bound accumulate of fit i + 1.  All K fits, solves included, complete
-inside the timed region.  --serial runs them back to back on one stream.
+throughput-bound accumulate of fit i + 1.  All K fits, solves included, complete inside the
+timed region.  --serial runs them back to back on one stream; the serial figure is also
+measured after the timed region and reported as `serial_ms_per_step`.
 
 The JSON line also carries
-  roofline      the dominant kernel (lagcov MFMA accumulate) timed live with
-                hipEvents on the stream it runs on (td_profile_*),
-  cpu_baseline  the NumPy restatement of the reference algorithm (oracle/) timed
-                on this host on a bounded slice of the same workload (rank 0, N=1),
-  decode        windows/s of the two-speaker decode (config C4), informational,
-  cca, loso     configs C3 (CCA accumulate + transform) and C5 (LOSO x lambda sweep on one
-                GPU), informational (N = 1; --no-extra skips them).
+  roofline      the dominant kernel (lagcov MFMA accumulate) timed live with hipEvents on the
+                stream it runs on (td_profile_*); `traffic` is the HBM bytes per launch from
+                this round's rocprofv3 PMC pass (profiles/, `traffic_source` says which),
+  cpu_baseline  the NumPy restatement of the reference algorithm (oracle/) timed on this host
+                on a bounded slice of the same workload (rank 0, N = 1): all cores, one thread
+                and the best of a thread sweep, with the BLAS the host runs,
+  decode        windows/s of the two-speaker decode (config C4), hipEvent-timed over >= 100
+                iterations, its HBM roofline, decision flips against the oracle, and the
+                reference harness' window sizes with hop = W // 2 (infer.py:376-378),
+  cca, loso     configs C3 (CCA fit = accumulate + device solve, and transform; also at the
+                codelab's shape K1 = 2553) and C5 (LOSO x lambda sweep on one GPU)
+                (N = 1; --no-extra skips them).
 """
 import argparse
 import json
@@ -38,46 +52,75 @@ sys.path.insert(0, ROOT)
 C, PRE, POST, D, LAMBDA = 64, 0, 31, 1, 0.1
 FILES_PER_GPU, FRAMES_PER_FILE = 10, 100000
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, dense f32 matrix peak
+PEAK_HBM_GBPS = 8000.0
 
 
-def make_workload(rank):
+def make_workload(seed_rank):
   from telluride_decoding_amd import synth
-  trials = synth.make_trials(2 + 1000 * rank, FILES_PER_GPU, FRAMES_PER_FILE, C)
+  trials = synth.make_trials(2 + 1000 * seed_rank, FILES_PER_GPU, FRAMES_PER_FILE, C)
   eeg = np.concatenate([t[0] for t in trials])
   env = np.concatenate([t[1][:, 0:1] for t in trials])      # attended speaker is 1
   offs = np.arange(FILES_PER_GPU + 1, dtype=np.int64) * FRAMES_PER_FILE
   return eeg, env, offs
 
 
-def cpu_baseline(eeg, env):
+def blas_info():
+  try:
+    import threadpoolctl
+    return [{k: d.get(k) for k in ('internal_api', 'version', 'num_threads', 'threading_layer')}
+            for d in threadpoolctl.threadpool_info() if d.get('user_api') == 'blas']
+  except Exception as e:       # pragma: no cover
+    return [{'error': str(e)}]
+
+
+def _fit_rate_cpu(eeg, env, n):
   """Reference algorithm (materialised lag matrix, per-minibatch x.T @ x, float32,
-  np.linalg.solve; brain_model.py:422-481) on a 40 000-frame slice, batch 1000."""
+  np.linalg.solve; brain_model.py:422-481) on the first n frames, batch 1000: projected
+  samples/s of the whole 1e6-frame fit (the accumulate is linear in the frames)."""
   from oracle import lag as o_lag
   from oracle import regression as o_reg
-  n = 40000
   files = [(eeg[:n], env[:n], env[:n], np.zeros((n, 1), np.float32))]
   t0 = time.perf_counter()
   batches = list(o_lag.minibatches(files, 1000, pre=PRE, post=POST))
+  _, _, cov_x, cov_xy, _ = o_reg.linear_regressor_from_batches(batches, lamb=LAMBDA)
   t1 = time.perf_counter()
-  w, b, cov_x, cov_xy, _ = o_reg.linear_regressor_from_batches(batches, lamb=LAMBDA)
-  t2 = time.perf_counter()
   np.linalg.solve(cov_x, cov_xy)
-  t3 = time.perf_counter()
-  t_solve = t3 - t2
-  t_acc = (t2 - t0) - t_solve                 # lag matrix + accumulate, linear in frames
+  t_solve = time.perf_counter() - t1
   full = FILES_PER_GPU * FRAMES_PER_FILE
-  projected = t_acc * full / n + t_solve
+  t_acc = (t1 - t0) - t_solve
+  return full / (t_acc * full / n + t_solve), t_acc, t_solve
+
+
+def cpu_baseline(eeg, env):
+  """All cores (the library default), one thread, and the best of a thread sweep."""
+  import threadpoolctl
+  cores = os.cpu_count()
+  info = blas_info()
+  n = 20000
+  _fit_rate_cpu(eeg, env, 4000)                         # page in BLAS
+  all_rate, t_acc, t_solve = _fit_rate_cpu(eeg, env, n)
+  sweep = {}
+  for threads in sorted(set([1, 4, 8, 16, 32, 64, 128]) & set(range(1, cores + 1))):
+    with threadpoolctl.threadpool_limits(limits=threads, user_api='blas'):
+      sweep[threads] = _fit_rate_cpu(eeg, env, n if threads > 2 else n // 4)[0]
+  best = max(sweep, key=sweep.get)
+  value = max(all_rate, sweep[best])
   return {
-      'value': full / projected, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
-      'sample': ('oracle (NumPy/OpenBLAS restatement of brain_model.py:422-481) on the first '
-                 '%d frames, batch 1000, float32: lag matrix %.2f s + accumulate %.2f s '
-                 '(both scaled x%d to 1e6 frames) + one %dx%d solve %.2f s'
-                 % (n, t1 - t0, t_acc - (t1 - t0), full // n, C * (POST + 1) + 1,
-                    C * (POST + 1) + 1, t_solve)),
+      'value': value, 'unit': 'samples/s', 'cores': best if sweep[best] >= all_rate else cores,
+      'kind': 'port',
+      'sample': ('oracle (NumPy restatement of brain_model.py:422-481) on the first %d frames, '
+                 'batch 1000, float32, scaled to the 1e6-frame fit + one %d x %d solve; best of '
+                 'the thread sweep' % (n, C * (POST + 1) + 1, C * (POST + 1) + 1)),
+      'all_cores': {'threads': cores, 'samples_per_s': all_rate, 'accumulate_s_on_slice': t_acc,
+                    'solve_s': t_solve},
+      'omp1': {'threads': 1, 'samples_per_s': sweep.get(1)},
+      'best_of_thread_sweep': {'threads': best, 'samples_per_s': sweep[best]},
+      'thread_sweep': {str(k): v for k, v in sweep.items()},
+      'host_cores': cores, 'blas': info,
   }
 
 
-def decode_leg(h, device):
+def decode_leg(h, device, iters=200):
   """Config C4: 200 trials x 6000 frames x 64 ch, two envelopes, 10 s windows
   (W = 1000) every 1 s (hop = 100): raw EEG -> decisions with td_decode_fused."""
   from telluride_decoding_amd import synth
@@ -99,63 +142,91 @@ def decode_leg(h, device):
   for spk in (0, 1):
     s = device.window_sums(envd[:, spk:spk + 1], pred, [0, n], n, n, handle=h).cpu().numpy()[0, 0]
     corr += [s[0] / n, s[1] / n, np.sqrt((s[2] - s[0] ** 2 / n) * (s[3] - s[1] ** 2 / n)) / n]
-  for _ in range(2):
-    scores, dec = device.decode_fused(xd, envd, offs, w, b, PRE, POST, 1000, 100, corr, handle=h)
-  reps = 5
-  h.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(reps):
-    scores, dec = device.decode_fused(xd, envd, offs, w, b, PRE, POST, 1000, 100, corr, handle=h)
-  h.synchronize()
-  dt = (time.perf_counter() - t0) / reps
+
+  def timed(width, hop):
+    for _ in range(3):
+      out = device.decode_fused(xd, envd, offs, w, b, PRE, POST, width, hop, corr, handle=h)
+    h.synchronize()
+    h.timer_start()                                      # hipEvents on the launching stream
+    for _ in range(iters):
+      out = device.decode_fused(xd, envd, offs, w, b, PRE, POST, width, hop, corr, handle=h)
+    return h.timer_stop() / iters, out
+
+  ms, (scores, dec) = timed(1000, 100)
   n_win = int(dec.shape[0])
   labels = device.window_means(h.to_device(att.astype(np.float64), np.float64).reshape(-1), offs,
                                1000, 100, handle=h).cpu().numpy()
   dec = dec.cpu().numpy()
+  scores = scores.cpu().numpy()
   clear = (labels < 0.05) | (labels > 0.95)
   acc = float(np.mean((dec[clear] == 1) == (labels[clear] < 0.5)))
-  # CPU: the reference's per-frame correlation + Python window loop + WTA on 4 trials
+  # CPU: the reference's per-frame correlation + Python window loop + WTA on the 20 DISTINCT
+  # trials (the other 180 are copies): decision flips of the device against the oracle
   from oracle import attention as o_att
   from oracle import correlator as o_cor
   from oracle import lag as o_lag
   from oracle import regression as o_reg
-  wn, bn = w.cpu().numpy(), b.cpu().numpy()
+  wn, bn = w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
   t0 = time.perf_counter()
-  cpu_win = 0
-  for t in trials[:4]:
-    p = o_reg.dense_forward(o_lag.lag_matrix(t[0], PRE, POST), wn, bn)
+  flips = cpu_win = 0
+  margins, acc_o = [], []
+  for ti, t in enumerate(base):
+    p = o_reg.dense_forward(o_lag.lag_matrix(t[0].astype(np.float64), PRE, POST), wn, bn)
     sc = []
     for spk in (0, 1):
       cor = o_cor.Correlator()
       cor.mean_x, cor.mean_y, cor.power = corr[3 * spk], corr[3 * spk + 1], corr[3 * spk + 2]
-      sc.append(o_cor.windowed_means(cor.correlate(t[1][:, spk:spk + 1], p), t[2], 1000, 100)[0])
-    cpu_win += len(o_att.wta_sequence(sc[0], sc[1]))
+      sc.append(o_cor.windowed_means(cor.correlate(t[1][:, spk:spk + 1].astype(np.float64), p),
+                                     t[2], 1000, 100)[0])
+    truth = o_att.wta_sequence(sc[0], sc[1])
+    got = dec[ti * len(truth):(ti + 1) * len(truth)]
+    flips += int(np.sum(got != truth))
+    cpu_win += len(truth)
+    margins.append(np.min(np.abs(sc[0] - sc[1])))
+    lab = labels[ti * len(truth):(ti + 1) * len(truth)]
+    ok = (lab < 0.05) | (lab > 0.95)
+    acc_o.append(np.mean((truth[ok] == 1) == (lab[ok] < 0.5)))
   cpu_dt = time.perf_counter() - t0
+  # the reference harness: W in {100, 200, 400, 700, 1000} with hop = W // 2 (infer.py:376-378;
+  # its W = 10 has gcd(W, hop) = 5 < 32 frames and takes the one-workgroup-per-window path)
+  native = {}
+  for width in (100, 200, 400, 700, 1000):
+    ms_w, (_, d_w) = timed(width, width // 2)
+    native['W%d' % width] = {'hop': width // 2, 'windows': int(d_w.shape[0]), 'ms': ms_w,
+                             'windows_per_s': int(d_w.shape[0]) / ms_w * 1e3,
+                             'hbm_frac': n * 4 * (C + 2) / (ms_w * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+  gbps = n * 4 * (C + 2) / (ms * 1e-3) / 1e9
   return {
       'workload': 'C4: 200 trials x 60 s x 64 ch, two envelopes, W=1000/hop=100 (10 s / 1 s)',
-      'windows': n_win, 'ms': dt * 1e3, 'windows_per_s': n_win / dt,
-      'algorithmic_bytes': int(n) * 4 * (C + 2),
-      'hbm_gbps_algorithmic': n * 4 * (C + 2) / dt / 1e9,
-      'roofline': {'bound': 'hbm', 'achieved': n * 4 * (C + 2) / dt / 1e9, 'peak': 8000.0,
-                   'unit': 'GB/s', 'frac': n * 4 * (C + 2) / dt / 8e12},
+      'windows': n_win, 'ms': ms, 'windows_per_s': n_win / ms * 1e3,
+      'timing': 'hipEvents around %d back-to-back td_decode_fused calls' % iters,
+      'algorithmic_bytes': int(n) * 4 * (C + 2), 'hbm_gbps_algorithmic': gbps,
+      'roofline': {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                   'frac': gbps / PEAK_HBM_GBPS},
       'wta_accuracy_clear_windows': acc,
+      'oracle_accuracy_clear_windows': float(np.mean(acc_o)),
+      'decision_flips_vs_oracle': flips, 'decisions_checked': cpu_win,
+      'min_margin_checked': float(np.min(margins)),
+      'accuracy_delta_vs_oracle': float(flips) / max(cpu_win, 1),
+      'reference_harness_hop_half_window': native,
       'cpu_baseline_windows_per_s': cpu_win / cpu_dt,
-      'cpu_sample': 'oracle on 4 trials (%d windows), %d cores' % (cpu_win, os.cpu_count()),
+      'cpu_sample': 'oracle on the 20 distinct trials (%d windows), NumPy default threads on %d cores'
+                    % (cpu_win, os.cpu_count()),
   }
 
 
 def cca_leg(h, device, eeg):
-  """Config C3: 64-ch EEG vs an 8-band envelope, 1e6 samples, no context: the moments of the CCA
-  fit (one-pass Gram kernel) and the transform of both streams onto 5 components."""
-  import torch
+  """Config C3: 64-ch EEG vs an 8-band envelope, 1e6 samples, no context: CCA fit =
+  accumulate (one-pass Gram kernel) + the dense stage on the device (td_cca_solve), and the
+  transform onto 5 components; plus the fit at the codelab's shape (69 ch x 37 lags = 2553
+  vs 31 lags of one envelope, doc/DecodingCodelab.md:709-713)."""
+  from telluride_decoding_amd import brain_data, cca
   n = eeg.shape[0]
   rng = np.random.default_rng(3)
   bands = (eeg[:, :8] * 0.5 + rng.standard_normal((n, 8))).astype(np.float32)
   x, x2 = h.to_device(eeg), h.to_device(bands)
   offs = np.array([0, n], np.int64)
   st = device.LagStats(C, 0, 0, 8, 0, 0, 0, handle=h)
-  mean1 = torch.zeros(C, device=x.device); mean2 = torch.zeros(8, device=x.device)
-  rot1 = torch.randn(C, 5, device=x.device); rot2 = torch.randn(8, 5, device=x.device)
 
   def timed(fn, reps=10):
     fn(); h.synchronize()
@@ -170,14 +241,36 @@ def cca_leg(h, device, eeg):
     st.accumulate(x, x2, None, offs)
 
   t_acc = timed(acc)
-  t_tr = timed(lambda: device.cca_transform(x, x2, offs, mean1, rot1, mean2, rot2, 0, 0, 0, 0,
+  t_solve = timed(lambda: st.cca_solve(n - 1, 0.1, 5))
+  rot_x, rot_y, mean_x, mean_y, e, _ = st.cca_solve(n - 1, 0.1, 5)
+  t_tr = timed(lambda: device.cca_transform(x, x2, offs, mean_x, rot_x, mean_y, rot_y, 0, 0, 0, 0,
                                             handle=h))
+  # codelab shape on 200k samples
+  m = 200000
+  xc = h.to_device(np.concatenate((eeg[:m], eeg[:m, :5]), axis=1))
+  yc = h.to_device(bands[:m, :1])
+  st2 = device.LagStats(69, 0, 36, 1, 15, 15, 0, handle=h)
+
+  def acc2():
+    st2.reset()
+    st2.accumulate(xc, yc, None, [0, m])
+
+  t_acc2 = timed(acc2, 3)
+  t_solve2 = timed(lambda: st2.cca_solve(m - 1, 0.1, 5), 2)
+  sweeps = st2.cca_solve(m - 1, 0.1, 5)[5]
   return {
       'workload': 'C3: CCA, 64-ch EEG vs 8-band envelope, 1e6 samples, no context, 5 components',
-      'accumulate_ms': t_acc * 1e3, 'transform_ms': t_tr * 1e3,
+      'fit_ms': (t_acc + t_solve) * 1e3, 'accumulate_ms': t_acc * 1e3,
+      'solve_ms': t_solve * 1e3, 'transform_ms': t_tr * 1e3,
       'accumulate_hbm_gbps_algorithmic': n * 4 * 72 / t_acc / 1e9,
       'transform_hbm_gbps_algorithmic': n * 4 * (72 + 10) / t_tr / 1e9,
-      'note': 'the 64x64 / 8x8 eig + SVD stage runs on the host (LAPACK) like the reference',
+      'first_canonical_correlations': [float(v) for v in e.cpu().numpy()],
+      'codelab_shape': {
+          'workload': 'K1 = 69 ch x 37 lags = 2553, K2 = 31 lags of one envelope, 200k samples',
+          'fit_ms': (t_acc2 + t_solve2) * 1e3, 'accumulate_ms': t_acc2 * 1e3,
+          'solve_ms': t_solve2 * 1e3, 'jacobi_sweeps_eig_xx_yy_svd': list(sweeps)},
+      'note': 'the dense stage (eig x 2, whitening, SVD) runs on the device in float64 '
+              '(td_cca_solve: block Jacobi with MFMA updates)',
   }
 
 
@@ -202,14 +295,16 @@ def loso_leg(eeg, env):
       'workload': 'C5: LOSO x 20 lambdas, 32 subjects x 31 250 samples x 64 ch, 32 lags, one GPU',
       'seconds': best, 'fits': n_subj * len(lams), 'fits_per_s': n_subj * len(lams) / best,
       'best_lambda': float(top[1]), 'best_mean_r': float(top[0]),
+      'includes': 'host->device upload of the recordings (256 MB)',
   }
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
   ap.add_argument('--no-decode', action='store_true', help='skip the informational decode leg')
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
   ap.add_argument('--no-extra', action='store_true', help='skip the C3 / C5 legs')
@@ -242,12 +337,10 @@ def main():
     else:
       dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-  from telluride_decoding_amd import device, distributed
+  from telluride_decoding_amd import device, distributed, pipeline
   h = device.default_handle()
-  eeg, env, offs = make_workload(rank)
-  x, y = h.to_device(eeg), h.to_device(env)
-  plan = distributed.ShardPlan([FRAMES_PER_FILE] * (FILES_PER_GPU * world), world)
   lam = [LAMBDA]
+  full = FILES_PER_GPU * FRAMES_PER_FILE
 
   def barrier():
     torch.cuda.synchronize()
@@ -255,102 +348,193 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
-  if args.serial:
-    st = device.LagStats(C, PRE, POST, d=D, handle=h)
-    h_prof = h
+  def time_region(run, steps, warmup):
+    """The contract's timed region: warmup, barrier + sync, K steps, barrier + sync, MAX over
+    ranks."""
+    out = run(warmup) if warmup > 0 else None
+    barrier()
+    t0 = time.perf_counter()
+    out = run(steps) or out
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+      t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      elapsed = float(t.item())
+    return elapsed, out
+
+  # ---------------------------------------------------------------- the two sharding modes
+  def weak_setup():
+    eeg, env, offs = make_workload(rank)
+    x, y = h.to_device(eeg), h.to_device(env)
+    plan = distributed.ShardPlan([FRAMES_PER_FILE] * (FILES_PER_GPU * world), world)
+    kw = {}
+    reduce_fn = (lambda s, hs: distributed.allreduce_stats(
+        s, plan, rank, total_frames=sum(plan.file_lengths), handle=hs)) if dist_on else None
+    return (eeg, env), (x, y, offs, kw), reduce_fn, None, full * world
+
+  def strong_setup():
+    eeg, env, offs = make_workload(0)                    # the SAME job on every rank
+    hw = PRE + POST + 1
+    plan = distributed.TimeShardPlan([FRAMES_PER_FILE] * FILES_PER_GPU, world, halo=hw)
+    pieces = plan.pieces_of(rank)
+    xs = np.concatenate([eeg[offs[f] + a:offs[f] + b] for f, a, b, *_ in pieces])
+    ys = np.concatenate([env[offs[f] + a:offs[f] + b] for f, a, b, *_ in pieces])
+    loc = np.concatenate(([0], np.cumsum([b - a for _, a, b, *_ in pieces]))).astype(np.int64)
+    kw = dict(rows_used=[p[6] for p in pieces], ranges=[(p[3], p[4]) for p in pieces],
+              edges=[p[5] for p in pieces])
+    x, y = h.to_device(xs), h.to_device(ys)
+    reduce_fn = (lambda s, hs: distributed.allreduce_stats(
+        s, plan, rank, total_frames=plan.total_frames, handle=hs)) if dist_on else None
+    solves = (lambda i: i % world == rank) if world > 1 else None
+    return (eeg, env), (x, y, loc, kw), reduce_fn, solves, full
+
+  def make_runner(shard, reduce_fn, solves, serial):
+    x, y, offs, kw = shard
+    if serial:
+      st = device.LagStats(C, PRE, POST, d=D, handle=h)
+
+      def run(k):
+        out = None
+        for i in range(k):
+          st.reset()
+          st.accumulate(x, None, y, offs, **kw)
+          if reduce_fn is not None:
+            reduce_fn(st, None)
+          if solves is None or solves(i):
+            out = st.ridge_solve(lam)
+        return out
+      return run, h, None
+    pipe = pipeline.FitPipeline(C, PRE, POST, d=D, solve_cus=args.solve_cus,
+                                targets_on_solve=not args.targets_on_acc, allreduce=reduce_fn,
+                                solves=solves)
 
     def run(k):
       out = None
       for _ in range(k):
-        st.reset()
-        st.accumulate(x, None, y, offs)
-        if dist_on:
-          distributed.allreduce_stats(st, plan, rank)
-        out = st.ridge_solve(lam)
-      return out
-  else:
-    from telluride_decoding_amd import pipeline
-    pipe = pipeline.FitPipeline(
-        C, PRE, POST, d=D, solve_cus=args.solve_cus, targets_on_solve=not args.targets_on_acc,
-        allreduce=(lambda s, hs: distributed.allreduce_stats(
-            s, plan, rank, total_frames=sum(plan.file_lengths), handle=hs)) if dist_on else None)
-    h_prof = pipe.h_acc
-
-    def run(k):
-      out = None
-      for _ in range(k):
-        r = pipe.submit(x, y, offs, lam)
+        r = pipe.submit(x, y, offs, lam, **kw)
         out = r if r is not None else out
-      rest = pipe.flush()                   # every fit is solved before the clock stops
-      return rest[-1] if rest else out
+      for r in pipe.flush():                # every fit is solved before the clock stops
+        out = r if r is not None else out
+      return out
+    return run, pipe.h_acc, pipe
 
-  w, b = run(args.warmup) if args.warmup > 0 else (None, None)
+  host_data, shard, reduce_fn, solves, samples_per_step = (
+      strong_setup() if args.scaling == 'strong' else weak_setup())
+  run, h_prof, pipe = make_runner(shard, reduce_fn, solves, args.serial)
+  if args.warmup > 0:
+    run(args.warmup)
   h_prof.profile_enable(True)
-  barrier()
-  t0 = time.perf_counter()
-  w, b = run(args.steps)
-  barrier()
-  elapsed = time.perf_counter() - t0
+  elapsed, out = time_region(run, args.steps, 0)
   launches, kernel_ms, kernel_samples = h_prof.profile_read()
   h_prof.profile_enable(False)
-  if dist_on:
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-  assert bool(torch.isfinite(w).all()), 'non-finite TRF weights'
+  if out is not None:
+    assert bool(torch.isfinite(out[0]).all()), 'non-finite TRF weights'
 
+  line = None
   if rank == 0:
-    samples_per_step = FILES_PER_GPU * FRAMES_PER_FILE * world
     value = samples_per_step * args.steps / elapsed
     k = C * (PRE + 1 + POST)
     flops_per_launch = 2.0 * C * k * (kernel_samples / max(launches, 1))
     avg_s = kernel_ms / max(launches, 1) / 1e3
     achieved = flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_lagcov_pmc.json')
-    if os.path.exists(pmc):
-      with open(pmc) as f:
-        traffic = json.load(f).get('hbm_bytes_per_launch')
+    traffic, traffic_source = None, None
+    for name in ('r02_lagcov_pmc.json', 'r01_lagcov_pmc.json'):
+      pmc = os.path.join(ROOT, 'profiles', name)
+      if os.path.exists(pmc) and args.scaling == 'weak':
+        with open(pmc) as f:
+          traffic = json.load(f).get('hbm_bytes_per_launch')
+        traffic_source = ('profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over the same '
+                          'kernel and launch shape (a separate run; not measured in this one)' % name)
+        break
     line = {
         'metric': 'TRF-fit samples/sec', 'value': value, 'unit': 'samples/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {
-            'workload': ('C2: 64-ch x 1e6-sample ridge TRF fit per GPU (10 recordings x 100k '
-                         'frames), 32 lags (K = 2048 + bias), lambda = 0.1, D = 1: lagged-'
-                         'covariance MFMA accumulate + float64 Cholesky solve'),
-            'samples_per_gpu': FILES_PER_GPU * FRAMES_PER_FILE, 'channels': C, 'lags': POST + 1,
-            'parallelism': ('recordings sharded over %d GPU(s), one all-reduce of the packed '
-                            'statistics' % world) if world > 1 else 'single GPU',
+            'workload': ('C2: 64-ch x 1e6-sample ridge TRF fit%s (10 recordings x 100k frames), '
+                         '32 lags (K = 2048 + bias), lambda = 0.1, D = 1: lagged-covariance MFMA '
+                         'accumulate + float64 Cholesky solve'
+                         % (' per GPU' if args.scaling == 'weak' else ', ONE job shared by all GPUs')),
+            'samples_per_step': samples_per_step, 'channels': C, 'lags': POST + 1,
+            'parallelism': ('single GPU' if world == 1 else
+                            ('recordings dealt to %d GPUs' % world if args.scaling == 'weak' else
+                             'time ranges (+ halo) over %d GPUs, fit i solved by rank i mod N' % world)
+                            + ', one all-reduce of the packed statistics per fit'),
             'pipelining': 'serial' if args.serial else 'accumulate(i+1) || solve(i) on two HIP streams',
         },
         'roofline': {
             'kernel': 'lagcov_mfma_kernel', 'bound': 'mfma', 'achieved': achieved,
             'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+            'traffic_source': traffic_source,
             'launches': launches, 'avg_launch_ms': kernel_ms / max(launches, 1),
             'algorithmic_flops_per_launch': flops_per_launch,
+            'algorithmic_bytes_per_launch': 4.0 * (C + D) * (kernel_samples / max(launches, 1)),
         },
     }
     if not args.serial:
-      # the same kernel alone on the whole chip (the pipelined region gives it 224 of the 256
-      # CUs and runs the solve beside it): 5 launches after the timed region, informational
       line['roofline']['cus'] = '%d of 256 (CU-masked accumulate stream)' % (256 - args.solve_cus) \
           if args.solve_cus else '256'
-      st1 = device.LagStats(C, PRE, POST, d=D, handle=h)
-      st1.accumulate(x, None, y, offs)
-      h.profile_enable(True)
-      for _ in range(5):
-        st1.reset()
-        st1.accumulate(x, None, y, offs)
-      l1, ms1, smp1 = h.profile_read()
-      h.profile_enable(False)
+
+  # ---------------------------------------------------------------- after the timed region
+  del pipe, run
+  torch.cuda.synchronize()
+  if not args.serial:
+    # the same fits back to back on one stream, and the dominant kernel alone on the whole chip
+    run_s, _, _ = make_runner(shard, reduce_fn, solves, True)
+    run_s(2)
+    h.profile_enable(True)
+    e_s, _ = time_region(run_s, 10, 0)
+    l1, ms1, smp1 = h.profile_read()
+    h.profile_enable(False)
+    if rank == 0:
+      k = C * (PRE + 1 + POST)
       a1 = 2.0 * C * k * (smp1 / max(l1, 1)) / (ms1 / max(l1, 1) / 1e3) / 1e12
+      line['serial_ms_per_step'] = e_s / 10 * 1e3
       line['roofline_whole_chip'] = {'kernel': 'lagcov_mfma_kernel', 'achieved': a1,
                                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                      'frac': a1 / PEAK_F32_MFMA_TFLOPS, 'launches': l1,
                                      'avg_launch_ms': ms1 / max(l1, 1)}
+    del run_s
+
+  def accumulate_only(shard_, steps=20):
+    """Covariance accumulate alone (no exchange, no solve) on this rank's shard."""
+    x, y, offs, kw = shard_
+    st = device.LagStats(C, PRE, POST, d=D, handle=h)
+
+    def run_a(kk):
+      for _ in range(kk):
+        st.reset()
+        st.accumulate(x, None, y, offs, **kw)
+    run_a(2)
+    e_a, _ = time_region(run_a, steps, 0)
+    return e_a / steps * 1e3
+
+  acc_ms = accumulate_only(shard)
+  if rank == 0:
+    line['accumulate_only_ms_per_step'] = acc_ms
+  if world > 1 and args.scaling == 'weak':
+    # informational strong-scaling leg: the ONE-GPU job cut into N time ranges
+    _, shard2, reduce2, solves2, _ = strong_setup()
+    run2, _, pipe2 = make_runner(shard2, reduce2, solves2, False)
+    run2(3)
+    e2, _ = time_region(run2, 50, 0)
+    del pipe2, run2
+    torch.cuda.synchronize()
+    acc2 = accumulate_only(shard2)
+    if rank == 0:
+      line['strong'] = {
+          'workload': 'the single-GPU job (1e6 samples) cut into %d time ranges + halo' % world,
+          'fit_ms_per_step': e2 / 50 * 1e3, 'samples_per_s': full * 50 / e2,
+          'accumulate_only_ms_per_step': acc2,
+          'note': 'divide the N = 1 run\'s accumulate_only_ms_per_step / ms_per_step by these for '
+                  'the strong-scaling speed-up',
+      }
+
+  if rank == 0:
+    eeg, env = host_data
     if world == 1 and not args.no_cpu:
       line['cpu_baseline'] = cpu_baseline(eeg, env)
     if world == 1 and not args.no_decode:

@@ -203,6 +203,16 @@ int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_
 int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
                          float* w_dev, float* b_dev, const int** singular_flag_host);
 
+/* Several statistics x several lambdas in one batched factorisation: the folds of a
+ * leave-one-file-out sweep (regression.jackknife_one_model / jackknife_over_regularizations,
+ * regression.py:151-242, 326-420, refit per (lambda, fold)).  stats_host[n_stats] share one
+ * layout.  w_dev [n_stats, n_lambda, k1, d], b_dev [n_stats, n_lambda, d] float32.
+ * singular_flag_host NULL: synchronous, TD_ERR_SINGULAR if any system is not positive definite;
+ * else as td_ridge_solve_async (one flag for the whole batch). */
+int td_ridge_solve_multi(td_handle* h, td_stats* const* stats_host, int n_stats,
+                         const double* lambdas_host, int n_lambda, float* w_dev, float* b_dev,
+                         const int** singular_flag_host);
+
 /* Generic SPD solve used by the above and by the shrinkage branch
  * (brain_model.py:456-477): a_dev [batch, n, n] float64 (destroyed),
  * rhs_dev [batch, n, nrhs] float64 (overwritten with the solution). */

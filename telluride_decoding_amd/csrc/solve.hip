@@ -729,6 +729,72 @@ int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_
   return ridge_solve_impl(h, s, lambdas_host, n_lambda, w_dev, b_dev, nullptr);
 }
 
+// Several statistics x several lambdas in ONE batched factorisation (the folds of a
+// leave-one-out sweep, regression.py:151-242): the blocked Cholesky is a chain of ~100 small
+// launches per solve whose late block steps cannot fill the chip with 20 systems; with
+// n_stats * n_lambda systems per launch the same chain serves them all.
+int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
+                         const double* lambdas_host, int n_lambda, float* w_dev, float* b_dev,
+                         const int** singular_flag_host) {
+  if (!h || !stats || !lambdas_host || !w_dev || !b_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_multi: NULL argument");
+  TD_REQUIRE(h, n_stats > 0 && n_lambda > 0, "td_ridge_solve_multi: empty batch");
+  int k1 = 0, d = 0;
+  int64_t frames = 0;
+  td_stats_layout(stats[0], &k1, &d, &frames);
+  TD_REQUIRE(h, d > 0 && d <= kMaxRhs, "td_ridge_solve_multi: outputs per solve must be in [1, %d]",
+             kMaxRhs);
+  for (int i = 0; i < n_stats; ++i) {
+    int ki = 0, di = 0;
+    int64_t fi = 0;
+    TD_REQUIRE(h, stats[i], "td_ridge_solve_multi: NULL statistics");
+    td_stats_layout(stats[i], &ki, &di, &fi);
+    TD_REQUIRE(h, ki == k1 && di == d, "td_ridge_solve_multi: layouts differ");
+    if (fi <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve_multi: no data accumulated");
+  }
+  const int n = k1 + 1;
+  const int np = (int)td_round_up(n, NB);
+  const size_t nn = (size_t)n * n;
+  const int batch = n_stats * n_lambda;
+  const size_t head = td_round_up((int64_t)(sizeof(double) * (nn + (size_t)n * d)), 256);
+  void* base = nullptr;
+  TD_TRY(td_workspace(h, head + carve(nullptr, np, batch).bytes, &base));
+  double* xtx = reinterpret_cast<double*>(base);
+  double* xty = xtx + nn;
+  const SolveWs w = carve(reinterpret_cast<char*>(base) + head, np, batch);
+  TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, w.lams));
+  for (int i = 0; i < n_stats; ++i) {
+    td_stats_layout(stats[i], &k1, &d, &frames);
+    TD_TRY(td_stats_moments(h, stats[i], xtx, xty, nullptr, nullptr, nullptr));
+    const double inv = 1.0 / (double)frames;
+    hipLaunchKernelGGL(pad_matrix_kernel, dim3(512, (unsigned)n_lambda), dim3(256), 0, h->stream, xtx,
+                       0LL, n, np, inv, w.lams, w.a + (size_t)i * n_lambda * np * np);
+    hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)n_lambda), dim3(256), 0, h->stream, xty,
+                       0LL, n, d, np, inv, w.rt + (size_t)i * n_lambda * kMaxRhs * np);
+  }
+  int* flag_dev = nullptr;
+  if (singular_flag_host) {
+    *singular_flag_host = nullptr;
+    if (!h->dev_flags) {
+      TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flags), sizeof(int) * td_handle::kAsyncFlags));
+      TD_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags),
+                              sizeof(int) * td_handle::kAsyncFlags, hipHostMallocDefault));
+    }
+    flag_dev = h->dev_flags + h->async_next;
+  }
+  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, d, batch, flag_dev));
+  hipLaunchKernelGGL(ridge_emit_kernel, dim3(256), dim3(256), 0, h->stream, w.sol, k1, d, np, batch,
+                     w_dev, b_dev);
+  TD_HIP(h, hipGetLastError());
+  if (!singular_flag_host) return spd_check_flag(h);
+  const int slot = h->async_next;
+  h->async_next = (h->async_next + 1) % td_handle::kAsyncFlags;
+  TD_HIP(h, hipMemcpyAsync(h->host_flags + slot, h->dev_flags + slot, sizeof(int),
+                           hipMemcpyDeviceToHost, h->stream));
+  *singular_flag_host = h->host_flags + slot;
+  return TD_OK;
+}
+
 int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
                          float* w_dev, float* b_dev, const int** singular_flag_host) {
   if (!h || !singular_flag_host)

@@ -280,6 +280,26 @@ class LagStats(object):
                                        ctypes.byref(ptr)))
     return w, b, (lambda: int(ptr[0]))
 
+  @staticmethod
+  def ridge_solve_multi(stats_list, lambdas, handle=None, wait=True):
+    """Every (statistics, lambda) pair in ONE batched factorisation (td_ridge_solve_multi):
+    W [n_stats, n_lambda, k1, d], b [n_stats, n_lambda, d] float32 device tensors.  wait=False
+    returns (W, b, flag) like ridge_solve_async."""
+    first = stats_list[0]
+    h = handle or first.h
+    lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
+    w = h.empty((len(stats_list), len(lam), first.k1, first.d), 'float32')
+    b = h.empty((len(stats_list), len(lam), first.d), 'float32')
+    arr = (ctypes.c_void_p * len(stats_list))(*[s.ptr for s in stats_list])
+    if wait:
+      h.check(h.lib.td_ridge_solve_multi(h.ptr, arr, len(stats_list), lam_p, len(lam), _ptr(w),
+                                         _ptr(b), None))
+      return w, b
+    ptr = ctypes.POINTER(ctypes.c_int)()
+    h.check(h.lib.td_ridge_solve_multi(h.ptr, arr, len(stats_list), lam_p, len(lam), _ptr(w),
+                                       _ptr(b), ctypes.byref(ptr)))
+    return w, b, (lambda: int(ptr[0]))
+
   def cca_solve(self, denom, regularization, dim, eps_eig=1e-12, handle=None):
     """CCA dense stage on the device (td_cca_solve; reference cca.py:337-367): returns float32
     device tensors (rot_x [k1, dim], rot_y [k2, dim], mean_x [1, k1], mean_y [1, k2], e [dim])

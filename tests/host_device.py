@@ -141,6 +141,12 @@ class LagStats(object):
     return (torch.from_numpy(np.stack(ws).astype(np.float32)),
             torch.from_numpy(np.stack(bs).astype(np.float32)))
 
+  @staticmethod
+  def ridge_solve_multi(stats_list, lambdas, handle=None, wait=True):
+    ws, bs = zip(*[st.ridge_solve(lambdas) for st in stats_list])
+    w, b = torch.stack(ws), torch.stack(bs)
+    return (w, b) if wait else (w, b, (lambda: 0))
+
   def ridge_solve_async(self, lambdas, handle=None):
     w, b = self.ridge_solve(lambdas)
     return w, b, (lambda: 0)

@@ -751,3 +751,33 @@ def test_time_range_shards_equal_whole_recordings(dev, world):
   w1, b1 = merged.ridge_solve([0.1])
   w0, b0 = whole.ridge_solve([0.1])
   np.testing.assert_allclose(w1.cpu().numpy(), w0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_ridge_solve_multi_equals_single_solves(dev):
+  """td_ridge_solve_multi: (statistics x lambdas) in one batched factorisation gives exactly
+  the weights of the per-statistics solves; a singular member fails the batch."""
+  rng = np.random.default_rng(8)
+  h = dev.default_handle()
+  lams = [1e-3, 0.1, 10.0]
+  sts = []
+  for i in range(4):
+    x = rng.standard_normal((1500 + 100 * i, 12)).astype(np.float32)
+    y = (x[:, :2] * (i + 1) + 0.1 * rng.standard_normal((x.shape[0], 2))).astype(np.float32)
+    st = dev.LagStats(12, 2, 3, d=2)
+    st.accumulate(h.to_device(x), None, h.to_device(y))
+    sts.append(st)
+  w, b = dev.LagStats.ridge_solve_multi(sts, lams)
+  assert tuple(w.shape) == (4, 3, 72, 2) and tuple(b.shape) == (4, 3, 2)
+  for i, st in enumerate(sts):
+    w1, b1 = st.ridge_solve(lams)
+    np.testing.assert_array_equal(w[i].cpu().numpy(), w1.cpu().numpy())
+    np.testing.assert_array_equal(b[i].cpu().numpy(), b1.cpu().numpy())
+  w2, b2, flag = dev.LagStats.ridge_solve_multi(sts, lams, wait=False)
+  h.synchronize()
+  assert flag() == 0
+  np.testing.assert_array_equal(w2.cpu().numpy(), w.cpu().numpy())
+  zero = dev.LagStats(12, 2, 3, d=2)
+  zero.accumulate(h.to_device(np.zeros((500, 12), np.float32)), None,
+                  h.to_device(np.zeros((500, 2), np.float32)))
+  with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
+    dev.LagStats.ridge_solve_multi(sts[:2] + [zero], [0.0])
