@@ -373,6 +373,15 @@ __device__ __forceinline__ UpdTile upd_tile(const CholParams& p, double* a_b, in
 __device__ __forceinline__ void tile_to_regs(f64x2 (&v)[8], const double* __restrict__ g, int ld,
                                              int rows_valid, int tid) {
   const int c = (tid & 31) * 2, r0 = tid >> 5;
+  if (rows_valid == NB) {
+    // full tile (every tile but the right-hand-side rows): no clamps, no masks, 32-bit offsets
+    // -- the update kernel ran 8 VALU instructions per MFMA (PMC), and VALU issue competes
+    // with the matrix pipe
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      v[i] = *reinterpret_cast<const f64x2*>(g + (unsigned)((r0 + 8 * i) * ld + c));
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = r0 + 8 * i;
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tr
         for (int r = 0; r < 4; ++r) {
           const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
           const int rc = row < cur.rows_valid ? row : 0;
-          cold[m][nn][r] = dst[(size_t)rc * n + col];
+          cold[m][nn][r] = dst[(unsigned)(rc * n + col)];
         }
     const int tn = t + stride;
     const bool more = tn < n_tiles;
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
-          if (row < cur.rows_valid) dst[(size_t)row * n + col] = cold[m][nn][r] - acc[m][nn][r];
+          if (row < cur.rows_valid) dst[(unsigned)(row * n + col)] = cold[m][nn][r] - acc[m][nn][r];
         }
     if (!more) break;
     __syncthreads();                  // LDS operands are free for the next tile

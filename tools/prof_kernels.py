@@ -1,12 +1,12 @@
 """Runs only the hot kernels a few times (for rocprofv3 kernel-trace / PMC passes):
-   python tools/prof_kernels.py [fit] [cca] [decode]"""
+   python tools/prof_kernels.py [fit] [cca] [ccasolve] [decode]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from telluride_decoding_amd import device
 
-what = sys.argv[1:] or ['fit', 'cca', 'decode']
+what = sys.argv[1:] or ['fit', 'cca', 'ccasolve', 'decode']
 h = device.default_handle()
 torch.manual_seed(0)
 if 'fit' in what:
@@ -27,6 +27,17 @@ if 'cca' in what:
   for rep in range(3):
     st.reset(); st.accumulate(x, x2, None, offs)
   m = st.moments(want_cca=True)
+  torch.cuda.synchronize()
+if 'ccasolve' in what:
+  # CCA dense stage (td_cca_solve): C3 and a lagged shape that takes the block-Jacobi path
+  n = 200000
+  x = torch.randn(n, 64, device='cuda'); x2 = (x[:, :8] + torch.randn(n, 8, device='cuda')).contiguous()
+  st = device.LagStats(64, 0, 0, 8, 0, 0, 0)
+  st.accumulate(x, x2, None, [0, n])
+  st.cca_solve(n - 1, 0.1, 5)
+  st2 = device.LagStats(64, 0, 7, 8, 1, 1, 0)          # K1 = 512, K2 = 24
+  st2.accumulate(x, x2, None, [0, n])
+  st2.cca_solve(n - 1, 0.1, 5)
   torch.cuda.synchronize()
 if 'decode' in what:
   trials, t, c = 200, 6000, 64
