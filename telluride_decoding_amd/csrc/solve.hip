@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tr
     __syncthreads();
     // loads that fly under the GEMM: the old values of this output tile, the operands of the next
     double* dst = cur.rows_i + (size_t)cur.bj * NB;
+    const bool full = cur.rows_valid == NB;         // every tile but the right-hand-side rows
     double cold[2][2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
-          const int rc = row < cur.rows_valid ? row : 0;
+          const int rc = (full || row < cur.rows_valid) ? row : 0;
           cold[m][nn][r] = dst[(unsigned)(rc * n + col)];
         }
     const int tn = t + stride;
@@ -465,15 +466,28 @@ __global__ __launch_bounds__(256) void chol_update_kernel(CholParams p, int n_tr
     }
     f64x4 acc[2][2];
     gemm_nt_64(xi, xj, wave, lane, acc);
+    if (full) {
+      // (one branch for the tile instead of one exec-masked block per store)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn)
+        for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
-          if (row < cur.rows_valid) dst[(unsigned)(row * n + col)] = cold[m][nn][r] - acc[m][nn][r];
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
+            dst[(unsigned)(row * n + col)] = cold[m][nn][r] - acc[m][nn][r];
+          }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = acc_row(wave, lane, m, r), col = acc_col(wave, lane, nn);
+            if (row < cur.rows_valid) dst[(unsigned)(row * n + col)] = cold[m][nn][r] - acc[m][nn][r];
+          }
+    }
     if (!more) break;
     __syncthreads();                  // LDS operands are free for the next tile
     cur = nxt;

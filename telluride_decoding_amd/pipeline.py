@@ -13,6 +13,26 @@ import numpy as np
 from telluride_decoding_amd import device
 
 
+class _MaskedStreams(object):
+  """Owns the CU-masked HIP streams of a pipeline.  The two handles (and through them every
+  LagStats that queues work on them) hold a reference, so the streams are destroyed only after
+  the last object that could still use them is gone -- not when the pipeline object dies."""
+
+  def __init__(self, ptrs):
+    self.ptrs = list(ptrs)
+
+  def __del__(self):
+    try:
+      from telluride_decoding_amd import _lib
+      import torch
+      torch.cuda.synchronize()
+      for p in self.ptrs:
+        _lib.load().td_stream_destroy(p)
+      self.ptrs = []
+    except Exception:  # interpreter shutdown
+      pass
+
+
 class FitPipeline(object):
   """submit() queues one fit and returns the solution of the fit before the previous one.
 
@@ -70,6 +90,8 @@ class FitPipeline(object):
       self.h_acc = device.Handle()
     with torch.cuda.stream(self.s_solve):
       self.h_solve = device.Handle()
+    owner = _MaskedStreams(self._masked)
+    self.h_acc.keepalive = self.h_solve.keepalive = owner
     # three statistics buffers: with two, accumulate i + 2 has to wait for solve i, and the two
     # stages (2.55 and 2.5 ms) end up waiting for each other's jitter
     self.stats = [device.LagStats(c, pre, post, d=d, handle=self.h_acc) for _ in range(buffers)]
@@ -149,12 +171,6 @@ class FitPipeline(object):
 
   def __del__(self):
     try:
-      from telluride_decoding_amd import _lib
-      self.torch.cuda.synchronize()
-      self.stats = []
-      self.h_acc = self.h_solve = None
-      for p in self._masked:
-        _lib.load().td_stream_destroy(p)
-      self._masked = []
+      self.torch.cuda.synchronize()      # (the streams themselves belong to _MaskedStreams)
     except Exception:  # interpreter shutdown
       pass
