@@ -187,10 +187,10 @@ def decode_leg(h, device, iters=200):
     ok = (lab < 0.05) | (lab > 0.95)
     acc_o.append(np.mean((truth[ok] == 1) == (lab[ok] < 0.5)))
   cpu_dt = time.perf_counter() - t0
-  # the reference harness: W in {100, 200, 400, 700, 1000} with hop = W // 2 (infer.py:376-378;
-  # its W = 10 has gcd(W, hop) = 5 < 32 frames and takes the one-workgroup-per-window path)
+  # the reference harness: W in {10, 100, 200, 400, 700, 1000} with hop = W // 2
+  # (infer.py:376-378; W = 10 shares no block of >= 32 frames: thread-per-window sums)
   native = {}
-  for width in (100, 200, 400, 700, 1000):
+  for width in (10, 100, 200, 400, 700, 1000):
     ms_w, (_, d_w) = timed(width, width // 2)
     native['W%d' % width] = {'hop': width // 2, 'windows': int(d_w.shape[0]), 'ms': ms_w,
                              'windows_per_s': int(d_w.shape[0]) / ms_w * 1e3,

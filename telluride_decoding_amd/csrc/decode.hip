@@ -514,6 +514,33 @@ __global__ __launch_bounds__(kThreads) void window_sums_kernel(
   }
 }
 
+// Short windows that share no whole blocks (the reference harness' W = 10 frames every 5,
+// infer.py:376-378: hundreds of thousands of windows of a few frames): one THREAD per window
+// and column, frames summed in ascending order; the window's first row comes from the per-trial
+// descriptor (first = first window of the trial), so nothing per window is uploaded.  (One
+// 256-thread workgroup per window and a host-built table of 240 k start rows took 0.63 ms per
+// stream at C4.)
+__global__ void window_sums_short_kernel(const float* __restrict__ a, long long lda,
+                                         const float* __restrict__ b, long long ldb, int cols,
+                                         const FileDesc* __restrict__ trials, int n_trials,
+                                         long long n_win, int width, int hop,
+                                         double* __restrict__ out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n_win * cols) return;
+  const long long w = i / cols;
+  const int col = (int)(i % cols);
+  const FileDesc tr = trials[find_file(trials, n_trials, w)];
+  const long long r0 = tr.row0 + (w - tr.first) * hop;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  for (int r = 0; r < width; ++r) {
+    const double av = (double)a[(r0 + r) * lda + col];
+    const double bv = (double)b[(r0 + r) * ldb + col];
+    s0 += av; s1 += bv; s2 += av * av; s3 += bv * bv; s4 += av * bv;
+  }
+  double* o = out + i * 5;
+  o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4;
+}
+
 // ---- two-stage window sums: block partials, then windows from blocks ---------
 // Overlapping windows share frames (width / hop = 10 at C4): with g = gcd(width,
 // hop) every window is a run of width / g whole blocks of g frames, so the frames
@@ -1357,6 +1384,24 @@ int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b
     TD_HIP(h, hipGetLastError());
     return TD_OK;
   }
+  if (width <= 256) {
+    std::vector<FileDesc> win_tab(num_trials);
+    long long nw = 0;
+    for (int t = 0; t < num_trials; ++t) {
+      const int64_t n = trial_offsets_host[t + 1] - trial_offsets_host[t];
+      FileDesc& w = win_tab[t];
+      w.row0 = trial_offsets_host[t]; w.nrows = n; w.out0 = 0; w.first = nw;
+      if (n >= width) nw += (n - width) / hop + 1;
+    }
+    if (nw == 0) return TD_OK;
+    const void* tab = nullptr;
+    TD_TRY(td_table_upload(h, win_tab.data(), sizeof(FileDesc) * num_trials, &tab));
+    hipLaunchKernelGGL(window_sums_short_kernel, dim3((unsigned)td_ceil_div(nw * cols, 256)),
+                       dim3(256), 0, h->stream, a_dev, (long long)lda, b_dev, (long long)ldb, cols,
+                       reinterpret_cast<const FileDesc*>(tab), num_trials, nw, width, hop, out_dev);
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
   std::vector<long long> row0;
   std::vector<int64_t> off;
   build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
@@ -1518,10 +1563,12 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
     std::vector<int64_t> off;
     build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
     const int64_t nw = (int64_t)row0.size();
+    // (predictions and sums in the solver-workspace arena: the window kernels use td_scratch
+    // themselves; no allocation, nothing waits for the device)
     float* pred = nullptr;
     const size_t bytes = td_round_up(sizeof(float) * rows, 256) +
                          sizeof(double) * (size_t)nw * (10 + 2) + 256;
-    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&pred), bytes));
+    TD_TRY(td_workspace(h, bytes, reinterpret_cast<void**>(&pred)));
     double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(pred) +
                                              td_round_up(sizeof(float) * rows, 256));
     double* s1 = sums + (size_t)nw * 10;
@@ -1543,8 +1590,6 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
       hipMemcpy2DAsync(scores_dev + 1, 2 * sizeof(double), s2, sizeof(double), sizeof(double), nw,
                        hipMemcpyDeviceToDevice, h->stream);
     }
-    hipStreamSynchronize(h->stream);
-    hipFree(pred);
     return rc;
   }
   // Three launches, one scratch block, per-trial descriptors from the table cache (uploaded

@@ -379,6 +379,29 @@ def test_decode_fused_matches_oracle(dev, width, hop, pre, post):
   assert flips == 0                   # attended-speaker argmax bit-exact
 
 
+@pytest.mark.parametrize('width,hop', [(10, 5), (7, 3), (200, 77), (300, 7)])
+def test_window_sums_without_shared_blocks(dev, width, hop):
+  """Windows whose width and hop share no block of >= 32 frames (the reference harness' W = 10,
+  hop = 5, infer.py:376-378): thread-per-window kernel for short windows, workgroup-per-window
+  beyond 256 frames; every window against float64 NumPy, and td_decode_fused on that shape
+  against the window sums."""
+  rng = np.random.default_rng(width)
+  h = dev.default_handle()
+  lens = (640, 9, 1201)
+  cols = 2
+  a = rng.standard_normal((sum(lens), cols)).astype(np.float32)
+  b = (0.5 * a + rng.standard_normal(a.shape)).astype(np.float32)
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  sums = dev.window_sums(h.to_device(a), h.to_device(b), offs, width, hop, handle=h).cpu().numpy()
+  a64, b64 = a.astype(np.float64), b.astype(np.float64)
+  starts = np.concatenate([offs[t] + o_cor.window_starts(lens[t], width, hop) for t in range(3)])
+  assert sums.shape == (len(starts), cols, 5)
+  want = np.stack([np.stack([a64[s:s + width].sum(0), b64[s:s + width].sum(0),
+                             (a64[s:s + width] ** 2).sum(0), (b64[s:s + width] ** 2).sum(0),
+                             (a64[s:s + width] * b64[s:s + width]).sum(0)], axis=1) for s in starts])
+  np.testing.assert_allclose(sums, want, rtol=1e-12, atol=1e-10)
+
+
 def test_pearson_functions(dev):
   from telluride_decoding_amd import brain_model, cca
   g = golden('g3_pearson')
