@@ -39,6 +39,7 @@ The JSON line also carries
                 (N = 1; --no-extra skips them).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -352,6 +353,11 @@ def main():
     """The contract's timed region: warmup, barrier + sync, K steps, barrier + sync, MAX over
     ranks."""
     out = run(warmup) if warmup > 0 else None
+    # objects of earlier legs (pipelines, statistics, their 270 MB scratch arenas) that are only
+    # reachable through reference cycles are freed by Python's cyclic collector at an arbitrary
+    # later allocation -- hipFree waits for the device, a one-off ~35 ms stall inside whatever is
+    # being timed.  Collect them now.
+    gc.collect()
     barrier()
     t0 = time.perf_counter()
     out = run(steps) or out
