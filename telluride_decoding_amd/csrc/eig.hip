@@ -54,7 +54,10 @@ __device__ __forceinline__ void mma_nt_64(const double* __restrict__ as,
   const int li = lane & 15, lk = lane >> 4;
   const double* ap = as + ((wave >> 1) * 32 + li) * LS + lk;
   const double* bp = bs + ((wave & 1) * 32 + li) * LS + lk;
-#pragma unroll 4
+  // (fully unrolled: with a rolled loop hipcc keeps the accumulators in VGPRs across the back
+  // edge and copies all 32 of them to AGPRs and back around every 16 MFMAs -- 4 of the 8 VALU
+  // instructions per MFMA that PMC counted in the batched update)
+#pragma unroll
   for (int s = 0; s < NB / 4; ++s) {
     const double a0 = ap[4 * s], a1 = ap[16 * LS + 4 * s];
     const double b0 = bp[4 * s], b1 = bp[16 * LS + 4 * s];

@@ -82,7 +82,10 @@ __device__ __forceinline__ void gemm_nt_64(const double* __restrict__ as,
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.0;
-#pragma unroll 4
+  // (fully unrolled: with a rolled loop hipcc keeps the accumulators in VGPRs across the back
+  // edge and copies all 32 of them to AGPRs and back around every 16 MFMAs -- 4 of the 8 VALU
+  // instructions per MFMA that PMC counted in the batched update)
+#pragma unroll
   for (int s = 0; s < NB / 4; ++s) {
     const double a0 = ap[4 * s], a1 = ap[16 * LS + 4 * s];
     const double b0 = bp[4 * s], b1 = bp[16 * LS + 4 * s];
