@@ -285,18 +285,33 @@ def loso_leg(eeg, env):
            for i in range(n_subj)]
   ds = brain_data.Dataset(files, 1000, pre_context=PRE, post_context=POST)
   lams = list(np.logspace(-6, 3, 20))
+  # first sweep: uploads the recordings (the dataset keeps its device copy) and grows the
+  # workspaces; then sweeps with the inputs resident in HBM, like the headline measurement
+  t0 = time.perf_counter()
+  res = regression.jackknife_over_regularizations(ds, lams)
+  first = time.perf_counter() - t0
   best = None
-  for _ in range(2):
+  for _ in range(3):
+    gc.collect()
     t0 = time.perf_counter()
     res = regression.jackknife_over_regularizations(ds, lams)
     dt = time.perf_counter() - t0
     best = dt if best is None else min(best, dt)
+  # the same with the upload inside the timed region (pageable host arrays, as the
+  # reference's callers hold them)
+  ds._device_cache = None
+  gc.collect()
+  t0 = time.perf_counter()
+  regression.jackknife_over_regularizations(ds, lams)
+  with_upload = time.perf_counter() - t0
   top = max((v[0], k) for k, v in res.items() if k != 'all_runs')
   return {
       'workload': 'C5: LOSO x 20 lambdas, 32 subjects x 31 250 samples x 64 ch, 32 lags, one GPU',
       'seconds': best, 'fits': n_subj * len(lams), 'fits_per_s': n_subj * len(lams) / best,
       'best_lambda': float(top[1]), 'best_mean_r': float(top[0]),
-      'includes': 'host->device upload of the recordings (256 MB)',
+      'inputs': 'resident in HBM (best of 3 sweeps)',
+      'seconds_with_upload': with_upload, 'seconds_first_sweep': first,
+      'upload': 'host->device copy of the recordings (264 MB, pageable) inside the timed region',
   }
 
 

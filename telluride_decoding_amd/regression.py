@@ -51,8 +51,9 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   pearson_correlation_first, like reference regression.py:411-420, plus the raw
   [Lambda, F] matrix under the key 'all_runs'.
 
-  A rank uploads only the recordings it touches: its own files (statistics), the held-out
-  files of its folds, and the last training file when a fold's stream has a remainder.  A
+  With several ranks a rank uploads only the recordings it touches: its own files (statistics),
+  the held-out files of its folds, and the last training file when a fold's stream has a
+  remainder; a single rank works on the dataset's device copy (Dataset.device_arrays).  A
   fold's lambdas are evaluated together: their weight vectors are the output columns of ONE
   FIR prediction of the held-out file, and one window-sums launch gives the per-minibatch
   Pearson correlation of every column (Keras `evaluate` = the unweighted mean over
@@ -76,12 +77,20 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   plan = distributed.ShardPlan(lengths, world_size)
 
   uploaded = {}
+  # One rank touches every recording: it takes them from the dataset's device copy (uploaded
+  # once and kept by the dataset -- a second sweep over the same dataset uploads nothing).  With
+  # several ranks each uploads only the recordings it touches, on first use.
+  whole = dataset.device_arrays(h) if world_size == 1 else None
 
   def file_arrays(i):
-    """(x, y) of recording i on the device, uploaded on first use."""
+    """(x, y) of recording i on the device."""
     if i not in uploaded:
-      f = dataset.files[i]
-      uploaded[i] = (h.to_device(f[0]), h.to_device(f[2]))
+      if whole is not None:
+        x_all, _, y_all, offs = whole
+        uploaded[i] = (x_all[int(offs[i]):int(offs[i + 1])], y_all[int(offs[i]):int(offs[i + 1])])
+      else:
+        f = dataset.files[i]
+        uploaded[i] = (h.to_device(f[0]), h.to_device(f[2]))
     return uploaded[i]
 
   def new_stats():

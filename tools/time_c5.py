@@ -9,8 +9,9 @@ trials = synth.make_trials(5, n_subj, n, c)
 files = [(eeg, env, env[:, 0:1].astype(np.float32), att) for eeg, env, att in trials]
 ds = brain_data.Dataset(files, 1000, pre_context=0, post_context=31)
 lams = list(np.logspace(-6, 3, 20))
-for rep in range(2):
-  torch.cuda.synchronize(); t0 = time.perf_counter()
+import gc
+for rep in range(5):
+  gc.collect(); torch.cuda.synchronize(); t0 = time.perf_counter()
   res = regression.jackknife_over_regularizations(ds, lams)
   torch.cuda.synchronize(); t1 = time.perf_counter()
   print('C5 LOSO x lambda sweep end to end: %.3f s (%d fits)' % (t1 - t0, n_subj * len(lams)))
