@@ -326,7 +326,9 @@ def main():
   ap.add_argument('--no-extra', action='store_true', help='skip the C3 / C5 legs')
   ap.add_argument('--targets-on-acc', action='store_true',
                   help='keep the y^T x part of the accumulate on the accumulate stream')
-  ap.add_argument('--solve-cus', type=int, default=32,
+  ap.add_argument('--solve-streams', type=int, default=2,
+                  help='solve streams of the pipeline (fit i on stream i mod n, same CU partition)')
+  ap.add_argument('--solve-cus', type=int, default=64,
                   help='CUs set aside for the solve stream of the pipeline (0 = no CU masks)')
   ap.add_argument('--force-dist', action='store_true',
                   help='run the N > 1 code path (RCCL all-reduce of the statistics) on one rank')
@@ -428,7 +430,7 @@ def main():
       return run, h, None
     pipe = pipeline.FitPipeline(C, PRE, POST, d=D, solve_cus=args.solve_cus,
                                 targets_on_solve=not args.targets_on_acc, allreduce=reduce_fn,
-                                solves=solves)
+                                solves=solves, solve_streams=args.solve_streams)
 
     def run(k):
       out = None

@@ -24,6 +24,8 @@
 //     sums the slabs in float64 (bitwise reproducible -- no float atomics);
 //   * blockIdx is remapped so the workgroups that share a time slab (the lag
 //     groups) land on one XCD and hit its L2.
+#include <cstdlib>
+
 #include "td_common.h"
 
 namespace {
@@ -385,6 +387,298 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
           const int j = cbt * 64 + n * 32 + lr;
           pe[(size_t)i * p.cb_pad + j] = acc[le][m][n][r];
         }
+  }
+}
+
+// ---- unified mode on the bf16 matrix pipe: three-way split of every float32 -----------------
+// gfx950 multiplies bf16 16 times faster than float32 (v_mfma_f32_32x32x16_bf16: 32x32x16 in
+// 32 cycles; v_mfma_f32_32x32x2_f32: 32x32x2 in 64) and has no TF32.  A float32 is EXACTLY the
+// sum of three bf16 numbers, x = h + m + l (round-to-nearest splits: |m| <= 2^-9 |x|,
+// |l| <= 2^-18 |x|), so
+//   x y = h_x h_y + (h_x m_y + m_x h_y) + (m_x m_y + h_x l_y + l_x h_y) + O(2^-27 |x y|)
+// -- six bf16 products, each exact in the float32 accumulator of the MFMA, reproduce the
+// float32 product to 2^-27 (the float32 MFMA itself rounds products to 2^-24) at 6/16 of the
+// matrix-pipe time.
+//
+// LDS image.  The K dimension of the bf16 MFMA is 16 time samples, 8 consecutive ones per lane,
+// so the tile is stored TRANSPOSED and split: [piece h/m/l][channel 0..63][time 0..159] bf16,
+// channel rows of 83 dwords.  83 is odd: the 32 channels that the lanes of a half wave read at
+// one time offset sit in 32 different banks (with the even 82 every dword read of the B operand
+// was a 2-way bank conflict and the LDS, not the matrix pipe, set the pace).
+//
+// Work split.  Workgroup = 512 threads = 8 waves = one slab x 8 consecutive lags e0 .. e0 + 7,
+// one workgroup per CU.  Wave w owns FOUR lags (e0 + 4 (w & 1) + 0..3) of ONE 32 x 32 channel
+// tile (m tile (w >> 1) & 1, n tile w >> 2).  Per k-step it reads its A rows once (16 bytes per
+// lane and piece) and ONE span of B: six dwords from sample t0 + 8 g + e0 + 4 (w & 1) cover the
+// 8-sample windows of all four lags -- lags +0 and +2 are dwords 0..3 and 1..4 as they are, lags
+// +1 and +3 the same spans moved by one sample (v_alignbit_b32, 8 per piece).  That is 7.6 KB of
+// LDS reads per 24 MFMAs; with one lag and a 64 x 64 tile per wave it was 15 KB and the LDS
+// array was the bottleneck (the float32 kernel needs a ninth of that per matrix-pipe cycle).
+//
+// Two-level accumulation.  The bf16 MFMA aligns its 16 products and the accumulator to the
+// largest exponent and TRUNCATES below a few guard bits: chains of a 2048-sample slab left the
+// diagonal of the Gram matrix (sums of squares: every term positive) 1.2e-6 low -- ten times the
+// error of the float32 kernel; chains of 512 samples -8e-8, of 128 samples -3e-10 (measured,
+// tools/bias_probe.py).  So an MFMA chain is ONE TILE (128 samples, 48 instructions) and the
+// tile sums are added into a second set of float32 registers by v_add_f32 (round to nearest):
+// 64 + 64 accumulator registers per lane.  The slab sums then leave as before (float32 partial
+// slabs, summed in float64).
+//
+// The LDS tile is double-buffered: the next tile is split and written into the other buffer in
+// the middle of the current tile's MFMAs, one barrier per tile.
+constexpr int kBfTile = 128;            // time samples per tile
+constexpr int kBfRows = 160;            // staged rows: tile + 24 (e0) + 8 halo
+constexpr int kBfRowDw = 83;            // dwords per channel row (166 samples)
+constexpr int kBfPieceDw = 64 * kBfRowDw;
+constexpr size_t kBfLdsBytes = sizeof(unsigned) * 2 * 3 * kBfPieceDw;   // double-buffered
+constexpr int kBfThreads = 512;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // low half = a (RNE)
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// (x0, x1) -> packed pairs of the three pieces
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = pack_bf16(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16);
+  const float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = pack_bf16(r0, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16);
+  const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = pack_bf16(s0, s1);
+}
+
+__device__ __forceinline__ float comp4(const float4& v, int q) {
+  return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// One k-step (16 time samples) of one wave: 4 lags x 6 products.  ap / bp: the lane's A row and
+// B span of piece 0 at this k-step (pieces kBfPieceDw apart).  kZero: first step of a chain (the
+// accumulators start from the inline constant 0).  a_mask: null, or 4 dword masks that cut A at
+// the end of a slab.
+template <bool kZero>
+__device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
+                                         const unsigned* __restrict__ bp,
+                                         const unsigned* a_mask, f32x16 (&acc)[4]) {
+  u32x4 a[3];
+  unsigned d[3][6];
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[pc][i] = ap[pc * kBfPieceDw + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[pc][i] = bp[pc * kBfPieceDw + i];
+  }
+  if (a_mask) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[pc][i] &= a_mask[i];
+  }
+  u32x4 b[4][3];                                       // [lag][piece]
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      b[0][pc][i] = d[pc][i];
+      b[1][pc][i] = __builtin_amdgcn_alignbit(d[pc][i + 1], d[pc][i], 16);
+      b[2][pc][i] = d[pc][i + 1];
+      b[3][pc][i] = __builtin_amdgcn_alignbit(d[pc][i + 2], d[pc][i + 1], 16);
+    }
+  f32x16 c[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (kZero) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) c[r][k] = 0.f;
+    } else {
+      c[r] = acc[r];
+    }
+  }
+  // (A piece, B piece) in the order l h, h l, m m, m h, h m, h h -- the four lags in turn
+  constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int t = 0; t < 6; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = mfma_bf16(a[pa[t]], b[r][pb[t]], c[r]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = c[r];
+}
+
+template <int kFrom, int kTo>
+__device__ __forceinline__ void bf_ksteps(const unsigned* __restrict__ ap,
+                                          const unsigned* __restrict__ bp, f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int s = kFrom; s < kTo; ++s) {
+    if (s == 0) bf_kstep<true>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+    else        bf_kstep<false>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+    // (without a fence hipcc hoists the LDS reads of all the unrolled steps to the top and spills)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <bool kVec4>
+__global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];   // [2][3][64][kBfRowDw]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave & 1, mt = (wave >> 1) & 1, nt = wave >> 2;
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int group = id % p.n_groups; id /= p.n_groups;
+  const LagWork w = p.works[id];
+  const int e0 = group * kLagsPerWg;                   // e_min == 0
+
+  f32x16 total[4];                                     // [lag], the slab's sums
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) total[r][k] = 0.f;
+
+  // staging: thread (c4, rg) moves channels c4 .. c4+3 of rows 4 rg .. 4 rg + 3 (two dwords per
+  // channel and piece); the threads of waves 0-3 also rows 128 + 2 rg, + 1 (a dword).
+  // (Rows from 136 + e0 on are never read by this workgroup's lags: whatever is there is staged.)
+  const int c4 = (tid & 15) * 4, rg = tid >> 4;
+  const bool has_tail = wave < 4;                      // rg < 16
+  const bool early = wave < 4;                         // stages after k-step 1 (else after 5):
+                                                       // the two waves of a SIMD at different points
+  float4 pf[6];
+  // a tile whose 160 staged rows all exist, 64 real channels: no clamps, no masks
+  auto interior = [&](long long ut) -> bool {
+    return kVec4 && p.ca == 64 && ut >= 0 && ut + kBfRows <= w.a_valid;
+  };
+  auto prefetch = [&](long long ut) {
+    if (interior(ut)) {
+      const float* base = p.a + (w.a_row0 + ut) * p.lda + c4;
+      const int ld = (int)p.lda;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        pf[s] = *reinterpret_cast<const float4*>(base + (4 * rg + s) * ld);
+      if (has_tail) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          pf[4 + s] = *reinterpret_cast<const float4*>(base + (kBfTile + 2 * rg + s) * ld);
+      }
+      return;
+    }
+    const RowWindow rw = row_window(p.a, p.lda, w.a_row0, ut, w.a_valid, 0, p.ca);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pf[s] = load_row4_raw<kVec4>(rw, 4 * rg + s, c4);
+    if (has_tail) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) pf[4 + s] = load_row4_raw<kVec4>(rw, kBfTile + 2 * rg + s, c4);
+    }
+  };
+  auto store = [&](long long ut, unsigned* buf) {
+    float4 v[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) v[s] = pf[s];
+    if (!interior(ut)) {
+      const RowWindow rw = row_window(p.a, p.lda, w.a_row0, ut, w.a_valid, 0, p.ca);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = mask_row4(rw, 4 * rg + s, true, c4, pf[s]);
+      if (has_tail) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) v[4 + s] = mask_row4(rw, kBfTile + 2 * rg + s, true, c4, pf[4 + s]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h[2], m[2], l[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+        split3(comp4(v[2 * d], q), comp4(v[2 * d + 1], q), h[d], m[d], l[d]);
+      unsigned* dst = buf + (c4 + q) * kBfRowDw + 2 * rg;        // samples 4 rg .. 4 rg + 3
+      dst[0] = h[0]; dst[1] = h[1];
+      dst[kBfPieceDw] = m[0]; dst[kBfPieceDw + 1] = m[1];
+      dst[2 * kBfPieceDw] = l[0]; dst[2 * kBfPieceDw + 1] = l[1];
+    }
+    if (has_tail) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned h, m, l;
+        split3(comp4(v[4], q), comp4(v[5], q), h, m, l);
+        unsigned* tail = buf + (c4 + q) * kBfRowDw + kBfTile / 2 + rg;   // samples 128 + 2 rg, + 1
+        tail[0] = h;
+        tail[kBfPieceDw] = m;
+        tail[2 * kBfPieceDw] = l;
+      }
+    }
+  };
+
+  const int lj = lane & 31, lg = lane >> 5;
+  const int a_off = (mt * 32 + lj) * kBfRowDw + 4 * lg;
+  const int b_off = (nt * 32 + lj) * kBfRowDw + 4 * lg + (e0 >> 1) + 2 * quad;
+
+  f32x16 acc[4];
+  unsigned* const buf0 = ldsu;
+  unsigned* const buf1 = ldsu + 3 * kBfPieceDw;
+  prefetch(w.u_begin);
+  store(w.u_begin, buf0);
+  __syncthreads();
+
+  int parity = 0;
+  for (long long ut = w.u_begin; ut < w.u_end; ut += kBfTile, parity ^= 1) {
+    const unsigned* cur = parity ? buf1 : buf0;
+    unsigned* nxt = parity ? buf0 : buf1;
+    const bool more = ut + kBfTile < w.u_end;
+    if (more) prefetch(ut + kBfTile);
+    const long long left = w.u_end - ut;
+    const unsigned* ap = cur + a_off;
+    const unsigned* bp = cur + b_off;
+    if (left >= kBfTile) {
+      // whole tile: 8 unrolled k-steps
+      bf_ksteps<0, 2>(ap, bp, acc);
+      if (more && early) store(ut + kBfTile, nxt);
+      bf_ksteps<2, 6>(ap, bp, acc);
+      if (more && !early) store(ut + kBfTile, nxt);
+      bf_ksteps<6, 8>(ap, bp, acc);
+    } else {
+      // the last, cut tile of a slab: A stops at nk
+      const int nk = (int)left;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+      for (int t0 = 0; t0 < nk; t0 += 16) {
+        const int cnt = nk - t0 - 8 * lg;              // may be <= 0 or >= 8
+        unsigned mask[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          mask[d] = cnt >= 2 * d + 2 ? 0xffffffffu : cnt == 2 * d + 1 ? 0x0000ffffu : 0u;
+        bf_kstep<false>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) total[r] += acc[r];
+    if (more) __syncthreads();
+  }
+
+  // Epilogue: the wave's 32 x 32 block of its four lags in the workgroup's partial slab.
+  const int lr = lane & 31, lk = lane >> 5;
+  float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* pe = slab + (size_t)(e0 + 4 * quad + r) * p.ca_pad * p.cb_pad;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * lk;
+      const int j = nt * 32 + lr;
+      pe[(size_t)i * p.cb_pad + j] = total[r][k];
+    }
   }
 }
 
@@ -1161,7 +1455,7 @@ __global__ __launch_bounds__(256) void ysum_reduce_kernel(const double* __restri
 template <typename T, int Q>
 __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     const T* __restrict__ partial, int n_work, int e_pad, int ca_pad, int cb_pad, int e_count,
-    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst) {
+    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst, int sym_first) {
   __shared__ double part[Q][64];
   const long long total = (long long)e_count * ca_eff * cb;
   const size_t slab = (size_t)e_pad * ca_pad * cb_pad;
@@ -1173,7 +1467,11 @@ __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     j = (int)(o % cb);
     i = (int)((o / cb) % ca_eff);
     e = (int)(o / ((long long)cb * ca_eff));
-    const T* src = partial + ((size_t)e * ca_pad + i) * cb_pad + j;
+    // sym_first: lag entry 0 is a Gram matrix whose (i, j) and (j, i) sums were formed in
+    // different orders (the bf16x3 kernel adds the six partial products of x_i x_j in an order
+    // that is not symmetric in i and j): both take the (min, max) sum -- exactly symmetric
+    const bool swap = sym_first && e == 0 && i > j;
+    const T* src = partial + ((size_t)e * ca_pad + (swap ? j : i)) * cb_pad + (swap ? i : j);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int w = q;
     for (; w + 3 * Q < n_work; w += 4 * Q) {
@@ -1199,17 +1497,17 @@ __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
 template <typename T>
 void launch_lagcov_reduce(td_handle* h, const T* partial, int n_work, int e_pad, int ca_pad,
                           int cb_pad, int e_count, int ca_eff, int cb, double* g, bool accumulate,
-                          int ca_dst) {
+                          int ca_dst, bool sym_first = false) {
   const long long outs = (long long)e_count * ca_eff * cb;
   const unsigned blocks = (unsigned)td_ceil_div(outs, 64);
   if (outs < 32768)
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 16>), dim3(blocks), dim3(1024), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst);
+                       ca_dst, sym_first ? 1 : 0);
   else
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst);
+                       ca_dst, sym_first ? 1 : 0);
 }
 
 // ---- float64 column sums (sum of y over the rows that enter the fit) --------
@@ -1292,6 +1590,13 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   p.a = a; p.b = b; p.lda = lda; p.ldb = ldb; p.ca = ca; p.cb = cb; p.a_ones = a_ones ? 1 : 0;
   p.e_min = e_min; p.e_count = e_count;
   p.n_groups = (int)td_ceil_div(e_count, lags_per_wg);
+  // The bf16x3 kernel (lagcov_bf16x3_kernel): the same stream and channel tile on both sides,
+  // lags 0 .. <= 31, 33 .. 64 channels.
+  static const bool force_f32 = getenv("TD_LAGCOV_F32") != nullptr;    // development: A/B runs
+  bool split = !small && !few && (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min == 0 &&
+               ca > 32 && ca <= 64 && e_count <= 32 && !force_f32;
+  for (const LagSeg& sg : segs)
+    if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) split = false;
   p.n_cat = small ? 1 : (int)td_ceil_div(ca_eff, 64);
   p.n_cbt = (int)td_ceil_div(cb, 64);
   p.e_pad = p.n_groups * (small ? kSmallLags : kLagsPerWg);   // slab entries per work item
@@ -1305,7 +1610,8 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   // 512 resident workgroup slots (2 per CU): a last round that is 83 % full costs as much
   // as a full one.  Slabs need not be multiples of the tile (the kernels cut the last tile).
   const long long per_item_wgs = (long long)p.n_groups * p.n_cat * p.n_cbt;
-  const long long kMaxSlab = 2048;
+  long long kMaxSlab = 2048;
+  if (const char* e = getenv("TD_MAX_SLAB")) kMaxSlab = atoll(e);   // development
   std::vector<long long> n_slabs(segs.size(), 0);
   long long min_items = 0, max_items = 0;
   for (size_t f = 0; f < segs.size(); ++f) {
@@ -1314,7 +1620,7 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
     min_items += n_slabs[f];
     max_items += td_ceil_div(len, kTile);          // never cut below one tile per slab
   }
-  long long items_per_round = 512 / per_item_wgs;
+  long long items_per_round = (split ? 256 : 512) / per_item_wgs;   // (bf16x3: one workgroup per CU)
   if (items_per_round < 1) items_per_round = 1;
   long long target = td_ceil_div(min_items, items_per_round) * items_per_round;
   if (target > max_items) target = max_items;
@@ -1405,7 +1711,22 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
       hipLaunchKernelGGL((lagcov_mfma_kernel<UNI, TILE, NPF, false, FEW>), dim3((unsigned)nwg),   \
                          dim3(kThreads), lds_bytes, h->stream, p);                                \
   } while (0)
-    if (few) {
+    if (split) {
+      static bool lds_set = false;                     // 123 KB of dynamic LDS: opt in once
+      if (!lds_set) {
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBfLdsBytes));
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBfLdsBytes));
+        lds_set = true;
+      }
+      if (aligned)
+        hipLaunchKernelGGL((lagcov_bf16x3_kernel<true>), dim3((unsigned)nwg), dim3(kBfThreads),
+                           kBfLdsBytes, h->stream, p);
+      else
+        hipLaunchKernelGGL((lagcov_bf16x3_kernel<false>), dim3((unsigned)nwg), dim3(kBfThreads),
+                           kBfLdsBytes, h->stream, p);
+    } else if (few) {
       if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU, true);
       else { unified = false; TD_LAUNCH_MFMA(false, kTileG, kNpfG, true); }
     } else if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU, false);
@@ -1420,7 +1741,7 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
                                 p.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, ca_eff);
   else
     launch_lagcov_reduce<float>(h, p.partial, p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff,
-                                cb, g_dev, accumulate, ca_eff);
+                                cb, g_dev, accumulate, ca_eff, split);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

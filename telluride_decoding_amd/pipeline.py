@@ -1,12 +1,15 @@
-"""Two-stream pipelining of independent fits on one GPU.
+"""Stream pipelining of independent fits on one GPU.
 
 The accumulate stage of a ridge fit (lagcov MFMA kernel) is throughput-bound and fills
 every CU; the solve stage (blocked Cholesky) is a latency-bound chain of small launches
-that occupies a handful of CUs.  Back to back they add up; on two HIP streams the solve of
-fit i runs underneath the accumulate of fit i + 1 (jackknife folds, subjects, sessions:
-the reference refits from scratch for every one of them, regression.py:151-242).  Each
-stream has its own C-ABI handle (stream, scratch arenas, error state); the statistics are
-double buffered and ordered with events.
+that occupies a handful of CUs.  Back to back they add up; on separate HIP streams the solve
+of fit i runs underneath the accumulate of fit i + 1 (jackknife folds, subjects, sessions:
+the reference refits from scratch for every one of them, regression.py:151-242).  The solve
+is a dependency chain (~100 launches, most of them a few workgroups), so TWO solve streams
+on the same CU partition -- fit i on one, fit i + 1 on the other -- fill each other's gaps:
+since the accumulate moved to the bf16 matrix pipe (1.3 ms) a single solve stream (1.7 ms
+beside it) was the slower stage.  Each stream has its own C-ABI handle (stream, scratch
+arenas, error state); the statistics are multi-buffered and ordered with events.
 """
 import numpy as np
 
@@ -34,17 +37,18 @@ class _MaskedStreams(object):
 
 
 class FitPipeline(object):
-  """submit() queues one fit and returns the solution of the fit before the previous one.
+  """submit() queues one fit and returns the solution of an earlier one (None while the
+  pipeline fills).
 
-  The host stays one solve ahead of the device: submit(i) queues accumulate(i) and solve(i - 1)
-  and then waits for solve(i - 2) only (whose result it returns), so the queues never run dry
-  behind the host.  flush() returns the solutions not yet handed out, oldest first.  Nothing in
+  The host stays ahead of the device: submit(i) queues accumulate(i) and solve(i - 1) and then
+  waits only for the oldest solve still outstanding once more than `solve_streams` are queued
+  (whose result it returns), so the queues never run dry behind the host.  flush() returns the solutions not yet handed out, oldest first.  Nothing in
   the loop touches the legacy default stream: any work queued there orders itself against every
   other blocking stream and serialises the two stages (measured: 3.44 ms instead of 2.68).
   """
 
-  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=32, targets_on_solve=True, buffers=3,
-               solves=None):
+  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=64, targets_on_solve=True,
+               buffers=None, solves=None, solve_streams=2):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -54,9 +58,15 @@ class FitPipeline(object):
     import ctypes
     import torch
     from telluride_decoding_amd import _lib
-    if buffers < 2:
+    solve_streams = max(1, int(solve_streams))
+    if buffers is None:
+      # one accumulating, one per solve in flight, one of slack: with fewer the stages end up
+      # waiting for each other's jitter
+      buffers = solve_streams + 2
+    if buffers < solve_streams + 1:
       # with one buffer submit(i + 1) would reset the statistics before solve(i) is even queued
-      raise ValueError('FitPipeline needs at least two statistics buffers, not %d' % buffers)
+      raise ValueError('FitPipeline needs at least %d statistics buffers for %d solve streams, '
+                       'not %d' % (solve_streams + 1, solve_streams, buffers))
     self.torch = torch
     self._masked = []
     # solves: optional callable(fit index) -> bool.  With several ranks sharing every fit
@@ -68,32 +78,36 @@ class FitPipeline(object):
     lib = _lib.load()
     dev = torch.cuda.current_device()
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    self.s_acc = self.s_solve = None
+    self.s_acc = None
+    self.s_solves = []
     if solve_cus and 0 < solve_cus < n_cu:
       ptrs = []
-      for first, count in ((solve_cus, n_cu - solve_cus), (0, solve_cus)):
+      for first, count in [(solve_cus, n_cu - solve_cus)] + [(0, solve_cus)] * solve_streams:
         p = ctypes.c_void_p()
         if lib.td_stream_create_masked(dev, first, count, ctypes.byref(p)) != _lib.TD_OK:
           break
         ptrs.append(p)
-      if len(ptrs) == 2:
+      if len(ptrs) == 1 + solve_streams:
         self._masked = ptrs
         self.s_acc = torch.cuda.ExternalStream(ptrs[0].value)
-        self.s_solve = torch.cuda.ExternalStream(ptrs[1].value)
+        self.s_solves = [torch.cuda.ExternalStream(p.value) for p in ptrs[1:]]
       else:
         for p in ptrs:
           lib.td_stream_destroy(p)
     if self.s_acc is None:
       self.s_acc = torch.cuda.Stream()
-      self.s_solve = torch.cuda.Stream()
+      self.s_solves = [torch.cuda.Stream() for _ in range(solve_streams)]
     with torch.cuda.stream(self.s_acc):
       self.h_acc = device.Handle()
-    with torch.cuda.stream(self.s_solve):
-      self.h_solve = device.Handle()
+    self.h_solves = []
+    for st in self.s_solves:
+      with torch.cuda.stream(st):
+        self.h_solves.append(device.Handle())
+    self.s_solve, self.h_solve = self.s_solves[0], self.h_solves[0]
     owner = _MaskedStreams(self._masked)
-    self.h_acc.keepalive = self.h_solve.keepalive = owner
-    # three statistics buffers: with two, accumulate i + 2 has to wait for solve i, and the two
-    # stages (2.55 and 2.5 ms) end up waiting for each other's jitter
+    self.h_acc.keepalive = owner
+    for hs in self.h_solves:
+      hs.keepalive = owner
     self.stats = [device.LagStats(c, pre, post, d=d, handle=self.h_acc) for _ in range(buffers)]
     self.ev_acc = [torch.cuda.Event() for _ in range(buffers)]
     self.ev_solved = [None] * buffers
@@ -106,8 +120,10 @@ class FitPipeline(object):
   def _solve(self, buf, lambdas, args, kw, index=0):
     """Queues targets + exchange + solve of one fit on the solve stream; nothing waits."""
     torch = self.torch
-    with torch.cuda.stream(self.s_solve):
-      self.s_solve.wait_event(self.ev_acc[buf])
+    s_solve = self.s_solves[index % len(self.s_solves)]
+    h_solve = self.h_solves[index % len(self.s_solves)]
+    with torch.cuda.stream(s_solve):
+      s_solve.wait_event(self.ev_acc[buf])
       # The y^T x part of the accumulate (LagStats.accumulate(parts=2)) also rides here: it is
       # HBM-bound (the MFMA targets kernel), the solve stream has slack, and every microsecond
       # taken off the accumulate stream is throughput.  With the earlier VALU-bound targets
@@ -116,19 +132,19 @@ class FitPipeline(object):
       # overloads this stream.
       if self.targets_on_solve:
         x, _, y, offs = args
-        self.stats[buf].accumulate(x, None, y, offs, parts=2, handle=self.h_solve, **kw)
+        self.stats[buf].accumulate(x, None, y, offs, parts=2, handle=h_solve, **kw)
       # The exchange of a multi-GPU fit belongs to this stream: the solve needs it, the next
       # accumulate (other statistics buffer) does not -- on the accumulate stream the
       # collective's latency and the ranks' skew would sit in front of every accumulate.
       if self.allreduce is not None:
-        self.allreduce(self.stats[buf], self.h_solve)
+        self.allreduce(self.stats[buf], h_solve)
       # (the singular-system flag follows the solve into the handle's pinned host ring)
       if self.solves is None or self.solves(index):
-        w, b, flag = self.stats[buf].ridge_solve_async(lambdas, handle=self.h_solve)
+        w, b, flag = self.stats[buf].ridge_solve_async(lambdas, handle=h_solve)
       else:
         w = b = flag = None
       ev = torch.cuda.Event()
-      ev.record(self.s_solve)
+      ev.record(s_solve)
       self.ev_solved[buf] = ev
     self._results.append((w, b, flag, ev))
 
@@ -156,7 +172,7 @@ class FitPipeline(object):
     if self.pending is not None:
       self._solve(*self.pending)
     self.pending = (buf, np.atleast_1d(lambdas), (x, None, y, file_offsets), kw, self.count - 1)
-    return self._pop() if len(self._results) > 1 else None
+    return self._pop() if len(self._results) > len(self.s_solves) else None
 
   def flush(self):
     """Solves the last submitted fit and returns every solution not yet handed out (a list,

@@ -335,17 +335,21 @@ def test_pipelined_fits_equal_serial_fits(dev):
     st.accumulate(x, None, y, offs)
     w, b = st.ridge_solve([0.1, 1.0])
     want.append((w.cpu().numpy(), b.cpu().numpy()))
-  # a singular fit (all-zero recording, lambda = 0) is reported when its result is due
-  pipe = pipeline.FitPipeline(c, pre, post, d=1)
+  # a singular fit (all-zero recording, lambda = 0) is reported when its result is due: with n
+  # solve streams submit(k) hands out fit k - (n + 1)
   zx = torch.zeros(n, c, device='cuda'); zy = torch.zeros(n, 1, device='cuda')
-  assert pipe.submit(zx, zy, offs, [0.0]) is None
-  assert pipe.submit(data[0][0], data[0][1], offs, [0.1, 1.0]) is None
-  with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
-    pipe.submit(data[1][0], data[1][1], offs, [0.1, 1.0])        # hands out fit 0
-  rest = pipe.flush()
-  assert len(rest) == 2
-  np.testing.assert_array_equal(rest[0][0].cpu().numpy(), want[0][0])
-  del pipe
+  for streams in (1, 2):
+    pipe = pipeline.FitPipeline(c, pre, post, d=1, solve_streams=streams)
+    assert pipe.submit(zx, zy, offs, [0.0]) is None
+    for k in range(streams):
+      assert pipe.submit(data[k][0], data[k][1], offs, [0.1, 1.0]) is None
+    with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
+      pipe.submit(data[streams][0], data[streams][1], offs, [0.1, 1.0])      # hands out fit 0
+    rest = pipe.flush()
+    assert len(rest) == streams + 1
+    for k in range(streams + 1):
+      np.testing.assert_array_equal(rest[k][0].cpu().numpy(), want[k][0])
+    del pipe
   # both placements of the y^T x part: on the solve stream (default) and on the accumulate stream
   for on_solve in (True, False):
     pipe = pipeline.FitPipeline(c, pre, post, d=1, targets_on_solve=on_solve)
