@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(256) void ysum_reduce_kernel(const double* __restri
 template <typename T, int Q>
 __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     const T* __restrict__ partial, int n_work, int e_pad, int ca_pad, int cb_pad, int e_count,
-    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst, int sym_first) {
+    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst) {
   __shared__ double part[Q][64];
   const long long total = (long long)e_count * ca_eff * cb;
   const size_t slab = (size_t)e_pad * ca_pad * cb_pad;
@@ -1467,11 +1467,7 @@ __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     j = (int)(o % cb);
     i = (int)((o / cb) % ca_eff);
     e = (int)(o / ((long long)cb * ca_eff));
-    // sym_first: lag entry 0 is a Gram matrix whose (i, j) and (j, i) sums were formed in
-    // different orders (the bf16x3 kernel adds the six partial products of x_i x_j in an order
-    // that is not symmetric in i and j): both take the (min, max) sum -- exactly symmetric
-    const bool swap = sym_first && e == 0 && i > j;
-    const T* src = partial + ((size_t)e * ca_pad + (swap ? j : i)) * cb_pad + (swap ? i : j);
+    const T* src = partial + ((size_t)e * ca_pad + i) * cb_pad + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int w = q;
     for (; w + 3 * Q < n_work; w += 4 * Q) {
@@ -1494,20 +1490,28 @@ __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
   }
 }
 
+// g [c][c]: element (i, j), i > j, := element (j, i)
+__global__ void mirror_upper_kernel(double* __restrict__ g, int c) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= c * c) return;
+  const int i = o / c, j = o % c;
+  if (i > j) g[o] = g[(size_t)j * c + i];
+}
+
 template <typename T>
 void launch_lagcov_reduce(td_handle* h, const T* partial, int n_work, int e_pad, int ca_pad,
                           int cb_pad, int e_count, int ca_eff, int cb, double* g, bool accumulate,
-                          int ca_dst, bool sym_first = false) {
+                          int ca_dst) {
   const long long outs = (long long)e_count * ca_eff * cb;
   const unsigned blocks = (unsigned)td_ceil_div(outs, 64);
   if (outs < 32768)
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 16>), dim3(blocks), dim3(1024), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst, sym_first ? 1 : 0);
+                       ca_dst);
   else
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst, sym_first ? 1 : 0);
+                       ca_dst);
 }
 
 // ---- float64 column sums (sum of y over the rows that enter the fit) --------
@@ -1741,7 +1745,14 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
                                 p.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, ca_eff);
   else
     launch_lagcov_reduce<float>(h, p.partial, p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff,
-                                cb, g_dev, accumulate, ca_eff, split);
+                                cb, g_dev, accumulate, ca_eff);
+  // The bf16x3 kernel adds the six partial products of x_i x_j in an order that is not symmetric
+  // in i and j, so the lag-0 Gram block comes out symmetric only to ~1e-9: the lower triangle
+  // takes the upper one's sums (the float32 kernel's block is symmetric by construction, and
+  // the moment matrix is promised exactly symmetric).
+  if (split)
+    hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)td_ceil_div((long long)ca * cb, 256)),
+                       dim3(256), 0, h->stream, g_dev, ca);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
