@@ -10,7 +10,8 @@ import re
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, 'libtd_hotpath.so')
+# (TD_HOTPATH_LIB: development -- A/B runs of two builds of the library in one GPU session)
+LIB_PATH = os.environ.get('TD_HOTPATH_LIB') or os.path.join(PKG, 'libtd_hotpath.so')
 HEADER = os.path.join(os.path.dirname(PKG), 'include', 'td_hotpath.h')
 
 TD_OK = 0

@@ -21,10 +21,12 @@ struct FirTile {
   long long out0;     // global OUTPUT row of stream frame 0 (the zipped-stream index)
 };
 
-constexpr int kFirWavesPerCu = 12;   // predict_fir_mfma_kernel: 3 per SIMD
+constexpr int kFirWavesPerCu = 8;    // predict_fir_mfma_kernel: 2 per SIMD (the bf16 pieces of the
+                                     // operands need the registers of a third)
 constexpr int kFirLagChunk = 32;
 constexpr int kFirChChunk = 64;
 constexpr int kFirMaxD = 16;
+constexpr int kFirTileDw = 4 * 3 * 64 * 4;   // dwords of one 32-lag weight tile: 4 groups x 3 pieces x 64 lanes x 16 B
 
 template <int DB>   // outputs handled per pass
 __global__ __launch_bounds__(kThreads) void predict_fir_kernel(
@@ -86,8 +88,11 @@ __global__ __launch_bounds__(kThreads) void predict_fir_kernel(
 
 // ---------------------------------------------------------------- FIR predict on MFMA
 // The same forward as predict_fir_kernel, restated for the matrix cores:
-//   P[u][(l, q)] = sum_c x~[u][c] * W[l*C + c][q]        (a [frames x C] . [C x L*D] GEMM:
-//                                                          v_mfma_f32_32x32x2_f32, exact f32)
+//   P[u][(l, q)] = sum_c x~[u][c] * W[l*C + c][q]        (a [frames x C] . [C x L*D] GEMM on the
+//                                                          bf16 matrix pipe: every float32 is
+//                                                          split exactly into three bf16 pieces,
+//                                                          six products per float32 product --
+//                                                          td_common.h; v_mfma_f32_32x32x16_bf16)
 //   out[t][q]    = b[q] + sum_l P[t + l - pre][(l, q)]    (diagonal sums of P)
 // so every x row is read from HBM exactly once (2.6 flop/B of VALU work left) and
 // the 2*K*D flops per frame run on the matrix pipe instead of LDS-fed VALU FMAs
@@ -129,7 +134,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // with ds_add_f32 was tried: LDS float atomics retire about one lane per clock and
 // the kernel ran 2.4x slower than with the tile + diagonal reads below.)
 template <int NCH, bool kVec4>
-__global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
+__global__ __launch_bounds__(kThreads, 2) void predict_fir_mfma_kernel(
     const float* __restrict__ x, long long ldx, const FileDesc* __restrict__ files, int n_files,
     long long n_strips, int strip_len, int c, int pre, int post, const float* __restrict__ w,
     const float* __restrict__ bias, int d_total, int q0, int dq, int tpq, int ring,
@@ -140,17 +145,26 @@ __global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
   const int nl = pre + 1 + post;
   const int nt_count = dq * tpq;
 
-  // ---- weights in MFMA B-operand order: wl[(nt*NCH + ch)*32 + s][lane] ----------
-  float* wl = fir_lds;
-  const int w_elems = nt_count * NCH * 32 * 64;
+  // ---- weights, split into bf16 pieces, in MFMA B-operand order:
+  //      wl[((nt*NCH + ch)*4 + q)*3 + piece][lane][4 dwords] -- lane (lag n = lane & 31,
+  //      half g = lane >> 5) holds channels ch*64 + 32 g + 8 q + 0..7 of its lag (the order of
+  //      the 16 k-values of an MFMA is free as long as A and B agree: see the A operand below)
+  unsigned* wl = reinterpret_cast<unsigned*>(fir_lds);
+  const int w_elems = nt_count * NCH * kFirTileDw;
   for (int idx = tid; idx < w_elems; idx += kThreads) {
-    const int ln = idx & 63, s = (idx >> 6) & 31, blk = idx >> 11;
+    const int dw = idx & 3, ln = (idx >> 2) & 63;
+    int rest = idx >> 8;
+    const int pc = rest % 3; rest /= 3;
+    const int q4 = rest & 3, blk = rest >> 2;
     const int ch = blk % NCH, nt = blk / NCH;
     const int q = nt / tpq, l = (nt - q * tpq) * 32 + (ln & 31);
-    const int ci = ch * 64 + (ln >> 5) * 32 + s;
-    float v = 0.f;
-    if (l < nl && ci < c) v = w[((long long)l * c + ci) * d_total + q0 + q];
-    wl[idx] = v;
+    const int ci = ch * 64 + (ln >> 5) * 32 + 8 * q4 + 2 * dw;
+    float w0 = 0.f, w1 = 0.f;
+    if (l < nl && ci < c) w0 = w[((long long)l * c + ci) * d_total + q0 + q];
+    if (l < nl && ci + 1 < c) w1 = w[((long long)l * c + ci + 1) * d_total + q0 + q];
+    unsigned ph, pm, pl;
+    td_split3(w0, w1, ph, pm, pl);
+    wl[idx] = pc == 0 ? ph : pc == 1 ? pm : pl;
   }
   // per wave: a [NCH][32][64] x tile (transposition buffer of the loads; its space is
   // reused as the [32][33] P tile during the MFMA chain) and the output ring [ring][dq]
@@ -252,6 +266,9 @@ __global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
   // (li + 1 + n) & 31: that element belongs to output li when li + n >= 31 and to
   // output li + 32 otherwise, so all reads are useful, unconditional and
   // bank-conflict free (row*33 + n).
+  // Loads run TWO blocks ahead of the MFMAs (16 KB per wave in flight): with two waves per
+  // SIMD one block ahead left 64 KB per CU in flight, about what 4 TB/s needs at this
+  // latency -- and that is where the kernel sat.
   float4 cur[NCH][8], nxt[NCH][8];
   int p_rel0 = 0, p_nt = 0;    // its rel0 and tile index
   bool have_prev = false;
@@ -282,6 +299,8 @@ __global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
     }
   };
 
+  // (Loading two blocks ahead -- two register sets swapping roles -- was measured: 0.096 ms per
+  // C4 decode instead of 0.093.)
   for (int j = 0; j < nb; ++j) {
     const long long row0 = rb + 32LL * j;
     if (j + 1 < nb) load_block(row0 + 32, nxt);
@@ -291,38 +310,49 @@ __global__ __launch_bounds__(kThreads, 3) void predict_fir_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       float s_lo = 0.f, s_hi = 0.f;
-      // B operands: a ring of 4 registers fed from LDS three MFMAs ahead (32 registers of
-      // preloaded weights cost a wave of occupancy)
-      const float* wb = wl + (nt * NCH) * 32 * 64 + lane;
-      float wv[4];
+      // One MFMA group per 8 channels of each lane half: lane (li, lh) holds channels
+      // 32 lh + 8 g4 .. + 7 of row li (two of its float4s), split into bf16 pieces on the spot;
+      // the weights' pieces come from LDS (one 16-byte read each).  Six products per group.
+      const td_u32x4* wb = reinterpret_cast<const td_u32x4*>(wl) + (size_t)(nt * NCH) * 4 * 3 * 64 + lane;
+      constexpr int kReads = 16 / (NCH * 4);     // diagonal reads of the previous P tile per group
+      float dcur[kReads];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) wv[k] = wb[k * 64];
-      float dprev = 0.f;           // diagonal read of the previous MFMA slot, consumed one slot later
+      for (int m = 0; m < NCH * 4; ++m) {
+        const float4 v0 = cur[m >> 2][2 * (m & 3)], v1 = cur[m >> 2][2 * (m & 3) + 1];
+        unsigned ph[4], pm[4], pl[4];
+        td_split3(v0.x, v0.y, ph[0], pm[0], pl[0]);
+        td_split3(v0.z, v0.w, ph[1], pm[1], pl[1]);
+        td_split3(v1.x, v1.y, ph[2], pm[2], pl[2]);
+        td_split3(v1.z, v1.w, ph[3], pm[3], pl[3]);
+        const td_u32x4 ah = {ph[0], ph[1], ph[2], ph[3]}, am = {pm[0], pm[1], pm[2], pm[3]},
+                       al = {pl[0], pl[1], pl[2], pl[3]};
+        const td_u32x4 bh = wb[(m * 3 + 0) * 64], bm = wb[(m * 3 + 1) * 64], bl = wb[(m * 3 + 2) * 64];
+        if (have_prev) {
+          // diagonal reads of the previous P tile (already in the LDS tile), consumed after
+          // this group's MFMAs
 #pragma unroll
-      for (int m = 0; m < NCH * 32; ++m) {
-        if (m + 3 < NCH * 32) wv[(m + 3) & 3] = wb[(m + 3) * 64];
-        const float4 av = cur[m >> 5][(m & 31) >> 2];
-        const float a = (m & 3) == 0 ? av.x : (m & 3) == 1 ? av.y : (m & 3) == 2 ? av.z : av.w;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[m & 3], acc, 0, 0, 0);
-        if (have_prev && m % (2 * NCH) == 0) {
-          // one diagonal read of the previous P tile (already in the LDS tile) per two MFMAs
-          const int k = m / (2 * NCH);         // 0..15
-          if (k > 0) {
-            const bool lo = li + 16 * lh + (k - 1) >= 31;
-            s_lo += lo ? dprev : 0.f;
-            s_hi += lo ? 0.f : dprev;
+          for (int r = 0; r < kReads; ++r) {
+            const int n = 16 * lh + m * kReads + r;
+            dcur[r] = tbuf[((li + 1 + n) & 31) * 33 + n];
           }
-          const int n = 16 * lh + k;
-          dprev = tbuf[((li + 1 + n) & 31) * 33 + n];
+        }
+        acc = td_mfma_bf16(al, bh, acc);
+        acc = td_mfma_bf16(ah, bl, acc);
+        acc = td_mfma_bf16(am, bm, acc);
+        acc = td_mfma_bf16(am, bh, acc);
+        acc = td_mfma_bf16(ah, bm, acc);
+        acc = td_mfma_bf16(ah, bh, acc);
+        if (have_prev) {
+#pragma unroll
+          for (int r = 0; r < kReads; ++r) {
+            const bool lo = li + 16 * lh + m * kReads + r >= 31;
+            s_lo += lo ? dcur[r] : 0.f;
+            s_hi += lo ? 0.f : dcur[r];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (have_prev) {
-        const bool lo = li + 16 * lh + 15 >= 31;
-        s_lo += lo ? dprev : 0.f;
-        s_hi += lo ? 0.f : dprev;
-        finish_prev(s_lo, s_hi);
-      }
+      if (have_prev) finish_prev(s_lo, s_hi);
       // this step's P tile goes to the LDS tile now (it is read during the next chain); at
       // the end of a block the same LDS space first transposes the next block's rows
       if (nt == nt_count - 1 && j + 1 < nb) transpose_block(nxt, cur);
@@ -1145,14 +1175,16 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   int ring = 64;
   while (ring < 32 + nl) ring *= 2;
   auto lds_for = [&](int dq) {
-    return sizeof(float) * ((size_t)dq * tpq * nch * 2048 +
+    return sizeof(float) * ((size_t)dq * tpq * nch * kFirTileDw +
                             (kThreads / 64) * ((size_t)nch * 2048 + (size_t)ring * dq));
   };
   int dq_max = d < 16 ? d : 16;
-  while (dq_max > 1 && lds_for(dq_max) > 64 * 1024) --dq_max;
+  // (two workgroups per CU: up to 80 KB each of the 160 KB)
+  constexpr size_t kFirLdsMax = 80 * 1024;
+  while (dq_max > 1 && lds_for(dq_max) > kFirLdsMax) --dq_max;
   // (16-byte aligned rows of at most 64 channels; everything else takes the lane-per-channel path)
   const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  const bool mfma_ok = c <= 64 && vec4 && lds_for(dq_max) <= 64 * 1024;
+  const bool mfma_ok = c <= 64 && vec4 && lds_for(dq_max) <= kFirLdsMax;
   if (nl == 1 && c >= 4 && c <= 64 && vec4 && d <= 32) {
     // no context: one MFMA tile holds all outputs (project_mfma_kernel)
     int64_t strip = td_round_up(td_ceil_div(total, 256 * kProjWavesPerCu), 64);
@@ -1199,6 +1231,12 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(FileDesc), &table_dev));
     const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
     const unsigned blocks = (unsigned)td_ceil_div(n_strips, kThreads / 64);
+    static bool lds_set = false;
+    if (!lds_set) {
+      TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&predict_fir_mfma_kernel<1, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFirLdsMax));
+      lds_set = true;
+    }
     for (int q0 = 0; q0 < d; q0 += dq_max) {
       const int dq = d - q0 < dq_max ? d - q0 : dq_max;
       hipLaunchKernelGGL((predict_fir_mfma_kernel<1, true>), dim3(blocks), dim3(kThreads),

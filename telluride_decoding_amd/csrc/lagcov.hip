@@ -433,34 +433,10 @@ constexpr int kBfPieceDw = 64 * kBfRowDw;
 constexpr size_t kBfLdsBytes = sizeof(unsigned) * 2 * 3 * kBfPieceDw;   // double-buffered
 constexpr int kBfThreads = 512;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // low half = a (RNE)
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-// (x0, x1) -> packed pairs of the three pieces
-__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = pack_bf16(x0, x1);
-  const float r0 = x0 - __builtin_bit_cast(float, h << 16);
-  const float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
-  m = pack_bf16(r0, r1);
-  const float s0 = r0 - __builtin_bit_cast(float, m << 16);
-  const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
-  l = pack_bf16(s0, s1);
-}
+typedef td_u32x4 u32x4;
 
 __device__ __forceinline__ float comp4(const float4& v, int q) {
   return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // One k-step (16 time samples) of one wave: 4 lags x 6 products.  ap / bp: the lane's A row and
@@ -511,7 +487,7 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
 #pragma unroll
   for (int t = 0; t < 6; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = mfma_bf16(a[pa[t]], b[r][pb[t]], c[r]);
+    for (int r = 0; r < 4; ++r) c[r] = td_mfma_bf16(a[pa[t]], b[r][pb[t]], c[r]);
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = c[r];
 }
@@ -523,7 +499,8 @@ __device__ __forceinline__ void bf_ksteps(const unsigned* __restrict__ ap,
   for (int s = kFrom; s < kTo; ++s) {
     if (s == 0) bf_kstep<true>(ap + 8 * s, bp + 8 * s, nullptr, acc);
     else        bf_kstep<false>(ap + 8 * s, bp + 8 * s, nullptr, acc);
-    // (without a fence hipcc hoists the LDS reads of all the unrolled steps to the top and spills)
+    // (without a fence hipcc hoists the LDS reads of all the unrolled steps to the top; fences
+    // after every step, every other step or none at all time the same)
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -600,7 +577,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
       unsigned h[2], m[2], l[2];
 #pragma unroll
       for (int d = 0; d < 2; ++d)
-        split3(comp4(v[2 * d], q), comp4(v[2 * d + 1], q), h[d], m[d], l[d]);
+        td_split3(comp4(v[2 * d], q), comp4(v[2 * d + 1], q), h[d], m[d], l[d]);
       unsigned* dst = buf + (c4 + q) * kBfRowDw + 2 * rg;        // samples 4 rg .. 4 rg + 3
       dst[0] = h[0]; dst[1] = h[1];
       dst[kBfPieceDw] = m[0]; dst[kBfPieceDw + 1] = m[1];
@@ -610,7 +587,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         unsigned h, m, l;
-        split3(comp4(v[4], q), comp4(v[5], q), h, m, l);
+        td_split3(comp4(v[4], q), comp4(v[5], q), h, m, l);
         unsigned* tail = buf + (c4 + q) * kBfRowDw + kBfTile / 2 + rg;   // samples 128 + 2 rg, + 1
         tail[0] = h;
         tail[kBfPieceDw] = m;
@@ -640,7 +617,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
     const unsigned* ap = cur + a_off;
     const unsigned* bp = cur + b_off;
     if (left >= kBfTile) {
-      // whole tile: 8 unrolled k-steps
+      // whole tile: unrolled k-steps
       bf_ksteps<0, 2>(ap, bp, acc);
       if (more && early) store(ut + kBfTile, nxt);
       bf_ksteps<2, 6>(ap, bp, acc);
@@ -668,11 +645,11 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
   }
 
   // Epilogue: the wave's 32 x 32 block of its four lags in the workgroup's partial slab.
-  const int lr = lane & 31, lk = lane >> 5;
   float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float* pe = slab + (size_t)(e0 + 4 * quad + r) * p.ca_pad * p.cb_pad;
+    const int lr = lane & 31, lk = lane >> 5;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int i = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * lk;

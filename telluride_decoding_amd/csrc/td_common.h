@@ -105,6 +105,40 @@ int td_upload_async(td_handle* h, const void* host, size_t bytes, void* dev_dst)
 // stream order, until kTableSlots other tables have been asked for.
 int td_table_upload(td_handle* h, const void* host, size_t bytes, const void** dev);
 
+// ---- float32 products on the bf16 matrix pipe (lagcov.hip, decode.hip) --------------------------
+// A float32 is EXACTLY the sum of three bf16 numbers, x = h + m + l (round-to-nearest splits:
+// |m| <= 2^-9 |x|, |l| <= 2^-18 |x|), so six bf16 products
+//   x y = h h' + (h m' + m h') + (m m' + h l' + l h') + O(2^-27 |x y|),
+// each exact in the float32 accumulator of v_mfma_f32_32x32x16_bf16, reproduce the float32
+// product at 6/16 of the matrix-pipe time of v_mfma_f32_32x32x2_f32 (gfx950 has no TF32).
+typedef __bf16 td_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 td_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float td_f32x2 __attribute__((ext_vector_type(2)));
+typedef float td_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned td_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned td_pack_bf16(float a, float b) {   // low half = a (RNE)
+  const td_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, td_bf16x2));
+}
+
+// (x0, x1) -> packed pairs of the three pieces
+__device__ __forceinline__ void td_split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = td_pack_bf16(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16);
+  const float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = td_pack_bf16(r0, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16);
+  const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = td_pack_bf16(s0, s1);
+}
+
+__device__ __forceinline__ td_f32x16 td_mfma_bf16(const td_u32x4& a, const td_u32x4& b,
+                                                  const td_f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(td_bf16x8, a),
+                                                 __builtin_bit_cast(td_bf16x8, b), c, 0, 0, 0);
+}
+
 static inline int64_t td_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t td_round_up(int64_t a, int64_t b) { return td_ceil_div(a, b) * b; }
 

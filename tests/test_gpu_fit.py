@@ -58,6 +58,14 @@ def _rel(a, b):
     (61, 0, 0, 31, 0, 0, 0, -3, (5000, 129), 7),     # widest x2 tile, input_offset < 0
     (32, 0, 0, 16, 0, 0, 0, 0, (100, 20000), 0),
     (65, 0, 0, 8, 0, 0, 0, 0, (1500, 700), 0),       # too wide for it: the lag kernels
+    # the bf16x3 accumulate kernel (33..64 channels, <= 32 lags): channel counts that need
+    # masks / scalar loads, files around the 128-sample tile and the 2048-sample slab, cut tiles
+    (37, 3, 8, 0, 0, 0, 1, 0, (700, 333, 1021, 5), 0),
+    (48, 0, 15, 0, 0, 0, 2, 1, (128, 129, 127, 160, 2049), 0),
+    (63, 5, 2, 0, 0, 0, 1, -2, (4097, 64), 31),
+    (33, 0, 4, 0, 0, 0, 1, 0, (10, 3000), 0),
+    (64, 16, 15, 0, 0, 0, 1, 0, (2048, 2048, 100), 0),
+    (64, 0, 8, 0, 0, 0, 1, 0, (6000, 1), 0),
 ])
 def test_moments_match_dense_lag_matrix(dev, c1, pre, post, c2, pre2, post2, d, off, lens, drop):
   rng = np.random.default_rng(1234 + c1 + pre * 7 + post)

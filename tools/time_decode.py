@@ -5,6 +5,7 @@ sizes with hop = W // 2 (infer.py:376-378).
     python tools/time_decode.py [--iters 200]
 """
 import argparse
+import gc
 import os
 import sys
 
@@ -33,6 +34,7 @@ def main():
                      (1000, 500)):
     for _ in range(3):
       s, d = device.decode_fused(x, env, offs, w, b, 0, 31, width, hop, corr, handle=h)
+    gc.collect()           # (a collection inside the loop can free a device arena: a 40 ms stall)
     h.synchronize()
     h.timer_start()
     for _ in range(args.iters):
