@@ -24,8 +24,9 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA 
   python3 tools/prof_summary.py $out/pmc$i --pmc > $out/${tag}_hotkernels_pmc$i.txt
   i=$((i+1))
 done
-# 3. the bench line of an un-profiled run
-python3 bench.py --steps 20 --warmup 3 > $out/bench_plain.log 2>&1
-tail -1 $out/bench_plain.log > $out/${tag}_bench_line.json
+# 3. (the bench line of an un-profiled run is taken AFTERWARDS, once profiles/<tag>_lagcov_pmc.json
+#    has been rebuilt from the PMC passes above -- bench.py reads its `traffic` from there:
+#      cp gpurun_out/profiles_<tag>/<tag>_* profiles/ ; python tools/make_pmc_json.py <tag>
+#      gpurun -- 'python bench.py > gpurun_out/bench_line.json' ; cp ... profiles/<tag>_bench_line.json)
 rm -rf $out/bench $out/serial $out/hot $out/pmc0 $out/pmc1 $out/pmc2
 ls -la $out
