@@ -68,6 +68,10 @@ int td_use_own_stream(td_handle* h);
  * serially).  *stream_out is a hipStream_t; free it with td_stream_destroy. */
 int td_stream_create_masked(int device_id, int cu_first, int cu_count, void** stream_out);
 int td_stream_destroy(void* hip_stream);
+/* Tells the handle how many CUs its (adopted, CU-masked) stream runs on: the accumulate plans
+ * its work items to fill whole rounds of them.  Default: every CU of the device.  No reference
+ * counterpart. */
+int td_set_cu_count(td_handle* h, int cu_count);
 int td_synchronize(td_handle* h);
 
 /* Device memory helpers for callers that do not bring their own allocator. */

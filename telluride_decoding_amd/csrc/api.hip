@@ -174,6 +174,9 @@ int td_create(int device_id, td_handle** out) {
   td_handle* h = new td_handle();
   h->device = device_id;
   TD_HIP(h, hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  TD_HIP(h, hipGetDeviceProperties(&prop, device_id));
+  h->cu_count = prop.multiProcessorCount;
   TD_HIP(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   TD_HIP(h, hipEventCreate(&h->ev_start));
@@ -203,6 +206,13 @@ int td_destroy(td_handle* h) {
   if (h->ev_stop) hipEventDestroy(h->ev_stop);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
+  return TD_OK;
+}
+
+int td_set_cu_count(td_handle* h, int cu_count) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "td_set_cu_count: NULL handle");
+  TD_REQUIRE(h, cu_count > 0, "td_set_cu_count: %d CUs", cu_count);
+  h->cu_count = cu_count;
   return TD_OK;
 }
 

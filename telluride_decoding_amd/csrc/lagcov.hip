@@ -1601,7 +1601,10 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
     min_items += n_slabs[f];
     max_items += td_ceil_div(len, kTile);          // never cut below one tile per slab
   }
-  long long items_per_round = (split ? 256 : 512) / per_item_wgs;   // (bf16x3: one workgroup per CU)
+  // (one workgroup per CU for the bf16x3 kernel, two for the float32 one; the CUs of the
+  // stream's mask if the caller declared one: td_set_cu_count)
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  long long items_per_round = (split ? cus : 2 * cus) / per_item_wgs;
   if (items_per_round < 1) items_per_round = 1;
   long long target = td_ceil_div(min_items, items_per_round) * items_per_round;
   if (target > max_items) target = max_items;

@@ -15,6 +15,7 @@
 
 struct td_handle {
   int device = 0;
+  int cu_count = 0;   // CUs the handle's stream runs on (the device's, or a CU mask's: td_set_cu_count)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // the one work is queued on (own or adopted)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;

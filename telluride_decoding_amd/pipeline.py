@@ -104,6 +104,11 @@ class FitPipeline(object):
       with torch.cuda.stream(st):
         self.h_solves.append(device.Handle())
     self.s_solve, self.h_solve = self.s_solves[0], self.h_solves[0]
+    if self._masked:
+      # the accumulate plans its work items for the CUs it really has
+      self.h_acc.check(lib.td_set_cu_count(self.h_acc.ptr, n_cu - solve_cus))
+      for hs in self.h_solves:
+        hs.check(lib.td_set_cu_count(hs.ptr, solve_cus))
     owner = _MaskedStreams(self._masked)
     self.h_acc.keepalive = owner
     for hs in self.h_solves:
