@@ -1591,7 +1591,11 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   // 512 resident workgroup slots (2 per CU): a last round that is 83 % full costs as much
   // as a full one.  Slabs need not be multiples of the tile (the kernels cut the last tile).
   const long long per_item_wgs = (long long)p.n_groups * p.n_cat * p.n_cbt;
-  long long kMaxSlab = 2048;
+  // (The bf16x3 kernel's MFMA chains are one tile long whatever the slab; its slab sums are
+  // float32 additions of at most 64 tile sums: slabs of up to 8192 samples -- a quarter of the
+  // partial-slab traffic and of the per-slab prologues; C2: 1.48 -> 1.41 ms per pipelined fit,
+  // diagonal of the Gram matrix 1.7e-8 (max) from the float64 sums instead of 0.9e-8.)
+  long long kMaxSlab = split ? 8192 : 2048;
   if (const char* e = getenv("TD_MAX_SLAB")) kMaxSlab = atoll(e);   // development
   std::vector<long long> n_slabs(segs.size(), 0);
   long long min_items = 0, max_items = 0;
