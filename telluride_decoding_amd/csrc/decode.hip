@@ -723,6 +723,67 @@ __global__ void decode_finalize_kernel(const double* __restrict__ bsums,
   decisions[w] = sc[0] > sc[1] ? 1 : 0;
 }
 
+// The same tail when every trial is short enough for ONE workgroup (C4: 200 trials of 6000
+// frames): windows never span trials, so a workgroup forms its trial's block sums in LDS -- 64
+// groups of 16 lanes, the arithmetic and summation order of block_sums_pair_kernel -- and then
+// its windows, scores and decisions from them (order of decode_finalize_kernel): one launch
+// instead of two latency-bound ones and no round trip of the block sums through HBM (10 + 8 us
+// and a gap at C4 -> 6 us).  Bit-identical to the two-kernel path.
+// Descriptor: row0 = first frame of the trial, nrows = its blocks, out0 = its windows,
+// first = index of its first window.
+constexpr int kTrialThreads = 1024;
+constexpr int kTrialBlocksMax = 1536;    // 5 float64 per block in LDS: 60 KB
+
+__global__ __launch_bounds__(kTrialThreads) void decode_trial_kernel(
+    const float* __restrict__ a, long long lda, const float* __restrict__ b,
+    const FileDesc* __restrict__ trials, int g, int blocks_per_win, int blocks_per_hop, int width,
+    FusedCorr fc, double* __restrict__ scores, unsigned char* __restrict__ decisions) {
+  extern __shared__ double tb_sums[];     // [block][5]: sum a0, sum a1, sum b, sum a0 b, sum a1 b
+  const FileDesc tr = trials[blockIdx.x];
+  const int n_blocks = (int)tr.nrows, n_win = (int)tr.out0;
+  const int sub = threadIdx.x & (kBlockLanes - 1), grp = threadIdx.x / kBlockLanes;
+  for (int base = 0; base < n_blocks; base += kTrialThreads / kBlockLanes) {
+    const int blk = base + grp;
+    const bool live = blk < n_blocks;               // dead groups stay for the shuffles
+    const long long r0 = tr.row0 + (long long)(live ? blk : n_blocks - 1) * g;
+    double sa0 = 0, sa1 = 0, sb = 0, p0 = 0, p1 = 0;
+    for (int r = sub; r < g; r += kBlockLanes) {
+      const double a0 = (double)a[(r0 + r) * lda], a1 = (double)a[(r0 + r) * lda + 1];
+      const double bv = (double)b[r0 + r];
+      sa0 += a0; sa1 += a1; sb += bv;
+      p0 += a0 * bv; p1 += a1 * bv;
+    }
+    sa0 = group16_sum(sa0); sa1 = group16_sum(sa1); sb = group16_sum(sb);
+    p0 = group16_sum(p0); p1 = group16_sum(p1);
+    if (sub == 0 && live) {
+      double* o = tb_sums + blk * 5;
+      o[0] = sa0; o[1] = sa1; o[2] = sb; o[3] = p0; o[4] = p1;
+    }
+  }
+  __syncthreads();
+  const double n = (double)width;
+  for (int w = threadIdx.x; w < n_win; w += kTrialThreads) {
+    const double* p = tb_sums + (size_t)w * blocks_per_hop * 5;
+    double sc[2];
+#pragma unroll
+    for (int spk = 0; spk < 2; ++spk) {
+      double sa = 0.0, sb = 0.0, sab = 0.0;
+      for (int j = 0; j < blocks_per_win; ++j) {
+        sa += p[j * 5 + spk];
+        sb += p[j * 5 + 2];
+        sab += p[j * 5 + 3 + spk];
+      }
+      const double num = sab - fc.mean_a[spk] * sb - fc.mean_b[spk] * sa +
+                         n * fc.mean_a[spk] * fc.mean_b[spk];
+      sc[spk] = num / (fc.power[spk] * n);
+    }
+    const long long wi = tr.first + w;
+    scores[wi * 2 + 0] = sc[0];
+    scores[wi * 2 + 1] = sc[1];
+    decisions[wi] = sc[0] > sc[1] ? 1 : 0;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void window_means_kernel(
     const double* __restrict__ v, const long long* __restrict__ win_row0, int width,
     double* __restrict__ out) {
@@ -1638,6 +1699,41 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
   int64_t n_blocks = 0, nwin = 0;
   build_block_tables(trial_offsets_host, num_trials, width, hop, g, &tabs, &win_tab, &n_blocks,
                      &nwin);
+  FusedCorr fc;
+  for (int spk = 0; spk < 2; ++spk) {
+    fc.mean_a[spk] = corr_host[3 * spk];
+    fc.mean_b[spk] = corr_host[3 * spk + 1];
+    fc.power[spk] = corr_host[3 * spk + 2];
+  }
+  // many short trials: one workgroup per trial does block sums, windows and decisions
+  int64_t max_tb = 0;
+  for (int t = 0; t < num_trials; ++t) {
+    const int64_t tb = (t + 1 < num_trials ? tabs[t + 1].first : n_blocks) - tabs[t].first;
+    if (tb > max_tb) max_tb = tb;
+  }
+  if (nwin > 0 && num_trials >= 16 && max_tb <= kTrialBlocksMax) {
+    std::vector<FileDesc> tt(num_trials);
+    for (int t = 0; t < num_trials; ++t) {
+      tt[t].row0 = trial_offsets_host[t];
+      tt[t].nrows = (t + 1 < num_trials ? tabs[t + 1].first : n_blocks) - tabs[t].first;
+      tt[t].out0 = (t + 1 < num_trials ? win_tab[t + 1].first : nwin) - win_tab[t].first;
+      tt[t].first = win_tab[t].first;
+    }
+    const size_t s_pred1 = td_round_up(sizeof(float) * rows, 256);
+    void* scratch1 = nullptr;
+    TD_TRY(td_scratch(h, s_pred1, &scratch1));
+    float* pred1 = reinterpret_cast<float*>(scratch1);
+    const void* tt_dev = nullptr;
+    TD_TRY(td_table_upload(h, tt.data(), sizeof(FileDesc) * tt.size(), &tt_dev));
+    TD_TRY(launch_fir(h, eeg_dev, ldx, trial_offsets_host, num_trials, c, pre, post, w_dev, b_dev, 1,
+                      pred1, 1, 0));
+    hipLaunchKernelGGL(decode_trial_kernel, dim3((unsigned)num_trials), dim3(kTrialThreads),
+                       sizeof(double) * 5 * (size_t)max_tb, h->stream, env_dev, (long long)ldenv,
+                       pred1, reinterpret_cast<const FileDesc*>(tt_dev), g, width / g, hop / g, width,
+                       fc, scores_dev, decisions_dev);
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
   tabs.insert(tabs.end(), win_tab.begin(), win_tab.end());
   const size_t s_pred = td_round_up(sizeof(float) * rows, 256);
   void* scratch = nullptr;
@@ -1658,12 +1754,6 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
                      dim3((unsigned)td_ceil_div(n_blocks, kThreads / kBlockLanes)), dim3(kThreads), 0,
                      h->stream, env_dev, (long long)ldenv, pred, d_blk, num_trials,
                      (long long)n_blocks, g, bsums);
-  FusedCorr fc;
-  for (int spk = 0; spk < 2; ++spk) {
-    fc.mean_a[spk] = corr_host[3 * spk];
-    fc.mean_b[spk] = corr_host[3 * spk + 1];
-    fc.power[spk] = corr_host[3 * spk + 2];
-  }
   hipLaunchKernelGGL(decode_finalize_kernel, dim3((unsigned)td_ceil_div(nwin, 256)), dim3(256), 0,
                      h->stream, bsums, d_win, num_trials, (long long)nwin, width / g, hop / g, width,
                      fc, scores_dev, decisions_dev);
