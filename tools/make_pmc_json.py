@@ -20,8 +20,8 @@ out = {}
 for key, kernel, algo, note in (
     ('lagcov', 'lagcov_bf16x3_kernel<true>', 256000000,
      'reads the 256 MB of input (the four lag-group workgroups of a time slab share one XCD L2); '
-     'writes ~270 MB = ~500 float32 partial slabs of 512 KB (one per <= 2048-sample slab), '
-     'summed in float64 by lagcov_reduce_kernel'),
+     'writes ~100 MB = 192 float32 partial slabs of 512 KB (one per <= 8192-sample slab; the count '
+     'fills whole rounds of the CUs), summed in float64 by lagcov_reduce_kernel'),
     ('gram', 'gram_mfma_kernel<true, 5>', 288000000,
      'C3 one-pass CCA moments: every input byte read once; 505 partial slabs of 15 KB')):
   name, fetch = counter(os.path.join(root, tag + '_hotkernels_pmc1.txt'), kernel, 'FETCH_SIZE')
