@@ -1292,11 +1292,10 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(FileDesc), &table_dev));
     const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
     const unsigned blocks = (unsigned)td_ceil_div(n_strips, kThreads / 64);
-    static bool lds_set = false;
-    if (!lds_set) {
+    if (!h->lds_opt_fir) {
       TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&predict_fir_mfma_kernel<1, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFirLdsMax));
-      lds_set = true;
+      h->lds_opt_fir = true;
     }
     for (int q0 = 0; q0 < d; q0 += dq_max) {
       const int dq = d - q0 < dq_max ? d - q0 : dq_max;

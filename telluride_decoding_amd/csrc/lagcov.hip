@@ -1700,13 +1700,12 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
                          dim3(kThreads), lds_bytes, h->stream, p);                                \
   } while (0)
     if (split) {
-      static bool lds_set = false;                     // 123 KB of dynamic LDS: opt in once
-      if (!lds_set) {
+      if (!h->lds_opt_lagcov) {                          // 123 KB of dynamic LDS: opt in once
         TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBfLdsBytes));
         TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBfLdsBytes));
-        lds_set = true;
+        h->lds_opt_lagcov = true;
       }
       if (aligned)
         hipLaunchKernelGGL((lagcov_bf16x3_kernel<true>), dim3((unsigned)nwg), dim3(kBfThreads),

@@ -16,6 +16,8 @@
 struct td_handle {
   int device = 0;
   int cu_count = 0;   // CUs the handle's stream runs on (the device's, or a CU mask's: td_set_cu_count)
+  // kernels that opted in to more than 64 KB of dynamic LDS on this handle's device
+  bool lds_opt_lagcov = false, lds_opt_fir = false;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // the one work is queued on (own or adopted)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
