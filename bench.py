@@ -530,6 +530,12 @@ def main():
       k = C * (PRE + 1 + POST)
       a1 = 2.0 * C * k * (smp1 / max(l1, 1)) / (ms1 / max(l1, 1) / 1e3) / 1e12
       line['serial_ms_per_step'] = e_s / 10 * 1e3
+      # what a bare loop of the kernel's MFMA sustains on this chip (power / clock ceiling)
+      sustained = h.probe_bf16_mfma(True)
+      line['roofline']['pipe_sustained'] = {
+          'split_shaped_operands_tflops': sustained, 'zero_operands_tflops': h.probe_bf16_mfma(False),
+          'what': 'bare register-only v_mfma_f32_32x32x16_bf16 loop, whole chip, ~1 ms (td_probe_bf16_mfma)',
+          'whole_chip_kernel_frac_of_sustained': a1 * SPLIT_PRODUCTS / sustained}
       line['roofline_whole_chip'] = {'kernel': 'lagcov_bf16x3_kernel',
                                      'achieved': a1 * SPLIT_PRODUCTS,
                                      'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -90,6 +90,11 @@ int td_timer_stop(td_handle* h, float* elapsed_ms); /* synchronises the stop eve
  * their summed duration and the samples they covered, and resets the counters. */
 int td_profile_enable(td_handle* h, int on);
 int td_profile_read(td_handle* h, int64_t* launches, double* total_ms, double* samples);
+/* Measurement aid: the rate (TFLOP/s) a bare register-only loop of v_mfma_f32_32x32x16_bf16
+ * sustains on the handle's CUs for ~1 ms -- the practical ceiling of the bf16x3 accumulate, which
+ * is power-bound.  split_shaped = 0: all-zero operands; 1: random operands with the magnitudes
+ * of the three bf16 pieces of a float32.  Blocking.  No reference counterpart. */
+int td_probe_bf16_mfma(td_handle* h, int split_shaped, double* tflops);
 
 /* ------------------------------------------------------------------ A1 + A2
  * Sufficient statistics of lagged regression / CCA inputs WITHOUT building the

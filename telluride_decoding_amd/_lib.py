@@ -57,6 +57,7 @@ SIGNATURES = {
     'td_timer_stop': [_vp, _c.POINTER(_f)],
     'td_profile_enable': [_vp, _i],
     'td_set_cu_count': [_vp, _i],
+    'td_probe_bf16_mfma': [_vp, _i, _pd],
     'td_profile_read': [_vp, _pi64, _pd, _pd],
     'td_stats_create': [_vp, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)],
     'td_stats_destroy': [_vp, _vp],

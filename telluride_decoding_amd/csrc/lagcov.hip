@@ -25,6 +25,7 @@
 //   * blockIdx is remapped so the workgroups that share a time slab (the lag
 //     groups) land on one XCD and hit its L2.
 #include <cstdlib>
+#include <cstring>
 
 #include "td_common.h"
 
@@ -657,6 +658,40 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
       pe[(size_t)i * p.cb_pad + j] = total[r][k];
     }
   }
+}
+
+// ---- measurement aid: what the bf16 matrix pipe sustains (td_probe_bf16_mfma) ----------------
+// A bare loop of the MFMA the kernel above issues, in its six-product order, operands in
+// registers, no memory and no LDS: the rate the chip holds under that load for ~1 ms.  With
+// all-zero operands it runs at ~0.9 of the nominal peak, with operands shaped like the three
+// pieces of a float32 split at 0.66-0.70: the power / clock ceiling the accumulate is measured
+// against (bench.py reports both next to its roofline).
+__global__ __launch_bounds__(256) void bf16_mfma_probe_kernel(const unsigned* __restrict__ ops,
+                                                              float* __restrict__ out, int iters) {
+  u32x4 a[3], b[3];
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) {
+    a[pc] = *reinterpret_cast<const u32x4*>(ops + (pc * 256 + threadIdx.x) * 4);
+    b[pc] = *reinterpret_cast<const u32x4*>(ops + ((3 + pc) * 256 + threadIdx.x) * 4);
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = td_mfma_bf16(a[pa[t]], b[pb[t]], acc[k]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[k][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
 // Synchronous staging of one tile (skinny-A kernel).
@@ -1899,5 +1934,44 @@ int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vect
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)td_ceil_div(ca, 64)), dim3(64), 0,
                      h->stream, partial, (int)works.size(), ca, out_dev, accumulate ? 1 : 0);
   TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+// Sustained rate of the bf16 matrix pipe (see bf16_mfma_probe_kernel): split_shaped = 0 runs
+// all-zero operands, 1 random operands with the magnitudes of float32 split pieces.  Blocking.
+extern "C" int td_probe_bf16_mfma(td_handle* h, int split_shaped, double* tflops) {
+  if (!h || !tflops) return td_fail(h, TD_ERR_INVALID, "td_probe_bf16_mfma: NULL argument");
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  const int grid = 2 * cus, iters = 800;            // two waves per SIMD, ~1 ms
+  std::vector<unsigned> host(6 * 256 * 4, 0u);
+  if (split_shaped) {
+    unsigned state = 12345u;
+    auto rnd = [&]() {                              // sum of 12 uniforms - 6: ~N(0, 1)
+      float u = 0.f;
+      for (int k = 0; k < 12; ++k) { state = state * 1664525u + 1013904223u; u += (state >> 8) * (1.f / 16777216.f); }
+      return u - 6.f;
+    };
+    auto bf = [](float x) { unsigned u; memcpy(&u, &x, 4); return (u + 0x8000u) >> 16; };
+    for (int pc = 0; pc < 6; ++pc) {
+      const float scale = pc % 3 == 0 ? 1.f : pc % 3 == 1 ? 1.f / 512 : 1.f / 262144;
+      for (int i = 0; i < 256 * 4; ++i) host[pc * 1024 + i] = bf(rnd() * scale) | (bf(rnd() * scale) << 16);
+    }
+  }
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, sizeof(unsigned) * host.size() + sizeof(float) * 256 * (size_t)grid, &scratch));
+  unsigned* ops = reinterpret_cast<unsigned*>(scratch);
+  float* out = reinterpret_cast<float*>(ops + host.size());
+  TD_HIP(h, hipMemcpyAsync(ops, host.data(), sizeof(unsigned) * host.size(), hipMemcpyHostToDevice, h->stream));
+  TD_HIP(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  for (int rep = 0; rep < 3; ++rep) {
+    TD_HIP(h, hipEventRecord(h->ev_start, h->stream));
+    hipLaunchKernelGGL(bf16_mfma_probe_kernel, dim3((unsigned)grid), dim3(256), 0, h->stream, ops, out, iters);
+    TD_HIP(h, hipEventRecord(h->ev_stop, h->stream));
+    TD_HIP(h, hipEventSynchronize(h->ev_stop));
+    TD_HIP(h, hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
+  }
+  const double mfma = (double)iters * 24 * grid * 4;
+  *tflops = mfma * 32768.0 / (ms * 1e-3) / 1e12;
   return TD_OK;
 }

@@ -75,6 +75,12 @@ class Handle(object):
                                         ctypes.byref(smp)))
     return int(n.value), float(ms.value), float(smp.value)
 
+  def probe_bf16_mfma(self, split_shaped=True):
+    """TFLOP/s a bare bf16 MFMA loop sustains on this handle's CUs (td_probe_bf16_mfma)."""
+    t = ctypes.c_double(0)
+    self.check(self.lib.td_probe_bf16_mfma(self.ptr, 1 if split_shaped else 0, ctypes.byref(t)))
+    return float(t.value)
+
   # -- memory plumbing ------------------------------------------------------
   def to_device(self, array, dtype=np.float32):
     """Host array (or tensor) -> contiguous 2-D device tensor."""
