@@ -916,7 +916,7 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   struct Ws {
     double *xtx, *x2tx2, *xtx2, *sum2, *cxx, *cyy, *cxy, *vals1, *vecs1, *vals2, *vecs2, *m1, *g,
         *sig, *gn, *vn, *rt;
-    void *eig, *svd;
+    void *eig, *svd, *chol;
   } w;
   auto carve = [&](void* base) {
     Carver cv(base);
@@ -939,6 +939,7 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
     w.rt = cv.take<double>((size_t)dim * std::max(k1, k2));
     w.eig = cv.take<char>(eig_ws_bytes(std::max(k1, k2)));
     w.svd = cv.take<char>(svd_ws_bytes(k));
+    w.chol = cv.take<char>(td_chol_ws_bytes(k1));
     return (size_t)(cv.p - reinterpret_cast<char*>(base));
   };
   void* base = nullptr;
@@ -960,19 +961,41 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
                      (long long)k2, mean_y_dev);
   TD_HIP(h, hipGetLastError());
   int sweeps[3] = {0, 0, 0};
-  // K11 = V f(lambda) V^T = W W^T (W into the cxx buffer, K11 into the vecs1 buffer)
-  TD_TRY(sym_eig(h, w.cxx, k1, k1, w.vals1, w.vecs1, w.eig, &sweeps[0]));
-  hipLaunchKernelGGL(whiten_scale_kernel, dim3(grid_for((long long)k1 * k1)), dim3(256), 0, h->stream,
-                     w.vecs1, w.vals1, k1, eps_eig, w.cxx);
+  // The whitening of the x side.  The reference takes the symmetric inverse square root of
+  // cov_xx + reg I from its eigen-decomposition, dropping eigenvalues <= eps_eig (cca.py:337-352).
+  // When nothing can be dropped -- reg > 2 eps_eig on a positive semi-definite covariance, and
+  // the Cholesky factorisation finds every pivot positive -- ANY whitening W (W C W^T = I) gives
+  // the same canonical directions W^T u, so the O(n^3 * sweeps) Jacobi eigen-decomposition of
+  // the large side is replaced by its Cholesky factor: T = L^-1 cov_xy K22 (the forward
+  // substitution rides along the factorisation), rot_x = L^-T u (backward substitution).
+  // Codelab shape (K1 = 2553): 290 ms -> a few ms.  The small side keeps the eigen route.
+  td_chol_state chol;
+  bool use_chol = regularization > 2.0 * eps_eig && k2 <= 64 && cols && getenv("TD_CCA_EIG") == nullptr;
+  if (use_chol) {
+    // right-hand sides as rows: cov_xy^T [k2][k1] (m1 is free until T is formed)
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)k1 * k2)), dim3(256), 0, h->stream,
+                       w.cxy, k1, k2, w.m1);
+    const int rc = td_chol_factor(h, w.chol, w.cxx, k1, w.m1, k2, &chol);
+    if (rc == TD_ERR_SINGULAR) use_chol = false;       // not positive definite: the eigen route decides
+    else if (rc != TD_OK) return rc;
+  }
   double* k11 = w.vecs1;
-  TD_TRY(gemm(h, w.cxx, k1, false, w.cxx, k1, true, k11, k1, k1, k1, k1));
+  if (!use_chol) {
+    // K11 = V f(lambda) V^T = W W^T (W into the cxx buffer, K11 into the vecs1 buffer)
+    TD_TRY(sym_eig(h, w.cxx, k1, k1, w.vals1, w.vecs1, w.eig, &sweeps[0]));
+    hipLaunchKernelGGL(whiten_scale_kernel, dim3(grid_for((long long)k1 * k1)), dim3(256), 0, h->stream,
+                       w.vecs1, w.vals1, k1, eps_eig, w.cxx);
+    TD_TRY(gemm(h, w.cxx, k1, false, w.cxx, k1, true, k11, k1, k1, k1, k1));
+  }
   TD_TRY(sym_eig(h, w.cyy, k2, k2, w.vals2, w.vecs2, w.eig, &sweeps[1]));
   hipLaunchKernelGGL(whiten_scale_kernel, dim3(grid_for((long long)k2 * k2)), dim3(256), 0, h->stream,
                      w.vecs2, w.vals2, k2, eps_eig, w.cyy);
   double* k22 = w.vecs2;
   TD_TRY(gemm(h, w.cyy, k2, false, w.cyy, k2, true, k22, k2, k2, k2, k2));
-  // T = K11 cov_xy K22, laid out with the vectors to orthogonalise as rows
-  if (cols) {   // g = T^T [k2][k1] = K22 (cov_xy^T K11)
+  // T = W_x cov_xy K22, laid out with the vectors to orthogonalise as rows
+  if (use_chol) {   // g = T^T [k2][k1] = K22 (L^-1 cov_xy)^T; the rows of (L^-1 cov_xy)^T are in chol.rt
+    TD_TRY(gemm(h, k22, k2, false, chol.rt, chol.np, false, w.g, k1, k2, k1, k2));
+  } else if (cols) {   // g = T^T [k2][k1] = K22 (cov_xy^T K11)
     TD_TRY(gemm(h, w.cxy, k2, true, k11, k1, false, w.m1, k1, k2, k1, k1));
     TD_TRY(gemm(h, k22, k2, false, w.m1, k1, false, w.g, k1, k2, k1, k2));
   } else {      // g = T [k1][k2] = K11 (cov_xy K22)
@@ -982,8 +1005,9 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   TD_TRY(jacobi_svd(h, w.g, len, k, len, dim, w.sig, w.gn, w.vn, w.svd, &sweeps[2]));
   const double* u_rows = cols ? w.gn : w.vn;   // [dim][k1]
   const double* v_rows = cols ? w.vn : w.gn;   // [dim][k2]
-  // rot_x^T [dim][k1] = u^T K11 (K11 symmetric), rot_y^T = v^T K22
-  TD_TRY(gemm(h, u_rows, k1, false, k11, k1, false, w.rt, k1, dim, k1, k1));
+  // rot_x^T [dim][k1] = u^T K11 (K11 symmetric) or (L^-T u)^T, rot_y^T = v^T K22
+  if (use_chol) TD_TRY(td_chol_back(h, &chol, u_rows, dim, w.rt));
+  else TD_TRY(gemm(h, u_rows, k1, false, k11, k1, false, w.rt, k1, dim, k1, k1));
   hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(grid_for((long long)dim * k1)), dim3(256), 0,
                      h->stream, w.rt, dim, k1, rot_x_dev);
   TD_TRY(gemm(h, v_rows, k2, false, k22, k2, false, w.rt, k2, dim, k2, k2));

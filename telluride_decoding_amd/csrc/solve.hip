@@ -49,6 +49,8 @@ struct CholParams {
   int jlo;          // update: first block column that is updated
   int col_mode;     // update: 1 = block column jlo only (left-looking step inside an outer block)
   int workers, batch;  // update: workgroups per system; systems
+  int rt_rows;         // rows of rt / sol per system (kMaxRhs for the ridge solves; up to 64 for
+                       // the forward-only right-hand sides of the CCA whitening)
   int* flag;        // set to 1 when a pivot is not positive
   const double* tol; // [batch] pivots at or below this are "not positive" (64 n eps max diag):
                      // an exactly singular matrix leaves a pivot of +-rounding noise, which
@@ -376,7 +378,7 @@ __device__ __forceinline__ UpdTile upd_tile(const CholParams& p, int sys, double
   }
   UpdTile u;
   if (bi == p.nblk) {
-    u.rows_i = p.rt + (size_t)sys * kMaxRhs * p.n;
+    u.rows_i = p.rt + (size_t)sys * p.rt_rows * p.n;
     u.rows_valid = p.nrhs;
   } else {
     u.rows_i = a_b + (size_t)bi * NB * p.n;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(CholParams p, int tiles
     const int bi = p.k + 1 + t;
     if (bi == p.nblk) {
       rows_valid = p.nrhs;
-      return p.rt + (size_t)blockIdx.y * kMaxRhs * n + k0;
+      return p.rt + (size_t)blockIdx.y * p.rt_rows * n + k0;
     }
     rows_valid = NB;
     return a_b + (size_t)bi * NB * n + k0;
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(256) void chol_back_kernel(CholParams p) {
   const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
   const int n = p.n, k0 = p.k * NB;
   const double* a_b = p.a + (size_t)blockIdx.y * n * n;
-  double* rt = p.rt + (size_t)blockIdx.y * kMaxRhs * n;
+  double* rt = p.rt + (size_t)blockIdx.y * p.rt_rows * n;
   const double* li = p.linv + ((size_t)blockIdx.y * p.nblk + p.k) * NB * NB;
   for (int idx = tid; idx < p.nrhs * NB; idx += 256) zs[idx >> 6][idx & 63] = rt[(size_t)(idx >> 6) * n + k0 + (idx & 63)];
   __syncthreads();
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(256) void chol_back_kernel(CholParams p) {
   }
   const int m = blockIdx.x;
   if (m == p.k) {
-    double* sol = p.sol + (size_t)blockIdx.y * kMaxRhs * n;
+    double* sol = p.sol + (size_t)blockIdx.y * p.rt_rows * n;
     for (int idx = tid; idx < p.nrhs * NB; idx += 256) sol[(size_t)(idx >> 6) * n + k0 + (idx & 63)] = ws[idx >> 6][idx & 63];
     return;
   }
@@ -732,9 +734,11 @@ __global__ __launch_bounds__(256) void diag_tol_kernel(const double* __restrict_
 }
 
 // Core: a [batch][n][n] (n a multiple of 64), rt [batch][kMaxRhs][n]; solution in sol.
-int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
-                     double* linv_dev, double* tol_dev, int n, int nrhs, int batch,
-                     int* flag_dev = nullptr) {
+// Factorisation with the forward substitution of the right-hand-side rows (rt: B^T in, z^T =
+// (L^-1 B)^T out); L and the inverses of its diagonal blocks stay in a_dev / linv_dev.
+int chol_factor_forward(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
+                        double* linv_dev, double* tol_dev, int n, int nrhs, int batch,
+                        int* flag_dev, int rt_rows) {
   if (!flag_dev) flag_dev = h->dev_flag;      // (a caller's flag outlives the next solve)
   TD_HIP(h, hipMemsetAsync(flag_dev, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(diag_tol_kernel, dim3((unsigned)batch), dim3(256), 0, h->stream, a_dev, n,
@@ -744,6 +748,7 @@ int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_de
   p.a = a_dev; p.rt = rt_dev; p.linv = linv_dev; p.sol = sol_dev; p.tol = tol_dev;
   p.n = n; p.nrhs = nrhs; p.nblk = nblk; p.flag = flag_dev;
   p.k = 0; p.kf = 0; p.jlo = 0; p.col_mode = 0; p.workers = 1; p.batch = batch;
+  p.rt_rows = rt_rows;
   hipLaunchKernelGGL(chol_diag_kernel, dim3(1, (unsigned)batch), dim3(256), 0, h->stream, p);
   // Outer blocks of `ow` block columns: left-looking inside (column c first takes the updates
   // of the columns of its outer block before it, then its panel), right-looking outside (the
@@ -788,6 +793,20 @@ int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_de
     }
     if (kb + ow < nblk) launch_update(kb, ow, kb + ow, 0);   // ... factors (kb + ow, kb + ow)
   }
+  if (hipGetLastError() != hipSuccess) return td_fail(h, TD_ERR_HIP, "cholesky launch failed");
+  return TD_OK;
+}
+
+// Backward substitution w^T = (L^-T z)^T of the rows in rt_dev (at most kMaxRhs per system)
+// into sol_dev, with the factors chol_factor_forward left behind.
+int chol_backward(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev, double* linv_dev,
+                  int n, int nrhs, int batch, int rt_rows) {
+  const int nblk = n / NB;
+  CholParams p;
+  p.a = a_dev; p.rt = rt_dev; p.linv = linv_dev; p.sol = sol_dev; p.tol = nullptr;
+  p.n = n; p.nrhs = nrhs; p.nblk = nblk; p.flag = nullptr;
+  p.k = 0; p.kf = 0; p.jlo = 0; p.col_mode = 0; p.workers = 1; p.batch = batch;
+  p.rt_rows = rt_rows;
   for (int k = nblk - 1; k >= 0; --k) {
     p.k = k;
     hipLaunchKernelGGL(chol_back_kernel, dim3((unsigned)(k + 1), (unsigned)batch), dim3(256), 0,
@@ -795,6 +814,14 @@ int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_de
   }
   if (hipGetLastError() != hipSuccess) return td_fail(h, TD_ERR_HIP, "cholesky launch failed");
   return TD_OK;
+}
+
+int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
+                     double* linv_dev, double* tol_dev, int n, int nrhs, int batch,
+                     int* flag_dev = nullptr) {
+  TD_TRY(chol_factor_forward(h, a_dev, rt_dev, sol_dev, linv_dev, tol_dev, n, nrhs, batch, flag_dev,
+                             kMaxRhs));
+  return chol_backward(h, a_dev, rt_dev, sol_dev, linv_dev, n, nrhs, batch, kMaxRhs);
 }
 
 int spd_check_flag(td_handle* h) {
@@ -896,7 +923,64 @@ SolveWs carve(void* base, int np, int batch) {
   return w;
 }
 
+// rows [nb][n] -> padded rows [rows][np] (zero beyond nb / n); and back
+__global__ void pad_rows_kernel(const double* __restrict__ src, int nb, int n, int rows, int np,
+                                double* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * np; i += gridDim.x * blockDim.x) {
+    const int q = i / np, r = i % np;
+    dst[i] = (q < nb && r < n) ? src[(size_t)q * n + r] : 0.0;
+  }
+}
+
+__global__ void unpad_rows_kernel(const double* __restrict__ src, int nb, int n, int np,
+                                  double* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * n; i += gridDim.x * blockDim.x)
+    dst[i] = src[(size_t)(i / n) * np + (i % n)];
+}
+
 }  // namespace
+
+// ---- Cholesky whitening for the CCA dense stage (eig.hip: td_cca_solve) -------------------------
+// C = L L^T of one n x n system with up to 64 forward right-hand sides given as ROWS (bt [nb][n] =
+// B^T): afterwards st->rt holds (L^-1 B)^T as rows of length st->np, and td_chol_back applies
+// L^-T to further rows (8 at a time).  `ws` is caller memory of td_chol_ws_bytes(n) bytes.
+size_t td_chol_ws_bytes(int n) {
+  const size_t np = (size_t)td_round_up(n, NB), nblk = np / NB;
+  return sizeof(double) * (np * np + 64 * np + 2 * kMaxRhs * np + nblk * NB * NB + 64) + 1024;
+}
+
+int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const double* bt_dev, int nb,
+                   td_chol_state* st) {
+  TD_REQUIRE(h, n > 0 && nb >= 0 && nb <= 64, "td_chol_factor: bad sizes");
+  const int np = (int)td_round_up(n, NB);
+  char* p = reinterpret_cast<char*>(ws);
+  st->n = n; st->np = np;
+  st->a = reinterpret_cast<double*>(p);     p += sizeof(double) * (size_t)np * np;
+  st->rt = reinterpret_cast<double*>(p);    p += sizeof(double) * (size_t)64 * np;
+  st->rt8 = reinterpret_cast<double*>(p);   p += sizeof(double) * (size_t)kMaxRhs * np;
+  st->sol = reinterpret_cast<double*>(p);   p += sizeof(double) * (size_t)kMaxRhs * np;
+  st->linv = reinterpret_cast<double*>(p);  p += sizeof(double) * (size_t)(np / NB) * NB * NB;
+  st->tol = reinterpret_cast<double*>(p);
+  hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), 1), dim3(256), 0, h->stream, c_dev, 0LL,
+                     n, np, 1.0, (const double*)nullptr, st->a);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(64), dim3(256), 0, h->stream, bt_dev, nb, n, 64, np, st->rt);
+  TD_TRY(chol_factor_forward(h, st->a, st->rt, st->sol, st->linv, st->tol, np, nb > 0 ? nb : 1, 1,
+                             nullptr, 64));
+  return spd_check_flag(h);            // TD_ERR_SINGULAR: not positive definite (blocking)
+}
+
+int td_chol_back(td_handle* h, const td_chol_state* st, const double* ut_dev, int nu, double* xt_dev) {
+  for (int q0 = 0; q0 < nu; q0 += kMaxRhs) {
+    const int nq = nu - q0 < kMaxRhs ? nu - q0 : kMaxRhs;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(16), dim3(256), 0, h->stream, ut_dev + (size_t)q0 * st->n,
+                       nq, st->n, kMaxRhs, st->np, st->rt8);
+    TD_TRY(chol_backward(h, st->a, st->rt8, st->sol, st->linv, st->np, nq, 1, kMaxRhs));
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3(16), dim3(256), 0, h->stream, st->sol, nq, st->n, st->np,
+                       xt_dev + (size_t)q0 * st->n);
+  }
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
 
 extern "C" {
 

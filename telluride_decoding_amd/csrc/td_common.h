@@ -183,3 +183,13 @@ int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, 
 // Column sums in float64 of rows [r0, r1) per segment (lagcov.hip).
 int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vector<LagSeg>& segs,
               double* out_dev, bool accumulate);
+
+// Cholesky whitening helpers of the CCA dense stage (solve.hip), see td_chol_factor there.
+struct td_chol_state {
+  double *a, *rt, *rt8, *sol, *linv, *tol;
+  int n, np;
+};
+size_t td_chol_ws_bytes(int n);
+int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const double* bt_dev, int nb,
+                   td_chol_state* st);
+int td_chol_back(td_handle* h, const td_chol_state* st, const double* ut_dev, int nu, double* xt_dev);

@@ -204,3 +204,31 @@ def test_cca_solve_matches_float64_lapack(dev, c1, l1, c2, l2, n, reg):
   np.testing.assert_allclose(b, wb, atol=tol * np.max(np.abs(wb)))
   np.testing.assert_allclose(mx.cpu().numpy(), sx, atol=1e-6)
   np.testing.assert_allclose(my.cpu().numpy(), sy, atol=1e-6)
+
+
+def test_cholesky_and_eigen_whitening_agree(dev, monkeypatch):
+  """With reg > 0 nothing can be filtered and td_cca_solve whitens the x side with its Cholesky
+  factor (no Jacobi sweeps on cov_xx); TD_CCA_EIG forces the reference's eigen route: same
+  canonical correlations and rotations.  With reg = 0 the eigen route is taken by itself."""
+  rng = np.random.default_rng(77)
+  h = dev.default_handle()
+  n, c1, l1, c2, l2 = 8000, 20, 7, 2, 5             # K1 = 140 (block Jacobi on the eigen route), K2 = 10
+  src = rng.standard_normal((n, 3)).astype(np.float32)
+  x = (src @ rng.standard_normal((3, c1)) + rng.standard_normal((n, c1))).astype(np.float32)
+  x2 = (src @ rng.standard_normal((3, c2)) + 0.5 * rng.standard_normal((n, c2))).astype(np.float32)
+  st = dev.LagStats(c1, 0, l1 - 1, c2, 0, l2 - 1)
+  st.accumulate(h.to_device(x), h.to_device(x2), None, [0, n])
+  dim = 4
+  ra, rb, _, _, e, sweeps = st.cca_solve(n - 1, 0.05, dim)
+  assert sweeps[0] == 0, 'the Cholesky route was not taken'
+  monkeypatch.setenv('TD_CCA_EIG', '1')
+  ra2, rb2, _, _, e2, sweeps2 = st.cca_solve(n - 1, 0.05, dim)
+  assert sweeps2[0] > 0, 'TD_CCA_EIG did not force the eigen route'
+  monkeypatch.delenv('TD_CCA_EIG')
+  np.testing.assert_allclose(e.cpu().numpy(), e2.cpu().numpy(), rtol=1e-6)
+  a, b = _aligned(ra.cpu().numpy().astype(np.float64), rb.cpu().numpy().astype(np.float64),
+                  ra2.cpu().numpy().astype(np.float64), rb2.cpu().numpy().astype(np.float64))
+  np.testing.assert_allclose(a, ra2.cpu().numpy(), atol=2e-5 * np.max(np.abs(a)))
+  np.testing.assert_allclose(b, rb2.cpu().numpy(), atol=2e-5 * np.max(np.abs(b)))
+  _, _, _, _, _, sweeps0 = st.cca_solve(n - 1, 0.0, dim)
+  assert sweeps0[0] > 0, 'reg = 0 must take the eigen route'
