@@ -272,8 +272,10 @@ def cca_leg(h, device, eeg):
           'workload': 'K1 = 69 ch x 37 lags = 2553, K2 = 31 lags of one envelope, 200k samples',
           'fit_ms': (t_acc2 + t_solve2) * 1e3, 'accumulate_ms': t_acc2 * 1e3,
           'solve_ms': t_solve2 * 1e3, 'jacobi_sweeps_eig_xx_yy_svd': list(sweeps)},
-      'note': 'the dense stage (eig x 2, whitening, SVD) runs on the device in float64 '
-              '(td_cca_solve: block Jacobi with MFMA updates)',
+      'note': 'the dense stage (whitening, SVD, rotations) runs on the device in float64 '
+              '(td_cca_solve): with reg > 0 the large side is whitened by its Cholesky factor '
+              '(blocked MFMA Cholesky), the small side -- and everything when reg = 0 -- by the '
+              'Jacobi eigen-decomposition the reference calls for',
   }
 
 
