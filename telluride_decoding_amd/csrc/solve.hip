@@ -739,6 +739,8 @@ __global__ __launch_bounds__(256) void diag_tol_kernel(const double* __restrict_
 int chol_factor_forward(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
                         double* linv_dev, double* tol_dev, int n, int nrhs, int batch,
                         int* flag_dev, int rt_rows) {
+  // (the update kernel addresses a system through a 32-bit buffer descriptor: n * n * 8 bytes)
+  TD_REQUIRE(h, n <= 16320, "cholesky: systems of more than 16320 unknowns are not supported (n = %d)", n);
   if (!flag_dev) flag_dev = h->dev_flag;      // (a caller's flag outlives the next solve)
   TD_HIP(h, hipMemsetAsync(flag_dev, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(diag_tol_kernel, dim3((unsigned)batch), dim3(256), 0, h->stream, a_dev, n,
