@@ -428,10 +428,13 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
 // The LDS tile is double-buffered: the next tile is split and written into the other buffer in
 // the middle of the current tile's MFMAs, one barrier per tile.
 constexpr int kBfTile = 128;            // time samples per tile
-constexpr int kBfRows = 160;            // staged rows: tile + 24 (e0) + 8 halo
-constexpr int kBfRowDw = 83;            // dwords per channel row (166 samples)
-constexpr int kBfPieceDw = 64 * kBfRowDw;
-constexpr size_t kBfLdsBytes = sizeof(unsigned) * 2 * 3 * kBfPieceDw;   // double-buffered
+// Two geometries: up to 32 lags stage 160 rows (tile + 24 (e0) + 8 halo) in channel rows of 83
+// dwords; up to 64 lags stage 192 rows in rows of 99 dwords (152 KB of LDS).  Both strides are odd.
+template <int kRowDw> struct BfGeom {
+  static constexpr int kRows = kRowDw == 83 ? 160 : 192;      // staged rows
+  static constexpr int kPieceDw = 64 * kRowDw;
+  static constexpr size_t kLdsBytes = sizeof(unsigned) * 2 * 3 * kPieceDw;   // double-buffered
+};
 constexpr int kBfThreads = 512;
 
 typedef td_u32x4 u32x4;
@@ -444,7 +447,7 @@ __device__ __forceinline__ float comp4(const float4& v, int q) {
 // B span of piece 0 at this k-step (pieces kBfPieceDw apart).  kZero: first step of a chain (the
 // accumulators start from the inline constant 0).  a_mask: null, or 4 dword masks that cut A at
 // the end of a slab.
-template <bool kZero>
+template <bool kZero, int kBfPieceDw>
 __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
                                          const unsigned* __restrict__ bp,
                                          const unsigned* a_mask, f32x16 (&acc)[4]) {
@@ -493,22 +496,24 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
   for (int r = 0; r < 4; ++r) acc[r] = c[r];
 }
 
-template <int kFrom, int kTo>
+template <int kFrom, int kTo, int kBfPieceDw>
 __device__ __forceinline__ void bf_ksteps(const unsigned* __restrict__ ap,
                                           const unsigned* __restrict__ bp, f32x16 (&acc)[4]) {
 #pragma unroll
   for (int s = kFrom; s < kTo; ++s) {
-    if (s == 0) bf_kstep<true>(ap + 8 * s, bp + 8 * s, nullptr, acc);
-    else        bf_kstep<false>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+    if (s == 0) bf_kstep<true, kBfPieceDw>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+    else        bf_kstep<false, kBfPieceDw>(ap + 8 * s, bp + 8 * s, nullptr, acc);
     // (without a fence hipcc hoists the LDS reads of all the unrolled steps to the top; fences
     // after every step, every other step or none at all time the same)
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <bool kVec4>
+template <bool kVec4, int kBfRowDw>
 __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];   // [2][3][64][kBfRowDw]
+  constexpr int kBfRows = BfGeom<kBfRowDw>::kRows;
+  constexpr int kBfPieceDw = BfGeom<kBfRowDw>::kPieceDw;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -530,7 +535,8 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
   // channel and piece); the threads of waves 0-3 also rows 128 + 2 rg, + 1 (a dword).
   // (Rows from 136 + e0 on are never read by this workgroup's lags: whatever is there is staged.)
   const int c4 = (tid & 15) * 4, rg = tid >> 4;
-  const bool has_tail = wave < 4;                      // rg < 16
+  // (rows 128 .. kBfRows - 1: two per thread -- 32 rows = the threads of waves 0-3, 64 rows = all)
+  const bool has_tail = kBfRows == 192 || wave < 4;
   const bool early = wave < 4;                         // stages after k-step 1 (else after 5):
                                                        // the two waves of a SIMD at different points
   float4 pf[6];
@@ -619,11 +625,11 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
     const unsigned* bp = cur + b_off;
     if (left >= kBfTile) {
       // whole tile: unrolled k-steps
-      bf_ksteps<0, 2>(ap, bp, acc);
+      bf_ksteps<0, 2, kBfPieceDw>(ap, bp, acc);
       if (more && early) store(ut + kBfTile, nxt);
-      bf_ksteps<2, 6>(ap, bp, acc);
+      bf_ksteps<2, 6, kBfPieceDw>(ap, bp, acc);
       if (more && !early) store(ut + kBfTile, nxt);
-      bf_ksteps<6, 8>(ap, bp, acc);
+      bf_ksteps<6, 8, kBfPieceDw>(ap, bp, acc);
     } else {
       // the last, cut tile of a slab: A stops at nk
       const int nk = (int)left;
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
 #pragma unroll
         for (int d = 0; d < 4; ++d)
           mask[d] = cnt >= 2 * d + 2 ? 0xffffffffu : cnt == 2 * d + 1 ? 0x0000ffffu : 0u;
-        bf_kstep<false>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc);
+        bf_kstep<false, kBfPieceDw>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc);
       }
     }
 #pragma unroll
@@ -1607,10 +1613,10 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   p.e_min = e_min; p.e_count = e_count;
   p.n_groups = (int)td_ceil_div(e_count, lags_per_wg);
   // The bf16x3 kernel (lagcov_bf16x3_kernel): the same stream and channel tile on both sides,
-  // lags 0 .. <= 31, 33 .. 64 channels.
+  // lags 0 .. <= 63, 33 .. 64 channels.
   static const bool force_f32 = getenv("TD_LAGCOV_F32") != nullptr;    // development: A/B runs
   bool split = !small && !few && (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min == 0 &&
-               ca > 32 && ca <= 64 && e_count <= 32 && !force_f32;
+               ca > 32 && ca <= 64 && e_count <= 64 && !force_f32;
   for (const LagSeg& sg : segs)
     if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) split = false;
   p.n_cat = small ? 1 : (int)td_ceil_div(ca_eff, 64);
@@ -1735,19 +1741,21 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
                          dim3(kThreads), lds_bytes, h->stream, p);                                \
   } while (0)
     if (split) {
-      if (!h->lds_opt_lagcov) {                          // 123 KB of dynamic LDS: opt in once
-        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBfLdsBytes));
-        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBfLdsBytes));
+      if (!h->lds_opt_lagcov) {                          // 124 / 152 KB of dynamic LDS: opt in once
+#define TD_BF_OPT(V, R)                                                                            \
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<V, R>),     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                      (int)BfGeom<R>::kLdsBytes))
+        TD_BF_OPT(true, 83); TD_BF_OPT(false, 83); TD_BF_OPT(true, 99); TD_BF_OPT(false, 99);
+#undef TD_BF_OPT
         h->lds_opt_lagcov = true;
       }
-      if (aligned)
-        hipLaunchKernelGGL((lagcov_bf16x3_kernel<true>), dim3((unsigned)nwg), dim3(kBfThreads),
-                           kBfLdsBytes, h->stream, p);
-      else
-        hipLaunchKernelGGL((lagcov_bf16x3_kernel<false>), dim3((unsigned)nwg), dim3(kBfThreads),
-                           kBfLdsBytes, h->stream, p);
+#define TD_BF_LAUNCH(V, R)                                                                         \
+      hipLaunchKernelGGL((lagcov_bf16x3_kernel<V, R>), dim3((unsigned)nwg), dim3(kBfThreads),        \
+                         BfGeom<R>::kLdsBytes, h->stream, p)
+      if (e_count <= 32) { if (aligned) TD_BF_LAUNCH(true, 83); else TD_BF_LAUNCH(false, 83); }
+      else               { if (aligned) TD_BF_LAUNCH(true, 99); else TD_BF_LAUNCH(false, 99); }
+#undef TD_BF_LAUNCH
     } else if (few) {
       if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU, true);
       else { unified = false; TD_LAUNCH_MFMA(false, kTileG, kNpfG, true); }

@@ -66,6 +66,10 @@ def _rel(a, b):
     (33, 0, 4, 0, 0, 0, 1, 0, (10, 3000), 0),
     (64, 16, 15, 0, 0, 0, 1, 0, (2048, 2048, 100), 0),
     (64, 0, 8, 0, 0, 0, 1, 0, (6000, 1), 0),
+    # 33 .. 64 lags: the 192-row geometry of the same kernel
+    (64, 40, 20, 0, 0, 0, 1, 0, (3000, 260, 129), 0),
+    (44, 0, 32, 0, 0, 0, 1, 3, (2500, 2049), 17),
+    (64, 31, 32, 0, 0, 0, 1, 0, (191, 192, 193, 5000), 0),
 ])
 def test_moments_match_dense_lag_matrix(dev, c1, pre, post, c2, pre2, post2, d, off, lens, drop):
   rng = np.random.default_rng(1234 + c1 + pre * 7 + post)
