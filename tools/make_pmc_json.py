@@ -18,7 +18,7 @@ def counter(path, kernel, name):
 
 out = {}
 for key, kernel, algo, note in (
-    ('lagcov', 'lagcov_bf16x3_kernel<true>', 256000000,
+    ('lagcov', 'lagcov_bf16x3_kernel<true, 83>', 256000000,
      'reads the 256 MB of input (the four lag-group workgroups of a time slab share one XCD L2); '
      'writes ~100 MB = 192 float32 partial slabs of 512 KB (one per <= 8192-sample slab; the count '
      'fills whole rounds of the CUs), summed in float64 by lagcov_reduce_kernel'),
