@@ -719,8 +719,9 @@ def test_general_solve_indefinite_and_singular(dev, n, nrhs):
       dev.general_solve(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), handle=h)
 
 
-@pytest.mark.parametrize('world', [2, 3, 8])
-def test_time_range_shards_equal_whole_recordings(dev, world):
+@pytest.mark.parametrize('world,shape', [(2, 'narrow'), (3, 'narrow'), (8, 'narrow'),
+                                         (2, 'c2'), (8, 'c2'), (5, 'wide')])
+def test_time_range_shards_equal_whole_recordings(dev, world, shape):
   """Strong-scaling unit of SURVEY 8e: ranks share long recordings by TIME RANGE (piece = range
   + halo; zero extension and edge corrections only at true ends; one packed all-reduce with
   per-recording boundary slots).  Summing the ranks' packed statistics reproduces the
@@ -728,20 +729,29 @@ def test_time_range_shards_equal_whole_recordings(dev, world):
   recording shorter than a range, a dropped remainder and cuts that fall inside the context."""
   from telluride_decoding_amd import distributed
   rng = np.random.default_rng(40 + world)
-  c1, pre, post, c2, pre2, post2, d = 8, 2, 5, 3, 1, 2, 2
-  lens = (1900, 130, 2777, 640)
+  if shape == 'narrow':        # float32 accumulate kernel, lagged CCA moments too
+    c1, pre, post, c2, pre2, post2, d = 8, 2, 5, 3, 1, 2, 2
+    lens = (1900, 130, 2777, 640)
+  elif shape == 'c2':          # the bf16x3 accumulate kernel at the C2 channel / lag counts
+    c1, pre, post, c2, pre2, post2, d = 64, 0, 31, 0, 0, 0, 1
+    lens = (9000, 150, 20011, 4100)
+  else:                        # its 192-row geometry (40 lags), 50 channels
+    c1, pre, post, c2, pre2, post2, d = 50, 30, 9, 0, 0, 0, 1
+    lens = (7000, 2600, 333)
   xs = [rng.standard_normal((n, c1)).astype(np.float32) for n in lens]
-  x2s = [rng.standard_normal((n, c2)).astype(np.float32) for n in lens]
+  x2s = [rng.standard_normal((n, max(c2, 1))).astype(np.float32) for n in lens]
   ys = [rng.standard_normal((n, d)).astype(np.float32) for n in lens]
   h = dev.default_handle()
   offs = np.concatenate(([0], np.cumsum(lens)))
   batch = 100
+  cca = c2 > 0
   rows_used = list(lens)
   rows_used[-1] -= sum(lens) % batch
   whole = dev.LagStats(c1, pre, post, c2, pre2, post2, d)
-  whole.accumulate(h.to_device(np.concatenate(xs)), h.to_device(np.concatenate(x2s)),
+  whole.accumulate(h.to_device(np.concatenate(xs)),
+                   h.to_device(np.concatenate(x2s)) if cca else None,
                    h.to_device(np.concatenate(ys)), offs, rows_used=rows_used)
-  want = whole.moments(want_cca=True)
+  want = whole.moments(want_cca=cca)
   plan = distributed.TimeShardPlan(lens, world, halo=whole.pre1 + whole.post1 + whole.pre2 +
                                    whole.post2 + 1, batch_size=batch)
   assert plan.total_frames == sum(rows_used) == sum(plan.frames_of(r) for r in range(world))
@@ -749,7 +759,8 @@ def test_time_range_shards_equal_whole_recordings(dev, world):
   for rank in range(world):
     st = whole.like()
     distributed.accumulate_time_shard(
-        st, plan, rank, lambda f, a, b: (h.to_device(xs[f][a:b]), h.to_device(x2s[f][a:b]),
+        st, plan, rank, lambda f, a, b: (h.to_device(xs[f][a:b]),
+                                         h.to_device(x2s[f][a:b]) if cca else None,
                                          h.to_device(ys[f][a:b])))
     assert st.counts()[0] == plan.frames_of(rank)
     part = st.pack(plan.total_files, plan.slot_of(rank))
@@ -757,9 +768,9 @@ def test_time_range_shards_equal_whole_recordings(dev, world):
   merged = whole.like()
   merged.unpack(buf, plan.total_files, plan.total_frames)
   assert merged.counts() == whole.counts()
-  got = merged.moments(want_cca=True)
+  got = merged.moments(want_cca=cca)
   scale = float(want['xtx'].abs().max())             # the diagonal: sum of squares of a channel
-  for key in ('xtx', 'xty', 'x2tx2', 'xtx2', 'sum_x2'):
+  for key in (('xtx', 'xty', 'x2tx2', 'xtx2', 'sum_x2') if cca else ('xtx', 'xty')):
     a, b = got[key].cpu().numpy(), want[key].cpu().numpy()
     # (a cut moves the boundaries of the kernel's float32 product chains -- <= 2048 samples each,
     # summed in float64 -- so the sums agree to float32-chain rounding, ~1e-8 of the diagonal)
