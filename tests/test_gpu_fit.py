@@ -808,3 +808,11 @@ def test_ridge_solve_multi_equals_single_solves(dev):
                   h.to_device(np.zeros((500, 2), np.float32)))
   with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
     dev.LagStats.ridge_solve_multi(sts[:2] + [zero], [0.0])
+
+
+def test_bf16_mfma_probe_reports_a_rate(dev):
+  """td_probe_bf16_mfma (bench.py's sustained-pipe figure): zero operands run faster than
+  split-shaped random ones, both well below the nominal 2516.6 TFLOP/s."""
+  h = dev.default_handle()
+  zeros, split = h.probe_bf16_mfma(False), h.probe_bf16_mfma(True)
+  assert 500.0 < split <= zeros * 1.05 and zeros < 2600.0
