@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(256) void ysum_reduce_kernel(const double* __restri
 template <typename T, int Q>
 __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     const T* __restrict__ partial, int n_work, int e_pad, int ca_pad, int cb_pad, int e_count,
-    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst) {
+    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst, int ldg) {
   __shared__ double part[Q][64];
   const long long total = (long long)e_count * ca_eff * cb;
   const size_t slab = (size_t)e_pad * ca_pad * cb_pad;
@@ -1503,33 +1503,34 @@ __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < Q; ++k) t += part[k][ol];
-    double* dst = g + ((long long)e * ca_dst + i) * cb + j;   // ca_dst >= ca_eff rows per lag
+    double* dst = g + ((long long)e * ca_dst + i) * ldg + j;  // ca_dst >= ca_eff rows of ldg per lag
     *dst = accumulate ? *dst + t : t;
   }
 }
 
-// g [c][c]: element (i, j), i > j, := element (j, i)
-__global__ void mirror_upper_kernel(double* __restrict__ g, int c) {
+// g [c][c] with row stride ld: element (i, j), i > j, := element (j, i)
+__global__ void mirror_upper_kernel(double* __restrict__ g, int c, int ld) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= c * c) return;
   const int i = o / c, j = o % c;
-  if (i > j) g[o] = g[(size_t)j * c + i];
+  if (i > j) g[(size_t)i * ld + j] = g[(size_t)j * ld + i];
 }
 
 template <typename T>
 void launch_lagcov_reduce(td_handle* h, const T* partial, int n_work, int e_pad, int ca_pad,
                           int cb_pad, int e_count, int ca_eff, int cb, double* g, bool accumulate,
-                          int ca_dst) {
+                          int ca_dst, int ldg = 0) {
+  if (ldg <= 0) ldg = cb;
   const long long outs = (long long)e_count * ca_eff * cb;
   const unsigned blocks = (unsigned)td_ceil_div(outs, 64);
   if (outs < 32768)
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 16>), dim3(blocks), dim3(1024), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst);
+                       ca_dst, ldg);
   else
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst);
+                       ca_dst, ldg);
 }
 
 // ---- float64 column sums (sum of y over the rows that enter the fit) --------
@@ -1586,16 +1587,30 @@ std::vector<LagWork> split_work(const std::vector<LagSeg>& segs, long long slab)
 
 }  // namespace
 
+// Lower triangle of a c x c block (row stride ld) := its upper triangle.
+int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld) {
+  hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)td_ceil_div((long long)c * c, 256)), dim3(256),
+                     0, h->stream, g_dev, c, ld);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate) {
+              double* g_dev, bool accumulate, int ldg, int rows_dst) {
   const int ca_eff = ca + (a_ones ? 1 : 0);
+  // (ldg / rows_dst: g_dev is a sub-block of lag matrices of rows_dst rows of ldg numbers --
+  // the channel-tile decomposition of td_lagcov_auto; 0 = dense [e][ca_eff][cb])
+  if (ldg <= 0) ldg = cb;
+  if (rows_dst <= 0) rows_dst = ca_eff;
   TD_REQUIRE(h, ca_eff > 0 && cb > 0 && e_count > 0, "lagcov: empty problem");
   long long total = 0;
   for (const LagSeg& s : segs) total += (s.u_end > s.u_begin) ? s.u_end - s.u_begin : 0;
   if (total == 0) {
-    if (!accumulate)
+    if (!accumulate) {
+      TD_REQUIRE(h, ldg == cb && rows_dst == ca_eff, "lagcov: overwrite mode needs a dense destination");
       TD_HIP(h, hipMemsetAsync(g_dev, 0, sizeof(double) * e_count * ca_eff * cb, h->stream));
+    }
     return TD_OK;
   }
   // the LDS-tiled VALU kernel only serves skinny [y | 1] operands that the streaming targets
@@ -1768,17 +1783,17 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   TD_HIP(h, hipGetLastError());
   if (few)   // [work][phase][n_groups * G lags]: S = 8 / G slabs per work item
     launch_lagcov_reduce<float>(h, p.partial, p.n_work * (8 / few_g), p.n_groups * few_g, p.ca_pad,
-                                p.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, ca_eff);
+                                p.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, rows_dst, ldg);
   else
     launch_lagcov_reduce<float>(h, p.partial, p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff,
-                                cb, g_dev, accumulate, ca_eff);
+                                cb, g_dev, accumulate, rows_dst, ldg);
   // The bf16x3 kernel adds the six partial products of x_i x_j in an order that is not symmetric
   // in i and j, so the lag-0 Gram block comes out symmetric only to ~1e-9: the lower triangle
   // takes the upper one's sums (the float32 kernel's block is symmetric by construction, and
   // the moment matrix is promised exactly symmetric).
   if (split)
     hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)td_ceil_div((long long)ca * cb, 256)),
-                       dim3(256), 0, h->stream, g_dev, ca);
+                       dim3(256), 0, h->stream, g_dev, ca, ldg);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

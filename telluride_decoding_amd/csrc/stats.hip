@@ -451,6 +451,29 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
                                     nullptr, parts);
 }
 
+// Auto-covariance G[e] = x~^T shift_e(x~), e = 0 .. l-1, accumulated into g [l][c][c].  Up to
+// 64 channels it is one td_lagcov call.  65 .. 128 channels are cut into two channel tiles
+// [0, 64) and [64, c): the two diagonal blocks are the same-stream case again (the bf16x3 kernel
+// for a tile of more than 32 channels), the two off-diagonal blocks go through the general
+// kernel with A and B pointing at different channels of the same rows -- instead of four padded
+// 64 x 64 tiles through the general kernel (the codelab's 69 channels: 3.4 -> 1.x ms).
+namespace {
+int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
+                int l, double* g) {
+  if (c <= 64 || c > 128)
+    return td_lagcov(h, x, ldx, c, false, x, ldx, c, segs, 0, l, g, true);
+  const int c1 = c - 64;
+  TD_TRY(td_lagcov(h, x, ldx, 64, false, x, ldx, 64, segs, 0, l, g, true, c, c));
+  TD_TRY(td_lagcov(h, x + 64, ldx, c1, false, x + 64, ldx, c1, segs, 0, l, g + (size_t)64 * c + 64, true,
+                   c, c));
+  TD_TRY(td_lagcov(h, x, ldx, 64, false, x + 64, ldx, c1, segs, 0, l, g + 64, true, c, c));
+  TD_TRY(td_lagcov(h, x + 64, ldx, c1, false, x, ldx, 64, segs, 0, l, g + (size_t)64 * c, true, c, c));
+  // (the lag-0 matrix is promised exactly symmetric: its two off-diagonal blocks come from two
+  // launches)
+  return td_mirror_upper(h, g, c, c);
+}
+}  // namespace
+
 int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
                                const float* x2_dev, int64_t ldx2, const float* y_dev, int64_t ldy,
                                const int64_t* file_offsets_host, int num_files, int input_offset,
@@ -559,8 +582,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
                      &handled));
       TD_REQUIRE(h, handled, "td_gram refused a shape the one-pass test accepted");
     } else {
-      TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1,
-                       s->g + s->off_fxx, true));
+      TD_TRY(lagcov_auto(h, x_dev, ldx, s->c1, sxx, s->l1, s->g + s->off_fxx));
     }
     if (s->c2 && !one_pass) {
       TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,

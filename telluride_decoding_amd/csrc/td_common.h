@@ -171,7 +171,8 @@ struct LagSeg {
 
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate);
+              double* g_dev, bool accumulate, int ldg = 0, int rows_dst = 0);
+int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld);
 
 // [y]^T x~ per signed lag on the lane-per-channel kernel, plus the per-segment column sums
 // of B over [u_begin, u_end) and the column sums of Y (lagcov.hip).  *handled = false when
