@@ -204,11 +204,6 @@ int td_destroy(td_handle* h) {
   if (h->host_flags) hipHostFree(h->host_flags);
   if (h->ev_start) hipEventDestroy(h->ev_start);
   if (h->ev_stop) hipEventDestroy(h->ev_stop);
-  if (h->ev_fork) hipEventDestroy(h->ev_fork);
-  for (int i = 0; i < td_handle::kSideStreams; ++i) {
-    if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
-    if (h->side[i]) hipStreamDestroy(h->side[i]);
-  }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return TD_OK;

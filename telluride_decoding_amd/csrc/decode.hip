@@ -1,6 +1,8 @@
 // Decode side of the hot path (SURVEY.md 8a rows A3'/A4 forward, A5-A9):
 // FIR prediction on the never-materialised lag view, windowed correlation sums,
 // per-window scores and the attended-speaker decision.
+#include <cstdlib>
+
 #include "td_common.h"
 
 namespace {
@@ -1297,38 +1299,16 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFirLdsMax));
       h->lds_opt_fir = true;
     }
-    // Several groups of outputs over a small input (the 20 lambdas of a held-out recording in a
-    // leave-one-out sweep: 7 launches of ~120 workgroups, each bound by latency): the groups go
-    // round-robin to side streams and run next to each other.
-    const int n_groups = (int)td_ceil_div(d, dq_max);
-    const bool fan_out = n_groups >= 3 && blocks < 512;
-    if (fan_out) {
-      if (!h->ev_fork) {
-        TD_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < td_handle::kSideStreams; ++i) {
-          TD_HIP(h, hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
-          TD_HIP(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-        }
-      }
-      TD_HIP(h, hipEventRecord(h->ev_fork, h->stream));
-      for (int i = 0; i < td_handle::kSideStreams; ++i)
-        TD_HIP(h, hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
-    }
-    int gi = 0;
-    for (int q0 = 0; q0 < d; q0 += dq_max, ++gi) {
+    // (Fanning the output groups of a many-output prediction out over side streams -- 20 lambdas
+    // of a held-out recording: 7 launches of ~120 workgroups -- took a lone call from 245 to
+    // 163 us but made the leave-one-out sweep inside a process with many live streams 20 % slower
+    // (0.097 -> 0.117 s in bench.py): one stream.)
+    for (int q0 = 0; q0 < d; q0 += dq_max) {
       const int dq = d - q0 < dq_max ? d - q0 : dq_max;
-      const int lane_ = gi % (td_handle::kSideStreams + 1);
-      hipStream_t st = (fan_out && lane_ > 0) ? h->side[lane_ - 1] : h->stream;
       hipLaunchKernelGGL((predict_fir_mfma_kernel<1, true>), dim3(blocks), dim3(kThreads),
-                         lds_for(dq), st, x, (long long)ldx, df, num_files, n_strips,
+                         lds_for(dq), h->stream, x, (long long)ldx, df, num_files, n_strips,
                          (int)strip, c, pre, post, w, bias, d, q0, dq, tpq, ring, out,
                          (long long)ldout);
-    }
-    if (fan_out) {
-      for (int i = 0; i < td_handle::kSideStreams; ++i) {
-        TD_HIP(h, hipEventRecord(h->ev_join[i], h->side[i]));
-        TD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
-      }
     }
     TD_HIP(h, hipGetLastError());
     return TD_OK;

@@ -20,11 +20,6 @@ struct td_handle {
   bool lds_opt_lagcov = false, lds_opt_fir = false;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // the one work is queued on (own or adopted)
-  // side streams for independent small launches of ONE call (the output groups of a
-  // many-output FIR prediction), forked from / joined to `stream` with events
-  static constexpr int kSideStreams = 3;
-  hipStream_t side[kSideStreams] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::string error;
   // grow-only device scratch (partial slabs, expanded matrices, ...)

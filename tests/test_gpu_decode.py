@@ -37,7 +37,7 @@ def _d64(h, v):
     (4, 6, 6, 1, (5, 3, 700), 0),       # files shorter than the context
     (63, 0, 31, 1, (1500, 200), 0),     # unaligned rows: lane-per-channel kernel, 32 taps
     (69, 2, 10, 3, (800, 333), 1),      # two channel passes, outputs in pairs
-    (64, 0, 31, 20, (3000, 500), 0),    # 20 outputs (a lambda sweep): output groups on side streams
+    (64, 0, 31, 20, (3000, 500), 0),    # 20 outputs (a lambda sweep): several output groups
     (48, 5, 8, 11, (2048,), 0),
     (7, 0, 0, 9, (640,), 0),            # no lags, more outputs than one pass holds
     (130, 1, 1, 2, (300, 77), 0),       # three channel passes of the short-filter variant
