@@ -516,6 +516,11 @@ def main():
     if not args.serial:
       line['roofline']['cus'] = '%d of 256 (CU-masked accumulate stream)' % (256 - args.solve_cus) \
           if args.solve_cus else '256'
+      if args.solve_cus:
+        # the pipelined run leaves the accumulate 256 - solve_cus CUs: the same launch against
+        # the peak of the CUs it has
+        share = (256 - args.solve_cus) / 256.0
+        line['roofline']['frac_of_its_cus_peak'] = line['roofline']['frac'] / share
 
   # ---------------------------------------------------------------- after the timed region
   del pipe, run
