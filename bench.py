@@ -319,6 +319,114 @@ def loso_leg(eeg, env):
   }
 
 
+def launch_ranks(args, argv):
+  """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver calls it
+  when it does not go through torch.distributed.run): this process touches no GPU; it starts N
+  worker processes -- one rank per GPU, the same environment torch.distributed.run would give
+  them, rendezvous on 127.0.0.1 -- relays rank 0's output (the JSON line last) and exits
+  non-zero if any worker does.  It never falls back to fewer ranks."""
+  import socket
+  import subprocess
+  n = args.gpus
+  if not args.dry_launch:
+    import torch                                        # device_count() does not initialise HIP
+    have = torch.cuda.device_count()
+    if have < n:
+      sys.stderr.write('bench.py: --gpus %d but this node shows %d GPU(s); refusing to run fewer '
+                       'ranks than asked for\n' % (n, have))
+      return 2
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  procs = []
+  for r in range(n):
+    env = dict(os.environ)
+    env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TD_BENCH_LAUNCHER='self')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                  stdout=subprocess.PIPE if r == 0 else None))
+  # rank 0's stdout is read to its end (its last line is the JSON line); a worker that dies takes
+  # the others down with it instead of leaving them in the rendezvous
+  import threading
+  out0 = []
+  reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+  reader.start()
+  failed = None
+  while True:
+    codes = [p.poll() for p in procs]
+    bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+    if bad and failed is None:
+      failed = bad[0]
+      for p in procs:
+        if p.poll() is None:
+          p.terminate()                                 # exactly the PIDs started above
+    if all(c is not None for c in codes):
+      break
+    time.sleep(0.05)
+  reader.join(timeout=10)
+  text = b''.join(out0).decode(errors='replace')
+  sys.stdout.write(text)
+  sys.stdout.flush()
+  if failed is not None:
+    sys.stderr.write('bench.py: rank %d exited with code %d; no result\n' % failed)
+    return 1
+  last = text.strip().splitlines()[-1] if text.strip() else ''
+  try:
+    seen = json.loads(last).get('ranks_seen')
+  except ValueError:
+    seen = None
+  if seen != n:
+    sys.stderr.write('bench.py: asked for %d ranks, the result line reports %r\n' % (n, seen))
+    return 1
+  return 0
+
+
+def dry_launch(args, rank, local_rank, world):
+  """--dry-launch: the launch / rendezvous / barrier / max-over-ranks / JSON plumbing of a
+  multi-rank run on CPU (gloo), with the sharding plans of the real run and NO compute: no
+  library call, no GPU.  `value` is null; the line says which recordings and which time ranges
+  each rank would have taken."""
+  import torch
+  import torch.distributed as dist
+  from telluride_decoding_amd import distributed
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  if os.environ.get('TD_BENCH_DRY_FAIL_RANK') == str(rank):      # tests: a worker that dies
+    os._exit(7)
+  plan = distributed.ShardPlan([FRAMES_PER_FILE] * (FILES_PER_GPU * world), world)
+  tplan = distributed.TimeShardPlan([FRAMES_PER_FILE] * FILES_PER_GPU, world, halo=PRE + POST + 1)
+  mine = torch.zeros(world, 3, dtype=torch.float64)
+  mine[rank, 0] = plan.frames_of(rank)
+  mine[rank, 1] = tplan.frames_of(rank)
+  mine[rank, 2] = 1
+  dist.barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    buf = mine.clone()
+    distributed.allreduce_packed(buf)                   # the product's collective wrapper
+  dist.barrier()
+  t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  seen = dist.get_world_size()
+  ok = bool((buf[:, 2] == 1).all()) and int(buf[:, 0].sum()) == FILES_PER_GPU * FRAMES_PER_FILE * world \
+      and int(buf[:, 1].sum()) == FILES_PER_GPU * FRAMES_PER_FILE
+  dist.barrier()
+  dist.destroy_process_group()
+  if not ok:
+    raise SystemExit('dry launch: the all-reduced shard table is wrong: %s' % buf.tolist())
+  if rank == 0:
+    print(json.dumps({
+        'metric': 'TRF-fit samples/sec', 'value': None, 'unit': 'samples/s', 'n_gpus': world,
+        'ranks_seen': seen, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': float(t.item()) / max(args.steps, 1) * 1e3, 'dry_launch': True,
+        'launcher': os.environ.get('TD_BENCH_LAUNCHER', 'torch.distributed.run'),
+        'backend': 'gloo', 'data': 'none (no compute: launch / rendezvous / collective plumbing only)',
+        'weak_frames_per_rank': [int(v) for v in buf[:, 0]],
+        'strong_frames_per_rank': [int(v) for v in buf[:, 1]]}), flush=True)
+  return 0
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -338,14 +446,28 @@ def main():
                   help='run the N > 1 code path (RCCL all-reduce of the statistics) on one rank')
   ap.add_argument('--serial', action='store_true',
                   help='one stream, fits back to back (no accumulate/solve overlap)')
+  ap.add_argument('--dry-launch', action='store_true',
+                  help='launch the ranks, rendezvous (gloo, CPU) and print the line without any '
+                       'compute: checks the multi-rank plumbing where there is no GPU')
   args = ap.parse_args()
+  if args.gpus < 1:
+    raise SystemExit('--gpus must be >= 1')
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    # not under torch.distributed.run: start the N ranks from here (before any GPU call)
+    sys.exit(launch_ranks(args, sys.argv[1:]))
 
-  import torch
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
-  if world != args.gpus and world > 1:
-    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+  if world != args.gpus:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d: refusing to run a different number of ranks '
+                     'than asked for' % (args.gpus, world))
+  if args.dry_launch:
+    sys.exit(dry_launch(args, rank, local_rank, world))
+  import torch
+  if torch.cuda.device_count() <= local_rank:
+    raise SystemExit('rank %d: no GPU %d on this node (%d visible)'
+                     % (rank, local_rank, torch.cuda.device_count()))
   torch.cuda.set_device(local_rank)
   dist_on = world > 1 or args.force_dist      # --force-dist: the N > 1 code path on one rank
   if dist_on:
@@ -358,6 +480,13 @@ def main():
                               device_id=torch.device('cuda', local_rank))
     else:
       dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  # what the communicator itself reports (RCCL's world size), counted once more by a collective
+  ranks_seen = 1
+  if dist_on:
+    ones = torch.ones(1, dtype=torch.float64, device='cuda')
+    dist.all_reduce(ones)
+    ranks_seen = int(ones.item())
+    assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
 
   from telluride_decoding_amd import device, distributed, pipeline
   h = device.default_handle()
@@ -476,7 +605,9 @@ def main():
         break
     line = {
         'metric': 'TRF-fit samples/sec', 'value': value, 'unit': 'samples/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
+        'launcher': os.environ.get('TD_BENCH_LAUNCHER',
+                                   'torch.distributed.run' if world > 1 else 'direct'),
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': args.scaling, 'vs_baseline': None,
         'dtype': 'f32 (products as exact bf16x3 splits on the bf16 MFMA, f32 accumulate; f64 solve)',

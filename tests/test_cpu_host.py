@@ -2,6 +2,7 @@
 host-side logic (datasets, window buffers, LDA, shard plan), and the N > 1 path
 with two gloo processes.  No compute call needs a GPU here."""
 import ctypes
+import json
 import os
 import subprocess
 import sys
@@ -335,3 +336,47 @@ def test_two_process_gloo_allreduce_protocol(tmp_path):
   res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
   assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
   assert 'rank 0 ok' in res.stdout and 'rank 1 ok' in res.stdout
+
+
+def _bench(args, extra_env=None, timeout=300):
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+  env.update(extra_env or {})
+  return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env,
+                        capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+  """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the
+  driver calls it) must itself start N ranks -- or fail; never run one rank and report
+  n_gpus 1.  --dry-launch runs the launcher, the rendezvous (gloo), the barrier / max-over-ranks
+  plumbing and the product's collective wrapper on CPU without any compute."""
+  res = _bench(['--gpus', '2', '--steps', '2', '--dry-launch'])
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+  line = json.loads(res.stdout.strip().splitlines()[-1])
+  assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launcher'] == 'self'
+  assert line['weak_frames_per_rank'] == [1000000, 1000000]
+  assert line['strong_frames_per_rank'] == [500000, 500000]
+  # the same through torch.distributed.run (how the driver launches N > 1)
+  port = 31500 + (os.getpid() % 2000)
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE')}
+  res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                        '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port',
+                        str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+                        '--dry-launch'], env=env, capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+  line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+  assert line['ranks_seen'] == 2 and line['launcher'] == 'torch.distributed.run'
+
+
+def test_bench_never_runs_fewer_ranks_than_asked():
+  """No GPU here: a real `--gpus 2` run must refuse (non-zero), not fall back to one rank; a
+  worker that dies fails the whole launch; a WORLD_SIZE that contradicts --gpus is an error."""
+  res = _bench(['--gpus', '2', '--steps', '1'])
+  assert res.returncode != 0 and 'refusing' in res.stderr
+  assert '"n_gpus"' not in res.stdout
+  res = _bench(['--gpus', '2', '--steps', '1', '--dry-launch'], {'TD_BENCH_DRY_FAIL_RANK': '1'},
+               timeout=120)
+  assert res.returncode != 0 and 'rank 1 exited with code 7' in res.stderr
+  res = _bench(['--gpus', '2', '--dry-launch'], {'WORLD_SIZE': '4', 'RANK': '0'})
+  assert res.returncode != 0 and 'WORLD_SIZE=4' in (res.stderr + res.stdout)
