@@ -325,6 +325,15 @@ int td_window_scores(td_handle* h, const double* sums_dev, int64_t total_windows
                      const double* mean_a_host, const double* mean_b_host,
                      const double* power_host, double* scores_dev);
 
+/* Per-window Pearson r of SEVERAL models at once: the columns are `cols / group` models of
+ * `group` outputs each (e.g. the weight vectors of every lambda of a jackknife fold, evaluated
+ * by one prediction pass; regression.py:197-214 evaluates them one by one).  The reference's
+ * zero rule (brain_model.py:72-79: a constant column zeroes the whole result of THAT
+ * pearson_correlation call) is applied per model: over its `group` columns only.
+ * td_window_scores(mode 1) is the case group == cols.  scores_dev [total_windows, cols]. */
+int td_window_pearson(td_handle* h, const double* sums_dev, int64_t total_windows, int cols,
+                      int group, int width, double* scores_dev);
+
 /* Per-frame reduced correlation score (Decoder.infer_one, infer_decoder.py:439-455)
  * for reductions that are not linear in the window sums.
  *   reduction: 0 first, 1 second, 2 mean, 3 mean-squared, 4 lda (affine map

@@ -90,6 +90,7 @@ SIGNATURES = {
     'td_window_count': [_pi64, _i, _i, _i, _pi64, _pi64],
     'td_window_sums': [_vp, _vp, _i64, _vp, _i64, _i, _pi64, _i, _i, _i, _vp],
     'td_window_scores': [_vp, _vp, _i64, _i, _i, _i, _i, _pd, _pd, _pd, _vp],
+    'td_window_pearson': [_vp, _vp, _i64, _i, _i, _i, _vp],
     'td_frame_scores': [_vp, _vp, _i64, _vp, _i64, _i, _i64, _i, _pd, _pd, _pd, _pd, _d,
                         _d, _vp],
     'td_window_means': [_vp, _vp, _pi64, _i, _i, _i, _vp],

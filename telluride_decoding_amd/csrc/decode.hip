@@ -819,8 +819,8 @@ __device__ __forceinline__ bool no_variance(double var, double sum_sq) {
 // columns; mode 1: per-window Pearson per column with the reference's "any
 // constant column zeroes everything" rule (brain_model.py:72-79).
 __global__ void window_scores_kernel(const double* __restrict__ sums, long long n_win, int cols,
-                                     int width, int mode, int reduction, ScoreParams sp,
-                                     double* __restrict__ scores) {
+                                     int width, int mode, int reduction, int group,
+                                     ScoreParams sp, double* __restrict__ scores) {
   const long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (w >= n_win) return;
   const double* s = sums + w * cols * 5;
@@ -837,17 +837,22 @@ __global__ void window_scores_kernel(const double* __restrict__ sums, long long 
     }
     scores[w] = acc / (double)(c_hi - c_lo);
   } else {
-    bool zero = false;
-    for (int c = 0; c < cols; ++c) {
-      const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
-      zero = zero || no_variance(s[c * 5 + 2] - sa * sa / n, s[c * 5 + 2]) ||
-             no_variance(s[c * 5 + 3] - sb * sb / n, s[c * 5 + 3]);
-    }
-    for (int c = 0; c < cols; ++c) {
-      const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
-      const double va = s[c * 5 + 2] - sa * sa / n, vb = s[c * 5 + 3] - sb * sb / n;
-      const double cov = s[c * 5 + 4] - sa * sb / n;
-      scores[w * cols + c] = zero ? 0.0 : cov / (sqrt(va) * sqrt(vb));
+    // the zero rule is per MODEL: columns [g0, g0 + group) are the outputs of one model (one
+    // pearson_correlation call in the reference); group == cols is a single model
+    for (int g0 = 0; g0 < cols; g0 += group) {
+      const int g1 = min(g0 + group, cols);
+      bool zero = false;
+      for (int c = g0; c < g1; ++c) {
+        const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
+        zero = zero || no_variance(s[c * 5 + 2] - sa * sa / n, s[c * 5 + 2]) ||
+               no_variance(s[c * 5 + 3] - sb * sb / n, s[c * 5 + 3]);
+      }
+      for (int c = g0; c < g1; ++c) {
+        const double sa = s[c * 5 + 0], sb = s[c * 5 + 1];
+        const double va = s[c * 5 + 2] - sa * sa / n, vb = s[c * 5 + 3] - sb * sb / n;
+        const double cov = s[c * 5 + 4] - sa * sb / n;
+        scores[w * cols + c] = zero ? 0.0 : cov / (sqrt(va) * sqrt(vb));
+      }
     }
   }
 }
@@ -1552,7 +1557,21 @@ int td_window_scores(td_handle* h, const double* sums_dev, int64_t total_windows
   if (total_windows <= 0) return TD_OK;
   hipLaunchKernelGGL(window_scores_kernel, dim3((unsigned)td_ceil_div(total_windows, 256)),
                      dim3(256), 0, h->stream, sums_dev, (long long)total_windows, cols, width, mode,
-                     reduction, sp, scores_dev);
+                     reduction, cols, sp, scores_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_window_pearson(td_handle* h, const double* sums_dev, int64_t total_windows, int cols,
+                      int group, int width, double* scores_dev) {
+  if (!h || !sums_dev || !scores_dev) return td_fail(h, TD_ERR_INVALID, "td_window_pearson: NULL");
+  TD_REQUIRE(h, cols >= 1 && group >= 1 && cols % group == 0,
+             "td_window_pearson: %d columns are not whole groups of %d", cols, group);
+  if (total_windows <= 0) return TD_OK;
+  ScoreParams sp = {nullptr, nullptr, nullptr, nullptr, 1.0, 0.0};
+  hipLaunchKernelGGL(window_scores_kernel, dim3((unsigned)td_ceil_div(total_windows, 256)),
+                     dim3(256), 0, h->stream, sums_dev, (long long)total_windows, cols, width, 1,
+                     0, group, sp, scores_dev);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

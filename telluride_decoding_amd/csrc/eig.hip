@@ -970,7 +970,14 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   // substitution rides along the factorisation), rot_x = L^-T u (backward substitution).
   // Codelab shape (K1 = 2553): 290 ms -> a few ms.  The small side keeps the eigen route.
   td_chol_state chol;
-  bool use_chol = regularization > 2.0 * eps_eig && k2 <= 64 && cols && getenv("TD_CCA_EIG") == nullptr;
+  // Positive semi-definiteness is what makes "nothing can be dropped" true: S / denom - m^T m
+  // = (frames / denom) (S / frames) - m^T m  >=  S / frames - m^T m  >=  0 needs denom <= frames
+  // (the reference's denom = minibatches x rows of the LAST minibatch - 1, cca.py:339-343, exceeds
+  // the frame count for iterables with uneven batches; the covariance can then be indefinite and
+  // still pass a Cholesky with eigenvalues in (0, eps_eig] that the reference drops).
+  static const bool force_eig = getenv("TD_CCA_EIG") != nullptr;     // development switch, read once
+  bool use_chol = regularization > 2.0 * eps_eig && k2 <= 64 && cols && !force_eig &&
+                  denom <= (double)frames;
   if (use_chol) {
     // right-hand sides as rows: cov_xy^T [k2][k1] (m1 is free until T is formed)
     hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)k1 * k2)), dim3(256), 0, h->stream,

@@ -40,9 +40,11 @@ class Handle(object):
     self.use_torch_stream()
 
   def use_torch_stream(self):
+    """Adopts torch's current stream: everything this handle queues goes there."""
     torch = _torch()
     stream = torch.cuda.current_stream(self.device)
     self.check(self.lib.td_set_stream(self.ptr, ctypes.c_void_p(stream.cuda_stream)))
+    self._stream = stream
 
   def check(self, status):
     _lib.check(self.ptr, status)
@@ -51,10 +53,11 @@ class Handle(object):
     self.check(self.lib.td_synchronize(self.ptr))
 
   def record_event(self):
-    """An event recorded on the stream this handle queues its work on (torch's current
-    stream); .synchronize() waits for everything queued before it."""
+    """An event recorded on the stream this handle queues its work on (the one it adopted,
+    which need not be torch's current stream any more); .synchronize() waits for everything
+    the handle queued before it."""
     ev = _torch().cuda.Event()
-    ev.record()
+    ev.record(self._stream)
     return ev
 
   def timer_start(self):
@@ -93,10 +96,6 @@ class Handle(object):
       return t.contiguous()
     arr = np.ascontiguousarray(array, dtype=dtype)
     return torch.from_numpy(arr).to(self.device)
-
-  def empty(self, shape, dtype='float32'):
-    torch = _torch()
-    return torch.empty(shape, dtype=getattr(torch, dtype), device=self.device)
 
   def zeros(self, shape, dtype='float32'):
     torch = _torch()
@@ -151,6 +150,8 @@ class LagStats(object):
     self.l2 = (self.pre2 + 1 + self.post2) if self.c2 else 0
     self.k1 = self.l1 * self.c1
     self.k2 = self.l2 * self.c2
+    # half width of a boundary window = the halo a time-range shard needs (TimeShardPlan)
+    self.hw = self.pre1 + self.post1 + self.pre2 + self.post2 + 1
     ptr = ctypes.c_void_p()
     self.h.check(self.h.lib.td_stats_create(
         self.h.ptr, self.c1, self.pre1, self.post1, self.c2, self.pre2, self.post2,
@@ -457,10 +458,16 @@ def window_sums(a, b, trial_offsets, width, hop, handle=None):
 
 
 def window_scores(sums, width, mode, reduction='first', mean_a=None, mean_b=None, power=None,
-                  handle=None):
+                  handle=None, group=None):
+  """group (mode 1): the columns are cols / group models of `group` outputs each; the Pearson
+  zero rule (a constant column zeroes the result) is applied per model (td_window_pearson)."""
   h = handle or default_handle()
   total, cols = int(sums.shape[0]), int(sums.shape[1])
   out = h.zeros((total,) if mode == 0 else (total, cols), 'float64')
+  if mode == 1 and group is not None and int(group) != cols:
+    h.check(h.lib.td_window_pearson(h.ptr, _ptr(sums), total, cols, int(group), int(width),
+                                    _ptr(out)))
+    return out
   args = []
   for v in (mean_a, mean_b, power):
     if v is None:

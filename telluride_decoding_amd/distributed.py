@@ -126,6 +126,13 @@ class TimeShardPlan(object):
 def accumulate_time_shard(stats, plan, rank, arrays, handle=None, parts=3):
   """Adds rank `rank`'s pieces to `stats`.  arrays(file, first, last) -> (x, x2, y) device
   tensors holding rows [first, last) of that recording (x2 / y may be None)."""
+  # the half width of the statistics' boundary windows (td_stats: hw), which covers the
+  # context of both lagged inputs
+  need = stats.pre1 + stats.post1 + stats.pre2 + stats.post2 + 1
+  if plan.world_size > 1 and plan.halo < need:
+    raise ValueError('TimeShardPlan halo of %d rows does not cover the context of the statistics '
+                     '(%d rows needed): lagged products across a cut would see zeros instead of '
+                     'the neighbouring rows' % (plan.halo, need))
   pieces = plan.pieces_of(rank)
   if not pieces:
     return stats

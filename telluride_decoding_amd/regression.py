@@ -43,6 +43,22 @@ def calculate_stats(values):
   return float(np.mean(values)), float(np.std(values))
 
 
+# Workspace budget of one batched solve (bytes).  288 GB of HBM make a few GB free; the budget
+# keeps wide configurations (more channels x lags) from asking for tens of GB.
+SOLVE_WORKSPACE_BYTES = 6 << 30
+MAX_SYSTEMS_PER_SOLVE = 160
+
+
+def _fold_chunk(n_folds, n_lambda, n):
+  """Folds per batched solve: (folds x lambdas) systems of an identity-padded n x n float64
+  matrix each, at most MAX_SYSTEMS_PER_SOLVE of them and SOLVE_WORKSPACE_BYTES in all."""
+  n_pad = (int(n) + 63) // 64 * 64
+  per_fold = max(1, int(n_lambda)) * n_pad * n_pad * 8
+  by_bytes = SOLVE_WORKSPACE_BYTES // per_fold
+  by_count = MAX_SYSTEMS_PER_SOLVE // max(1, int(n_lambda))
+  return int(max(1, min(n_folds, by_bytes, by_count)))
+
+
 def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, world_size=1,
                                    group=None, device=None):
   """dataset: brain_data.Dataset whose files are the jackknife units (subjects).
@@ -57,7 +73,11 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   fold's lambdas are evaluated together: their weight vectors are the output columns of ONE
   FIR prediction of the held-out file, and one window-sums launch gives the per-minibatch
   Pearson correlation of every column (Keras `evaluate` = the unweighted mean over
-  minibatches, reference brain_model.py:206-253).
+  minibatches, reference brain_model.py:206-253).  Each (lambda, fold) model is still scored
+  ON ITS OWN like the reference does (regression.py:197-214): the Pearson zero rule
+  (brain_model.py:72-79) looks at the d outputs of that one model only (td_window_pearson with
+  groups of d columns) -- a lambda whose prediction is constant zeroes its own score, not its
+  neighbours'.
 
   device: the device layer (default: telluride_decoding_amd.device, the HIP path); the CPU
   tests of the multi-rank orchestration pass a NumPy stand-in with the same interface.
@@ -158,16 +178,26 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
 
   # Folds go through the solver in chunks: (folds in the chunk) x (lambdas) systems in ONE
   # batched Cholesky -- the late block steps of the factorisation cannot fill the chip with the
-  # 20 systems of a single fold (measured at C5: 32 solves of 20 systems 110 ms).  ~160 systems
-  # of n = 2049 are 5.7 GB of workspace.
-  chunk = max(1, min(len(my_folds), 160 // max(n_lam, 1)))
+  # 20 systems of a single fold (measured at C5: 32 solves of 20 systems 110 ms).  The chunk is
+  # sized by BYTES: a system takes an identity-padded (ceil(n / 64) * 64)^2 float64 workspace
+  # that the handle keeps (grow-only), so ~160 systems of n = 2049 are 5.7 GB, but the same
+  # count at 64 ch x 64 lags would be 23 GB.
+  chunk = _fold_chunk(len(my_folds), n_lam, proto.k1 + 1)
   trains = [proto.like() for _ in range(chunk)]
-  for c0 in range(0, len(my_folds), chunk):
+  c0 = 0
+  while c0 < len(my_folds):
     folds = my_folds[c0:c0 + chunk]
     for train, f in zip(trains, folds):
       fold_statistics(f, train)
-    w_all_folds, b_all_folds, flag = dev.LagStats.ridge_solve_multi(
-        trains[:len(folds)], lambdas, handle=h, wait=False)      # [folds, Lambda, K, D]
+    try:
+      w_all_folds, b_all_folds, flag = dev.LagStats.ridge_solve_multi(
+          trains[:len(folds)], lambdas, handle=h, wait=False)      # [folds, Lambda, K, D]
+    except MemoryError:
+      if chunk == 1:
+        raise
+      chunk = 1              # TD_ERR_NOMEM: the workspace did not fit; one fold at a time
+      continue
+    c0 += len(folds)
     outstanding.append((h.record_event(), flag, folds[0]))
     check(keep=4)
     for fi, f in enumerate(folds):
@@ -181,11 +211,13 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
       xf, yf = file_arrays(f)
       pred = dev.predict_fir(xf, [0, int(xf.shape[0])], w_all, b.reshape(-1).contiguous(),
                              dataset.pre, dataset.post, handle=h, input_offset=off)
-      p0 = pred[:u, ::d].contiguous()                    # first output of every lambda
-      y0 = yf[dy:dy + u, 0:1].expand(u, n_lam).contiguous()
-      sums = dev.window_sums(y0, p0, [0, u], bsz, bsz, handle=h)
-      r = dev.window_scores(sums, bsz, mode=1, handle=h)   # [minibatches, Lambda]
-      scores.append(r.mean(dim=0))
+      # columns = (lambda, output); the truth repeats per lambda.  pearson_correlation_first =
+      # output 0 of each model, with the zero rule taken over that model's d outputs
+      p_all = pred[:u] if pred.shape[0] != u else pred
+      y_all = yf[dy:dy + u].repeat(1, n_lam)
+      sums = dev.window_sums(y_all, p_all, [0, u], bsz, bsz, handle=h)
+      r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)   # [minibatches, Lambda * d]
+      scores.append(r[:, ::d].mean(dim=0))
   check(keep=0)
   rows = (np.stack([s.cpu().numpy() for s in scores]) if scores else np.zeros((0, n_lam)))
   # 5. gather

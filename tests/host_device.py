@@ -175,16 +175,21 @@ def window_sums(a, b, trial_offsets, width, hop, handle=None):
 
 
 def window_scores(sums, width, mode, reduction='first', mean_a=None, mean_b=None, power=None,
-                  handle=None):
+                  handle=None, group=None):
   assert mode == 1
   s = np.asarray(sums, np.float64)
   n = float(width)
+  cols = s.shape[1]
+  group = cols if group is None else int(group)
   va = s[..., 2] - s[..., 0] ** 2 / n
   vb = s[..., 3] - s[..., 1] ** 2 / n
   cov = s[..., 4] - s[..., 0] * s[..., 1] / n
   tiny = 32 * np.finfo(np.float64).eps
-  zero = np.any(va <= tiny * s[..., 2], axis=1) | np.any(vb <= tiny * s[..., 3], axis=1)
   with np.errstate(invalid='ignore', divide='ignore'):
     r = cov / np.sqrt(va * vb)
-  r[zero] = 0.0
+  for g0 in range(0, cols, group):                      # the zero rule is per model
+    sl = slice(g0, g0 + group)
+    zero = (np.any(va[:, sl] <= tiny * s[:, sl, 2], axis=1) |
+            np.any(vb[:, sl] <= tiny * s[:, sl, 3], axis=1))
+    r[zero, sl] = 0.0
   return torch.from_numpy(r)

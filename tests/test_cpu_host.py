@@ -380,3 +380,68 @@ def test_bench_never_runs_fewer_ranks_than_asked():
   assert res.returncode != 0 and 'rank 1 exited with code 7' in res.stderr
   res = _bench(['--gpus', '2', '--dry-launch'], {'WORLD_SIZE': '4', 'RANK': '0'})
   assert res.returncode != 0 and 'WORLD_SIZE=4' in (res.stderr + res.stdout)
+
+
+def test_streaming_attention_is_host_arithmetic_and_matches_goldens():
+  """the per-window `attention(r1, r2)` of the WTA and step decoders is one
+  float64 compare (+ a clipped +-0.1) on the host -- no upload, no launch -- and reproduces
+  the reference's literal sequences (test/attention_decoder_test.py:111-150, golden G7)."""
+  from telluride_decoding_amd import attention_decoder as ad
+  g = golden('g7_decoders')
+  wta = ad.create_attention_decoder('wta')
+  assert wta.attention(0.6, 0.4) == (True, 0, 0) and wta.attention(0.4, 0.6) == (False, 0, 0)
+  assert wta.attention(0.5, 0.5)[0] is False                       # strict >: ties go to 2
+  assert wta.attention(0.6 * np.ones(5), 0.4 * np.ones(5)) == (True, 0, 0)
+  got = [wta.attention(a, b)[0] for a, b in zip(g['cor1'], g['cor2'])]
+  np.testing.assert_array_equal(got, g['wta_lit'])
+  stp = ad.create_attention_decoder('stepped')
+  got = [stp.attention(a, b)[0] for a, b in zip(g['cor1'], g['cor2'])]
+  np.testing.assert_array_equal(got, g['step_lit'])
+
+
+def test_loso_scores_every_model_on_its_own():
+  """VERDICT r2 #9 / ADVICE r2: the reference evaluates each (lambda, fold) model alone
+  (regression.py:197-214) and pearson_correlation's zero rule (brain_model.py:72-79) looks at
+  the d outputs of THAT model.  (a) a lambda so large that its float32 weights underflow to 0
+  predicts a constant: its score is exactly 0, its neighbours' scores are untouched;
+  (b) a constant SECOND output zeroes every model's score (all d outputs enter the rule)."""
+  from telluride_decoding_amd import brain_data, regression
+  from tests import host_device
+  files = _loso_case()
+  batch, pre, post = 100, 1, 2
+  ds = brain_data.Dataset(files, batch, pre, post)
+  lambdas = [1e-3, 1e60, 0.1]
+  res = regression.jackknife_over_regularizations(ds, lambdas, device=host_device)
+  want = _loso_refits(files, batch, pre, post, 0, [1e-3, 0.1])
+  np.testing.assert_allclose(res['all_runs'][[0, 2]], want, rtol=0, atol=2e-6)
+  assert np.all(np.abs(want) > 1e-3)
+  np.testing.assert_array_equal(res['all_runs'][1], np.zeros(len(files)))
+  flat = [(f[0], f[1], np.concatenate((f[2][:, :1], np.zeros_like(f[2][:, :1])), axis=1), f[3])
+          for f in files]
+  res = regression.jackknife_over_regularizations(brain_data.Dataset(flat, batch, pre, post),
+                                                  [1e-3, 0.1], device=host_device)
+  np.testing.assert_array_equal(res['all_runs'], np.zeros((2, len(files))))
+
+
+def test_fold_chunk_is_sized_by_bytes():
+  """the folds per batched solve follow the workspace bytes, not a fixed
+  160 systems -- 160 systems are 5.7 GB at n = 2049 but 23 GB at 64 ch x 64 lags."""
+  from telluride_decoding_amd import regression as r
+  assert r._fold_chunk(32, 20, 2049) == 8                       # C5: 160 systems, 5.7 GB
+  for n_lam, n in ((20, 2554), (20, 4097), (7, 4097), (1, 8193), (20, 17), (100, 4097)):
+    chunk = r._fold_chunk(32, n_lam, n)
+    n_pad = (n + 63) // 64 * 64
+    assert chunk >= 1 and chunk * n_lam <= max(r.MAX_SYSTEMS_PER_SOLVE, n_lam)
+    assert chunk == 1 or chunk * n_lam * n_pad * n_pad * 8 <= r.SOLVE_WORKSPACE_BYTES
+  assert r._fold_chunk(3, 2, 17) == 3
+
+
+def test_time_shard_halo_must_cover_the_context():
+  """a halo shorter than the context would zero-extend at interior cuts and the
+  all-reduced moments would be silently wrong."""
+  from telluride_decoding_amd import distributed
+  from tests import host_device
+  plan = distributed.TimeShardPlan([500, 500], 2, halo=2)
+  st = host_device.LagStats(4, 2, 3, d=1)
+  with pytest.raises(ValueError, match='halo'):
+    distributed.accumulate_time_shard(st, plan, 0, lambda f, a, b: (None, None, None))

@@ -232,3 +232,39 @@ def test_cholesky_and_eigen_whitening_agree(dev, monkeypatch):
   np.testing.assert_allclose(b, rb2.cpu().numpy(), atol=2e-5 * np.max(np.abs(b)))
   _, _, _, _, _, sweeps0 = st.cca_solve(n - 1, 0.0, dim)
   assert sweeps0[0] > 0, 'reg = 0 must take the eigen route'
+
+
+def test_uneven_batches_denominator_takes_the_eigen_route(dev):
+  """the reference's denominator is (minibatches x rows of the LAST minibatch) - 1
+  (cca.py:339-343); for an iterable with uneven batches it can exceed the frame count, the
+  "covariance" S / denom - m^T m is then not positive semi-definite, and eigenvalues <= 1e-12
+  (negative ones included) are dropped by the reference.  The Cholesky shortcut assumes
+  nothing can be dropped, so td_cca_solve must take the eigen route there: compared with the
+  dense stage through LAPACK on the device's own moments."""
+  rng = np.random.default_rng(11)
+  h = dev.default_handle()
+  n, c1, c2, reg, dim = 6000, 12, 4, 0.1, 3
+  src = rng.standard_normal((n, 3)).astype(np.float32)
+  x = (src @ rng.standard_normal((3, c1)) + rng.standard_normal((n, c1))).astype(np.float32)
+  x[:, :2] += 4.0                       # a large mean: S / (2n) - m^T m is indefinite
+  x2 = (src @ rng.standard_normal((3, c2)) + 0.5 * rng.standard_normal((n, c2))).astype(np.float32)
+  st = dev.LagStats(c1, 0, 0, c2, 0, 0)
+  st.accumulate(h.to_device(x), h.to_device(x2), None, [0, n])
+  denom = 2 * n - 1
+  ra, rb, _, _, e, sweeps = st.cca_solve(denom, reg, dim)
+  assert sweeps[0] > 0, 'denom > frames must not take the Cholesky shortcut'
+  m = st.moments(want_xtx=True, want_xty=False, want_cca=True)
+  xtx = m['xtx'].cpu().numpy()
+  sx = xtx[c1:, :c1] / n
+  sy = m['sum_x2'].cpu().numpy().reshape(1, -1) / n
+  cxx = xtx[:c1, :c1] / denom - sx.T @ sx + reg * np.eye(c1)
+  cyy = m['x2tx2'].cpu().numpy() / denom - sy.T @ sy + reg * np.eye(c2)
+  cxy = m['xtx2'].cpu().numpy() / denom - sx.T @ sy
+  assert np.linalg.eigvalsh(cxx)[0] < 0          # the case the shortcut would get wrong
+  wa, wb, we = _numpy_dense_stage(cxx, cyy, cxy, dim)
+  np.testing.assert_allclose(e.cpu().numpy(), we, rtol=2e-6, atol=1e-7)
+  a, b = _aligned(ra.cpu().numpy().astype(np.float64), rb.cpu().numpy().astype(np.float64), wa, wb)
+  np.testing.assert_allclose(a, wa, atol=2e-5 * np.max(np.abs(wa)))
+  np.testing.assert_allclose(b, wb, atol=2e-5 * np.max(np.abs(wb)))
+  # with the usual denominator (frames - 1) the same statistics take the shortcut
+  assert st.cca_solve(n - 1, reg, dim)[5][0] == 0

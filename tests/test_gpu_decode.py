@@ -60,6 +60,38 @@ def test_predict_fir_matches_dense_forward(dev, c, pre, post, d, lens, off):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
+def test_window_pearson_zero_rule_is_per_model(dev):
+  """td_window_pearson: the columns are several models of `group` outputs each (the lambdas of a
+  jackknife fold); a constant column zeroes the Pearson result of ITS model only -- the
+  reference calls pearson_correlation once per model (regression.py:197-214,
+  brain_model.py:72-79)."""
+  rng = np.random.default_rng(5)
+  h = dev.default_handle()
+  n, width, group, models = 1200, 400, 2, 3
+  cols = group * models
+  a = rng.standard_normal((n, cols)).astype(np.float32)
+  b = (0.5 * a + rng.standard_normal((n, cols))).astype(np.float32)
+  b[:400, 3] = 1.25                      # window 0: second output of model 1 is constant
+  a[400:800, 4] = -3.0                   # window 1: first truth column of model 2 is constant
+  sums = dev.window_sums(h.to_device(a), h.to_device(b), [0, n], width, width, handle=h)
+  got = dev.window_scores(sums, width, 1, handle=h, group=group).cpu().numpy()
+  a64, b64 = a.astype(np.float64), b.astype(np.float64)
+  for wi in range(3):
+    r = slice(wi * width, (wi + 1) * width)
+    for m in range(models):
+      c = slice(m * group, (m + 1) * group)
+      want = o_p.pearson_correlation(a64[r, c], b64[r, c])
+      want = want if np.ndim(want) == 1 else np.zeros(group)
+      np.testing.assert_allclose(got[wi, c], want, rtol=1e-9, atol=1e-12)
+  assert np.all(got[0, 2:4] == 0) and np.all(got[0, :2] != 0) and np.all(got[0, 4:] != 0)
+  assert np.all(got[1, 4:] == 0) and np.all(got[1, :4] != 0)
+  # one group over all the columns = the single-model rule of td_window_scores(mode 1)
+  whole = dev.window_scores(sums, width, 1, handle=h).cpu().numpy()
+  assert np.all(whole[0] == 0) and np.all(whole[1] == 0) and np.all(whole[2] != 0)
+  with pytest.raises(ValueError, match='whole groups'):
+    dev.window_scores(sums, width, 1, handle=h, group=4)
+
+
 def test_window_sums_and_scores(dev):
   rng = np.random.default_rng(3)
   h = dev.default_handle()

@@ -522,6 +522,28 @@ def test_loso_sweep_ragged_files_and_offset(dev, off):
   np.testing.assert_allclose(got['all_runs'], want, rtol=1e-4, atol=3e-5)
 
 
+def test_loso_scores_every_model_on_its_own_on_the_device(dev):
+  """VERDICT r2 #9 on the HIP path: a lambda whose float32 weights underflow to zero predicts
+  a constant and scores exactly 0 -- without zeroing the other lambdas of its fold; a constant
+  second output zeroes every model (all d outputs of a model enter the zero rule,
+  brain_model.py:72-79)."""
+  from telluride_decoding_amd import brain_data, regression
+  from tests.test_cpu_host import _loso_case, _loso_refits
+  files = _loso_case()
+  batch, pre, post = 100, 1, 2
+  lambdas = [1e-3, 1e60, 0.1]
+  got = regression.jackknife_over_regularizations(brain_data.Dataset(files, batch, pre, post),
+                                                  lambdas)
+  want = _loso_refits(files, batch, pre, post, 0, [1e-3, 0.1])
+  np.testing.assert_allclose(got['all_runs'][[0, 2]], want, rtol=1e-4, atol=3e-5)
+  np.testing.assert_array_equal(got['all_runs'][1], np.zeros(len(files)))
+  flat = [(f[0], f[1], np.concatenate((f[2][:, :1], np.zeros_like(f[2][:, :1])), axis=1), f[3])
+          for f in files]
+  got = regression.jackknife_over_regularizations(brain_data.Dataset(flat, batch, pre, post),
+                                                  [1e-3, 0.1])
+  np.testing.assert_array_equal(got['all_runs'], np.zeros((2, len(files))))
+
+
 def test_tfrecord_ingress_to_trf_fit(dev):
   """F3 end to end on real data: a slice of the reference's MEG recording (148 channels: three
   channel tiles) read by the dependency-free TFRecord parser, z-scored, ridge TRF envelope <-
