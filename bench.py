@@ -727,6 +727,7 @@ def main():
       line['loso'] = loso_leg(eeg, env)
   if dist_on:
     dist.barrier()
+    distributed.close_native_comms()
     dist.destroy_process_group()
   if rank == 0:
     # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer until exit: flush it

@@ -184,6 +184,28 @@ int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev,
 int td_stats_unpack_known(td_handle* h, td_stats* s, const double* buf_dev,
                           int64_t total_file_slots, int64_t total_frames);
 
+/* The exchange step of a multi-GPU fit (SURVEY.md 8e, 8b(3) "stats_allreduce(handle, rccl_comm)"):
+ * pack -> ONE ncclAllReduce(sum, float64) over `rccl_comm` (an ncclComm_t) -> unpack, all
+ * queued on the handle's stream; nothing waits on the host when total_frames (the frames of all
+ * ranks; < 0: read back from the reduced buffer) is given.  Afterwards every rank holds the
+ * statistics of all recordings.  total_file_slots / file_slot as in td_stats_pack.  The
+ * reference has no counterpart: it fans out OS processes per (lambda, held-out file) and refits
+ * from scratch (doc/DecodingCodelab.md:354-381, regression.py:381-409).
+ * RCCL is bound at run time (dlopen; TD_RCCL_LIB overrides the path; inside a PyTorch process
+ * the librccl PyTorch mapped is used), so a binding needs no torch and a single-GPU user no RCCL. */
+int td_stats_allreduce(td_handle* h, td_stats* s, void* rccl_comm, int64_t total_file_slots,
+                       int64_t file_slot, int64_t total_frames);
+/* In-place all-reduce(sum) of a float64 device buffer on the handle's stream (the per-recording
+ * statistics table of the leave-one-out sweep, regression.py:326-420). */
+int td_allreduce_f64(td_handle* h, double* buf_dev, int64_t count, void* rccl_comm);
+/* Communicator plumbing for callers that have no ncclComm_t of their own: rank 0 makes a
+ * 128-byte id (ncclGetUniqueId), hands it to the other ranks by any means, then every rank
+ * creates its communicator on the handle's device (ncclCommInitRank; collective). */
+int td_rccl_unique_id(td_handle* h, void* id_out_128);
+int td_rccl_comm_create(td_handle* h, int num_ranks, int rank, const void* id_128, void** comm_out);
+int td_rccl_comm_count(td_handle* h, void* comm, int* num_ranks);
+int td_rccl_comm_destroy(td_handle* h, void* comm);
+
 /* Dense moment matrices (float64, device), expanded from the compact lag
  * statistics with exact file-edge corrections.  k1 = c1*(pre1+1+post1),
  * k2 = c2*(pre2+1+post2).

@@ -74,6 +74,12 @@ SIGNATURES = {
     'td_stats_pack': [_vp, _vp, _vp, _i64, _i64],
     'td_stats_unpack': [_vp, _vp, _vp, _i64],
     'td_stats_unpack_known': [_vp, _vp, _vp, _i64, _i64],
+    'td_stats_allreduce': [_vp, _vp, _vp, _i64, _i64, _i64],
+    'td_allreduce_f64': [_vp, _vp, _i64, _vp],
+    'td_rccl_unique_id': [_vp, _vp],
+    'td_rccl_comm_create': [_vp, _i, _i, _vp, _c.POINTER(_vp)],
+    'td_rccl_comm_count': [_vp, _vp, _c.POINTER(_i)],
+    'td_rccl_comm_destroy': [_vp, _vp],
     'td_stats_moments': [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'td_ridge_solve': [_vp, _vp, _pd, _i, _vp, _vp],
     'td_ridge_solve_async': [_vp, _vp, _pd, _i, _vp, _vp, _vp],

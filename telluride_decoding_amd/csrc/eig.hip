@@ -975,7 +975,9 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   // (the reference's denom = minibatches x rows of the LAST minibatch - 1, cca.py:339-343, exceeds
   // the frame count for iterables with uneven batches; the covariance can then be indefinite and
   // still pass a Cholesky with eigenvalues in (0, eps_eig] that the reference drops).
-  static const bool force_eig = getenv("TD_CCA_EIG") != nullptr;     // development switch, read once
+  // (development A/B switch, read per call so that one process can compare both routes; a
+  // getenv is ~50 ns against a dense stage of >= 0.28 ms that ends in a stream synchronisation)
+  const bool force_eig = getenv("TD_CCA_EIG") != nullptr;
   bool use_chol = regularization > 2.0 * eps_eig && k2 <= 64 && cols && !force_eig &&
                   denom <= (double)frames;
   if (use_chol) {

@@ -150,13 +150,91 @@ def accumulate_time_shard(stats, plan, rank, arrays, handle=None, parts=3):
   return stats
 
 
-def allreduce_packed(buf, group=None):
-  """Sum a packed statistics buffer over ranks, in place (RCCL on GPU tensors,
-  gloo on CPU tensors in the tests)."""
+class RcclComm(object):
+  """An RCCL communicator owned by the C-ABI (td_rccl_comm_create), one rank per process:
+  what td_stats_allreduce / td_allreduce_f64 run on.  Rank 0 makes the 128-byte id
+  (ncclGetUniqueId), `exchange(id_bytes) -> id_bytes` hands it to the other ranks by any
+  means (here: a torch.distributed broadcast, which works over gloo and over RCCL alike)."""
+
+  def __init__(self, handle, rank, world_size, exchange):
+    import ctypes
+    self.h, self.rank, self.world_size = handle, int(rank), int(world_size)
+    ident = (ctypes.c_char * 128)()
+    if self.rank == 0:
+      handle.check(handle.lib.td_rccl_unique_id(handle.ptr, ident))
+    ident = (ctypes.c_char * 128).from_buffer_copy(exchange(bytes(ident.raw)))
+    ptr = ctypes.c_void_p()
+    handle.check(handle.lib.td_rccl_comm_create(handle.ptr, self.world_size, self.rank, ident,
+                                                ctypes.byref(ptr)))
+    self.ptr = ptr
+    n = ctypes.c_int(0)
+    handle.check(handle.lib.td_rccl_comm_count(handle.ptr, self.ptr, ctypes.byref(n)))
+    if n.value != self.world_size:
+      raise RuntimeError('RCCL reports %d ranks, expected %d' % (n.value, self.world_size))
+
+  def close(self):
+    if getattr(self, 'ptr', None):
+      self.h.lib.td_rccl_comm_destroy(None, self.ptr)    # (the handle may be gone by now)
+      self.ptr = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # interpreter shutdown
+      pass
+
+
+_comms = {}
+
+
+def native_comm(handle, group=None):
+  """The C-ABI's own communicator over the ranks of `group` (created once per process group, the
+  id broadcast through torch.distributed), or None when the exchange has to go through
+  torch.distributed itself: no process group, a CPU (gloo) group -- the CPU tests' NumPy device
+  stand-in -- or TD_ALLREDUCE_TORCH set (A/B switch)."""
+  dist = _dist()
+  if not (dist.is_available() and dist.is_initialized()) or os.environ.get('TD_ALLREDUCE_TORCH'):
+    return None
+  if not hasattr(handle, 'lib') or dist.get_backend(group) != 'nccl':
+    return None
+  world = dist.get_world_size(group)
+  if world == 1 and not os.environ.get('TD_ALLREDUCE_ALWAYS'):
+    return None
+  key = (id(group) if group is not None else 0, handle.device_id)
+  if key not in _comms:
+    import torch
+
+    def exchange(ident):
+      t = torch.tensor(list(ident), dtype=torch.uint8, device=handle.device)
+      dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+      return bytes(t.cpu().tolist())
+    _comms[key] = RcclComm(handle, dist.get_rank(group), world, exchange)
+  return _comms[key]
+
+
+def close_native_comms():
+  """Destroys the C-ABI communicators (before torch.distributed.destroy_process_group)."""
+  for c in _comms.values():
+    c.close()
+  _comms.clear()
+
+
+def allreduce_packed(buf, group=None, handle=None):
+  """Sum a packed statistics buffer over ranks, in place: td_allreduce_f64 over the C-ABI's
+  RCCL communicator for device buffers (on `handle`'s stream), torch.distributed (gloo) for
+  the CPU tensors of the tests."""
   dist = _dist()
   if dist.is_available() and dist.is_initialized() and (
       dist.get_world_size(group) > 1 or os.environ.get('TD_ALLREDUCE_ALWAYS')):
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    comm = native_comm(handle, group) if (handle is not None and buf.is_cuda) else None
+    if comm is not None:
+      import ctypes
+      if str(buf.dtype) != 'torch.float64' or not buf.is_contiguous():
+        raise TypeError('the packed buffer must be a contiguous float64 tensor')
+      handle.check(handle.lib.td_allreduce_f64(handle.ptr, ctypes.c_void_p(buf.data_ptr()),
+                                               buf.numel(), comm.ptr))
+    else:
+      dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
   return buf
 
 
@@ -164,9 +242,19 @@ def allreduce_stats(stats, plan, rank, group=None, total_frames=None, handle=Non
   """Every rank ends with the statistics of all files (one all-reduce).  total_frames: the
   frames of all ranks if known on the host (no dropped remainders / offsets: the sum of the
   file lengths) -- spares the unpack a stream synchronisation, which matters when fits are
-  pipelined.  handle: queue pack / unpack on that handle's stream (the caller has made it
-  torch's current stream, which is where the collective is ordered) instead of the
-  statistics' own."""
+  pipelined.  handle: queue pack / collective / unpack on that handle's stream instead of the
+  statistics' own.
+
+  On the device this is ONE C-ABI call, td_stats_allreduce (pack -> ncclAllReduce -> unpack on
+  the handle's stream); under gloo (CPU tests, NumPy stand-in of the device
+  layer) the same three steps go through torch.distributed."""
+  h = handle or getattr(stats, 'h', None)
+  comm = native_comm(h, group) if h is not None else None
+  if comm is not None:
+    h.check(h.lib.td_stats_allreduce(
+        h.ptr, stats.ptr, comm.ptr, int(plan.total_files), int(plan.slot_of(rank)),
+        -1 if total_frames is None else int(total_frames)))
+    return stats
   buf = stats.pack(plan.total_files, plan.slot_of(rank), handle=handle)
   allreduce_packed(buf, group)
   stats.unpack(buf, plan.total_files, total_frames, handle=handle)

@@ -131,7 +131,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   table = h.zeros((n_files, plen), 'float64')
   for i, st in per_file.items():
     table[i] = st.pack(1, 0)
-  distributed.allreduce_packed(table, group)
+  distributed.allreduce_packed(table, group, handle=h)
   stats = []
   for i in range(n_files):
     if i in per_file and world_size == 1:

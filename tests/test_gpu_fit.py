@@ -641,9 +641,62 @@ def test_single_rank_rccl_allreduce_round_trip(dev):
     for w2, b2 in outs:
       np.testing.assert_array_equal(w2.cpu().numpy(), w0.cpu().numpy())
       np.testing.assert_array_equal(b2.cpu().numpy(), b0.cpu().numpy())
+    # the same exchange through torch.distributed's own all-reduce (the A/B switch)
+    os.environ['TD_ALLREDUCE_TORCH'] = '1'
+    try:
+      distributed.allreduce_stats(st, plan, 0)
+    finally:
+      del os.environ['TD_ALLREDUCE_TORCH']
+    np.testing.assert_array_equal(st.moments()['xtx'].cpu().numpy(), m0.cpu().numpy())
+    assert distributed._comms, 'the C-ABI communicator was not used'
   finally:
+    distributed.close_native_comms()
     if created:
       dist.destroy_process_group()
+
+
+def test_c_abi_stats_allreduce_needs_no_torch_distributed(dev):
+  """SURVEY 8b(3) `stats_allreduce(handle, rccl_comm)` as a C export: a binding
+  without PyTorch makes the communicator itself (td_rccl_unique_id -> td_rccl_comm_create) and
+  calls td_stats_allreduce on raw symbols; on one rank the sum over ranks is the identity, the
+  boundary slots land where `file_slot` says, the frame count is taken from the buffer."""
+  import ctypes
+  rng = np.random.default_rng(43)
+  h = dev.default_handle()
+  lib = h.lib
+  ident = (ctypes.c_char * 128)()
+  assert lib.td_rccl_unique_id(h.ptr, ident) == 0, lib.td_last_error(h.ptr)
+  comm = ctypes.c_void_p()
+  assert lib.td_rccl_comm_create(h.ptr, 1, 0, ident, ctypes.byref(comm)) == 0, lib.td_last_error(h.ptr)
+  n = ctypes.c_int(0)
+  assert lib.td_rccl_comm_count(h.ptr, comm, ctypes.byref(n)) == 0 and n.value == 1
+  try:
+    lens = [800, 1000]
+    x = h.to_device(rng.standard_normal((sum(lens), 40)).astype(np.float32))
+    x2 = h.to_device(rng.standard_normal((sum(lens), 3)).astype(np.float32))
+    y = h.to_device(rng.standard_normal((sum(lens), 2)).astype(np.float32))
+    st = dev.LagStats(40, 0, 7, 3, 1, 1, 2)
+    st.accumulate(x, x2, y, np.concatenate(([0], np.cumsum(lens))))
+    want = {k: v.clone() for k, v in st.moments(want_cca=True).items() if v is not None}
+    # two of four slots are this rank's (slots 1..2); frame count read back from the buffer
+    assert lib.td_stats_allreduce(h.ptr, st.ptr, comm, 4, 1, -1) == 0, lib.td_last_error(h.ptr)
+    assert st.counts() == (sum(lens), 4)
+    # the statistics are unchanged where they were, and the two foreign slots are empty: the
+    # moments (which sum the edge corrections over all four slots) are the same
+    got = st.moments(want_cca=True)
+    for k, v in want.items():
+      np.testing.assert_array_equal(got[k].cpu().numpy(), v.cpu().numpy())
+    # a raw buffer: in-place sum over one rank = identity
+    buf = h.to_device(rng.standard_normal((1000, 1)), np.float64)
+    ref = buf.clone()
+    assert lib.td_allreduce_f64(h.ptr, ctypes.c_void_p(buf.data_ptr()), buf.numel(), comm) == 0
+    h.synchronize()
+    np.testing.assert_array_equal(buf.cpu().numpy(), ref.cpu().numpy())
+    # errors: a slot range that does not fit, a NULL communicator
+    assert lib.td_stats_allreduce(h.ptr, st.ptr, comm, 4, 3, -1) == -1
+    assert lib.td_stats_allreduce(h.ptr, st.ptr, None, 4, 0, -1) == -1
+  finally:
+    assert lib.td_rccl_comm_destroy(h.ptr, comm) == 0
 
 
 def _lw_moment_numpy(batches):
