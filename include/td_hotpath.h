@@ -297,7 +297,8 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
  *   rot_x_dev [k1, dim], rot_y_dev [k2, dim], mean_x_dev [k1], mean_y_dev [k2], e_dev [dim]:
  *   float32 on the device, the dtype the reference returns for float32 inputs.
  *   dim <= min(k1, k2) (the caller clips, as the reference's slicing does).
- *   info_host (may be NULL) receives the Jacobi sweep counts {eig xx, eig yy, svd}.
+ *   info_host (may be NULL, else int[4]) receives the Jacobi sweep counts {eig xx, eig yy, svd}
+ *   and in [3] which whitening the x side took: 1 = Cholesky factor, 0 = eigen-decomposition.
  * Singular vectors are defined up to a joint sign of (rot_x[:, i], rot_y[:, i]). */
 int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization, double eps_eig,
                  int dim, float* rot_x_dev, float* rot_y_dev, float* mean_x_dev, float* mean_y_dev,

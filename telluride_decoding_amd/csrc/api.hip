@@ -200,6 +200,7 @@ int td_destroy(td_handle* h) {
   for (auto& slot : h->tables)
     if (slot.dev) hipFree(slot.dev);
   if (h->dev_flag) hipFree(h->dev_flag);
+  if (h->chan_max) hipFree(h->chan_max);
   if (h->dev_flags) hipFree(h->dev_flags);
   if (h->host_flags) hipHostFree(h->host_flags);
   if (h->ev_start) hipEventDestroy(h->ev_start);

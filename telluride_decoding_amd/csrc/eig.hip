@@ -1026,7 +1026,10 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
                      e_dev);
   TD_HIP(h, hipGetLastError());
   TD_HIP(h, hipStreamSynchronize(h->stream));
-  if (info_host) { info_host[0] = sweeps[0]; info_host[1] = sweeps[1]; info_host[2] = sweeps[2]; }
+  if (info_host) {
+    info_host[0] = sweeps[0]; info_host[1] = sweeps[1]; info_host[2] = sweeps[2];
+    info_host[3] = use_chol ? 1 : 0;      // which whitening the x side took
+  }
   return TD_OK;
 }
 

@@ -42,24 +42,6 @@ constexpr int kNpfG = 9;       // general: 64 + 72 = 136 rows
 constexpr int kLagsPerWg = 8;  // lags per workgroup (2 per wave)
 constexpr int kHalo = 8;       // extra B rows (7 needed)
 
-struct LagWork {
-  long long a_row0, a_valid, b_row0, b_valid, u_begin, u_end;
-};
-
-struct LagParams {
-  const float* a;
-  const float* b;
-  long long lda, ldb;
-  int ca, cb;        // real channel counts
-  int a_ones;        // append a ones column to A at index ca
-  const LagWork* works;
-  int n_work, n_groups, n_cat, n_cbt;
-  int e_min, e_count;
-  float* partial;    // [n_work][e_pad][ca_pad][cb_pad]
-  int e_pad, ca_pad, cb_pad;
-  int lag_g, lag_lg;   // lags per workgroup (8, or 4/2/1 with the 8 wave slots split over time) and log2
-};
-
 // Bijective XCD-aware remap: physical block b runs on XCD b % 8 (observed
 // round-robin dispatch; speed only).  Give each XCD a contiguous range of
 // logical ids so that neighbours in logical order share an L2.
@@ -430,10 +412,23 @@ __global__ __launch_bounds__(kThreads, 2) void lagcov_mfma_kernel(LagParams p) {
 constexpr int kBfTile = 128;            // time samples per tile
 // Two geometries: up to 32 lags stage 160 rows (tile + 24 (e0) + 8 halo) in channel rows of 83
 // dwords; up to 64 lags stage 192 rows in rows of 99 dwords (152 KB of LDS).  Both strides are odd.
-template <int kRowDw> struct BfGeom {
+//
+// kF16: the two-piece float16 form of the same kernel (td_split2_f16, td_common.h): every
+// channel is scaled by its own power of two (from the largest magnitude of the call's input:
+// LagParams::chan_max, filled by chan_max_kernel), split into h + l, and a float32 product is
+// THREE float16 products l h', h l', h h' on v_mfma_f32_32x32x16_f16 -- half the matrix
+// instructions.  The kernel is bound by the power the matrix pipe draws (time linear in the
+// number of products: 2 / 4 / 6 -> 0.58 / 0.88 / 1.22 ms at C2), so that is the lever.  Same
+// tile pipeline, same two-level accumulation; the slab sums carry the product of the two
+// channels' scales, divided out exactly by the float64 reduction.
+template <int kRowDw, int kPieces> struct BfGeom {
   static constexpr int kRows = kRowDw == 83 ? 160 : 192;      // staged rows
   static constexpr int kPieceDw = 64 * kRowDw;
-  static constexpr size_t kLdsBytes = sizeof(unsigned) * 2 * 3 * kPieceDw;   // double-buffered
+  static constexpr int kYDw = 96;      // one piece of the staged targets: 160 float16 (+ slack)
+  // double-buffered tile + (float16 form) double-buffered two pieces of the tile's targets
+  // + (float16 form) the eight waves' 32 x 32 float32 blocks of target sums
+  static constexpr size_t kLdsBytes =
+      sizeof(unsigned) * (2 * kPieces * kPieceDw + (kPieces == 2 ? 2 * 2 * kYDw + 8 * 1024 : 0));
 };
 constexpr int kBfThreads = 512;
 
@@ -443,18 +438,29 @@ __device__ __forceinline__ float comp4(const float4& v, int q) {
   return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
 }
 
-// One k-step (16 time samples) of one wave: 4 lags x 6 products.  ap / bp: the lane's A row and
-// B span of piece 0 at this k-step (pieces kBfPieceDw apart).  kZero: first step of a chain (the
-// accumulators start from the inline constant 0).  a_mask: null, or 4 dword masks that cut A at
-// the end of a slab.
-template <bool kZero, int kBfPieceDw>
+// One k-step (16 time samples) of one wave: 4 lags x 6 (3) products.  ap / bp: the lane's A row
+// and B span of piece 0 at this k-step (pieces kBfPieceDw apart).  kZero: first step of a chain
+// (the accumulators start from the inline constant 0).  a_mask: null, or 4 dword masks that cut A
+// at the end of a slab.
+//
+// ll0 (float16 form): also the product l l' of lag slot 0.  The three products drop l l', which
+// is zero-mean EXCEPT where both factors are the same number -- the diagonal of the lag-0 Gram
+// block, sums of x^2 -- where it is l^2 > 0: a bias of -5e-8 relative (measured,
+// tools/bias_probe.py).  The two waves that own the diagonal 32 x 32 tiles of lag 0 add that one
+// product (1/12 more matrix work for 2 of the 32 waves of a slab); everywhere else the dropped
+// term stays a zero-mean 2^-22.
+//
+// (The regression targets ride along in the same kernel: tgt_tile below.)
+template <bool kZero, int kBfPieceDw, bool kF16>
 __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
                                          const unsigned* __restrict__ bp,
-                                         const unsigned* a_mask, f32x16 (&acc)[4]) {
-  u32x4 a[3];
-  unsigned d[3][6];
+                                         const unsigned* a_mask, f32x16 (&acc)[4],
+                                         bool ll0 = false) {
+  constexpr int kP = kF16 ? 2 : 3;
+  u32x4 a[kP];
+  unsigned d[kP][6];
 #pragma unroll
-  for (int pc = 0; pc < 3; ++pc) {
+  for (int pc = 0; pc < kP; ++pc) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[pc][i] = ap[pc * kBfPieceDw + i];
 #pragma unroll
@@ -462,13 +468,13 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
   }
   if (a_mask) {
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
+    for (int pc = 0; pc < kP; ++pc)
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[pc][i] &= a_mask[i];
   }
-  u32x4 b[4][3];                                       // [lag][piece]
+  u32x4 b[4][kP];                                      // [lag][piece]
 #pragma unroll
-  for (int pc = 0; pc < 3; ++pc)
+  for (int pc = 0; pc < kP; ++pc)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       b[0][pc][i] = d[pc][i];
@@ -486,34 +492,128 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
       c[r] = acc[r];
     }
   }
-  // (A piece, B piece) in the order l h, h l, m m, m h, h m, h h -- the four lags in turn
-  constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+  if constexpr (kF16) {
+    // (A piece, B piece) in the order l h, h l, h h -- the four lags in turn
+    constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};
 #pragma unroll
-  for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = td_mfma_bf16(a[pa[t]], b[r][pb[t]], c[r]);
+      for (int r = 0; r < 4; ++r) c[r] = td_mfma_f16(a[pa[t] % kP], b[r][pb[t] % kP], c[r]);
+    if (ll0) c[0] = td_mfma_f16(a[1 % kP], b[0][1 % kP], c[0]);
+  } else {
+    // (A piece, B piece) in the order l h, h l, m m, m h, h m, h h -- the four lags in turn
+    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = td_mfma_bf16(a[pa[t] % kP], b[r][pb[t] % kP], c[r]);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = c[r];
 }
 
-template <int kFrom, int kTo, int kBfPieceDw>
+// kChain: k-steps per MFMA chain; the chain's sums are added into `total` (v_add_f32) when it ends.
+template <int kFrom, int kTo, int kBfPieceDw, bool kF16, int kChain>
 __device__ __forceinline__ void bf_ksteps(const unsigned* __restrict__ ap,
-                                          const unsigned* __restrict__ bp, f32x16 (&acc)[4]) {
+                                          const unsigned* __restrict__ bp, f32x16 (&acc)[4],
+                                          f32x16 (&total)[4], bool ll0) {
 #pragma unroll
   for (int s = kFrom; s < kTo; ++s) {
-    if (s == 0) bf_kstep<true, kBfPieceDw>(ap + 8 * s, bp + 8 * s, nullptr, acc);
-    else        bf_kstep<false, kBfPieceDw>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+    if (s % kChain == 0) bf_kstep<true, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc, ll0);
+    else                 bf_kstep<false, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc, ll0);
+    if ((s + 1) % kChain == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) total[r] += acc[r];
+    }
     // (without a fence hipcc hoists the LDS reads of all the unrolled steps to the top; fences
     // after every step, every other step or none at all time the same)
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <bool kVec4, int kBfRowDw>
-__global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];   // [2][3][64][kBfRowDw]
-  constexpr int kBfRows = BfGeom<kBfRowDw>::kRows;
-  constexpr int kBfPieceDw = BfGeom<kBfRowDw>::kPieceDw;
+// ---- the regression targets ride along (float16 form) -------------------------------------------
+// yT x~ per lag is the product T[e][j] = sum_v A[e][v] x~[v][j] with A[e][v] = y[v - e]
+// (Toeplitz): M = lag, K = time, N = channel -- and the B operand of that product (lane ->
+// channel, 8 consecutive samples of a 16-sample k-step) is exactly what a wave reads as the A
+// operand of its Gram tiles.  So the tile of x in LDS serves the targets too: no second pass
+// over x (the separate targets kernel read all of it again: 65 us at C2).
+//
+// Work split: the 8 k-steps of a tile are dealt to the lag groups (workgroups) of the slab --
+// step s belongs to group s % n_groups -- and the three products y_h x_h, y_h x_l, y_l x_h of a
+// step to three of the four waves that hold the same m tile (wi = 0..3), rotating from step to
+// step: one or two MFMAs per wave and tile, done at the END of the tile, when the 64 registers of
+// the Gram chains are free: one short MFMA chain, then ONE read-modify-write of the wave's 32 x 32
+// block of running float32 sums, which lives in LDS (16 more accumulator registers per lane do
+// not fit beside the 128 of the Gram tiles).
+//
+// The rows past the end: x~[v] for v = end .. end + 30 of a recording's summed range (real rows
+// when a remainder was dropped or another rank holds them) still pair with the last targets,
+// y[v - e] x~[v] for e > v - end.  A tile carries 32 staged rows past its 128 and the staged
+// targets are zero from `end` on, so the slab that ends a recording's range runs its k-steps over
+// those rows as well (steps 8 and 9 of a full tile), and keeps the rows >= nk of the step it cut.
+__device__ __forceinline__ int tgt_product(int s, int group, int n_groups, int wi) {
+  if (s % n_groups != group) return -1;
+  const int prod = (wi - 3 * (s / n_groups)) & 3;      // 0: y_h x_h, 1: y_h x_l, 2: y_l x_h
+  return prod == 3 ? -1 : prod;
+}
+
+struct TgtLane {
+  const unsigned* y;     // the lane's dword span of piece h of the staged targets at k-step 0
+  unsigned shift;        // 0 or 16: the span starts at an odd sample
+  float* sums;           // the lane's slot of the wave's block of running sums: [4][64 lanes][4]
+};
+
+// ap: the lane's A-operand span of piece h at k-step 0.  nk: rows of the tile that belong to the
+// slab (128, or fewer in its last tile); seg_end: the slab ends its recording's summed range.
+template <int kBfPieceDw, int kYDw>
+__device__ __forceinline__ void tgt_tile(const unsigned* __restrict__ ap, const TgtLane& tl, int nk,
+                                         bool seg_end, int group, int n_groups, int wi, int lg) {
+  f32x16 t;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = 0.f;
+  bool any = false;
+#pragma unroll
+  for (int s = 0; s < 10; ++s) {
+    const int prod = tgt_product(s, group, n_groups, wi);
+    if (prod < 0 || !(16 * s < nk || (seg_end && 16 * s < nk + 31))) continue;     // (wave-uniform)
+    const int cnt = nk - 16 * s - 8 * lg;              // rows of this lane's k half inside the slab
+    const unsigned* xa = ap + 8 * s + (prod == 1 ? kBfPieceDw : 0);
+    const unsigned* ys = tl.y + 8 * s + (prod == 2 ? kYDw : 0);
+    u32x4 a, ya;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const unsigned keep = (seg_end || cnt >= 2 * d + 2) ? 0xffffffffu : cnt == 2 * d + 1 ? 0x0000ffffu : 0u;
+      a[d] = xa[d] & keep;
+      ya[d] = __builtin_amdgcn_alignbit(ys[d + 1], ys[d], tl.shift);
+    }
+    t = td_mfma_f16(ya, a, t);
+    any = true;
+  }
+  if (!any) return;
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) {
+    float4* slot = reinterpret_cast<float4*>(tl.sums) + k4 * 64;
+    float4 v = *slot;
+    v.x += t[4 * k4]; v.y += t[4 * k4 + 1]; v.z += t[4 * k4 + 2]; v.w += t[4 * k4 + 3];
+    *slot = v;
+  }
+}
+
+// kTgt (float16 form only): one target column rides along (tgt_tile).  A variant of its own: the
+// extra code costs the plain kernel 20 registers and ~6 % of its time even when it is switched off.
+template <bool kVec4, int kBfRowDw, bool kF16, bool kTgt>
+__global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
+  static_assert(kF16 || !kTgt, "targets ride along in the float16 form only");
+#ifndef TD_F16_CHAIN
+#define TD_F16_CHAIN 8
+#endif
+  // k-steps (of 16 samples) per MFMA chain: a whole tile for the bf16 pieces (16-bit products:
+  // nothing is lost aligning them to a 128-sample sum)
+  constexpr int kChain = kF16 ? TD_F16_CHAIN : 8;
+  constexpr int kP = kF16 ? 2 : 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned ldsu[];   // [2][kP][64][kBfRowDw]
+  constexpr int kBfRows = BfGeom<kBfRowDw, kP>::kRows;
+  constexpr int kBfPieceDw = BfGeom<kBfRowDw, kP>::kPieceDw;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -539,6 +639,53 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
   const bool has_tail = kBfRows == 192 || wave < 4;
   const bool early = wave < 4;                         // stages after k-step 1 (else after 5):
                                                        // the two waves of a SIMD at different points
+  // float16 form: the power-of-two scales of this thread's four channels
+  float sc[4] = {1.f, 1.f, 1.f, 1.f};
+  if (kF16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = td_f16_scale_exp(td_chan_max_of(p.chan_max, min(c4 + q, 63)));
+      sc[q] = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+    }
+    // one workgroup leaves the combined maxima in the table's last row (the finalize launch
+    // divides the scales out and runs after this kernel)
+    if (blockIdx.x == 0 && tid < 128) {
+      unsigned* all = const_cast<unsigned*>(p.chan_max);
+      all[kChanShards * 128 + tid] = td_chan_max_of(p.chan_max, tid);
+    }
+  }
+  // float16 form with targets (p.ty): the staged targets and the wave's block of running sums
+  const bool t_on = kTgt && p.ty != nullptr;
+  const int wi = quad + 2 * nt;                        // which of the four waves of its m tile
+  constexpr int kYDw = BfGeom<kBfRowDw, kP>::kYDw;
+  unsigned* const ybuf = ldsu + 2 * kP * kBfPieceDw;   // [2 buffers][2 pieces][kYDw]
+  float* const tsums = reinterpret_cast<float*>(ybuf + 4 * kYDw) + wave * 1024;   // [4][64][4] per wave
+  TgtWork tw = {0, 0, 0, 0};
+  float sy = 1.f, pfy = 0.f;
+  if (t_on) {
+    tw = p.tworks[id];
+    sy = __builtin_bit_cast(float, (unsigned)(127 + td_f16_scale_exp(td_chan_max_of(p.ty_max, 0))) << 23);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+      reinterpret_cast<float4*>(tsums)[k4 * 64 + lane] = float4{0.f, 0.f, 0.f, 0.f};
+    // the slack behind the 160 staged targets of each piece is read by the k-steps past a
+    // recording's end (where every target is zero): it holds zeros, and nothing writes it again
+    if (tid < 64) ybuf[(tid >> 4) * kYDw + 80 + (tid & 15)] = 0u;
+  }
+  // sample u = ut - 31 + tid of the targets (tid < 160): zero outside the rows this call sums
+  auto prefetch_y = [&](long long ut) {
+    if (!t_on || tid >= 160) return;
+    const long long u = ut - 31 + tid;
+    const bool ok = u >= tw.seg_begin && u < tw.seg_end && u >= 0 && u < tw.y_valid;
+    pfy = ok ? p.ty[(tw.y_row0 + u) * p.ldty] : 0.f;
+  };
+  auto store_y = [&](unsigned* yb) {
+    if (!t_on || tid >= 160) return;
+    unsigned h, l;
+    td_split2_f16(pfy * sy, 0.f, h, l);
+    reinterpret_cast<unsigned short*>(yb)[tid] = (unsigned short)(h & 0xffffu);
+    reinterpret_cast<unsigned short*>(yb + kYDw)[tid] = (unsigned short)(l & 0xffffu);
+  };
   float4 pf[6];
   // a tile whose 160 staged rows all exist, 64 real channels: no clamps, no masks
   auto interior = [&](long long ut) -> bool {
@@ -581,24 +728,40 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      unsigned h[2], m[2], l[2];
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-        td_split3(comp4(v[2 * d], q), comp4(v[2 * d + 1], q), h[d], m[d], l[d]);
       unsigned* dst = buf + (c4 + q) * kBfRowDw + 2 * rg;        // samples 4 rg .. 4 rg + 3
-      dst[0] = h[0]; dst[1] = h[1];
-      dst[kBfPieceDw] = m[0]; dst[kBfPieceDw + 1] = m[1];
-      dst[2 * kBfPieceDw] = l[0]; dst[2 * kBfPieceDw + 1] = l[1];
+      if (kF16) {
+        unsigned h[2], l[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          td_split2_f16(comp4(v[2 * d], q) * sc[q], comp4(v[2 * d + 1], q) * sc[q], h[d], l[d]);
+        dst[0] = h[0]; dst[1] = h[1];
+        dst[kBfPieceDw] = l[0]; dst[kBfPieceDw + 1] = l[1];
+      } else {
+        unsigned h[2], m[2], l[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          td_split3(comp4(v[2 * d], q), comp4(v[2 * d + 1], q), h[d], m[d], l[d]);
+        dst[0] = h[0]; dst[1] = h[1];
+        dst[kBfPieceDw] = m[0]; dst[kBfPieceDw + 1] = m[1];
+        dst[(kP - 1) * kBfPieceDw] = l[0]; dst[(kP - 1) * kBfPieceDw + 1] = l[1];
+      }
     }
     if (has_tail) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        unsigned h, m, l;
-        td_split3(comp4(v[4], q), comp4(v[5], q), h, m, l);
         unsigned* tail = buf + (c4 + q) * kBfRowDw + kBfTile / 2 + rg;   // samples 128 + 2 rg, + 1
-        tail[0] = h;
-        tail[kBfPieceDw] = m;
-        tail[2 * kBfPieceDw] = l;
+        if (kF16) {
+          unsigned h, l;
+          td_split2_f16(comp4(v[4], q) * sc[q], comp4(v[5], q) * sc[q], h, l);
+          tail[0] = h;
+          tail[kBfPieceDw] = l;
+        } else {
+          unsigned h, m, l;
+          td_split3(comp4(v[4], q), comp4(v[5], q), h, m, l);
+          tail[0] = h;
+          tail[kBfPieceDw] = m;
+          tail[(kP - 1) * kBfPieceDw] = l;
+        }
       }
     }
   };
@@ -607,29 +770,43 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
   const int a_off = (mt * 32 + lj) * kBfRowDw + 4 * lg;
   const int b_off = (nt * 32 + lj) * kBfRowDw + 4 * lg + (e0 >> 1) + 2 * quad;
 
+  // the diagonal 32 x 32 tiles of lag 0 also take the product l l' (see bf_kstep)
+  const bool ll0 = kF16 && group == 0 && quad == 0 && mt == nt;
+  // Toeplitz operand of the targets: lane (lag m = lj, k half lg) reads y[v - m] for the 8 samples
+  // v of its k half: staged index 16 s + 8 lg - m + 31 (the buffer starts at sample ut - 31)
+  TgtLane tl;
+  tl.y = nullptr;
+  tl.shift = ((8 * lg - lj + 31) & 1) * 16;
+  tl.sums = tsums + 4 * lane;
+  const int y_lane = (8 * lg - lj + 31) >> 1;
+
   f32x16 acc[4];
   unsigned* const buf0 = ldsu;
-  unsigned* const buf1 = ldsu + 3 * kBfPieceDw;
+  unsigned* const buf1 = ldsu + kP * kBfPieceDw;
   prefetch(w.u_begin);
+  prefetch_y(w.u_begin);
   store(w.u_begin, buf0);
+  store_y(ybuf);
   __syncthreads();
 
   int parity = 0;
   for (long long ut = w.u_begin; ut < w.u_end; ut += kBfTile, parity ^= 1) {
     const unsigned* cur = parity ? buf1 : buf0;
     unsigned* nxt = parity ? buf0 : buf1;
+    unsigned* ynxt = ybuf + (parity ? 0 : 2 * kYDw);
+    tl.y = ybuf + (parity ? 2 * kYDw : 0) + y_lane;
     const bool more = ut + kBfTile < w.u_end;
-    if (more) prefetch(ut + kBfTile);
+    if (more) { prefetch(ut + kBfTile); prefetch_y(ut + kBfTile); }
     const long long left = w.u_end - ut;
     const unsigned* ap = cur + a_off;
     const unsigned* bp = cur + b_off;
     if (left >= kBfTile) {
       // whole tile: unrolled k-steps
-      bf_ksteps<0, 2, kBfPieceDw>(ap, bp, acc);
-      if (more && early) store(ut + kBfTile, nxt);
-      bf_ksteps<2, 6, kBfPieceDw>(ap, bp, acc);
-      if (more && !early) store(ut + kBfTile, nxt);
-      bf_ksteps<6, 8, kBfPieceDw>(ap, bp, acc);
+      bf_ksteps<0, 2, kBfPieceDw, kF16, kChain>(ap, bp, acc, total, ll0);
+      if (more && early) { store(ut + kBfTile, nxt); store_y(ynxt); }
+      bf_ksteps<2, 6, kBfPieceDw, kF16, kChain>(ap, bp, acc, total, ll0);
+      if (more && !early) { store(ut + kBfTile, nxt); store_y(ynxt); }
+      bf_ksteps<6, 8, kBfPieceDw, kF16, kChain>(ap, bp, acc, total, ll0);
     } else {
       // the last, cut tile of a slab: A stops at nk
       const int nk = (int)left;
@@ -643,11 +820,16 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
 #pragma unroll
         for (int d = 0; d < 4; ++d)
           mask[d] = cnt >= 2 * d + 2 ? 0xffffffffu : cnt == 2 * d + 1 ? 0x0000ffffu : 0u;
-        bf_kstep<false, kBfPieceDw>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc);
+        bf_kstep<false, kBfPieceDw, kF16>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc, ll0);
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) total[r] += acc[r];
+      for (int r = 0; r < 4; ++r) total[r] += acc[r];
+    }
+    if constexpr (kTgt) {
+      if (t_on)
+        tgt_tile<kBfPieceDw, kYDw>(ap, tl, left < kBfTile ? (int)left : kBfTile,
+                                   !more && w.u_end == tw.seg_end, group, p.n_groups, wi, lg);
+    }
     if (more) __syncthreads();
   }
 
@@ -663,6 +845,174 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_bf16x3_kernel(LagParams p) 
       const int j = nt * 32 + lr;
       pe[(size_t)i * p.cb_pad + j] = total[r][k];
     }
+  }
+  if (t_on) {
+    // targets: the blocks of the four waves of an m tile are summed (fixed order) and leave as
+    // ONE [32 lags][64 channels] float32 block per workgroup.  Wave block layout [k4][lane][4]:
+    // C/D register k = 4 k4 + q of lane (col = lane & 31, k half lk) is lag (k & 3) + 8 (k >> 2) +
+    // 4 lk = q + 8 k4 + 4 lk of channel mt * 32 + col.
+    __syncthreads();
+    const float* all = reinterpret_cast<const float*>(ybuf + 4 * kYDw);     // [8 waves][1024]
+    float* tp = p.tpartial + ((size_t)id * p.n_groups + group) * 32 * 64;
+#pragma unroll
+    for (int o = tid; o < 32 * 64; o += kBfThreads) {
+      const int e = o >> 6, ch = o & 63;
+      const int m_t = ch >> 5, col = ch & 31, lk = (e >> 2) & 1, q = e & 3, k4 = e >> 3;
+      const int idx = (k4 * 64 + lk * 32 + col) * 4 + q;
+      // waves of m tile m_t: wave = quad + 2 m_t + 4 nt
+      const float* b0 = all + (2 * m_t) * 1024 + idx;
+      tp[o] = (b0[0] + b0[1024]) + (b0[4 * 1024] + b0[5 * 1024]);
+    }
+  }
+}
+
+// Largest magnitude of every channel over the rows [row0, row1) of a time x channel array, as
+// float bits (non-negative floats order like unsigned integers; a NaN is "larger" than
+// everything) atomically maxed into tab[channel]: the scales of the float16 kernel above.
+// Order-independent, so the result is reproducible.  tab holds zeros before the call.
+__global__ __launch_bounds__(256) void chan_max_kernel(const float* __restrict__ x, long long ld,
+                                                       int c, long long row0, long long row1,
+                                                       unsigned* __restrict__ tab, int vec4) {
+  __shared__ unsigned red[16][64];
+  const int tid = threadIdx.x, c4 = (tid & 15) * 4, rl = tid >> 4;
+  unsigned m[4] = {0u, 0u, 0u, 0u};
+  const long long stride = (long long)gridDim.x * 16;
+  if (vec4) {
+    if (c4 < c) {
+      // four rows in flight per thread
+      long long r = row0 + (long long)blockIdx.x * 16 + rl;
+      for (; r + 3 * stride < row1; r += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(x + (r + k * stride) * ld + c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m[0] = max(m[0], __float_as_uint(v[k].x) & 0x7fffffffu);
+          m[1] = max(m[1], __float_as_uint(v[k].y) & 0x7fffffffu);
+          m[2] = max(m[2], __float_as_uint(v[k].z) & 0x7fffffffu);
+          m[3] = max(m[3], __float_as_uint(v[k].w) & 0x7fffffffu);
+        }
+      }
+      for (; r < row1; r += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c4);
+        m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu);
+        m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
+        m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu);
+        m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+      }
+    }
+  } else {
+    for (long long r = row0 + (long long)blockIdx.x * 16 + rl; r < row1; r += stride)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c4 + q < c) m[q] = max(m[q], __float_as_uint(x[r * ld + c4 + q]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[rl][c4 + q] = m[q];
+  __syncthreads();
+  if (tid < 64) {
+    unsigned t = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t = max(t, red[k][tid]);
+    if (tid < c && t) atomicMax(tab + (blockIdx.x % kChanShards) * 128 + tid, t);
+  }
+}
+
+// The streaming pre-pass of a float16 accumulate with targets: ONE read of x (and y) gives
+//   * the largest magnitude of every channel of x and of y (atomic max into tab: [0, 64) x
+//     channels, [64] y) -- the power-of-two scales of the float16 split,
+//   * per workgroup the float64 column sums of x over the rows this call sums (the bias moments:
+//     the all-ones row of [y | 1]^T x~ follows from them and the file ends, stats.hip) and the sum of y.
+// Workgroup b takes strips b, b + gridDim.x, ...; a strip's rows [u_begin, u_end) enter the sums,
+// the maxima also cover `halo` rows beyond it (what the lag kernel reads past a slab's end).
+__global__ __launch_bounds__(256) void chan_prepass_kernel(
+    const float* __restrict__ x, long long ldx, int c, const float* __restrict__ y, long long ldy,
+    const LagWork* __restrict__ strips, int n_strips, int halo, unsigned* __restrict__ tab,
+    double* __restrict__ csum, double* __restrict__ ysum, int vec4) {
+  __shared__ double red[16][65];
+  __shared__ unsigned redm[16][64];
+  const int tid = threadIdx.x, c4 = (tid & 15) * 4, rl = tid >> 4;
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};
+  unsigned m[4] = {0u, 0u, 0u, 0u};
+  double ys = 0.0;
+  unsigned ym = 0u;
+  const bool col_ok = c4 < c;
+  for (int si = blockIdx.x; si < n_strips; si += gridDim.x) {
+    const LagWork w = strips[si];
+    // x: rows [u_begin, u_end) clipped to the stream
+    const long long r0 = w.u_begin < 0 ? 0 : w.u_begin;
+    const long long r1 = w.u_end < w.b_valid ? w.u_end : w.b_valid;
+    const long long r2 = r1 + halo < w.b_valid ? r1 + halo : w.b_valid;      // maxima only
+    const float* xb = x + w.b_row0 * ldx;
+    if (vec4 && col_ok) {
+      long long r = r0 + rl;
+      for (; r + 48 < r1; r += 64) {                   // four rows in flight per thread
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(xb + (r + 16 * k) * ldx + c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          cs[0] += (double)v[k].x; cs[1] += (double)v[k].y; cs[2] += (double)v[k].z; cs[3] += (double)v[k].w;
+          m[0] = max(m[0], __float_as_uint(v[k].x) & 0x7fffffffu);
+          m[1] = max(m[1], __float_as_uint(v[k].y) & 0x7fffffffu);
+          m[2] = max(m[2], __float_as_uint(v[k].z) & 0x7fffffffu);
+          m[3] = max(m[3], __float_as_uint(v[k].w) & 0x7fffffffu);
+        }
+      }
+      for (; r < r2; r += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + r * ldx + c4);
+        const double in = r < r1 ? 1.0 : 0.0;
+        cs[0] += in * (double)v.x; cs[1] += in * (double)v.y; cs[2] += in * (double)v.z; cs[3] += in * (double)v.w;
+        m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu);
+        m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
+        m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu);
+        m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+      }
+    } else if (!vec4) {
+      for (long long r = r0 + rl; r < r2; r += 16)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c4 + q < c) {
+            const float v = xb[r * ldx + c4 + q];
+            if (r < r1) cs[q] += (double)v;
+            m[q] = max(m[q], __float_as_uint(v) & 0x7fffffffu);
+          }
+    }
+    // y: rows [u_begin, u_end) clipped to ITS stream
+    if (y) {
+      const long long y1 = w.u_end < w.a_valid ? w.u_end : w.a_valid;
+      for (long long u = r0 + tid; u < y1; u += 256) {
+        const float v = y[(w.a_row0 + u) * ldy];
+        ys += (double)v;
+        ym = max(ym, __float_as_uint(v) & 0x7fffffffu);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { red[rl][c4 + q] = cs[q]; redm[rl][c4 + q] = m[q]; }
+  __syncthreads();
+  if (tid < 64) {
+    double t = 0.0;
+    unsigned tm = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { t += red[k][tid]; tm = max(tm, redm[k][tid]); }
+    csum[(size_t)blockIdx.x * 64 + tid] = tid < c ? t : 0.0;
+    if (tid < c && tm) atomicMax(tab + (blockIdx.x % kChanShards) * 128 + tid, tm);
+  }
+  __syncthreads();
+  // sum and maximum of y over the workgroup
+  double* yr = &red[0][0];
+  unsigned* ymr = &redm[0][0];
+  yr[tid] = ys;
+  ymr[tid] = ym;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { yr[tid] += yr[tid + off]; ymr[tid] = max(ymr[tid], ymr[tid + off]); }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    ysum[blockIdx.x] = yr[0];
+    if (ymr[0]) atomicMax(tab + (blockIdx.x % kChanShards) * 128 + 64, ymr[0]);
   }
 }
 
@@ -1282,28 +1632,34 @@ __device__ __forceinline__ void tgt_stage_targets(const LagParams& p, const LagW
 // The four waves of a workgroup share one strip of up to kTgtStrip rows and take its 32-row
 // bodies in turn (wave w: bodies w, w + 4, ...); every wave owns a private slab (index
 // 4 * strip + wave), so nothing is combined across waves here.
+//
+// The kernel streams every row of x the accumulate touches (the rows past a range's end too), so
+// it also measures the largest magnitude of every channel for the float16 lag kernel that runs
+// next (maxtab: atomic max of float bits, td_f16_scale_exp) -- the pre-pass that kernel needs
+// costs nothing here.  The four waves' sums meet in LDS (fixed order): one slab per strip.
 template <bool kVec2>
 __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams p,
                                                                        double* __restrict__ part64,
                                                                        double* __restrict__ csum,
-                                                                       double* __restrict__ ysum) {
+                                                                       double* __restrict__ ysum,
+                                                                       unsigned* __restrict__ maxtab) {
   constexpr int E = 32, P = kTgtPrefetch, kPad = 32, kRowsBody = 2 * kTgtBody;
   constexpr int kBodiesMax = (kTgtStrip + E - 1 + kRowsBody - 1) / kRowsBody;
   __shared__ float ya[kPad + kBodiesMax * kRowsBody];
+  __shared__ double comb[3][16][64];                   // waves 1-3 -> wave 0, 16 registers at a time
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cbt = (int)(blockIdx.x % p.n_cbt);
-  const int wi = (int)(blockIdx.x / p.n_cbt);          // strip; p.n_work counts the SLABS (4 per strip)
+  const int wi = (int)(blockIdx.x / p.n_cbt);          // strip = slab
   const LagWork w = p.works[wi];
   const TgtStrip ts = tgt_strip(p, w);
-  const int slab_i = wi * 4 + wave;
+  const int slab_i = wi;
   tgt_stage_targets(p, w, ts.len, ts.n_body, kPad, ya, tid);
   __syncthreads();
-  if (cbt == 0 && ysum) {
-    // the strip's column sum of y lands in wave 0's slot, the other waves' slots are zero
+  if (cbt == 0 && ysum && wave == 0) {
+    // the strip's column sum of y
     double sy = 0.0;
-    if (wave == 0)
-      for (int t = lane; t < ts.len; t += 64) sy += (double)ya[kPad + t];
+    for (int t = lane; t < ts.len; t += 64) sy += (double)ya[kPad + t];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sy += __shfl_down(sy, off, 64);
     if (lane == 0) ysum[slab_i] = sy;
@@ -1323,6 +1679,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; big0[r] = 0.0; big1[r] = 0.0; }
   double cs0 = 0.0, cs1 = 0.0;        // column sums of x over [u_begin, u_end)
+  float mx0 = 0.f, mx1 = 0.f;         // largest magnitudes of the two channels (every row streamed)
   const float* yp = ya + kPad + g - n;                // A operand of step kk: yp[2 kk]
   if (nb > 0) {
     float xr[P][2];
@@ -1348,6 +1705,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
       for (int s = 0; s < kTgtBody; ++s) {
         const float x0 = xr[s % P][0], x1 = xr[s % P][1];
         c0s += x0; c1s += x1;
+        mx0 = fmaxf(mx0, fabsf(x0)); mx1 = fmaxf(mx1, fabsf(x1));
         const float a = yp[(b * kTgtBody + s) * 2];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);
@@ -1387,6 +1745,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
       const int r = (b * kTgtBody + s) * 2 + g;
       const float m = (r >= ts.r_lo && (long long)r <= ts.last) ? 1.f : 0.f;
       const float x0 = xe[s][0] * m, x1 = xe[s][1] * m;
+      mx0 = fmaxf(mx0, fabsf(x0)); mx1 = fmaxf(mx1, fabsf(x1));
       const float in = (r >= ts.t_lo && r < ts.t_hi) ? 1.f : 0.f;
       c0s = fmaf(in, x0, c0s); c1s = fmaf(in, x1, c1s);
       const float a = yp[(b * kTgtBody + s) * 2];
@@ -1401,6 +1760,39 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
       big1[r] += (double)acc1[r]; acc1[r] = 0.f;
     }
   }
+  // the two row parities of a channel sit in lanes n and n + 32
+  cs0 += __shfl_xor(cs0, 32, 64);
+  cs1 += __shfl_xor(cs1, 32, 64);
+  mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
+  mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
+  // (per WAVE here: four of them max into the row of their workgroup's shard)
+  if (maxtab && g == 0) {
+    unsigned* row = maxtab + (blockIdx.x % kChanShards) * 128;
+    if (ok0 && mx0 > 0.f) atomicMax(row + c0, __float_as_uint(mx0));
+    if (ok1 && mx1 > 0.f) atomicMax(row + c0 + 1, __float_as_uint(mx1));
+  }
+  // the four waves' sums -> wave 0 (fixed order), 16 registers at a time: big0, big1, column sums
+#pragma unroll
+  for (int round = 0; round < 3; ++round) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        comb[wave - 1][r][lane] = round == 0 ? big0[r] : round == 1 ? big1[r] : (r == 0 ? cs0 : r == 1 ? cs1 : 0.0);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const double others = comb[0][r][lane] + (comb[1][r][lane] + comb[2][r][lane]);
+        if (round == 0) big0[r] += others;
+        else if (round == 1) big1[r] += others;
+        else if (r == 0) cs0 += others;
+        else if (r == 1) cs1 += others;
+      }
+    }
+  }
+  if (wave != 0) return;
   // C/D map: col = lane & 31 (channel pair n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (lag)
   double* slab = part64 + (size_t)slab_i * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
@@ -1411,9 +1803,6 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
       slab[(size_t)k * p.ca_pad * p.cb_pad + c0 + 1] = big1[r];
     }
   }
-  // the two row parities of a channel sit in lanes n and n + 32
-  cs0 += __shfl_xor(cs0, 32, 64);
-  cs1 += __shfl_xor(cs1, 32, 64);
   if (g == 0) {
     csum[(size_t)slab_i * p.cb_pad + c0] = cs0;
     csum[(size_t)slab_i * p.cb_pad + c0 + 1] = cs1;
@@ -1595,24 +1984,19 @@ int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld) {
   return TD_OK;
 }
 
-int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
-              int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate, int ldg, int rows_dst) {
+int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
+                   int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+                   LagcovPlan* plan) {
   const int ca_eff = ca + (a_ones ? 1 : 0);
-  // (ldg / rows_dst: g_dev is a sub-block of lag matrices of rows_dst rows of ldg numbers --
-  // the channel-tile decomposition of td_lagcov_auto; 0 = dense [e][ca_eff][cb])
-  if (ldg <= 0) ldg = cb;
-  if (rows_dst <= 0) rows_dst = ca_eff;
   TD_REQUIRE(h, ca_eff > 0 && cb > 0 && e_count > 0, "lagcov: empty problem");
+  plan->ca_eff = ca_eff; plan->cb = cb; plan->e_count = e_count;
   long long total = 0;
   for (const LagSeg& s : segs) total += (s.u_end > s.u_begin) ? s.u_end - s.u_begin : 0;
-  if (total == 0) {
-    if (!accumulate) {
-      TD_REQUIRE(h, ldg == cb && rows_dst == ca_eff, "lagcov: overwrite mode needs a dense destination");
-      TD_HIP(h, hipMemsetAsync(g_dev, 0, sizeof(double) * e_count * ca_eff * cb, h->stream));
-    }
-    return TD_OK;
-  }
+  plan->total = total;
+  plan->works.clear();
+  plan->scratch_bytes = 0;
+  plan->nwg = 0;
+  if (total == 0) return TD_OK;
   // the LDS-tiled VALU kernel only serves skinny [y | 1] operands that the streaming targets
   // kernel does not take; narrow real operands (an 8-band envelope) go to the matrix cores
   const bool small = a_ones && ca_eff <= 8;
@@ -1621,13 +2005,13 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   const int few_g = e_count >= 5 ? 8 : e_count >= 3 ? 4 : e_count;
   const bool few = !small && few_g < 8;
   const int lags_per_wg = small ? kSmallLags : few_g;
-  LagParams p;
+  LagParams& p = plan->p;
   p.lag_g = few_g;
   p.lag_lg = few_g == 8 ? 3 : few_g == 4 ? 2 : few_g == 2 ? 1 : 0;
   p.a = a; p.b = b; p.lda = lda; p.ldb = ldb; p.ca = ca; p.cb = cb; p.a_ones = a_ones ? 1 : 0;
   p.e_min = e_min; p.e_count = e_count;
   p.n_groups = (int)td_ceil_div(e_count, lags_per_wg);
-  // The bf16x3 kernel (lagcov_bf16x3_kernel): the same stream and channel tile on both sides,
+  // The split kernels (lagcov_split_kernel): the same stream and channel tile on both sides,
   // lags 0 .. <= 63, 33 .. 64 channels.
   static const bool force_f32 = getenv("TD_LAGCOV_F32") != nullptr;    // development: A/B runs
   bool split = !small && !few && (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min == 0 &&
@@ -1639,6 +2023,11 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   p.e_pad = p.n_groups * (small ? kSmallLags : kLagsPerWg);   // slab entries per work item
   p.ca_pad = small ? 8 : p.n_cat * 64;
   p.cb_pad = p.n_cbt * 64;
+  plan->small = small; plan->few = few; plan->split = split; plan->few_g = few_g;
+  // the two-piece float16 form of the split kernel (half the matrix instructions): for callers
+  // that reduce through the finalize launch, which divides the channel scales out (allow_f16)
+  static const bool force_bf16 = getenv("TD_LAGCOV_BF16X3") != nullptr;   // development: A/B runs
+  plan->f16 = split && plan->allow_f16 && !force_bf16;
 
   // Slab plan.  Every slab is ONE f32 accumulation chain (relative error ~ eps/2 *
   // sqrt(len/3)) and slabs are summed in float64, so at most 2048 samples per slab keep the
@@ -1692,35 +2081,93 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
       ++n_slabs[best];
     }
   }
-  std::vector<LagWork> works;
+  std::vector<LagWork>& works = plan->works;
+  plan->work_seg.clear();
   for (size_t f = 0; f < segs.size(); ++f) {
     if (n_slabs[f] == 0) continue;
     const long long len = segs[f].u_end - segs[f].u_begin;
     std::vector<LagSeg> one(1, segs[f]);
     std::vector<LagWork> ws = split_work(one, td_ceil_div(len, n_slabs[f]));
     works.insert(works.end(), ws.begin(), ws.end());
+    plan->work_seg.insert(plan->work_seg.end(), ws.size(), (int)f);
   }
   p.n_work = (int)works.size();
-
   const size_t slab_elems = (size_t)p.e_pad * p.ca_pad * p.cb_pad;
-  const size_t table_bytes = td_round_up(works.size() * sizeof(LagWork), 256);
-  void* scratch = nullptr;
-  TD_TRY(td_scratch(h, table_bytes + slab_elems * works.size() * sizeof(float), &scratch));
-  // the work list by content (td_table_upload): refits of the same recordings skip the upload
-  // and the ~25 us the copy engine leaves the stream idle in front of the kernel
-  const void* works_dev = nullptr;
-  TD_TRY(td_table_upload(h, works.data(), works.size() * sizeof(LagWork), &works_dev));
-  p.works = reinterpret_cast<const LagWork*>(works_dev);
-  p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + table_bytes);
-
+  plan->scratch_bytes = td_round_up(slab_elems * works.size() * sizeof(float), 256);
   const bool b_aligned =
       (ldb % 4 == 0) && (cb % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
   const bool a_aligned =
       (lda % 4 == 0) && (ca % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
   // the skinny-A kernel reads A with scalar loads: only B's alignment matters
-  const bool aligned = small ? b_aligned : (a_aligned && b_aligned);
-  const long long nwg = (long long)p.n_work * per_item_wgs;
-  TD_REQUIRE(h, nwg < (1LL << 31), "lagcov: too many workgroups");
+  plan->aligned = small ? b_aligned : (a_aligned && b_aligned);
+  plan->nwg = (long long)p.n_work * per_item_wgs;
+  TD_REQUIRE(h, plan->nwg < (1LL << 31), "lagcov: too many workgroups");
+  return TD_OK;
+}
+
+int td_chan_tab(td_handle* h, unsigned** tab) {
+  if (!h->chan_max) {
+    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->chan_max), sizeof(unsigned) * 2 * kChanTab));
+    TD_HIP(h, hipMemsetAsync(h->chan_max, 0, sizeof(unsigned) * 2 * kChanTab, h->stream));
+  }
+  *tab = h->chan_max + kChanTab * (h->chan_phase & 1);
+  return TD_OK;
+}
+
+bool td_lagcov_plan_targets(LagcovPlan* plan) {
+  if (!plan->f16 || plan->e_count > 32 || plan->p.e_min != 0 || plan->works.empty()) return false;
+  plan->tpartial_bytes = td_round_up((size_t)plan->p.n_work * plan->p.n_groups * 32 * 64 * sizeof(float), 256);
+  return true;
+}
+
+int td_chan_prepass_plan(td_handle* h, const std::vector<LagSeg>& syx, PrepassPlan* plan) {
+  long long total = 0;
+  for (const LagSeg& sg : syx) total += sg.u_end > sg.u_begin ? sg.u_end - sg.u_begin : 0;
+  // two workgroups of 256 threads per CU, one strip each; strips of at least 256 rows
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  long long strip = td_round_up(td_ceil_div(total > 0 ? total : 1, 2 * cus), 16);
+  if (strip < 256) strip = 256;
+  plan->strips = split_work(syx, strip);
+  plan->blocks = (int)(plan->strips.size() < (size_t)(2 * cus) ? plan->strips.size() : 2 * cus);
+  if (plan->blocks < 1) plan->blocks = 1;
+  plan->scratch_bytes = td_round_up((size_t)plan->blocks * 65 * sizeof(double), 256);
+  return TD_OK;
+}
+
+int td_chan_prepass_launch(td_handle* h, PrepassPlan* plan, const float* x, int64_t ldx, int c,
+                           const float* y, int64_t ldy, int halo, unsigned* tab, void* scratch,
+                           const double** csum, const double** ysum) {
+  double* cs = reinterpret_cast<double*>(scratch);
+  double* ys = cs + (size_t)plan->blocks * 64;
+  *csum = cs;
+  *ysum = ys;
+  const void* strips_dev = nullptr;
+  TD_TRY(td_table_upload(h, plan->strips.data(), plan->strips.size() * sizeof(LagWork), &strips_dev));
+  const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipLaunchKernelGGL(chan_prepass_kernel, dim3((unsigned)plan->blocks), dim3(256), 0, h->stream, x,
+                     (long long)ldx, c, y, (long long)ldy, reinterpret_cast<const LagWork*>(strips_dev),
+                     (int)plan->strips.size(), halo, tab, cs, ys, vec4 ? 1 : 0);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_dev, bool accumulate,
+                     int ldg, int rows_dst, LagReduceJob* job, double* tg_dev, bool t_accumulate,
+                     int t_rows, LagReduceJob* tjob) {
+  LagParams& p = plan->p;
+  const bool small = plan->small, few = plan->few, split = plan->split, aligned = plan->aligned;
+  const int few_g = plan->few_g, e_count = plan->e_count, ca_eff = plan->ca_eff, cb = plan->cb;
+  const long long nwg = plan->nwg;
+  if (ldg <= 0) ldg = cb;
+  if (rows_dst <= 0) rows_dst = ca_eff;
+  // the work list by content (td_table_upload): refits of the same recordings skip the upload
+  // and the ~25 us the copy engine leaves the stream idle in front of the kernel
+  const void* works_dev = nullptr;
+  TD_TRY(td_table_upload(h, plan->works.data(), plan->works.size() * sizeof(LagWork), &works_dev));
+  p.works = reinterpret_cast<const LagWork*>(works_dev);
+  p.partial = reinterpret_cast<float*>(scratch);
+  const float* a = p.a; const float* b = p.b;
+  const int e_min = p.e_min;
   if (small) {
     const int ni = ca_eff <= 1 ? 1 : ca_eff <= 2 ? 2 : ca_eff <= 4 ? 4 : 8;
 #define TD_LAUNCH_SMALL(NI)                                                              \
@@ -1740,11 +2187,41 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   } else {
     // Unified mode: both operands are the same stream and channel tile.
     const int rows_u = kTile + kHalo + e_min + (p.n_groups - 1) * few_g;
-    bool unified = (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min >= 0 &&
+    bool unified = (a == b) && (p.lda == p.ldb) && (p.ca == p.cb) && !p.a_ones && e_min >= 0 &&
                    p.n_cat == 1 && p.n_cbt == 1 && rows_u <= 16 * kNpfU2;
-    for (const LagSeg& sg : segs)
-      if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) unified = false;
-    TD_TRY(td_profile_mark(h, true, (double)total));
+    for (const LagWork& wk : plan->works)
+      if (wk.a_row0 != wk.b_row0 || wk.a_valid != wk.b_valid) unified = false;
+    p.chan_max = nullptr;
+    p.ty = nullptr; p.ldty = 0; p.tworks = nullptr; p.tpartial = nullptr; p.ty_max = nullptr;
+    if (plan->f16 && plan->tab) {
+      p.chan_max = plan->tab;          // the caller's pre-pass filled it
+      if (plan->ty && plan->tpartial_bytes) {
+        std::vector<TgtWork> tw(plan->works.size());
+        for (size_t i = 0; i < tw.size(); ++i) tw[i] = plan->tsegs[plan->work_seg[i]];
+        const void* tw_dev = nullptr;
+        TD_TRY(td_table_upload(h, tw.data(), tw.size() * sizeof(TgtWork), &tw_dev));
+        p.ty = plan->ty; p.ldty = plan->ldty;
+        p.tworks = reinterpret_cast<const TgtWork*>(tw_dev);
+        p.tpartial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + plan->scratch_bytes);
+        p.ty_max = plan->tab + 64;
+      }
+    } else if (plan->f16) {
+      // channel scales of the float16 form: largest magnitude of every channel over the rows
+      // of the array that hold this call's recordings (a superset of what the kernel reads)
+      unsigned* tab = nullptr;
+      TD_TRY(td_chan_tab(h, &tab));
+      long long lo = plan->works[0].a_row0, hi = lo;
+      for (const LagWork& wk : plan->works) {
+        lo = wk.a_row0 < lo ? wk.a_row0 : lo;
+        hi = wk.a_row0 + wk.a_valid > hi ? wk.a_row0 + wk.a_valid : hi;
+      }
+      const long long blocks = td_ceil_div(hi - lo, 16 * 8);     // >= 8 rows per thread
+      hipLaunchKernelGGL(chan_max_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)),
+                         dim3(256), 0, h->stream, p.a, (long long)p.lda, p.ca, lo, hi, tab,
+                         aligned ? 1 : 0);
+      p.chan_max = tab;
+    }
+    TD_TRY(td_profile_mark(h, true, (double)plan->total));
 #define TD_LAUNCH_MFMA(UNI, TILE, NPF, FEW)                                                       \
   do {                                                                                            \
     const size_t lds_bytes = sizeof(float) * 64 * 16 * (NPF);                                     \
@@ -1756,20 +2233,31 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
                          dim3(kThreads), lds_bytes, h->stream, p);                                \
   } while (0)
     if (split) {
-      if (!h->lds_opt_lagcov) {                          // 124 / 152 KB of dynamic LDS: opt in once
-#define TD_BF_OPT(V, R)                                                                            \
-        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_bf16x3_kernel<V, R>),     \
+      if (!h->lds_opt_lagcov) {                          // 83 .. 152 KB of dynamic LDS: opt in once
+#define TD_BF_OPT(V, R, F, T)                                                                      \
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_split_kernel<V, R, F, T>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize,                  \
-                                      (int)BfGeom<R>::kLdsBytes))
-        TD_BF_OPT(true, 83); TD_BF_OPT(false, 83); TD_BF_OPT(true, 99); TD_BF_OPT(false, 99);
+                                      (int)BfGeom<R, ((F) ? 2 : 3)>::kLdsBytes))
+        TD_BF_OPT(true, 83, false, false); TD_BF_OPT(false, 83, false, false);
+        TD_BF_OPT(true, 99, false, false); TD_BF_OPT(false, 99, false, false);
+        TD_BF_OPT(true, 83, true, false); TD_BF_OPT(false, 83, true, false);
+        TD_BF_OPT(true, 99, true, false); TD_BF_OPT(false, 99, true, false);
+        TD_BF_OPT(true, 83, true, true); TD_BF_OPT(false, 83, true, true);
 #undef TD_BF_OPT
         h->lds_opt_lagcov = true;
       }
-#define TD_BF_LAUNCH(V, R)                                                                         \
-      hipLaunchKernelGGL((lagcov_bf16x3_kernel<V, R>), dim3((unsigned)nwg), dim3(kBfThreads),        \
-                         BfGeom<R>::kLdsBytes, h->stream, p)
-      if (e_count <= 32) { if (aligned) TD_BF_LAUNCH(true, 83); else TD_BF_LAUNCH(false, 83); }
-      else               { if (aligned) TD_BF_LAUNCH(true, 99); else TD_BF_LAUNCH(false, 99); }
+#define TD_BF_LAUNCH(V, R, F, T)                                                                   \
+      hipLaunchKernelGGL((lagcov_split_kernel<V, R, F, T>), dim3((unsigned)nwg), dim3(kBfThreads),   \
+                         (BfGeom<R, ((F) ? 2 : 3)>::kLdsBytes), h->stream, p)
+      if (plan->f16 && p.ty) {   // (one target column rides along: <= 32 lags)
+        if (aligned) TD_BF_LAUNCH(true, 83, true, true); else TD_BF_LAUNCH(false, 83, true, true);
+      } else if (plan->f16) {
+        if (e_count <= 32) { if (aligned) TD_BF_LAUNCH(true, 83, true, false); else TD_BF_LAUNCH(false, 83, true, false); }
+        else               { if (aligned) TD_BF_LAUNCH(true, 99, true, false); else TD_BF_LAUNCH(false, 99, true, false); }
+      } else {
+        if (e_count <= 32) { if (aligned) TD_BF_LAUNCH(true, 83, false, false); else TD_BF_LAUNCH(false, 83, false, false); }
+        else               { if (aligned) TD_BF_LAUNCH(true, 99, false, false); else TD_BF_LAUNCH(false, 99, false, false); }
+      }
 #undef TD_BF_LAUNCH
     } else if (few) {
       if (unified && rows_u <= 16 * kNpfU) TD_LAUNCH_MFMA(true, kTile, kNpfU, true);
@@ -1781,17 +2269,57 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
     TD_TRY(td_profile_mark(h, false, 0.0));
   }
   TD_HIP(h, hipGetLastError());
-  if (few)   // [work][phase][n_groups * G lags]: S = 8 / G slabs per work item
-    launch_lagcov_reduce<float>(h, p.partial, p.n_work * (8 / few_g), p.n_groups * few_g, p.ca_pad,
-                                p.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, rows_dst, ldg);
-  else
-    launch_lagcov_reduce<float>(h, p.partial, p.n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, ca_eff,
-                                cb, g_dev, accumulate, rows_dst, ldg);
+  *job = LagReduceJob{};
+  job->partial = p.partial; job->is_f64 = 0;
+  // few: [work][phase][n_groups * G lags]: S = 8 / G slabs per work item
+  job->n_work = few ? p.n_work * (8 / few_g) : p.n_work;
+  job->e_pad = few ? p.n_groups * few_g : p.e_pad;
+  job->ca_pad = p.ca_pad; job->cb_pad = p.cb_pad;
+  job->e_count = e_count; job->ca_eff = ca_eff; job->cb = cb;
+  job->g = g_dev; job->accumulate = accumulate ? 1 : 0; job->ca_dst = rows_dst; job->ldg = ldg;
   // The bf16x3 kernel adds the six partial products of x_i x_j in an order that is not symmetric
   // in i and j, so the lag-0 Gram block comes out symmetric only to ~1e-9: the lower triangle
   // takes the upper one's sums (the float32 kernel's block is symmetric by construction, and
   // the moment matrix is promised exactly symmetric).
-  if (split)
+  job->mirror = split ? 1 : 0;
+  job->scale_a = job->scale_b = plan->f16 ? p.chan_max + kChanShards * 128 : nullptr;
+  if (tjob && p.ty) {
+    *tjob = LagReduceJob{};
+    tjob->partial = p.tpartial; tjob->is_f64 = 0;
+    tjob->n_work = p.n_work * p.n_groups;
+    tjob->e_pad = 32; tjob->ca_pad = 1; tjob->cb_pad = 64;
+    tjob->e_count = e_count; tjob->ca_eff = 1; tjob->cb = cb;
+    tjob->g = tg_dev; tjob->accumulate = t_accumulate ? 1 : 0; tjob->ca_dst = t_rows; tjob->ldg = cb;
+    tjob->scale_a = p.ty_max + kChanShards * 128; tjob->scale_b = p.chan_max + kChanShards * 128;
+  }
+  return TD_OK;
+}
+
+int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
+              int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+              double* g_dev, bool accumulate, int ldg, int rows_dst) {
+  // (ldg / rows_dst: g_dev is a sub-block of lag matrices of rows_dst rows of ldg numbers --
+  // the channel-tile decomposition of td_lagcov_auto; 0 = dense [e][ca_eff][cb])
+  LagcovPlan plan;
+  TD_TRY(td_lagcov_plan(h, a, lda, ca, a_ones, b, ldb, cb, segs, e_min, e_count, &plan));
+  const int ca_eff = plan.ca_eff;
+  if (ldg <= 0) ldg = cb;
+  if (rows_dst <= 0) rows_dst = ca_eff;
+  if (plan.total == 0) {
+    if (!accumulate) {
+      TD_REQUIRE(h, ldg == cb && rows_dst == ca_eff, "lagcov: overwrite mode needs a dense destination");
+      TD_HIP(h, hipMemsetAsync(g_dev, 0, sizeof(double) * e_count * ca_eff * cb, h->stream));
+    }
+    return TD_OK;
+  }
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, plan.scratch_bytes, &scratch));
+  LagReduceJob job;
+  TD_TRY(td_lagcov_launch(h, &plan, scratch, g_dev, accumulate, ldg, rows_dst, &job));
+  launch_lagcov_reduce<float>(h, reinterpret_cast<const float*>(job.partial), job.n_work, job.e_pad,
+                              job.ca_pad, job.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, rows_dst,
+                              ldg);
+  if (job.mirror)
     hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)td_ceil_div((long long)ca * cb, 256)),
                        dim3(256), 0, h->stream, g_dev, ca, ldg);
   TD_HIP(h, hipGetLastError());
@@ -1803,89 +2331,138 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
 // per-segment column sums of B over [u_begin, u_end) in colsum_seg_dev [n_segs][cb]
 // (overwritten) and, if sy_dev, the accumulated column sums of Y.  Returns TD_ERR_STATE-free
 // false in *handled when the shape needs the generic kernel (more than 32 lags / 4 targets).
-int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
-                      int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled) {
-  *handled = false;
+int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, const float* b,
+                           int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min,
+                           int e_count, TargetsPlan* plan) {
+  plan->handled = false;
+  plan->scratch_bytes = 0;
+  plan->works.clear();
+  plan->seg_work0.clear();
   if (e_count > 32 || d > 4 || e_min > 0 || e_min + e_count - 1 < 0) return TD_OK;
-  *handled = true;
-  if (segs.empty()) return TD_OK;
+  plan->handled = true;
   const int n_segs = (int)segs.size();
+  plan->d = d; plan->cb = cb; plan->e_count = e_count; plan->n_segs = n_segs;
   // Strips.  Without targets (column sums only: lagcov_wave_kernel) a strip is kWaveStrip rows
   // and one wave; with targets (lagcov_targets_mfma_kernel) a strip is kTgtStrip rows and one
   // WORKGROUP whose four waves each fill their own slab.  Every segment gets at least one
   // (possibly empty) strip so that the per-segment column sums are defined.  seg_work0 counts
   // slabs.
   const int ni = d > 0 ? 1 : 0;     // one target column per launch
-  const int slabs_per_strip = ni > 0 ? 4 : 1;
-  std::vector<LagWork> works;
-  std::vector<int> seg_work0(n_segs + 1, 0);
+  const int slabs_per_strip = 1;
+  // strips of the targets kernel: <= kTgtStrip rows, shorter when the call is short, so that
+  // there are ~4 workgroups per CU (a rank's 1/8 share of the C2 job ran on 61 workgroups)
+  long long total = 0;
+  for (const LagSeg& sg : segs) total += sg.u_end > sg.u_begin ? sg.u_end - sg.u_begin : 0;
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  long long t_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, 4 * cus), 32);
+  t_strip = t_strip < 512 ? 512 : (t_strip > kTgtStrip ? kTgtStrip : t_strip);
+  plan->seg_work0.assign(n_segs + 1, 0);
   for (int f = 0; f < n_segs; ++f) {
-    seg_work0[f] = (int)works.size() * slabs_per_strip;
+    plan->seg_work0[f] = (int)plan->works.size() * slabs_per_strip;
     std::vector<LagSeg> one(1, segs[f]);
-    std::vector<LagWork> ws = split_work(one, ni > 0 ? kTgtStrip : kWaveStrip);
-    works.insert(works.end(), ws.begin(), ws.end());
+    std::vector<LagWork> ws = split_work(one, ni > 0 ? t_strip : kWaveStrip);
+    plan->works.insert(plan->works.end(), ws.begin(), ws.end());
   }
-  seg_work0[n_segs] = (int)works.size() * slabs_per_strip;
-  const int n_strips = (int)works.size();
-  const int n_work = n_strips * slabs_per_strip;     // slabs
-  if (n_work == 0) {
-    TD_HIP(h, hipMemsetAsync(colsum_seg_dev, 0, sizeof(double) * n_segs * cb, h->stream));
-    return TD_OK;
-  }
-  LagParams p;
+  plan->seg_work0[n_segs] = (int)plan->works.size() * slabs_per_strip;
+  plan->n_strips = (int)plan->works.size();
+  plan->n_work = plan->n_strips * slabs_per_strip;     // slabs
+  LagParams& p = plan->p;
   p.a = y; p.b = b; p.lda = ldy; p.ldb = ldb; p.ca = d; p.cb = cb; p.a_ones = 0;
   p.e_min = e_min; p.e_count = e_count;
   p.n_groups = 1; p.n_cat = 1; p.n_cbt = (int)td_ceil_div(cb, 64);
   p.e_pad = e_count; p.ca_pad = ni > 0 ? ni : 1; p.cb_pad = p.n_cbt * 64;
-  p.n_work = n_work;
+  p.n_work = plan->n_work;
+  p.lag_g = 8; p.lag_lg = 3; p.partial = nullptr; p.works = nullptr;
   const size_t slab_elems = ni > 0 ? (size_t)p.e_pad * p.ca_pad * p.cb_pad : 0;
-  const size_t s_tab = td_round_up(works.size() * sizeof(LagWork), 256);
-  const size_t s_seg = td_round_up((n_segs + 1) * sizeof(int), 256);
-  const size_t s_part = td_round_up(slab_elems * n_work * sizeof(double), 256);
-  const size_t s_cs = td_round_up((size_t)n_work * p.cb_pad * sizeof(double), 256);
-  const size_t s_ys = td_round_up((size_t)n_work * (ni > 0 ? ni : 1) * sizeof(double), 256);
-  void* scratch = nullptr;
-  TD_TRY(td_scratch(h, s_tab + s_seg + s_part + s_cs + s_ys, &scratch));
+  plan->part_bytes = td_round_up(slab_elems * plan->n_work * sizeof(double), 256);
+  plan->cs_bytes = td_round_up((size_t)plan->n_work * p.cb_pad * sizeof(double), 256);
+  plan->ys_bytes = td_round_up((size_t)plan->n_work * sizeof(double), 256);
+  const int cols = d > 0 ? d : 1;
+  plan->scratch_bytes = plan->cs_bytes + cols * (plan->part_bytes + plan->ys_bytes);
+  return TD_OK;
+}
+
+int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, double* g_dev,
+                             bool accumulate, TargetsOutputs* out) {
+  LagParams p = plan->p;
+  const int d = plan->d, cb = plan->cb, e_count = plan->e_count, n_work = plan->n_work;
   char* base = reinterpret_cast<char*>(scratch);
+  double* csum = reinterpret_cast<double*>(base);
+  out->csum = csum; out->n_work = n_work; out->cb_pad = p.cb_pad;
+  for (int i = 0; i < 4; ++i) out->ysum[i] = nullptr;
+  if (n_work == 0) return TD_OK;
   const void* works_dev = nullptr;
-  const void* seg_dev = nullptr;
-  TD_TRY(td_table_upload(h, works.data(), works.size() * sizeof(LagWork), &works_dev));
-  TD_TRY(td_table_upload(h, seg_work0.data(), (n_segs + 1) * sizeof(int), &seg_dev));
+  TD_TRY(td_table_upload(h, plan->works.data(), plan->works.size() * sizeof(LagWork), &works_dev));
   p.works = reinterpret_cast<const LagWork*>(works_dev);
-  const int* d_seg = reinterpret_cast<const int*>(seg_dev);
-  p.partial = nullptr;
-  double* part64 = reinterpret_cast<double*>(base + s_tab + s_seg);
-  double* csum = reinterpret_cast<double*>(base + s_tab + s_seg + s_part);
-  double* ysum = reinterpret_cast<double*>(base + s_tab + s_seg + s_part + s_cs);
-  const unsigned blocks = (unsigned)td_ceil_div((int64_t)n_work * p.n_cbt, kThreads / 64);
-  if (ni == 0) {
+  const int cols = d > 0 ? d : 1;
+  if (d == 0) {
+    double* ysum = reinterpret_cast<double*>(base + plan->cs_bytes + plan->part_bytes);
+    const unsigned blocks = (unsigned)td_ceil_div((int64_t)n_work * p.n_cbt, kThreads / 64);
     hipLaunchKernelGGL((lagcov_wave_kernel<32, 0>), dim3(blocks), dim3(kThreads), 0, h->stream, p,
-                       part64, csum, ysum);
+                       nullptr, csum, ysum);
   } else {
-    for (int i = 0; i < d; ++i) {
+    const float* y = p.a;
+    const bool vec2 = (p.ldb % 2 == 0) && (cb % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 7) == 0);
+    const dim3 grid((unsigned)(plan->n_strips * p.n_cbt));
+    for (int i = 0; i < cols; ++i) {
       // target column i: A = y + i (one column), output row i of every lag
       LagParams pi = p;
       pi.a = y + i;
       pi.ca = 1;
-      const bool vec2 = (ldb % 2 == 0) && (cb % 2 == 0) && ((reinterpret_cast<uintptr_t>(b) & 7) == 0);
-      const dim3 grid((unsigned)(n_strips * p.n_cbt));
+      char* col = base + plan->cs_bytes + (size_t)i * (plan->part_bytes + plan->ys_bytes);
+      double* part64 = reinterpret_cast<double*>(col);
+      double* ysum = reinterpret_cast<double*>(col + plan->part_bytes);
+      unsigned* maxtab = i == 0 ? out->maxtab : nullptr;        // (one column's pass is enough)
       if (vec2)
         hipLaunchKernelGGL((lagcov_targets_mfma_kernel<true>), grid, dim3(kThreads), 0, h->stream,
-                           pi, part64, csum, ysum);
+                           pi, part64, csum, ysum, maxtab);
       else
         hipLaunchKernelGGL((lagcov_targets_mfma_kernel<false>), grid, dim3(kThreads), 0, h->stream,
-                           pi, part64, csum, ysum);
-      launch_lagcov_reduce<double>(h, part64, n_work, p.e_pad, p.ca_pad, p.cb_pad, e_count, 1, cb,
-                                   g_dev + (size_t)i * cb, true, d + 1);
-      if (sy_dev)
-        hipLaunchKernelGGL(ysum_reduce_kernel, dim3(1), dim3(256), 0, h->stream, ysum, n_work, 1,
-                           sy_dev + i, 1);
+                           pi, part64, csum, ysum, maxtab);
+      LagReduceJob& job = out->jobs[i];
+      job = LagReduceJob{};
+      job.partial = part64; job.is_f64 = 1;
+      job.n_work = n_work; job.e_pad = p.e_pad; job.ca_pad = p.ca_pad; job.cb_pad = p.cb_pad;
+      job.e_count = e_count; job.ca_eff = 1; job.cb = cb;
+      job.g = g_dev + (size_t)i * cb; job.accumulate = accumulate ? 1 : 0; job.ca_dst = d + 1;
+      job.ldg = cb; job.mirror = 0;
+      out->ysum[i] = ysum;
     }
   }
   TD_HIP(h, hipGetLastError());
-  hipLaunchKernelGGL(colsum_file_reduce_kernel, dim3((unsigned)n_segs, (unsigned)p.n_cbt), dim3(1024), 0,
-                     h->stream, csum, p.cb_pad, cb, d_seg, colsum_seg_dev);
+  return TD_OK;
+}
+
+int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
+                      int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled) {
+  TargetsPlan plan;
+  TD_TRY(td_lagcov_targets_plan(h, y, ldy, d, b, ldb, cb, segs, e_min, e_count, &plan));
+  *handled = plan.handled;
+  if (!plan.handled || segs.empty()) return TD_OK;
+  const int n_segs = plan.n_segs;
+  if (plan.n_work == 0) {
+    TD_HIP(h, hipMemsetAsync(colsum_seg_dev, 0, sizeof(double) * n_segs * cb, h->stream));
+    return TD_OK;
+  }
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, plan.scratch_bytes, &scratch));
+  TargetsOutputs out;
+  out.maxtab = nullptr;
+  TD_TRY(td_lagcov_targets_launch(h, &plan, scratch, g_dev, true, &out));
+  for (int i = 0; i < d; ++i) {
+    const LagReduceJob& job = out.jobs[i];
+    launch_lagcov_reduce<double>(h, reinterpret_cast<const double*>(job.partial), job.n_work, job.e_pad,
+                                 job.ca_pad, job.cb_pad, e_count, 1, cb, job.g, true, d + 1);
+    if (sy_dev)
+      hipLaunchKernelGGL(ysum_reduce_kernel, dim3(1), dim3(256), 0, h->stream, out.ysum[i], job.n_work,
+                         1, sy_dev + i, 1);
+  }
+  const void* seg_dev = nullptr;
+  TD_TRY(td_table_upload(h, plan.seg_work0.data(), (n_segs + 1) * sizeof(int), &seg_dev));
+  hipLaunchKernelGGL(colsum_file_reduce_kernel, dim3((unsigned)n_segs, (unsigned)plan.p.n_cbt),
+                     dim3(1024), 0, h->stream, out.csum, plan.p.cb_pad, cb,
+                     reinterpret_cast<const int*>(seg_dev), colsum_seg_dev);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

@@ -717,20 +717,25 @@ __global__ __launch_bounds__(256) void chol_back_kernel(CholParams p) {
   }
 }
 
-// tol[b] = 64 n eps max_i a[i][i]
-__global__ __launch_bounds__(256) void diag_tol_kernel(const double* __restrict__ a, int n,
+// tol[b] = 64 n eps max_{i < n_real} a[i][i]; the identity padding (rows n_real .. n - 1, decoupled
+// from the system) takes that maximum as its diagonal, so that its pivots sit on the system's own
+// scale: with a fixed 1.0 a system whose diagonal is ~1e13 or more (a huge ridge lambda) had its
+// PADDING reported as "not positive definite", and a tiny one had its tolerance set by the padding.
+__global__ __launch_bounds__(256) void diag_tol_kernel(double* __restrict__ a, int n, int n_real,
                                                        double* __restrict__ tol) {
   __shared__ double red[256];
-  const double* ab = a + (size_t)blockIdx.x * n * n;
+  double* ab = a + (size_t)blockIdx.x * n * n;
   double m = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, fabs(ab[(size_t)i * n + i]));
+  for (int i = threadIdx.x; i < n_real; i += 256) m = fmax(m, fabs(ab[(size_t)i * n + i]));
   red[threadIdx.x] = m;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) tol[blockIdx.x] = 64.0 * n * 2.220446049250313e-16 * red[0];
+  if (threadIdx.x == 0) tol[blockIdx.x] = 64.0 * n_real * 2.220446049250313e-16 * red[0];
+  const double top = red[0] > 0.0 ? red[0] : 1.0;
+  for (int i = n_real + threadIdx.x; i < n; i += 256) ab[(size_t)i * n + i] = top;
 }
 
 // Core: a [batch][n][n] (n a multiple of 64), rt [batch][kMaxRhs][n]; solution in sol.
@@ -738,13 +743,13 @@ __global__ __launch_bounds__(256) void diag_tol_kernel(const double* __restrict_
 // (L^-1 B)^T out); L and the inverses of its diagonal blocks stay in a_dev / linv_dev.
 int chol_factor_forward(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
                         double* linv_dev, double* tol_dev, int n, int nrhs, int batch,
-                        int* flag_dev, int rt_rows) {
+                        int* flag_dev, int rt_rows, int n_real) {
   // (the update kernel addresses a system through a 32-bit buffer descriptor: n * n * 8 bytes)
   TD_REQUIRE(h, n <= 16320, "cholesky: systems of more than 16320 unknowns are not supported (n = %d)", n);
   if (!flag_dev) flag_dev = h->dev_flag;      // (a caller's flag outlives the next solve)
   TD_HIP(h, hipMemsetAsync(flag_dev, 0, sizeof(int), h->stream));
   hipLaunchKernelGGL(diag_tol_kernel, dim3((unsigned)batch), dim3(256), 0, h->stream, a_dev, n,
-                     tol_dev);
+                     n_real, tol_dev);
   const int nblk = n / NB;
   CholParams p;
   p.a = a_dev; p.rt = rt_dev; p.linv = linv_dev; p.sol = sol_dev; p.tol = tol_dev;
@@ -819,10 +824,10 @@ int chol_backward(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev, 
 }
 
 int spd_solve_padded(td_handle* h, double* a_dev, double* rt_dev, double* sol_dev,
-                     double* linv_dev, double* tol_dev, int n, int nrhs, int batch,
+                     double* linv_dev, double* tol_dev, int n, int n_real, int nrhs, int batch,
                      int* flag_dev = nullptr) {
   TD_TRY(chol_factor_forward(h, a_dev, rt_dev, sol_dev, linv_dev, tol_dev, n, nrhs, batch, flag_dev,
-                             kMaxRhs));
+                             kMaxRhs, n_real));
   return chol_backward(h, a_dev, rt_dev, sol_dev, linv_dev, n, nrhs, batch, kMaxRhs);
 }
 
@@ -967,7 +972,7 @@ int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const dou
                      n, np, 1.0, (const double*)nullptr, st->a);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(64), dim3(256), 0, h->stream, bt_dev, nb, n, 64, np, st->rt);
   TD_TRY(chol_factor_forward(h, st->a, st->rt, st->sol, st->linv, st->tol, np, nb > 0 ? nb : 1, 1,
-                             nullptr, 64));
+                             nullptr, 64, n));
   return spd_check_flag(h);            // TD_ERR_SINGULAR: not positive definite (blocking)
 }
 
@@ -999,7 +1004,7 @@ int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, 
                      (long long)n * n, n, np, 1.0, (const double*)nullptr, w.a);
   hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)batch), dim3(256), 0, h->stream, rhs_dev,
                      (long long)n * nrhs, n, nrhs, np, 1.0, w.rt);
-  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, nrhs, batch));
+  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, n, nrhs, batch));
   hipLaunchKernelGGL(unpad_sol_kernel, dim3(16, (unsigned)batch), dim3(256), 0, h->stream, w.sol, n,
                      nrhs, np, rhs_dev);
   TD_HIP(h, hipGetLastError());
@@ -1037,7 +1042,7 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
                      0LL, n, np, inv, w.lams, w.a);
   hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)n_lambda), dim3(256), 0, h->stream, xty, 0LL,
                      n, d, np, inv, w.rt);
-  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, d, n_lambda, flag_dev));
+  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, n, d, n_lambda, flag_dev));
   hipLaunchKernelGGL(ridge_emit_kernel, dim3(256), dim3(256), 0, h->stream, w.sol, k1, d, np,
                      n_lambda, w_dev, b_dev);
   TD_HIP(h, hipGetLastError());
@@ -1102,7 +1107,7 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
     }
     flag_dev = h->dev_flags + h->async_next;
   }
-  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, d, batch, flag_dev));
+  TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, n, d, batch, flag_dev));
   hipLaunchKernelGGL(ridge_emit_kernel, dim3(256), dim3(256), 0, h->stream, w.sol, k1, d, np, batch,
                      w_dev, b_dev);
   TD_HIP(h, hipGetLastError());

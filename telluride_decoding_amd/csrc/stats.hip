@@ -39,6 +39,11 @@ struct td_stats {
   float* win2 = nullptr;
   int64_t n_files = 0, cap_files = 0;
   int64_t frames = 0;
+  // A reset that has not been written yet (regression statistics only, see stats_fusable): the
+  // next accumulate call's finalize launch OVERWRITES its half of `g` instead of adding to it --
+  // `fresh_main` covers fxx and n, `fresh_tgt` gxo and sy -- and no memset is queued.  Every
+  // other reader of `g` calls stats_materialize first.
+  bool fresh_main = false, fresh_tgt = false;
 };
 
 namespace {
@@ -109,6 +114,250 @@ inline void launch_ones_rows(td_handle* h, double* g, int rows, int row, int c, 
                      e_min, colsum_seg, win, hw, first_slot, contrib);
   hipLaunchKernelGGL(ones_rows_kernel, dim3(bx), dim3(256), 0, h->stream, g, rows, row, c, l, contrib,
                      n_files);
+}
+
+// ---- one finalize launch per accumulate call -----------------------------------------------
+// Everything an accumulate call does around its matrix kernels -- the float64 reductions of
+// their partial slabs (with the lag-0 mirror), the column sums of y, the bias moments (the
+// all-ones row of [y | 1]^T x~), the boundary windows and the frame count -- used to be a dozen
+// launches of a few microseconds each with a launch gap in front of every one: ~75 us per call
+// that do not shrink with the time range a rank holds, i.e. the strong-scaling ceiling of the
+// accumulate (5.4x on 8 GPUs).  They are independent of each other once the matrix kernels have
+// written their slabs, so they are ONE launch: workgroups take jobs by blockIdx range.  With
+// `fresh` statistics (td_stats_reset pending) every job overwrites instead of adding and the
+// memset of the reset goes away too.
+constexpr int kFinThreads = 1024;
+constexpr int kFinMaxReduce = 5;      // F'xx + up to 4 target columns
+
+struct FinalizeParams {
+  LagReduceJob red[kFinMaxReduce];
+  int red_q[kFinMaxReduce];           // slab phases per output: 4 (256 outputs per workgroup) or 16 (64)
+  int red_block0[kFinMaxReduce + 1];  // first workgroup of each reduction
+  int n_red;
+  // column sums of y: sy[i] (+)= sum_w ysum[i][w]     (one workgroup per target column)
+  const double* ysum[4];
+  int ys_cols, ys_n_work, ys_accumulate;
+  double* sy;
+  // the all-ones row (bias moments) of gxo [l][rows][c], one workgroup per lag
+  int ones_l;                         // 0 = none
+  const double* csum;                 // [n_work][cs_pad] per-slab column sums of x over the rows summed
+  int cs_n_work, cs_pad;
+  const float* x;                     // the stream itself: the file ends are read in place
+  long long ldx;
+  const WinJob* jobs;
+  int n_files, c, e_min, rows, row, ones_accumulate;
+  double* gxo;
+  // boundary windows of the new files (two workgroups per file)
+  float* win;                         // null = none
+  int hw;
+  long long first_slot;
+  // frame count
+  double* n_dst;
+  double n_value;
+  unsigned* zero_tab;                 // the channel-maximum table of the NEXT call (float16 kernel), or null
+  int b_ysum, b_ones, b_win;          // first workgroup of each job kind
+};
+
+__device__ __forceinline__ void fin_reduce(const LagReduceJob& jb, int q_phases, int block,
+                                           double* part) {
+  const int outs_per = kFinThreads / q_phases;
+  const int ol = threadIdx.x % outs_per, q = threadIdx.x / outs_per;
+  const long long total = (long long)jb.e_count * jb.ca_eff * jb.cb;
+  const size_t slab = (size_t)jb.e_pad * jb.ca_pad * jb.cb_pad;
+  const long long o = (long long)block * outs_per + ol;
+  double s = 0.0;
+  int j = 0, i = 0, e = 0;
+  if (o < total) {
+    j = (int)(o % jb.cb);
+    i = (int)((o / jb.cb) % jb.ca_eff);
+    e = (int)(o / ((long long)jb.cb * jb.ca_eff));
+    // a symmetric lag-0 block takes the sums of its upper triangle on both sides
+    const bool flip = jb.mirror && e == 0 && i > j;
+    const int is = flip ? j : i, js = flip ? i : j;
+    const size_t off = ((size_t)e * jb.ca_pad + is) * jb.cb_pad + js;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // eight loads in flight
+    int w = q;
+    if (jb.is_f64) {
+      const double* src = reinterpret_cast<const double*>(jb.partial) + off;
+      for (; w + 7 * q_phases < jb.n_work; w += 8 * q_phases) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(w + k * q_phases) * slab];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += v[k];
+      }
+      for (; w < jb.n_work; w += q_phases) a[0] += src[(size_t)w * slab];
+    } else {
+      const float* src = reinterpret_cast<const float*>(jb.partial) + off;
+      for (; w + 7 * q_phases < jb.n_work; w += 8 * q_phases) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(w + k * q_phases) * slab];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += (double)v[k];
+      }
+      for (; w < jb.n_work; w += q_phases) a[0] += (double)src[(size_t)w * slab];
+    }
+    const double s0 = a[0] + a[4], s1 = a[1] + a[5], s2 = a[2] + a[6], s3 = a[3] + a[7];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[q * outs_per + ol] = s;
+  __syncthreads();
+  if (q == 0 && o < total) {
+    double t = 0.0;
+    for (int k = 0; k < q_phases; ++k) t += part[k * outs_per + ol];
+    // float16 kernel: the sums carry the two channels' power-of-two scales
+    if (jb.scale_a) t = ldexp(t, -(td_f16_scale_exp(jb.scale_a[i]) + td_f16_scale_exp(jb.scale_b[j])));
+    double* dst = jb.g + ((long long)e * jb.ca_dst + i) * jb.ldg + j;
+    *dst = jb.accumulate ? *dst + t : t;
+  }
+}
+
+// The same for float32 slabs whose rows are whole float4s: a thread sums FOUR consecutive outputs
+// (16-byte loads: 64 KB in flight per CU instead of 16) in q_phases = 8 slab phases, 512 outputs
+// per workgroup.  The lag-0 mirror needs no transposed reads here: the thread that holds (i, j),
+// j > i, of a symmetric block also writes (j, i), and the lower half's own sums are dropped.
+__device__ __forceinline__ void fin_reduce4(const LagReduceJob& jb, int block, double* part) {
+  constexpr int Q = 8, kGroups = kFinThreads / Q;       // 128 groups of 4 outputs
+  const int ol = threadIdx.x % kGroups, q = threadIdx.x / kGroups;
+  const long long total = (long long)jb.e_count * jb.ca_eff * jb.cb;
+  const size_t slab = (size_t)jb.e_pad * jb.ca_pad * jb.cb_pad;
+  const long long o = ((long long)block * kGroups + ol) * 4;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  int j = 0, i = 0, e = 0;
+  if (o < total) {
+    j = (int)(o % jb.cb);
+    i = (int)((o / jb.cb) % jb.ca_eff);
+    e = (int)(o / ((long long)jb.cb * jb.ca_eff));
+    const float* src = reinterpret_cast<const float*>(jb.partial) + ((size_t)e * jb.ca_pad + i) * jb.cb_pad + j;
+    double a[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[c][k] = 0.0;
+    int w = q;
+    for (; w + 3 * Q < jb.n_work; w += 4 * Q) {
+      float4 v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(src + (size_t)(w + c * Q) * slab);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a[c][0] += (double)v[c].x; a[c][1] += (double)v[c].y; a[c][2] += (double)v[c].z; a[c][3] += (double)v[c].w;
+      }
+    }
+    for (; w < jb.n_work; w += Q) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)w * slab);
+      a[0][0] += (double)v.x; a[0][1] += (double)v.y; a[0][2] += (double)v.z; a[0][3] += (double)v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = (a[0][k] + a[1][k]) + (a[2][k] + a[3][k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) part[(q * kGroups + ol) * 4 + k] = s[k];
+  __syncthreads();
+  if (q == 0 && o < total) {
+    const bool sym = jb.mirror && e == 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double t = 0.0;
+#pragma unroll
+      for (int ph = 0; ph < Q; ++ph) t += part[(ph * kGroups + ol) * 4 + k];
+      const int jj = j + k;
+      if (jb.scale_a) t = ldexp(t, -(td_f16_scale_exp(jb.scale_a[i]) + td_f16_scale_exp(jb.scale_b[jj])));
+      if (sym && jj < i) continue;                     // written by the holder of (jj, i)
+      double* dst = jb.g + ((long long)e * jb.ca_dst + i) * jb.ldg + jj;
+      *dst = jb.accumulate ? *dst + t : t;
+      if (sym && jj > i) {
+        double* low = jb.g + ((long long)e * jb.ca_dst + jj) * jb.ldg + i;
+        *low = jb.accumulate ? *low + t : t;
+      }
+    }
+  }
+}
+
+// x~[u] of a file for the bias moments: zero outside the file and at an end another rank owns
+__device__ __forceinline__ double fin_edge(const FinalizeParams& p, const WinJob& jw, long long u,
+                                           bool own, int col) {
+  return (own && u >= 0 && u < jw.valid) ? (double)p.x[(jw.row0 + u) * p.ldx + col] : 0.0;
+}
+
+__global__ __launch_bounds__(kFinThreads) void stats_finalize_kernel(FinalizeParams p) {
+  __shared__ double part[4 * kFinThreads];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && tid == 0 && p.n_dst) *p.n_dst = p.n_value;
+  if (b == 0 && p.zero_tab)
+    for (int i = tid; i < kChanTab; i += kFinThreads) p.zero_tab[i] = 0u;
+  if (b < p.b_ysum) {                                   // ---- slab reductions
+    int r = 0;
+    while (r + 1 < p.n_red && b >= p.red_block0[r + 1]) ++r;
+    if (p.red_q[r] == 0) fin_reduce4(p.red[r], b - p.red_block0[r], part);     // (0 = the float4 form)
+    else fin_reduce(p.red[r], p.red_q[r], b - p.red_block0[r], part);
+    return;
+  }
+  if (b < p.b_ones) {                                   // ---- column sum of one target column
+    const int i = b - p.b_ysum;
+    double s = 0.0;
+    for (int w = tid; w < p.ys_n_work; w += kFinThreads) s += p.ysum[i][w];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = kFinThreads / 2; off > 0; off >>= 1) {
+      if (tid < off) part[tid] += part[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) p.sy[i] = p.ys_accumulate ? p.sy[i] + part[0] : part[0];
+    return;
+  }
+  if (b < p.b_win) {                                    // ---- bias moments of one lag
+    // sum_f sum_{t < N'_f} x~_f[t + e] = (column sum of every row summed) + sum_f corr_f(e):
+    //   e > 0: corr = - sum_{v < e} x~[v] + sum_{v = N'}^{N' + e - 1} x~[v]
+    //   e < 0: corr = - sum_{v = N' + e}^{N' - 1} x~[v]
+    const int k = b - p.b_ones, e = p.e_min + k;
+    const int j = tid & 63, q = tid >> 6;               // 16 phases; c <= 64
+    double s = 0.0;
+    if (j < p.c) {
+      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // eight loads in flight
+      int w = q;
+      for (; w + 7 * 16 < p.cs_n_work; w += 8 * 16) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p.csum[(size_t)(w + 16 * k) * p.cs_pad + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += v[k];
+      }
+      for (; w < p.cs_n_work; w += 16) a[0] += p.csum[(size_t)w * p.cs_pad + j];
+      s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      for (int f = q; f < p.n_files; f += 16) {
+        const WinJob jw = p.jobs[f];
+        double v = 0.0;
+        for (int m = 0; m < e; ++m)
+          v += fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j) - fin_edge(p, jw, m, jw.head != 0, j);
+        for (int m = e; m < 0; ++m) v -= fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j);
+        s += v;
+      }
+    }
+    part[q * 64 + j] = s;
+    __syncthreads();
+    if (q == 0 && j < p.c) {
+      double t = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) t += part[kk * 64 + j];
+      double* dst = p.gxo + ((long long)k * p.rows + p.row) * p.c + j;
+      *dst = p.ones_accumulate ? *dst + t : t;
+    }
+    return;
+  }
+  if (p.win) {                                          // ---- boundary windows of one file end
+    const int f = (b - p.b_win) >> 1, which = (b - p.b_win) & 1;
+    const WinJob jw = p.jobs[f];
+    float* dst = p.win + ((p.first_slot + f) * 2 + which) * (long long)(2 * p.hw) * p.c;
+    const long long base = which == 0 ? -p.hw : jw.nprime - p.hw;
+    const bool own = which == 0 ? jw.head != 0 : jw.tail != 0;
+    for (int idx = tid; idx < 2 * p.hw * p.c; idx += kFinThreads) {
+      const int r = idx / p.c, col = idx % p.c;
+      const long long u = base + r;
+      dst[idx] = (own && u >= 0 && u < jw.valid) ? p.x[(jw.row0 + u) * p.ldx + col] : 0.f;
+    }
+  }
 }
 
 // Expansion in two phases (both fill the chip, neither depends on the number of
@@ -327,6 +576,27 @@ int ensure_window_capacity(td_handle* h, td_stats* s, int64_t need) {
   return TD_OK;
 }
 
+// The shape whose accumulate runs as matrix kernels + ONE finalize launch (accumulate_fused):
+// regression statistics (no second view), up to 64 channels and 32 lags, 1..4 target columns.
+inline bool stats_fusable(const td_stats* s) {
+  return s->c2 == 0 && s->d >= 1 && s->d <= 4 && s->c1 <= 64 && s->l1 <= 32;
+}
+
+// Writes a pending reset (see td_stats::fresh_*): the part of `g` nobody has overwritten yet is
+// zeroed on the handle's stream.  main = [0, off_gxo) + [off_n, g_len), targets = [off_gxo, off_n).
+int stats_materialize(td_handle* h, td_stats* s) {
+  if (s->fresh_main) {
+    TD_HIP(h, hipMemsetAsync(s->g, 0, sizeof(double) * s->off_gxo, h->stream));
+    TD_HIP(h, hipMemsetAsync(s->g + s->off_n, 0, sizeof(double) * (s->g_len - s->off_n), h->stream));
+    s->fresh_main = false;
+  }
+  if (s->fresh_tgt) {
+    TD_HIP(h, hipMemsetAsync(s->g + s->off_gxo, 0, sizeof(double) * (s->off_n - s->off_gxo), h->stream));
+    s->fresh_tgt = false;
+  }
+  return TD_OK;
+}
+
 int expand_block(td_handle* h, const double* g, int e_min, int e_count, int ca, int prea,
                  int posta, int cb, int preb, int postb, const float* wina, const float* winb,
                  int hw, int64_t n_files, double* m, int64_t ldm, bool symmetric) {
@@ -420,7 +690,12 @@ int td_stats_destroy(td_handle* h, td_stats* s) {
 
 int td_stats_reset(td_handle* h, td_stats* s) {
   if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_reset: NULL argument");
-  TD_HIP(h, hipMemsetAsync(s->g, 0, sizeof(double) * s->g_len, h->stream));
+  if (stats_fusable(s)) {
+    // nothing is queued: the next accumulate call overwrites (td_stats::fresh_*)
+    s->fresh_main = s->fresh_tgt = true;
+  } else {
+    TD_HIP(h, hipMemsetAsync(s->g, 0, sizeof(double) * s->g_len, h->stream));
+  }
   s->n_files = 0;
   s->frames = 0;
   return TD_OK;
@@ -471,6 +746,140 @@ int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vec
   // (the lag-0 matrix is promised exactly symmetric: its two off-diagonal blocks come from two
   // launches)
   return td_mirror_upper(h, g, c, c);
+}
+}  // namespace
+
+namespace {
+// Regression statistics (stats_fusable): the matrix kernels of the call run out of ONE scratch
+// block and ONE finalize launch does everything else (stats_finalize_kernel).  A call is
+//   MAIN    : lagcov kernel (F'xx slabs)                      + finalize {reduce + mirror, windows, n}
+//   TARGETS : one targets kernel per column (y^T x~, sums)    + finalize {reduces, sum y, bias row}
+//   both    : the kernels of both                             + ONE finalize with all of it
+// -- 3 launches for the C2 fit where there were 12 -- and fresh statistics are overwritten, so
+// td_stats_reset queues nothing.
+int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx, const float* y_dev,
+                     int64_t ldy, const std::vector<LagSeg>& sxx, const std::vector<LagSeg>& syx,
+                     const std::vector<WinJob>& j1, int num_files, int64_t new_frames,
+                     int64_t first_slot, bool do_main, bool do_targets) {
+  LagcovPlan mp;
+  TargetsPlan tp;
+  PrepassPlan pp;
+  if (do_main) {
+    TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
+    mp.allow_f16 = true;         // the finalize launch divides the channel scales out
+    TD_TRY(td_lagcov_plan(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1, &mp));
+  }
+  // Two forms, 3 launches and two reads of x each:
+  //   default: targets kernel (yT x~, column sums, channel maxima) -> lag kernel -> finalize;
+  //   FOLDED (one target column, no pre-context, the float16 kernel): a streaming pre-pass
+  //   (channel maxima, column sums of x, sum of y) -> the lag kernel with the targets riding
+  //   along (tgt_tile, lagcov.hip) -> finalize.
+  // (Measured at C2: the targets inside the lag kernel cost it 42 us, 6 %, and still need the
+  // 49 us pre-pass; as a pass of their own -- which is HBM-bound, has the matrix pipe to spare
+  // and measures the channel maxima on the way -- they cost 62 us in all.  So the folded form is
+  // opt-in: TD_ACC_FOLDED.)
+  static const bool want_fold = getenv("TD_ACC_FOLDED") != nullptr;      // development: A/B runs
+  const bool folded = do_main && do_targets && s->d == 1 && s->pre1 == 0 && want_fold &&
+                      td_lagcov_plan_targets(&mp);
+  if (folded) {
+    TD_TRY(td_chan_prepass_plan(h, syx, &pp));
+  } else if (do_targets) {
+    TD_TRY(td_lagcov_targets_plan(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1, &tp));
+    TD_REQUIRE(h, tp.handled && tp.n_work > 0, "accumulate_fused: the targets kernel refused the shape");
+  }
+  const size_t main_bytes = do_main ? mp.scratch_bytes + (folded ? mp.tpartial_bytes : 0) : 0;
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, main_bytes + (folded ? pp.scratch_bytes : do_targets ? tp.scratch_bytes : 0),
+                    &scratch));
+  char* base = reinterpret_cast<char*>(scratch);
+  FinalizeParams fp;
+  memset(&fp, 0, sizeof(fp));
+  int blocks = 0;
+  auto add_reduce = [&](const LagReduceJob& job) {
+    const long long outs = (long long)job.e_count * job.ca_eff * job.cb;
+    const bool vec = !job.is_f64 && outs >= 32768 && job.cb % 4 == 0 && job.cb_pad % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(job.partial) & 15) == 0;
+    const int q = vec ? 0 : outs < 32768 ? 16 : 4;
+    fp.red[fp.n_red] = job;
+    fp.red_q[fp.n_red] = q;
+    fp.red_block0[fp.n_red] = blocks;
+    blocks += (int)td_ceil_div(outs, vec ? 512 : kFinThreads / q);
+    fp.red_block0[++fp.n_red] = blocks;
+  };
+  const void* jobs_dev = nullptr;
+  TD_TRY(td_table_upload(h, j1.data(), sizeof(WinJob) * num_files, &jobs_dev));
+  fp.jobs = reinterpret_cast<const WinJob*>(jobs_dev);
+  fp.x = x_dev; fp.ldx = ldx; fp.c = s->c1; fp.n_files = num_files; fp.hw = s->hw;
+  TargetsOutputs to;
+  const double* pre_csum = nullptr;
+  const double* pre_ysum = nullptr;
+  if (folded) {
+    unsigned* tab = nullptr;
+    TD_TRY(td_chan_tab(h, &tab));
+    // (the lag kernel stages up to 64 rows past a slab's end: they must not overflow float16)
+    TD_TRY(td_chan_prepass_launch(h, &pp, x_dev, ldx, s->c1, y_dev, ldy, 64, tab, base + main_bytes,
+                                  &pre_csum, &pre_ysum));
+    mp.tab = tab; mp.ty = y_dev; mp.ldty = ldy;
+    mp.tsegs.resize(syx.size());
+    for (size_t f = 0; f < syx.size(); ++f)
+      mp.tsegs[f] = TgtWork{syx[f].a_row0, syx[f].a_valid, syx[f].u_begin, syx[f].u_end};
+  }
+  // The targets kernels run first: they stream every row the lag kernel will touch, so the first
+  // of them also measures the channel maxima the float16 lag kernel scales by (no pre-context:
+  // with one the lag kernel reaches further past a range's end than the targets do, and it
+  // measures for itself: chan_max_kernel).
+  if (do_targets && !folded) {
+    to.maxtab = nullptr;
+    if (do_main && mp.f16 && s->pre1 == 0) {
+      TD_TRY(td_chan_tab(h, &to.maxtab));
+      mp.tab = to.maxtab;
+    }
+    TD_TRY(td_lagcov_targets_launch(h, &tp, base + main_bytes, s->g + s->off_gxo, !s->fresh_tgt, &to));
+  }
+  if (do_main) {
+    LagReduceJob job, tjob;
+    TD_TRY(td_lagcov_launch(h, &mp, base, s->g + s->off_fxx, !s->fresh_main, 0, 0, &job,
+                            s->g + s->off_gxo, !s->fresh_tgt, s->d + 1, folded ? &tjob : nullptr));
+    add_reduce(job);
+    if (folded) add_reduce(tjob);
+    if (mp.f16) {                // this call used table chan_phase & 1: clear the other for the next
+      ++h->chan_phase;
+      fp.zero_tab = h->chan_max + kChanTab * (h->chan_phase & 1);
+    }
+    s->n_files += num_files;
+    s->frames += new_frames;
+    fp.n_dst = s->g + s->off_n;              // (n travels in the all-reduce)
+    fp.n_value = (double)s->frames;
+    s->fresh_main = false;
+  }
+  if (do_targets && !folded)
+    for (int i = 0; i < s->d; ++i) add_reduce(to.jobs[i]);
+  fp.b_ysum = blocks;
+  if (do_targets) {
+    if (folded) { fp.ysum[0] = pre_ysum; fp.ys_n_work = pp.blocks; }
+    else { for (int i = 0; i < s->d; ++i) fp.ysum[i] = to.ysum[i]; fp.ys_n_work = to.n_work; }
+    fp.ys_cols = s->d; fp.ys_accumulate = s->fresh_tgt ? 0 : 1;
+    fp.sy = s->g + s->off_sy;
+    blocks += s->d;
+  }
+  fp.b_ones = blocks;
+  if (do_targets) {
+    fp.ones_l = s->l1;
+    if (folded) { fp.csum = pre_csum; fp.cs_n_work = pp.blocks; fp.cs_pad = 64; }
+    else { fp.csum = to.csum; fp.cs_n_work = to.n_work; fp.cs_pad = to.cb_pad; }
+    fp.e_min = -s->pre1; fp.rows = s->d + 1; fp.row = s->d; fp.ones_accumulate = s->fresh_tgt ? 0 : 1;
+    fp.gxo = s->g + s->off_gxo;
+    blocks += s->l1;
+    s->fresh_tgt = false;
+  }
+  fp.b_win = blocks;
+  if (do_main) {
+    fp.win = s->win1; fp.first_slot = first_slot;
+    blocks += 2 * num_files;
+  }
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)blocks), dim3(kFinThreads), 0, h->stream, fp);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
 }
 }  // namespace
 
@@ -554,6 +963,12 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
   // CCA without context on either input: every moment is one Gram matrix of [x | x2 | 1]
   // (td_gram), done by MAIN; TARGETS then has nothing left to add.
   const bool one_pass = s->c2 > 0 && s->d == 0 && s->l1 == 1 && s->l2 == 1 && s->c1 <= 64 && s->c2 <= 31;
+
+  static const bool no_fuse = getenv("TD_ACC_UNFUSED") != nullptr;     // development: A/B runs
+  if (stats_fusable(s) && new_frames > 0 && !no_fuse)
+    return accumulate_fused(h, s, x_dev, ldx, y_dev, ldy, sxx, syx, j1, num_files, new_frames,
+                            first_slot, do_main, do_targets);
+  TD_TRY(stats_materialize(h, s));
 
   if (do_main) {
     // Boundary windows of the new files (also feed the all-ones rows below).
@@ -673,6 +1088,7 @@ __global__ void combine_windows_kernel(const CombineSrc* __restrict__ srcs, long
 int td_stats_combine(td_handle* h, td_stats* dst, td_stats* const* srcs, int n) {
   if (!h || !dst || (n > 0 && !srcs)) return td_fail(h, TD_ERR_INVALID, "td_stats_combine: NULL");
   TD_TRY(td_stats_reset(h, dst));
+  if (n == 0) return stats_materialize(h, dst);
   int64_t files = 0;
   for (int i = 0; i < n; ++i) {
     const td_stats* s = srcs[i];
@@ -682,7 +1098,8 @@ int td_stats_combine(td_handle* h, td_stats* dst, td_stats* const* srcs, int n) 
                "td_stats_combine: layouts differ");
     files += s->n_files;
   }
-  if (n == 0) return TD_OK;
+  for (int i = 0; i < n; ++i) TD_TRY(stats_materialize(h, srcs[i]));
+  dst->fresh_main = dst->fresh_tgt = false;    // combine_sum_kernel writes every number of dst->g
   TD_TRY(ensure_window_capacity(h, dst, files));
   std::vector<CombineSrc> table((size_t)n);
   int64_t frames = 0, slot = 0, max_files = 0;
@@ -727,6 +1144,7 @@ int td_stats_packed_len(td_handle* h, const td_stats* s, int64_t total_file_slot
 int td_stats_pack(td_handle* h, const td_stats* s, double* buf_dev, int64_t total_file_slots,
                   int64_t file_slot) {
   if (!h || !s || !buf_dev) return td_fail(h, TD_ERR_INVALID, "td_stats_pack: NULL");
+  TD_TRY(stats_materialize(h, const_cast<td_stats*>(s)));
   TD_REQUIRE(h, file_slot >= 0 && file_slot + s->n_files <= total_file_slots,
              "td_stats_pack: files [%lld, %lld) do not fit %lld slots", (long long)file_slot,
              (long long)(file_slot + s->n_files), (long long)total_file_slots);
@@ -752,6 +1170,7 @@ int td_stats_pack(td_handle* h, const td_stats* s, double* buf_dev, int64_t tota
 int td_stats_unpack_known(td_handle* h, td_stats* s, const double* buf_dev, int64_t total_file_slots,
                           int64_t total_frames) {
   if (!h || !s || !buf_dev) return td_fail(h, TD_ERR_INVALID, "td_stats_unpack: NULL");
+  s->fresh_main = s->fresh_tgt = false;        // every number of g is overwritten below
   TD_TRY(ensure_window_capacity(h, s, total_file_slots));
   TD_HIP(h, hipMemcpyAsync(s->g, buf_dev, sizeof(double) * s->g_len, hipMemcpyDeviceToDevice,
                            h->stream));
@@ -785,6 +1204,7 @@ int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev, int64_t to
 int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev,
                      double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev) {
   if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_moments: NULL argument");
+  TD_TRY(stats_materialize(h, s));
   if (xtx_dev)
     TD_TRY(expand_block(h, s->g + s->off_fxx, 0, s->l1, s->c1, s->pre1, s->post1, s->c1, s->pre1,
                         s->post1, s->win1, s->win1, s->hw, s->n_files, xtx_dev, s->k1 + 1, true));

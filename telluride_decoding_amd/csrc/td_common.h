@@ -13,6 +13,9 @@
 
 #include "td_hotpath.h"
 
+constexpr int kChanShards = 16;
+constexpr int kChanTab = (kChanShards + 1) * 128;     // unsigned per table
+
 struct td_handle {
   int device = 0;
   int cu_count = 0;   // CUs the handle's stream runs on (the device's, or a CU mask's: td_set_cu_count)
@@ -54,6 +57,14 @@ struct td_handle {
   TableSlot tables[kTableSlots];
   uint64_t table_clock = 0;
   int* dev_flag = nullptr;  // device int used for "not positive definite" reports
+  // Channel maxima (float bits) of the float16 accumulate, two tables used in turn: call k fills
+  // and reads table k & 1, its finalize launch clears the other one for call k + 1.  A table is
+  // kChanShards + 1 rows of 128 ([0, 64) channels of x, [64, 68) target columns): the measuring
+  // kernels max into row (workgroup % kChanShards) -- a thousand workgroups maxing into ONE row
+  // serialise on its 64 addresses (measured: +115 us) -- the lag kernel combines the rows and
+  // leaves the result in the last row for the finalize launch.
+  unsigned* chan_max = nullptr;
+  int chan_phase = 0;
   // asynchronous solves: rings of device flags and of pinned host ints they are copied to
   static constexpr int kAsyncFlags = 8;
   int* dev_flags = nullptr;
@@ -142,6 +153,56 @@ __device__ __forceinline__ td_f32x16 td_mfma_bf16(const td_u32x4& a, const td_u3
                                                  __builtin_bit_cast(td_bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- float32 products as TWO float16 pieces (lagcov.hip: lagcov_split_kernel<..., true>) -------
+// With a power-of-two scale s per channel that puts the channel's largest magnitude in
+// [2^14, 2^15), x s = h + l + r with h, l float16 (11 significant bits each) and |r| <= 2^-22 |x s|
+// for |x s| >= 2^-3 (below that l goes subnormal and the error is <= 2^-25 absolute, i.e. 2^-39
+// of the channel's maximum).  Three products h h' + h l' + l h', each exact in the float32
+// accumulator of v_mfma_f32_32x32x16_f16, give x y to ~2^-22 -- half the matrix instructions of
+// the three-piece bf16 split, which is what bounds a power-limited kernel.  The scales are
+// divided out exactly (powers of two) when the slabs are summed in float64.
+typedef _Float16 td_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 td_f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned td_pack_f16(float a, float b) {    // low half = a (RNE)
+  const td_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, td_f16x2));
+}
+
+// (x0, x1), already scaled -> packed pairs of the two pieces.  Clamped to the finite float16
+// range first: a staged row that is never multiplied must still not become an infinity (0 x inf).
+__device__ __forceinline__ void td_split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
+  // (a NaN fails the comparison and stays a NaN, as it would in float32 arithmetic)
+  x0 = __builtin_fabsf(x0) > 65504.f ? __builtin_copysignf(65504.f, x0) : x0;
+  x1 = __builtin_fabsf(x1) > 65504.f ? __builtin_copysignf(65504.f, x1) : x1;
+  h = td_pack_f16(x0, x1);
+  const td_f16x2 hv = __builtin_bit_cast(td_f16x2, h);
+  l = td_pack_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+}
+
+__device__ __forceinline__ td_f32x16 td_mfma_f16(const td_u32x4& a, const td_u32x4& b,
+                                                 const td_f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(td_f16x8, a),
+                                                __builtin_bit_cast(td_f16x8, b), c, 0, 0, 0);
+}
+
+// The largest magnitude of channel ch over the shards of a channel-maximum table.
+__device__ __forceinline__ unsigned td_chan_max_of(const unsigned* tab, int ch) {
+  unsigned m = 0u;
+#pragma unroll
+  for (int sh = 0; sh < kChanShards; ++sh) m = max(m, tab[sh * 128 + ch]);
+  return m;
+}
+
+// Power-of-two scale of a channel from the largest magnitude seen (as float bits; 0 = nothing
+// seen): max * scale in [2^14, 2^15).  Zero, infinite or NaN maxima scale by 1.
+__host__ __device__ __forceinline__ int td_f16_scale_exp(unsigned max_bits) {
+  const int e = (int)((max_bits >> 23) & 0xff);          // biased exponent of the maximum
+  if (max_bits == 0 || e == 0xff) return 0;
+  int k = 14 - (e - 127);                                // denormal maxima (e = 0) take k = 126
+  return k > 126 ? 126 : (k < -126 ? -126 : k);
+}
+
 static inline int64_t td_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t td_round_up(int64_t a, int64_t b) { return td_ceil_div(a, b) * b; }
 
@@ -163,6 +224,130 @@ struct LagSeg {
   int64_t u_begin;  // first u (relative to the segment) to sum
   int64_t u_end;    // one past the last u
 };
+
+// One work item of the lag kernels: a slab [u_begin, u_end) of one segment.
+struct LagWork {
+  long long a_row0, a_valid, b_row0, b_valid, u_begin, u_end;
+};
+
+struct LagParams {
+  const float* a;
+  const float* b;
+  long long lda, ldb;
+  int ca, cb;        // real channel counts
+  int a_ones;        // append a ones column to A at index ca
+  const LagWork* works;
+  int n_work, n_groups, n_cat, n_cbt;
+  int e_min, e_count;
+  float* partial;    // [n_work][e_pad][ca_pad][cb_pad]
+  int e_pad, ca_pad, cb_pad;
+  int lag_g, lag_lg;   // lags per workgroup (8, or 4/2/1 with the 8 wave slots split over time) and log2
+  const unsigned* chan_max;   // float16 form: largest magnitude of each channel, float bits [64]
+  // float16 form, optional: one regression target column rides along (see bf_kstep).  tworks[i]
+  // belongs to works[i]; tpartial [n_work * n_groups][32 lags][64 channels] float32 sums of
+  // (y s_y)(x_j s_j); ty_max[0] = largest |y| (float bits).
+  const float* ty;
+  long long ldty;
+  const struct TgtWork* tworks;
+  float* tpartial;
+  const unsigned* ty_max;
+};
+
+// Where work item i finds its targets: y[u] = ty[(y_row0 + u) * ldty], zero outside
+// [seg_begin, seg_end) (the rows of the recording this call sums) and outside [0, y_valid).
+struct TgtWork {
+  long long y_row0, y_valid, seg_begin, seg_end;
+};
+
+// One float64 reduction of partial slabs, run by a reduction launch of its own (td_lagcov) or
+// as one job of the fused finalize kernel of an accumulate call (stats.hip):
+//   g[(e * ca_dst + i) * ldg + j] (+)= sum_w partial[w][e][i][j]
+// summed in a fixed order (q slab phases per output, combined in order): bitwise reproducible.
+struct LagReduceJob {
+  const void* partial;   // float (is_f64 = 0) or double slabs
+  int is_f64;
+  int n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb;
+  double* g;
+  int accumulate, ca_dst, ldg;
+  int mirror;            // lag 0 is a symmetric Gram block: (i, j), i > j, takes the sums of (j, i)
+  // float16 form: the slabs hold sums of (x_i s_i)(x_j s_j); the power-of-two scales s = 2^k,
+  // k = td_f16_scale_exp(chan_max[.]), are divided out (exactly) as the sum is stored.  Null = none.
+  const unsigned* scale_a;
+  const unsigned* scale_b;
+};
+
+// td_lagcov in two steps, for callers that run several kernels out of ONE scratch block and
+// reduce them in one launch: the plan fixes the work list and the scratch bytes, the launch
+// queues the matrix kernel only and describes the reduction it leaves to the caller.
+struct LagcovPlan {
+  LagParams p;
+  std::vector<LagWork> works;
+  bool small = false, few = false, split = false, aligned = false;
+  bool allow_f16 = false;        // set by the caller BEFORE td_lagcov_plan: the reduction divides scales out
+  bool f16 = false;              // the two-piece float16 form of the split kernel was chosen
+  std::vector<int> work_seg;     // the segment each work item belongs to
+  // float16 form, set by the caller between plan and launch:
+  unsigned* tab = nullptr;       // channel maxima [0, 64) x, [64] y -- already filled (td_chan_prepass);
+                                 // null: the launch measures the maxima of x itself (chan_max_kernel)
+  const float* ty = nullptr;     // one target column rides along (needs tab, e_min = 0, <= 32 lags)
+  long long ldty = 0;
+  std::vector<TgtWork> tsegs;    // per SEGMENT: where its targets are
+  size_t tpartial_bytes = 0;     // (set by td_lagcov_plan_targets) scratch behind the Gram slabs
+  int few_g = 8, ca_eff = 0, cb = 0, e_count = 0;
+  long long total = 0, nwg = 0;
+  size_t scratch_bytes = 0;      // the float partial slabs
+};
+int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
+                   int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
+                   LagcovPlan* plan);
+// scratch: plan.scratch_bytes (+ plan.tpartial_bytes) of device memory that stays untouched until
+// the reduction ran.  tjob (with plan.ty): the reduction of the targets' sums into row 0 of
+// tg_dev [e][t_rows][cb].
+int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_dev, bool accumulate,
+                     int ldg, int rows_dst, LagReduceJob* job, double* tg_dev = nullptr,
+                     bool t_accumulate = false, int t_rows = 0, LagReduceJob* tjob = nullptr);
+// Asks the planned float16 launch to carry a target column: sizes its scratch.  False when the
+// plan cannot (not the float16 split kernel, or more than 32 lags).
+bool td_lagcov_plan_targets(LagcovPlan* plan);
+
+// The streaming pre-pass of a float16 accumulate (chan_prepass_kernel, lagcov.hip): channel
+// maxima into tab, per-workgroup column sums of x and sums of y into scratch.
+struct PrepassPlan {
+  std::vector<LagWork> strips;   // a_* = y stream, b_* = x stream
+  int blocks = 0;
+  size_t scratch_bytes = 0;
+};
+// The handle's channel-maximum table for the call that is being queued (allocated on first use).
+int td_chan_tab(td_handle* h, unsigned** tab);
+int td_chan_prepass_plan(td_handle* h, const std::vector<LagSeg>& syx, PrepassPlan* plan);
+int td_chan_prepass_launch(td_handle* h, PrepassPlan* plan, const float* x, int64_t ldx, int c,
+                           const float* y, int64_t ldy, int halo, unsigned* tab, void* scratch,
+                           const double** csum, const double** ysum);
+
+// The same for the targets path (td_lagcov_targets): one matrix-core kernel per target column.
+struct TargetsPlan {
+  LagParams p;
+  std::vector<LagWork> works;
+  std::vector<int> seg_work0;
+  int d = 0, cb = 0, e_count = 0, n_segs = 0, n_strips = 0, n_work = 0;
+  size_t part_bytes = 0, cs_bytes = 0, ys_bytes = 0;   // per target column / once / per column
+  size_t scratch_bytes = 0;
+  bool handled = false;
+};
+int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, const float* b,
+                           int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min,
+                           int e_count, TargetsPlan* plan);
+// Queues the d kernels; jobs[i] reduces target column i into row i of g_dev [e][d + 1][cb];
+// csum [n_work][cb_pad] holds the per-slab column sums of B, ysum[i] [n_work] those of y_i.
+struct TargetsOutputs {
+  unsigned* maxtab;      // IN: null, or the channel-maximum table the first column's kernel fills
+  LagReduceJob jobs[4];
+  const double* csum;
+  const double* ysum[4];
+  int n_work, cb_pad;
+};
+int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, double* g_dev,
+                             bool accumulate, TargetsOutputs* out);
 
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,

@@ -252,7 +252,7 @@ def test_uneven_batches_denominator_takes_the_eigen_route(dev):
   st.accumulate(h.to_device(x), h.to_device(x2), None, [0, n])
   denom = 2 * n - 1
   ra, rb, _, _, e, sweeps = st.cca_solve(denom, reg, dim)
-  assert sweeps[0] > 0, 'denom > frames must not take the Cholesky shortcut'
+  assert st.last_cca_route == 'eigen', 'denom > frames must not take the Cholesky shortcut'
   m = st.moments(want_xtx=True, want_xty=False, want_cca=True)
   xtx = m['xtx'].cpu().numpy()
   sx = xtx[c1:, :c1] / n
@@ -267,4 +267,5 @@ def test_uneven_batches_denominator_takes_the_eigen_route(dev):
   np.testing.assert_allclose(a, wa, atol=2e-5 * np.max(np.abs(wa)))
   np.testing.assert_allclose(b, wb, atol=2e-5 * np.max(np.abs(wb)))
   # with the usual denominator (frames - 1) the same statistics take the shortcut
-  assert st.cca_solve(n - 1, reg, dim)[5][0] == 0
+  st.cca_solve(n - 1, reg, dim)
+  assert st.last_cca_route == 'cholesky'

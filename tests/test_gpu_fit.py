@@ -66,6 +66,12 @@ def _rel(a, b):
     (33, 0, 4, 0, 0, 0, 1, 0, (10, 3000), 0),
     (64, 16, 15, 0, 0, 0, 1, 0, (2048, 2048, 100), 0),
     (64, 0, 8, 0, 0, 0, 1, 0, (6000, 1), 0),
+    # the float16 kernel with the target column riding along (one target, no pre-context):
+    # offsets of either sign, recordings shorter than the lag span, a dropped remainder that
+    # leaves real rows behind the summed range (they pair with the last targets)
+    (40, 0, 20, 0, 0, 0, 1, 2, (130, 129, 2050, 131), 77),
+    (64, 0, 31, 0, 0, 0, 1, -3, (4097, 640), 5),
+    (57, 0, 31, 0, 0, 0, 1, 0, (17, 9000, 400), 130),
     # 65 .. 128 channels: two channel tiles (diagonal blocks on the same-stream kernels, the
     # off-diagonal ones on the general kernel)
     (69, 0, 36, 0, 0, 0, 1, 0, (2500, 700), 0),
@@ -247,6 +253,21 @@ def test_spd_solve_sizes(dev):
     h.check(h.lib.td_spd_solve(h.ptr, ctypes.c_void_p(ad.data_ptr()),
                                ctypes.c_void_p(rd.data_ptr()), n, nrhs, batch))
     np.testing.assert_allclose(rd.cpu().numpy(), want, rtol=1e-9, atol=1e-11)
+  # The identity padding (n is rounded up to whole 64 x 64 tiles) sits on the system's own
+  # scale: a system whose diagonal is ~1e15 (a huge ridge lambda) or ~1e-20 is as solvable as
+  # np.linalg.solve finds it -- with a fixed 1.0 on the padding's diagonal the first had its
+  # padding reported as "not positive definite", the second its tolerance set by the padding.
+  for scale in (1e15, 1e-20):
+    n, nrhs = 70, 2
+    a = rng.standard_normal((1, n, n + 8))
+    a = (a @ a.transpose(0, 2, 1) + 0.5 * np.eye(n)) * scale
+    rhs = rng.standard_normal((1, n, nrhs))
+    want = np.linalg.solve(a, rhs)
+    ad = torch.from_numpy(a.copy()).cuda()
+    rd = torch.from_numpy(rhs.copy()).cuda()
+    h.check(h.lib.td_spd_solve(h.ptr, ctypes.c_void_p(ad.data_ptr()),
+                               ctypes.c_void_p(rd.data_ptr()), n, nrhs, 1))
+    np.testing.assert_allclose(rd.cpu().numpy(), want, rtol=1e-9, atol=1e-11 / scale)
 
 
 def test_c2_shape_fit_against_float64_oracle(dev):
