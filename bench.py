@@ -53,8 +53,8 @@ sys.path.insert(0, ROOT)
 C, PRE, POST, D, LAMBDA = 64, 0, 31, 1, 0.1
 FILES_PER_GPU, FRAMES_PER_FILE = 10, 100000
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md, dense f32 matrix peak
-PEAK_BF16_MFMA_TFLOPS = 2516.6      # dense bf16: 256 CUs x 4 SIMDs x 32x32x16 per 32 cycles at 2.4 GHz
-SPLIT_PRODUCTS = 6                  # bf16 products per float32 product (lagcov_bf16x3_kernel)
+PEAK_BF16_MFMA_TFLOPS = 2516.6      # dense bf16 = dense f16: 256 CUs x 4 SIMDs x 32x32x16 per 32 cycles at 2.4 GHz
+SPLIT_PRODUCTS = 3                  # float16 products per float32 product (lagcov_split_kernel, float16 form)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -436,8 +436,9 @@ def main():
   ap.add_argument('--no-decode', action='store_true', help='skip the informational decode leg')
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
   ap.add_argument('--no-extra', action='store_true', help='skip the C3 / C5 legs')
-  ap.add_argument('--targets-on-acc', action='store_true',
-                  help='keep the y^T x part of the accumulate on the accumulate stream')
+  ap.add_argument('--targets-on-solve', action='store_true',
+                  help='run the y^T x part of the accumulate on the solve streams (the round-2 '
+                       'arrangement; the accumulate then measures its channel maxima in a pass of its own)')
   ap.add_argument('--solve-streams', type=int, default=2,
                   help='solve streams of the pipeline (fit i on stream i mod n, same CU partition)')
   ap.add_argument('--solve-cus', type=int, default=64,
@@ -562,7 +563,7 @@ def main():
         return out
       return run, h, None
     pipe = pipeline.FitPipeline(C, PRE, POST, d=D, solve_cus=args.solve_cus,
-                                targets_on_solve=not args.targets_on_acc, allreduce=reduce_fn,
+                                targets_on_solve=args.targets_on_solve, allreduce=reduce_fn,
                                 solves=solves, solve_streams=args.solve_streams)
 
     def run(k):
@@ -595,7 +596,7 @@ def main():
     avg_s = kernel_ms / max(launches, 1) / 1e3
     achieved = flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
     traffic, traffic_source = None, None
-    for name in ('r02_lagcov_pmc.json',):
+    for name in ('r03_lagcov_pmc.json',):
       pmc = os.path.join(ROOT, 'profiles', name)
       if os.path.exists(pmc) and args.scaling == 'weak':
         with open(pmc) as f:
@@ -610,7 +611,8 @@ def main():
                                    'torch.distributed.run' if world > 1 else 'direct'),
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': args.scaling, 'vs_baseline': None,
-        'dtype': 'f32 (products as exact bf16x3 splits on the bf16 MFMA, f32 accumulate; f64 solve)',
+        'dtype': 'f32 (every product as 3 float16 products of a 2-piece split on the f16 MFMA, f32 '
+                 'accumulate, f64 slab sums; f64 solve)',
         'data': 'synthetic',
         'config': {
             'workload': ('C2: 64-ch x 1e6-sample ridge TRF fit%s (10 recordings x 100k frames), '
@@ -626,13 +628,13 @@ def main():
                            'accumulate(i+1) || solves on %d streams (%d-CU partition)'
                            % (args.solve_streams, args.solve_cus)),
         },
-        # The accumulate runs on the bf16 matrix pipe: every float32 product is six bf16 MFMA
-        # products (exact 3-way split, lagcov.hip).  `achieved` counts the bf16 flops the kernel
-        # executes (6 x the algorithmic float32 flops) against the dense bf16 peak; the same
-        # launch as float32-equivalent arithmetic is `algorithmic_tflops` (the float32 MFMA peak
-        # it replaces is 157.3 TFLOP/s).
+        # The accumulate runs on the float16 matrix pipe: every float32 product is three float16
+        # MFMA products (2-piece split with per-channel power-of-two scales, lagcov.hip).
+        # `achieved` counts the float16 flops the kernel executes (3 x the algorithmic float32
+        # flops) against the dense f16 peak; the same launch as float32-equivalent arithmetic is
+        # `algorithmic_tflops` (the float32 MFMA peak it replaces is 157.3 TFLOP/s).
         'roofline': {
-            'kernel': 'lagcov_bf16x3_kernel', 'bound': 'mfma',
+            'kernel': 'lagcov_split_kernel<float16 x 2>', 'bound': 'mfma',
             'achieved': achieved * SPLIT_PRODUCTS, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved * SPLIT_PRODUCTS / PEAK_BF16_MFMA_TFLOPS, 'traffic': traffic,
             'traffic_source': traffic_source,
@@ -640,7 +642,7 @@ def main():
             'algorithmic_flops_per_launch': flops_per_launch,
             'algorithmic_tflops': achieved,
             'algorithmic_frac_of_f32_mfma_peak': achieved / PEAK_F32_MFMA_TFLOPS,
-            'executed_bf16_flops_per_launch': flops_per_launch * SPLIT_PRODUCTS,
+            'executed_f16_flops_per_launch': flops_per_launch * SPLIT_PRODUCTS,
             'algorithmic_bytes_per_launch': 4.0 * (C + D) * (kernel_samples / max(launches, 1)),
         },
     }
@@ -674,7 +676,7 @@ def main():
           'split_shaped_operands_tflops': sustained, 'zero_operands_tflops': h.probe_bf16_mfma(False),
           'what': 'bare register-only v_mfma_f32_32x32x16_bf16 loop, whole chip, ~1 ms (td_probe_bf16_mfma)',
           'whole_chip_kernel_frac_of_sustained': a1 * SPLIT_PRODUCTS / sustained}
-      line['roofline_whole_chip'] = {'kernel': 'lagcov_bf16x3_kernel',
+      line['roofline_whole_chip'] = {'kernel': 'lagcov_split_kernel<float16 x 2>',
                                      'achieved': a1 * SPLIT_PRODUCTS,
                                      'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                      'frac': a1 * SPLIT_PRODUCTS / PEAK_BF16_MFMA_TFLOPS,

@@ -72,6 +72,16 @@ int td_stream_destroy(void* hip_stream);
  * its work items to fill whole rounds of them.  Default: every CU of the device.  No reference
  * counterpart. */
 int td_set_cu_count(td_handle* h, int cu_count);
+/* How the lagged-covariance kernel multiplies float32 numbers (same-stream shapes of 33..64
+ * channels; everything else is float32 MFMA).  The reference multiplies in float32
+ * (brain_model.py:437, np.matmul); all three modes are closer to exact arithmetic than that:
+ *   TD_ACC_F16X2  (default) two float16 pieces per number, per-channel power-of-two scales, three
+ *                 products on the float16 matrix pipe: sums of squares come out ~5e-8 low (the
+ *                 pipe truncates 22-bit products when it aligns them), everything else zero-mean;
+ *   TD_ACC_BF16X3 three bfloat16 pieces, six products: exact to 2^-27 per product, 1.6x the time;
+ *   TD_ACC_F32    the float32 matrix instruction: 3x the time. */
+enum { TD_ACC_F16X2 = 0, TD_ACC_BF16X3 = 1, TD_ACC_F32 = 2 };
+int td_set_accumulate_mode(td_handle* h, int mode);
 int td_synchronize(td_handle* h);
 
 /* Device memory helpers for callers that do not bring their own allocator. */

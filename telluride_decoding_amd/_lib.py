@@ -47,6 +47,7 @@ SIGNATURES = {
     'td_use_own_stream': [_vp],
     'td_stream_create_masked': [_i, _i, _i, _c.POINTER(_vp)],
     'td_stream_destroy': [_vp],
+    'td_set_accumulate_mode': [_vp, _i],
     'td_synchronize': [_vp],
     'td_malloc': [_vp, _sz, _c.POINTER(_vp)],
     'td_free': [_vp, _vp],

@@ -217,6 +217,13 @@ int td_set_cu_count(td_handle* h, int cu_count) {
   return TD_OK;
 }
 
+int td_set_accumulate_mode(td_handle* h, int mode) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "td_set_accumulate_mode: NULL handle");
+  TD_REQUIRE(h, mode >= TD_ACC_F16X2 && mode <= TD_ACC_F32, "td_set_accumulate_mode: unknown mode %d", mode);
+  h->acc_mode = mode;
+  return TD_OK;
+}
+
 const char* td_last_error(const td_handle* h) {
   return h ? h->error.c_str() : td_global_error.c_str();
 }

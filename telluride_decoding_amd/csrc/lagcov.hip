@@ -443,19 +443,17 @@ __device__ __forceinline__ float comp4(const float4& v, int q) {
 // (the accumulators start from the inline constant 0).  a_mask: null, or 4 dword masks that cut A
 // at the end of a slab.
 //
-// ll0 (float16 form): also the product l l' of lag slot 0.  The three products drop l l', which
-// is zero-mean EXCEPT where both factors are the same number -- the diagonal of the lag-0 Gram
-// block, sums of x^2 -- where it is l^2 > 0: a bias of -5e-8 relative (measured,
-// tools/bias_probe.py).  The two waves that own the diagonal 32 x 32 tiles of lag 0 add that one
-// product (1/12 more matrix work for 2 of the 32 waves of a slab); everywhere else the dropped
-// term stays a zero-mean 2^-22.
+// (float16 form: the dropped product l l' is zero-mean except on the diagonal of the lag-0 Gram
+// block, where it is l^2 > 0, 3e-8 of x^2.  Adding it back there was tried and changed nothing
+// measurable: the -5e-8 the sums of squares come out low by is the matrix pipe truncating the
+// 22-bit products h h' when it aligns the 16 products of an instruction -- the same bias with
+// MFMA chains of 128, 64 and 32 samples; tools/bias_probe.py.)
 //
 // (The regression targets ride along in the same kernel: tgt_tile below.)
 template <bool kZero, int kBfPieceDw, bool kF16>
 __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
                                          const unsigned* __restrict__ bp,
-                                         const unsigned* a_mask, f32x16 (&acc)[4],
-                                         bool ll0 = false) {
+                                         const unsigned* a_mask, f32x16 (&acc)[4]) {
   constexpr int kP = kF16 ? 2 : 3;
   u32x4 a[kP];
   unsigned d[kP][6];
@@ -499,7 +497,6 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[r] = td_mfma_f16(a[pa[t] % kP], b[r][pb[t] % kP], c[r]);
-    if (ll0) c[0] = td_mfma_f16(a[1 % kP], b[0][1 % kP], c[0]);
   } else {
     // (A piece, B piece) in the order l h, h l, m m, m h, h m, h h -- the four lags in turn
     constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
@@ -516,11 +513,11 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
 template <int kFrom, int kTo, int kBfPieceDw, bool kF16, int kChain>
 __device__ __forceinline__ void bf_ksteps(const unsigned* __restrict__ ap,
                                           const unsigned* __restrict__ bp, f32x16 (&acc)[4],
-                                          f32x16 (&total)[4], bool ll0) {
+                                          f32x16 (&total)[4]) {
 #pragma unroll
   for (int s = kFrom; s < kTo; ++s) {
-    if (s % kChain == 0) bf_kstep<true, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc, ll0);
-    else                 bf_kstep<false, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc, ll0);
+    if (s % kChain == 0) bf_kstep<true, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+    else                 bf_kstep<false, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc);
     if ((s + 1) % kChain == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) total[r] += acc[r];
@@ -770,8 +767,6 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   const int a_off = (mt * 32 + lj) * kBfRowDw + 4 * lg;
   const int b_off = (nt * 32 + lj) * kBfRowDw + 4 * lg + (e0 >> 1) + 2 * quad;
 
-  // the diagonal 32 x 32 tiles of lag 0 also take the product l l' (see bf_kstep)
-  const bool ll0 = kF16 && group == 0 && quad == 0 && mt == nt;
   // Toeplitz operand of the targets: lane (lag m = lj, k half lg) reads y[v - m] for the 8 samples
   // v of its k half: staged index 16 s + 8 lg - m + 31 (the buffer starts at sample ut - 31)
   TgtLane tl;
@@ -780,6 +775,9 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   tl.sums = tsums + 4 * lane;
   const int y_lane = (8 * lg - lj + 31) >> 1;
 
+#ifdef TD_SETPRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for the younger half
+#endif
   f32x16 acc[4];
   unsigned* const buf0 = ldsu;
   unsigned* const buf1 = ldsu + kP * kBfPieceDw;
@@ -802,11 +800,11 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     const unsigned* bp = cur + b_off;
     if (left >= kBfTile) {
       // whole tile: unrolled k-steps
-      bf_ksteps<0, 2, kBfPieceDw, kF16, kChain>(ap, bp, acc, total, ll0);
+      bf_ksteps<0, 2, kBfPieceDw, kF16, kChain>(ap, bp, acc, total);
       if (more && early) { store(ut + kBfTile, nxt); store_y(ynxt); }
-      bf_ksteps<2, 6, kBfPieceDw, kF16, kChain>(ap, bp, acc, total, ll0);
+      bf_ksteps<2, 6, kBfPieceDw, kF16, kChain>(ap, bp, acc, total);
       if (more && !early) { store(ut + kBfTile, nxt); store_y(ynxt); }
-      bf_ksteps<6, 8, kBfPieceDw, kF16, kChain>(ap, bp, acc, total, ll0);
+      bf_ksteps<6, 8, kBfPieceDw, kF16, kChain>(ap, bp, acc, total);
     } else {
       // the last, cut tile of a slab: A stops at nk
       const int nk = (int)left;
@@ -820,7 +818,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d)
           mask[d] = cnt >= 2 * d + 2 ? 0xffffffffu : cnt == 2 * d + 1 ? 0x0000ffffu : 0u;
-        bf_kstep<false, kBfPieceDw, kF16>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc, ll0);
+        bf_kstep<false, kBfPieceDw, kF16>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) total[r] += acc[r];
@@ -2013,7 +2011,9 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   p.n_groups = (int)td_ceil_div(e_count, lags_per_wg);
   // The split kernels (lagcov_split_kernel): the same stream and channel tile on both sides,
   // lags 0 .. <= 63, 33 .. 64 channels.
-  static const bool force_f32 = getenv("TD_LAGCOV_F32") != nullptr;    // development: A/B runs
+  // (the environment switches are for A/B runs inside one process tree; td_set_accumulate_mode is the API)
+  static const bool env_f32 = getenv("TD_LAGCOV_F32") != nullptr;
+  const bool force_f32 = env_f32 || h->acc_mode == TD_ACC_F32;
   bool split = !small && !few && (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min == 0 &&
                ca > 32 && ca <= 64 && e_count <= 64 && !force_f32;
   for (const LagSeg& sg : segs)
@@ -2026,8 +2026,8 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   plan->small = small; plan->few = few; plan->split = split; plan->few_g = few_g;
   // the two-piece float16 form of the split kernel (half the matrix instructions): for callers
   // that reduce through the finalize launch, which divides the channel scales out (allow_f16)
-  static const bool force_bf16 = getenv("TD_LAGCOV_BF16X3") != nullptr;   // development: A/B runs
-  plan->f16 = split && plan->allow_f16 && !force_bf16;
+  static const bool env_bf16 = getenv("TD_LAGCOV_BF16X3") != nullptr;
+  plan->f16 = split && plan->allow_f16 && !env_bf16 && h->acc_mode == TD_ACC_F16X2;
 
   // Slab plan.  Every slab is ONE f32 accumulation chain (relative error ~ eps/2 *
   // sqrt(len/3)) and slabs are summed in float64, so at most 2048 samples per slab keep the

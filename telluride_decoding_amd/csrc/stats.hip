@@ -207,7 +207,11 @@ __device__ __forceinline__ void fin_reduce(const LagReduceJob& jb, int q_phases,
     double t = 0.0;
     for (int k = 0; k < q_phases; ++k) t += part[k * outs_per + ol];
     // float16 kernel: the sums carry the two channels' power-of-two scales
-    if (jb.scale_a) t = ldexp(t, -(td_f16_scale_exp(jb.scale_a[i]) + td_f16_scale_exp(jb.scale_b[j])));
+    if (jb.scale_a) {
+      t = ldexp(t, -(td_f16_scale_exp(jb.scale_a[i]) + td_f16_scale_exp(jb.scale_b[j])));
+      // an infinity or a NaN in either channel: what float32 arithmetic would have made of it
+      if (td_chan_not_finite(jb.scale_a[i]) || td_chan_not_finite(jb.scale_b[j])) t = __builtin_nan("");
+    }
     double* dst = jb.g + ((long long)e * jb.ca_dst + i) * jb.ldg + j;
     *dst = jb.accumulate ? *dst + t : t;
   }
@@ -263,7 +267,10 @@ __device__ __forceinline__ void fin_reduce4(const LagReduceJob& jb, int block, d
 #pragma unroll
       for (int ph = 0; ph < Q; ++ph) t += part[(ph * kGroups + ol) * 4 + k];
       const int jj = j + k;
-      if (jb.scale_a) t = ldexp(t, -(td_f16_scale_exp(jb.scale_a[i]) + td_f16_scale_exp(jb.scale_b[jj])));
+      if (jb.scale_a) {
+        t = ldexp(t, -(td_f16_scale_exp(jb.scale_a[i]) + td_f16_scale_exp(jb.scale_b[jj])));
+        if (td_chan_not_finite(jb.scale_a[i]) || td_chan_not_finite(jb.scale_b[jj])) t = __builtin_nan("");
+      }
       if (sym && jj < i) continue;                     // written by the holder of (jj, i)
       double* dst = jb.g + ((long long)e * jb.ca_dst + i) * jb.ldg + jj;
       *dst = jb.accumulate ? *dst + t : t;

@@ -18,6 +18,7 @@ constexpr int kChanTab = (kChanShards + 1) * 128;     // unsigned per table
 
 struct td_handle {
   int device = 0;
+  int acc_mode = 0;   // td_set_accumulate_mode: how the lag kernel multiplies float32 numbers
   int cu_count = 0;   // CUs the handle's stream runs on (the device's, or a CU mask's: td_set_cu_count)
   // kernels that opted in to more than 64 KB of dynamic LDS on this handle's device
   bool lds_opt_lagcov = false, lds_opt_fir = false;
@@ -170,11 +171,12 @@ __device__ __forceinline__ unsigned td_pack_f16(float a, float b) {    // low ha
 }
 
 // (x0, x1), already scaled -> packed pairs of the two pieces.  Clamped to the finite float16
-// range first: a staged row that is never multiplied must still not become an infinity (0 x inf).
+// range first (one v_med3 each): a staged row that is never multiplied must still not become an
+// infinity (0 x inf).  A NaN does not survive the clamp; the channel's maximum remembers it and
+// the float64 reduction puts it back (fin_reduce, stats.hip).
 __device__ __forceinline__ void td_split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
-  // (a NaN fails the comparison and stays a NaN, as it would in float32 arithmetic)
-  x0 = __builtin_fabsf(x0) > 65504.f ? __builtin_copysignf(65504.f, x0) : x0;
-  x1 = __builtin_fabsf(x1) > 65504.f ? __builtin_copysignf(65504.f, x1) : x1;
+  x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+  x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
   h = td_pack_f16(x0, x1);
   const td_f16x2 hv = __builtin_bit_cast(td_f16x2, h);
   l = td_pack_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
@@ -192,6 +194,11 @@ __device__ __forceinline__ unsigned td_chan_max_of(const unsigned* tab, int ch) 
 #pragma unroll
   for (int sh = 0; sh < kChanShards; ++sh) m = max(m, tab[sh * 128 + ch]);
   return m;
+}
+
+// A channel that held an infinity or a NaN (its maximum's exponent field is all ones).
+__host__ __device__ __forceinline__ bool td_chan_not_finite(unsigned max_bits) {
+  return ((max_bits >> 23) & 0xff) == 0xff;
 }
 
 // Power-of-two scale of a channel from the largest magnitude seen (as float bits; 0 = nothing

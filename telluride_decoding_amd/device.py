@@ -60,6 +60,13 @@ class Handle(object):
     ev.record(self._stream)
     return ev
 
+  ACCUMULATE_MODES = {'f16x2': 0, 'bf16x3': 1, 'f32': 2}
+
+  def set_accumulate_mode(self, mode):
+    """'f16x2' (default: two float16 pieces, 3 products), 'bf16x3' (6 products, exact to 2^-27)
+    or 'f32' (the float32 matrix instruction): td_set_accumulate_mode."""
+    self.check(self.lib.td_set_accumulate_mode(self.ptr, self.ACCUMULATE_MODES[mode]))
+
   def timer_start(self):
     self.check(self.lib.td_timer_start(self.ptr))
 

@@ -47,7 +47,7 @@ class FitPipeline(object):
   other blocking stream and serialises the two stages (measured: 3.44 ms instead of 2.68).
   """
 
-  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=64, targets_on_solve=True,
+  def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=64, targets_on_solve=False,
                buffers=None, solves=None, solve_streams=2):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
@@ -129,12 +129,11 @@ class FitPipeline(object):
     h_solve = self.h_solves[index % len(self.s_solves)]
     with torch.cuda.stream(s_solve):
       s_solve.wait_event(self.ev_acc[buf])
-      # The y^T x part of the accumulate (LagStats.accumulate(parts=2)) also rides here: it is
-      # HBM-bound (the MFMA targets kernel), the solve stream has slack, and every microsecond
-      # taken off the accumulate stream is throughput.  With the earlier VALU-bound targets
-      # kernel the same move cost more on this stream's 32 CUs than it saved, and moving the
-      # float64 reduction of the accumulate kernel's partial slabs (268 MB) over as well
-      # overloads this stream.
+      # Optionally the y^T x part of the accumulate (LagStats.accumulate(parts=2)) rides here.
+      # That was the round-2 default (the accumulate stream bounded throughput and this one had
+      # slack).  With the float16 accumulate the solve streams are the slower stage, and the
+      # targets kernel on the accumulate stream also measures the channel maxima the float16
+      # kernel needs (split off, the accumulate spends a pass of its own on them): default off.
       if self.targets_on_solve:
         x, _, y, offs = args
         self.stats[buf].accumulate(x, None, y, offs, parts=2, handle=h_solve, **kw)

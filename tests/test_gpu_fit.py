@@ -565,6 +565,61 @@ def test_loso_scores_every_model_on_its_own_on_the_device(dev):
   np.testing.assert_array_equal(got['all_runs'], np.zeros((2, len(files))))
 
 
+def test_accumulate_modes_agree(dev):
+  """td_set_accumulate_mode: the float16 two-piece form (default), the bf16 three-piece form and
+  the float32 matrix instruction give the same moments -- each well inside what the reference's
+  own float32 np.matmul delivers (1e-6 on a 20k-sample sum); the bf16x3 form is the tightest."""
+  rng = np.random.default_rng(12)
+  h = dev.default_handle()
+  n, c = 20000, 64
+  x = (rng.standard_normal((n, c)) * np.logspace(-2, 3, c)).astype(np.float32)   # 5 decades of scale
+  x[:, 5] += 40.0                                                                # a large offset
+  y = (x[:, 3:4] * 0.7 + rng.standard_normal((n, 1))).astype(np.float32)
+  xl = o_lag.lag_matrix(x.astype(np.float64), 0, 15)
+  xl1 = np.hstack((xl, np.ones((n, 1))))
+  want, want_y = xl1.T @ xl1, xl1.T @ y.astype(np.float64)
+  scale = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+  errs = {}
+  try:
+    for mode in ('f16x2', 'bf16x3', 'f32'):
+      h.set_accumulate_mode(mode)
+      st = dev.LagStats(c, 0, 15, d=1)
+      st.accumulate(h.to_device(x), None, h.to_device(y), [0, n])
+      m = st.moments()
+      errs[mode] = float(np.max(np.abs(m['xtx'].cpu().numpy() - want) / scale))
+      ey = float(np.max(np.abs(m['xty'].cpu().numpy() - want_y) / np.sqrt(np.diag(want)[:, None] * (y.astype(np.float64) ** 2).sum())))
+      assert errs[mode] < 2e-7 and ey < 2e-7, (mode, errs[mode], ey)
+  finally:
+    h.set_accumulate_mode('f16x2')
+  assert errs['bf16x3'] <= errs['f16x2']
+  with pytest.raises(KeyError):
+    h.set_accumulate_mode('fp8')
+
+
+def test_nan_in_one_channel_poisons_that_channel_only(dev):
+  """A NaN (or an infinity) in the input must come out as float32 arithmetic would leave it:
+  NaN in every moment that involves the channel, finite numbers elsewhere.  The float16 form
+  clamps what it stages (a NaN does not survive v_med3); the channel's maximum remembers it and
+  the float64 reduction puts it back."""
+  rng = np.random.default_rng(13)
+  h = dev.default_handle()
+  n, c = 3000, 40
+  x = rng.standard_normal((n, c)).astype(np.float32)
+  y = rng.standard_normal((n, 1)).astype(np.float32)
+  x[1234, 7] = np.nan
+  x[77, 30] = np.inf
+  st = dev.LagStats(c, 0, 3, d=1)
+  st.accumulate(h.to_device(x), None, h.to_device(y), [0, n])
+  m = st.moments()
+  xtx, xty = m['xtx'].cpu().numpy(), m['xty'].cpu().numpy()
+  bad = np.zeros(c * 4 + 1, bool)
+  for lag in range(4):
+    bad[lag * c + 7] = bad[lag * c + 30] = True
+  assert np.all(~np.isfinite(xtx[bad][:, :])) and np.all(~np.isfinite(xtx[:, bad]))
+  assert np.all(np.isfinite(xtx[~bad][:, ~bad]))
+  assert np.all(~np.isfinite(xty[bad])) and np.all(np.isfinite(xty[~bad]))
+
+
 def test_tfrecord_ingress_to_trf_fit(dev):
   """F3 end to end on real data: a slice of the reference's MEG recording (148 channels: three
   channel tiles) read by the dependency-free TFRecord parser, z-scored, ridge TRF envelope <-
