@@ -1218,6 +1218,200 @@ __global__ __launch_bounds__(kThreads, 3) void project_mfma_kernel(
   }
 }
 
+// ---- CCA transform without context, both views in ONE pass ---------------------------------------
+//   out[t] = [ (x[t] - m1) R1 | (x2[t] - m2) R2 ]                         (cca.py:157-161)
+// is one product z W + b with z = [x | x2] (<= 64 + 32 columns), W = diag(R1, R2) (<= 16 output
+// columns) and b = -[m1 R1 | m2 R2].  project_mfma_kernel above ran it as two launches (+ two for
+// the bias) whose loads are operand-shaped (a lane reads half a row: 64 different cache lines per
+// wave instruction): 92 + 26 us at C3, 2.7 TB/s.  Here, as in gram_bf16x3_kernel:
+//   * a WAVE owns 32-row chunks; it loads them with whole-line float4s one chunk ahead, writes
+//     them row-major into a wave-private LDS tile (row stride 76 / 108 floats: the b128 operand
+//     reads of 16 rows hit 64 different banks) and reads back, per lane, 8 consecutive channels of
+//     ITS row -- the A operand of v_mfma_f32_16x16x32_bf16 after the exact three-way bf16 split
+//     (six products; W is split once per wave);
+//   * the 16 x 16 result goes back through the tile so that the rows leave as whole lines.
+// No workgroup barrier in the loop; the bias is formed once per workgroup.
+struct ProjFile {
+  long long xrow0, yrow0, out0;    // first row of the file in x / x2 (after the offset shift) / out
+  long long nx, ny;                // rows of each stream that exist
+  long long first;                 // first strip of the file
+};
+
+struct ProjParams {
+  const float* x; const float* x2;
+  long long ldx, ldx2, ldout;
+  int c1, c2, dims;
+  const float* mean1; const float* rot1; const float* mean2; const float* rot2;
+  const ProjFile* files;
+  int n_files;
+  long long n_strips;
+  int strip;                        // rows per workgroup (a multiple of 32)
+  float* out;
+};
+
+constexpr int kProjWaves = 4;
+typedef td_u32x4 pj_u32x4;
+typedef float pj_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int kLd>     // 76: c2 <= 8 (one K step of x2, a quarter of it live), 108: c2 <= 32
+__global__ __launch_bounds__(64 * kProjWaves, 3) void cca_project_kernel(ProjParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[kProjWaves * 32 * kLd];
+  __shared__ float bias[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d2 = 2 * p.dims;
+  // bias[q] = -(mean . rot[:, q]) of the view that owns output q
+  if (tid < 16) {
+    double s = 0.0;
+    if (tid < p.dims) for (int f = 0; f < p.c1; ++f) s += (double)p.mean1[f] * (double)p.rot1[f * p.dims + tid];
+    else if (tid < d2) for (int f = 0; f < p.c2; ++f) s += (double)p.mean2[f] * (double)p.rot2[f * p.dims + tid - p.dims];
+    bias[tid] = (float)(-s);
+  }
+  // strip -> file
+  const long long sid = blockIdx.x;
+  int lo = 0, hi = p.n_files - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.files[mid].first <= sid) lo = mid; else hi = mid - 1;
+  }
+  const ProjFile fd = p.files[lo];
+  const long long t0 = (sid - fd.first) * p.strip;
+  const long long nmax = fd.nx > fd.ny ? fd.nx : fd.ny;
+  const int rows = (int)(nmax - t0 < p.strip ? nmax - t0 : p.strip);
+  const int n_chunks = (rows + 31) / 32;
+  float* tile = lds + wave * 32 * kLd;
+  // W = diag(R1, R2) as the B operand: lane (n = lane & 15 output, kq = lane >> 4) holds the
+  // channels 32 s + 8 kq + kk of K step s, split once
+  constexpr int kSteps = 3;                            // channels [0, 32), [32, 64) of x, then x2
+  const int li = lane & 15, kq = lane >> 4;
+  pj_u32x4 wh[kSteps], wm[kSteps], wl[kSteps];
+#pragma unroll
+  for (int s2 = 0; s2 < kSteps; ++s2) {
+    float v[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int ch = 32 * s2 + 8 * kq + kk;
+      float wv = 0.f;
+      if (ch < 64) { if (ch < p.c1 && li < p.dims) wv = p.rot1[ch * p.dims + li]; }
+      else if (ch - 64 < p.c2 && li >= p.dims && li < d2) wv = p.rot2[(ch - 64) * p.dims + li - p.dims];
+      v[kk] = wv;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      unsigned a, b, c;
+      td_split3(v[2 * d], v[2 * d + 1], a, b, c);
+      wh[s2][d] = a; wm[s2][d] = b; wl[s2][d] = c;
+    }
+  }
+  __syncthreads();                                     // bias
+  const float bq = bias[li];
+
+  const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+  const int n2 = (p.c2 + 3) >> 2;                      // float4s per row of x2
+  constexpr int kN2 = kLd == 76 ? 1 : 4;               // x2 float4s per lane and chunk
+  const bool x_ok = c4 < p.c1;
+  float4 pfx[8], pfy[kN2];
+  auto prefetch = [&](int ch) {
+    const long long ut = t0 + 32LL * ch;
+    const float* xb = p.x + (fd.xrow0 + ut) * p.ldx + (x_ok ? c4 : 0);
+    const long long last_x = fd.nx - 1 - ut;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + 4 * i;
+      const long long rc = r <= last_x ? r : (last_x < 0 ? -ut : last_x);
+      pfx[i] = *reinterpret_cast<const float4*>(xb + rc * p.ldx);
+    }
+    const float* yb = p.x2 + (fd.yrow0 + ut) * p.ldx2;
+    const long long last_y = fd.ny - 1 - ut;
+#pragma unroll
+    for (int q = 0; q < kN2; ++q) {
+      const int t = lane + 64 * q;
+      int r = t / n2;
+      const int f = t - r * n2;
+      r = r < 32 ? r : 31;
+      const long long rc = r <= last_y ? r : (last_y < 0 ? -ut : last_y);
+      pfy[q] = *reinterpret_cast<const float4*>(yb + rc * p.ldx2 + 4 * f);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float4 v = pfx[i];
+      if (!x_ok) v = float4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<float4*>(tile + (r0 + 4 * i) * kLd + c4) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < kN2; ++q) {
+      const int t = lane + 64 * q;
+      const int r = t / n2, f = t - r * n2;
+      if (r < 32) {
+        float4 v = pfy[q];
+        v.x = 4 * f + 0 < p.c2 ? v.x : 0.f; v.y = 4 * f + 1 < p.c2 ? v.y : 0.f;
+        v.z = 4 * f + 2 < p.c2 ? v.z : 0.f; v.w = 4 * f + 3 < p.c2 ? v.w : 0.f;
+        *reinterpret_cast<float4*>(tile + r * kLd + 64 + 4 * f) = v;
+      }
+    }
+  };
+  // (rows that do not exist are loaded from a clamped address and never stored to `out`: a row's
+  // outputs depend on that row alone)
+  if (wave < n_chunks) prefetch(wave);
+  for (int ch = wave; ch < n_chunks; ch += kProjWaves) {
+    store();
+    if (ch + kProjWaves < n_chunks) prefetch(ch + kProjWaves);
+    __builtin_amdgcn_wave_barrier();
+    pj_f32x4 acc[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      pj_f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      const float* row = tile + (16 * half + li) * kLd + 8 * kq;
+#pragma unroll
+      for (int s2 = 0; s2 < kSteps; ++s2) {
+        float v[8];
+        if (s2 < 2 || (64 + 8 * kq) < 64 + ((p.c2 + 7) & ~7)) {
+          const float4 v0 = *reinterpret_cast<const float4*>(row + 32 * s2);
+          const float4 v1 = *reinterpret_cast<const float4*>(row + 32 * s2 + 4);
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+          if (s2 == 2) {                                // columns beyond c2 were never staged
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) v[kk] = 8 * kq + kk < p.c2 ? v[kk] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) v[kk] = 0.f;
+        }
+        pj_u32x4 zh, zm, zl;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          unsigned a, b, cc;
+          td_split3(v[2 * d], v[2 * d + 1], a, b, cc);
+          zh[d] = a; zm[d] = b; zl[d] = cc;
+        }
+#define TD_PMFMA(A, B) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(td_bf16x8, A), __builtin_bit_cast(td_bf16x8, B), c, 0, 0, 0)
+        TD_PMFMA(zl, wh[s2]); TD_PMFMA(zh, wl[s2]); TD_PMFMA(zm, wm[s2]);
+        TD_PMFMA(zm, wh[s2]); TD_PMFMA(zh, wm[s2]); TD_PMFMA(zh, wh[s2]);
+#undef TD_PMFMA
+      }
+      acc[half] = c;
+    }
+    // C/D map: col = lane & 15 (output), row = 4 (lane >> 4) + r: back through the tile, [32][16]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(16 * half + 4 * kq + r) * 16 + li] = acc[half][r] + bq;
+    __builtin_amdgcn_wave_barrier();
+    const long long ut = t0 + 32LL * ch;
+    float* op = p.out + (fd.out0 + ut) * p.ldout;
+    for (int idx = lane; idx < 32 * d2; idx += 64) {
+      const int r = idx / d2, q = idx - r * d2;
+      const long long t = ut + r;
+      const bool ok = q < p.dims ? t < fd.nx : t < fd.ny;
+      if (ok) op[r * p.ldout + q] = tile[r * 16 + q];
+    }
+    __builtin_amdgcn_wave_barrier();                   // the tile is free for the next chunk
+  }
+}
+
 // The per-file descriptor table goes through the handle's content-cached table slots
 // (td_table_upload): no td_scratch use, and no upload at all when the layout repeats.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
@@ -1425,6 +1619,47 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
   TD_REQUIRE(h, dims > 0 && dims <= kFirMaxD, "td_cca_transform: dims must be in [1, %d]", kFirMaxD);
   TD_REQUIRE(h, ldout >= 2 * dims, "td_cca_transform: ldout too small");
   const int k1 = c1 * (pre1 + 1 + post1), k2 = c2 * (pre2 + 1 + post2);
+  // no context on either view, aligned rows, at most 16 outputs: one fused pass (cca_project_kernel)
+  static const bool old_proj = getenv("TD_PROJECT_F32") != nullptr;        // development: A/B runs
+  const bool aligned = (ldx % 4 == 0) && (c1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0) &&
+                       (ldx2 % 4 == 0) && (c2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x2_dev) & 15) == 0);
+  if (k1 == c1 && k2 == c2 && c1 <= 64 && c2 <= 32 && 2 * dims <= 16 && aligned && !old_proj &&
+      h->acc_mode != TD_ACC_F32) {
+    const int64_t dx = input_offset > 0 ? input_offset : 0, dy = input_offset < 0 ? -input_offset : 0;
+    int64_t total = 0;
+    for (int f = 0; f < num_files; ++f) total += file_offsets_host[f + 1] - file_offsets_host[f];
+    if (total == 0) return TD_OK;
+    const int cus = h->cu_count > 0 ? h->cu_count : 256;
+    int64_t strip = td_round_up(td_ceil_div(total, 3 * cus), 32 * kProjWaves);    // three workgroups per CU
+    if (strip < 32 * kProjWaves) strip = 32 * kProjWaves;
+    std::vector<ProjFile> files(num_files);
+    long long n_strips = 0;
+    for (int f = 0; f < num_files; ++f) {
+      const int64_t n = file_offsets_host[f + 1] - file_offsets_host[f];
+      ProjFile& pf = files[f];
+      pf.xrow0 = file_offsets_host[f] + dx; pf.yrow0 = file_offsets_host[f] + dy;
+      pf.out0 = file_offsets_host[f];
+      pf.nx = n - dx > 0 ? n - dx : 0; pf.ny = n - dy > 0 ? n - dy : 0;
+      pf.first = n_strips;
+      const int64_t nmax = pf.nx > pf.ny ? pf.nx : pf.ny;
+      n_strips += td_ceil_div(nmax, strip);
+    }
+    if (n_strips == 0) return TD_OK;
+    const void* table_dev = nullptr;
+    TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(ProjFile), &table_dev));
+    ProjParams pp;
+    pp.x = x_dev; pp.x2 = x2_dev; pp.ldx = ldx; pp.ldx2 = ldx2; pp.ldout = ldout;
+    pp.c1 = c1; pp.c2 = c2; pp.dims = dims;
+    pp.mean1 = mean1_dev; pp.rot1 = rot1_dev; pp.mean2 = mean2_dev; pp.rot2 = rot2_dev;
+    pp.files = reinterpret_cast<const ProjFile*>(table_dev);
+    pp.n_files = num_files; pp.n_strips = n_strips; pp.strip = (int)strip; pp.out = out_dev;
+    if (c2 <= 8)
+      hipLaunchKernelGGL((cca_project_kernel<76>), dim3((unsigned)n_strips), dim3(64 * kProjWaves), 0, h->stream, pp);
+    else
+      hipLaunchKernelGGL((cca_project_kernel<108>), dim3((unsigned)n_strips), dim3(64 * kProjWaves), 0, h->stream, pp);
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
   // the centring folded into a bias: stream-ordered scratch in the solver workspace arena
   // (launch_fir uses td_scratch for its tables)
   void* ws = nullptr;

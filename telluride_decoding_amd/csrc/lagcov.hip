@@ -1377,6 +1377,178 @@ __global__ __launch_bounds__(kGramThreads, 4) void gram_mfma_kernel(GramParams p
   }
 }
 
+// ---- the same Gram matrix on the bf16 matrix pipe ------------------------------------------------
+// gram_mfma_kernel above is co-limited: its float32 MFMAs alone are 49 us of matrix-pipe time at
+// C3 (15 blocks x 1e6 / 4 rows x 32 cycles over 1024 SIMDs), its loads 46 us, and the two only
+// partly overlap (82 us).  With the exact three-way bf16 split (td_split3: six products, each exact
+// in the float32 accumulator) the same block is v_mfma_f32_16x16x32_bf16 -- K = 32 rows per
+// instruction at half the cycles -- 18 us of matrix time, and the kernel is left with its loads.
+//
+// No workgroup barriers: a WAVE owns 32-row chunks (chunk w, w + 4, ... of its workgroup's slab).
+// It loads a chunk with whole-line float4s one chunk ahead (8 x 1 KB of x, the rows of x2), writes
+// it row-major into a wave-private LDS tile (row stride 80 / 112 floats), and every lane reads
+// back the 8 rows {4 kk + kq} of ITS column of each 16-column group -- the K order inside an MFMA
+// is free, and with that interleave and those strides the 64 lanes of a read hit 64 banks -- splits
+// them in registers and multiplies.  A chain is the wave's share of a slab (~10 chunks).
+template <int kG> struct Gram2 {
+  static constexpr int kLd = kG == 5 ? 80 : 112;       // floats; kLd mod 64 = 16 or 48
+  static constexpr int kN2 = kG == 5 ? 2 : 4;          // float4 of x2 per lane and chunk (32 rows x (kG - 4) x 4)
+  static constexpr int kTileFloats = 32 * kLd;
+  static constexpr int kPairs = kG * (kG + 1) / 2;
+};
+constexpr int kGram2Waves = 4;
+
+template <int kG>
+__global__ __launch_bounds__(64 * kGram2Waves, 2) void gram_bf16x3_kernel(GramParams p) {
+  using G = Gram2<kG>;
+  constexpr int kLd = G::kLd, kPairs = G::kPairs;
+  // four wave tiles (40 / 56 KB: three / two workgroups per CU), reused at the end by the
+  // cross-wave sum (two blocks of pairs x 256 floats)
+  static_assert(kGram2Waves * G::kTileFloats >= 2 * kPairs * 256, "the cross-wave sum reuses the tiles");
+  __shared__ __attribute__((aligned(16))) float lds[kGram2Waves * G::kTileFloats];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const LagWork w = p.works[blockIdx.x];
+  float* tile = lds + wave * G::kTileFloats;
+  const int n_chunks = (int)((w.u_end - w.u_begin + 31) / 32);
+
+  // load map: x float4 (row = (lane >> 4) + 4 i, columns 4 (lane & 15)); x2 item t = lane + 64 q:
+  // row t / n2, float4 t % n2 of the row, n2 = float4s per row of x2
+  const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+  const int n2 = (p.c2 + 3) >> 2;
+  const bool x_ok = c4 < p.c1;
+  float4 pfx[8], pfy[G::kN2];
+  auto prefetch = [&](int ch) {
+    const long long ut = w.u_begin + 32LL * ch;
+    const float* xb = p.x + (w.a_row0 + ut) * p.ldx + (x_ok ? c4 : 0);
+    const long long last_x = w.a_valid - 1 - ut;       // tile-relative last row that exists
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + 4 * i;
+      const long long rc = r <= last_x ? r : (last_x < 0 ? -ut : last_x);      // clamped: always addressable
+      pfx[i] = *reinterpret_cast<const float4*>(xb + rc * p.ldx);
+    }
+    const float* yb = p.x2 + (w.b_row0 + ut) * p.ldx2;
+    const long long last_y = w.b_valid - 1 - ut;
+#pragma unroll
+    for (int q = 0; q < G::kN2; ++q) {
+      const int t = lane + 64 * q;
+      const int r = t / n2, f = t - r * n2;
+      const int rr = r < 32 ? r : 31;
+      const long long rc = rr <= last_y ? rr : (last_y < 0 ? -ut : last_y);
+      pfy[q] = *reinterpret_cast<const float4*>(yb + rc * p.ldx2 + 4 * f);
+    }
+  };
+  // rows of the chunk that count: inside [u_begin, u_end) and inside the streams
+  auto store = [&](int ch) {
+    const long long ut = w.u_begin + 32LL * ch;
+    const long long lim_s = w.u_end - ut;
+    const long long lim_x = w.a_valid - ut, lim_y = w.b_valid - ut;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + 4 * i;
+      const bool k = x_ok && r < lim_s && r < lim_x;
+      float4 v = pfx[i];
+      v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+      *reinterpret_cast<float4*>(tile + r * kLd + c4) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < G::kN2; ++q) {
+      const int t = lane + 64 * q;
+      const int r = t / n2, f = t - r * n2;
+      if (r < 32) {
+        const bool k = r < lim_s && r < lim_y;
+        float4 v = pfy[q];
+        v.x = (k && 4 * f + 0 < p.c2) ? v.x : 0.f; v.y = (k && 4 * f + 1 < p.c2) ? v.y : 0.f;
+        v.z = (k && 4 * f + 2 < p.c2) ? v.z : 0.f; v.w = (k && 4 * f + 3 < p.c2) ? v.w : 0.f;
+        *reinterpret_cast<float4*>(tile + r * kLd + 64 + 4 * f) = v;
+      }
+    }
+  };
+
+  f32x4 acc[kPairs];
+#pragma unroll
+  for (int q = 0; q < kPairs; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kq = lane >> 4;
+  const int ones_col = 16 * (kG - 4) - 1;              // column of [x2 | 1] that holds the ones
+  if (wave < n_chunks) prefetch(wave);
+  for (int ch = wave; ch < n_chunks; ch += kGram2Waves) {
+    store(ch);
+    if (ch + kGram2Waves < n_chunks) prefetch(ch + kGram2Waves);
+    __builtin_amdgcn_wave_barrier();
+    // operands: lane (column li of group g, k quarter kq) holds rows 4 kk + kq, kk = 0..7
+    u32x4 zh[kG], zm[kG], zl[kG];
+    const long long lim_s = w.u_end - (w.u_begin + 32LL * ch);
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      float v[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) v[kk] = tile[(4 * kk + kq) * kLd + 16 * g + li];
+      if (g >= 4) {
+        // [x2 | 1]: columns beyond c2 are not staged; the last one is the ones column
+        const int col = 16 * (g - 4) + li;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+          v[kk] = col < p.c2 ? v[kk] : (col == ones_col && 4 * kk + kq < lim_s) ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        unsigned hh, mm, ll;
+        td_split3(v[2 * d], v[2 * d + 1], hh, mm, ll);
+        zh[g][d] = hh; zm[g][d] = mm; zl[g][d] = ll;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                   // the tile may be overwritten from here on
+    int q = 0;
+#pragma unroll
+    for (int gi = 0; gi < kG; ++gi)
+#pragma unroll
+      for (int gj = gi; gj < kG; ++gj, ++q) {
+        f32x4 c = acc[q];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(td_bf16x8, zl[gi]), __builtin_bit_cast(td_bf16x8, zh[gj]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(td_bf16x8, zh[gi]), __builtin_bit_cast(td_bf16x8, zl[gj]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(td_bf16x8, zm[gi]), __builtin_bit_cast(td_bf16x8, zm[gj]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(td_bf16x8, zm[gi]), __builtin_bit_cast(td_bf16x8, zh[gj]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(td_bf16x8, zh[gi]), __builtin_bit_cast(td_bf16x8, zm[gj]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(td_bf16x8, zh[gi]), __builtin_bit_cast(td_bf16x8, zh[gj]), c, 0, 0, 0);
+        acc[q] = c;
+      }
+  }
+  // cross-wave sum (fixed order): waves 2, 3 -> 0, 1; wave 1 -> 0.  C/D map of the 16x16 MFMA:
+  // col = lane & 15, row = 4 (lane >> 4) + r.
+  __syncthreads();
+  float* slot = lds + (wave & 1) * kPairs * 256 + (4 * kq) * 16 + li;
+  if (wave >= 2) {
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slot[q * 256 + r * 16] = acc[q][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] += slot[q * 256 + r * 16];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slot[q * 256 + r * 16] = acc[q][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float* other = slot + kPairs * 256;
+    float* slab = p.partial + (size_t)blockIdx.x * kPairs * 256 + (4 * kq) * 16 + li;
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[q * 256 + r * 16] = acc[q][r] + other[q * 256 + r * 16];
+  }
+}
+
 // Sums the partial blocks in float64 (fixed order) and adds them into the statistics.  Block t
 // is the t-th pair (gi <= gj) of 16-column groups of z in row-major order; element (i, j) of
 // the Gram matrix goes to both triangles of its destination.
@@ -1386,8 +1558,10 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(const float* __restri
                                                            double* __restrict__ fyy,
                                                            double* __restrict__ gxy,
                                                            double* __restrict__ sx,
-                                                           double* __restrict__ sx2) {
+                                                           double* __restrict__ sx2, int accumulate,
+                                                           double* __restrict__ n_dst, double n_value) {
   __shared__ double part[16][64];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_dst) *n_dst = n_value;     // the frame count
   const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int o = blockIdx.x * 64 + ol;               // 0 .. pairs * 256 - 1
   const size_t stride = (size_t)n_groups * (n_groups + 1) / 2 * 256;
@@ -1410,23 +1584,26 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(const float* __restri
   const int i = gi * 16 + ((o >> 4) & 15), j = gj * 16 + (o & 15);   // columns of z
   const int ones = 16 * n_groups - 1;
   if (i > j) return;                                 // diagonal blocks hold both triangles
+  // accumulate = 0: the statistics are fresh (td_stats_reset pending): every number this kernel
+  // owns is overwritten, so the reset needs no memset
+  auto put = [&](double* dst) { *dst = accumulate ? *dst + v : v; };
   if (j < 64) {                                      // x^T x
     if (j < c1) {
-      fxx[(size_t)i * c1 + j] += v;
-      if (i != j) fxx[(size_t)j * c1 + i] += v;
+      put(fxx + (size_t)i * c1 + j);
+      if (i != j) put(fxx + (size_t)j * c1 + i);
     }
   } else if (i < 64) {                               // x^T [x2 | 1]
     if (i < c1) {
-      if (j - 64 < c2) gxy[(size_t)i * c2 + (j - 64)] += v;
-      else if (j == ones) sx[i] += v;
+      if (j - 64 < c2) put(gxy + (size_t)i * c2 + (j - 64));
+      else if (j == ones) put(sx + i);
     }
   } else {                                           // [x2 | 1]^T [x2 | 1]
     const int a = i - 64, b = j - 64;
     if (b < c2) {
-      fyy[(size_t)a * c2 + b] += v;
-      if (a != b) fyy[(size_t)b * c2 + a] += v;
+      put(fyy + (size_t)a * c2 + b);
+      if (a != b) put(fyy + (size_t)b * c2 + a);
     } else if (j == ones && a < c2) {
-      sx2[a] += v;
+      put(sx2 + a);
     }
   }
 }
@@ -2472,25 +2649,37 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
 // done) when the shape does not fit the 64 + 31 + 1 column layout.
 int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, int64_t ldx2, int c2,
             const std::vector<LagSeg>& segs, double* fxx, double* fyy, double* gxy, double* sx,
-            double* sx2, bool* handled) {
+            double* sx2, bool* handled, bool accumulate, double* n_dst, double n_value,
+            GramReduceJob* defer) {
   *handled = false;
   if (c1 > 64 || c2 > 31 || c1 <= 0 || c2 <= 0) return TD_OK;
   *handled = true;
   long long total = 0;
   for (const LagSeg& sg : segs) total += (sg.u_end > sg.u_begin) ? sg.u_end - sg.u_begin : 0;
-  if (total == 0) return TD_OK;
-  // slabs of whole 64-row tiles, at most 2048 rows (f32 chains of 512 row quads per wave),
-  // whole rounds of 512 resident workgroups
-  const int slots = 512;   // two 512-thread workgroups per CU
-  long long slab = td_round_up(td_ceil_div(total, slots * td_ceil_div(total, (long long)slots * 2048)),
-                               kGramTile);
+  if (total == 0) {
+    TD_REQUIRE(h, accumulate, "td_gram: nothing to write into fresh statistics");
+    return TD_OK;
+  }
+  const int n_groups = c2 <= 15 ? 5 : 6;
+  const bool vec4 = (ldx % 4 == 0) && (c1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                    (ldx2 % 4 == 0) && (c2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x2) & 15) == 0);
+  // the bf16x3 kernel (aligned rows): slabs of whole 32-row chunks, two 4-wave workgroups per CU
+  // (211 registers), a wave's MFMA chain <= 16 chunks
+  static const bool old_gram = getenv("TD_GRAM_F32") != nullptr;          // development: A/B runs
+  const bool bf = vec4 && !old_gram && h->acc_mode != TD_ACC_F32;
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  // float32 kernel: slabs of whole 64-row tiles, at most 2048 rows (f32 chains of 512 row quads
+  // per wave), whole rounds of 512 resident workgroups
+  const int slots = 2 * cus;
+  const long long max_slab = bf ? 64 * 32 : 2048;
+  long long slab = td_round_up(td_ceil_div(total, slots * td_ceil_div(total, (long long)slots * max_slab)),
+                               bf ? 32 : kGramTile);
   std::vector<LagWork> works = split_work(segs, slab);
   GramParams p;
   p.x = x; p.x2 = x2; p.ldx = ldx; p.ldx2 = ldx2; p.c1 = c1; p.c2 = c2;
   p.n_work = (int)works.size();
   const size_t table_bytes = td_round_up(works.size() * sizeof(LagWork), 256);
   void* scratch = nullptr;
-  const int n_groups = c2 <= 15 ? 5 : 6;
   const size_t pair_floats = (size_t)n_groups * (n_groups + 1) / 2 * 256;
   TD_TRY(td_scratch(h, table_bytes + works.size() * pair_floats * sizeof(float), &scratch));
   // the work list by content (td_table_upload): refits of the same recordings skip the upload
@@ -2499,18 +2688,29 @@ int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, 
   TD_TRY(td_table_upload(h, works.data(), works.size() * sizeof(LagWork), &works_dev));
   p.works = reinterpret_cast<const LagWork*>(works_dev);
   p.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + table_bytes);
-  const bool vec4 = (ldx % 4 == 0) && (c1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                    (ldx2 % 4 == 0) && (c2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x2) & 15) == 0);
   const dim3 grid((unsigned)works.size()), block(kGramThreads);
 #define TD_GRAM(V, G) hipLaunchKernelGGL((gram_mfma_kernel<V, G>), grid, block, 0, h->stream, p)
-  if (vec4) {
+  if (bf) {
+    if (n_groups == 5)
+      hipLaunchKernelGGL((gram_bf16x3_kernel<5>), grid, dim3(64 * kGram2Waves), 0, h->stream, p);
+    else
+      hipLaunchKernelGGL((gram_bf16x3_kernel<6>), grid, dim3(64 * kGram2Waves), 0, h->stream, p);
+  } else if (vec4) {
     if (n_groups == 5) TD_GRAM(true, 5); else TD_GRAM(true, 6);
   } else {
     if (n_groups == 5) TD_GRAM(false, 5); else TD_GRAM(false, 6);
   }
 #undef TD_GRAM
+  if (defer) {
+    defer->partial = p.partial; defer->n_slabs = (int)works.size(); defer->n_groups = n_groups;
+    defer->c1 = c1; defer->c2 = c2; defer->accumulate = accumulate ? 1 : 0;
+    defer->fxx = fxx; defer->fyy = fyy; defer->gxy = gxy; defer->sx = sx; defer->sx2 = sx2;
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)(pair_floats / 64)), dim3(1024), 0, h->stream,
-                     p.partial, (int)works.size(), n_groups, c1, c2, fxx, fyy, gxy, sx, sx2);
+                     p.partial, (int)works.size(), n_groups, c1, c2, fxx, fyy, gxy, sx, sx2,
+                     accumulate ? 1 : 0, n_dst, n_value);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

@@ -151,6 +151,15 @@ struct FinalizeParams {
   float* win;                         // null = none
   int hw;
   long long first_slot;
+  // ... and of the second view (CCA): its own stream, rows and channel count
+  float* win2;
+  const float* x2;
+  long long ldx2;
+  const WinJob* jobs2;
+  int c2;
+  // the Gram reduction of the one-pass CCA accumulate (64 outputs x 16 slab phases per workgroup)
+  GramReduceJob gram;
+  int b_win2, b_gram, n_blocks;
   // frame count
   double* n_dst;
   double n_value;
@@ -288,6 +297,53 @@ __device__ __forceinline__ double fin_edge(const FinalizeParams& p, const WinJob
   return (own && u >= 0 && u < jw.valid) ? (double)p.x[(jw.row0 + u) * p.ldx + col] : 0.0;
 }
 
+// gram_reduce_kernel (lagcov.hip) as a finalize job: block t of the partial slabs is the t-th pair
+// (gi <= gj) of 16-column groups of z = [x | x2 | 1]; element (i, j) goes to both triangles.
+__device__ __forceinline__ void fin_gram(const GramReduceJob& jb, int block, double* part) {
+  const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int o = block * 64 + ol;
+  const size_t stride = (size_t)jb.n_groups * (jb.n_groups + 1) / 2 * 256;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  int wk = q;
+  for (; wk + 48 < jb.n_slabs; wk += 64) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += (double)jb.partial[(size_t)(wk + 16 * k) * stride + o];
+  }
+  for (; wk < jb.n_slabs; wk += 16) a[0] += (double)jb.partial[(size_t)wk * stride + o];
+  part[q * 64 + ol] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+  if (q != 0) return;
+  double v = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v += part[k * 64 + ol];
+  int t = o >> 8, gi = 0;
+  while (t >= jb.n_groups - gi) { t -= jb.n_groups - gi; ++gi; }
+  const int gj = gi + t;
+  const int i = gi * 16 + ((o >> 4) & 15), j = gj * 16 + (o & 15);   // columns of z
+  const int ones = 16 * jb.n_groups - 1;
+  if (i > j) return;                                 // diagonal blocks hold both triangles
+  auto put = [&](double* dst) { *dst = jb.accumulate ? *dst + v : v; };
+  if (j < 64) {                                      // x^T x
+    if (j < jb.c1) {
+      put(jb.fxx + (size_t)i * jb.c1 + j);
+      if (i != j) put(jb.fxx + (size_t)j * jb.c1 + i);
+    }
+  } else if (i < 64) {                               // x^T [x2 | 1]
+    if (i < jb.c1) {
+      if (j - 64 < jb.c2) put(jb.gxy + (size_t)i * jb.c2 + (j - 64));
+      else if (j == ones) put(jb.sx + i);
+    }
+  } else {                                           // [x2 | 1]^T [x2 | 1]
+    const int aa = i - 64, bb = j - 64;
+    if (bb < jb.c2) {
+      put(jb.fyy + (size_t)aa * jb.c2 + bb);
+      if (aa != bb) put(jb.fyy + (size_t)bb * jb.c2 + aa);
+    } else if (j == ones && aa < jb.c2) {
+      put(jb.sx2 + aa);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kFinThreads) void stats_finalize_kernel(FinalizeParams p) {
   __shared__ double part[4 * kFinThreads];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -353,16 +409,26 @@ __global__ __launch_bounds__(kFinThreads) void stats_finalize_kernel(FinalizePar
     }
     return;
   }
-  if (p.win) {                                          // ---- boundary windows of one file end
-    const int f = (b - p.b_win) >> 1, which = (b - p.b_win) & 1;
-    const WinJob jw = p.jobs[f];
-    float* dst = p.win + ((p.first_slot + f) * 2 + which) * (long long)(2 * p.hw) * p.c;
+  if (b >= p.b_gram && p.n_blocks) {                    // ---- one-pass CCA: the Gram reduction
+    fin_gram(p.gram, b - p.b_gram, part);
+    return;
+  }
+  const bool second = p.win2 && b >= p.b_win2;          // ---- boundary windows of one file end
+  float* win = second ? p.win2 : p.win;
+  if (win) {
+    const int rel = b - (second ? p.b_win2 : p.b_win);
+    const int f = rel >> 1, which = rel & 1;
+    const WinJob jw = second ? p.jobs2[f] : p.jobs[f];
+    const float* src = second ? p.x2 : p.x;
+    const long long ld = second ? p.ldx2 : p.ldx;
+    const int c = second ? p.c2 : p.c;
+    float* dst = win + ((p.first_slot + f) * 2 + which) * (long long)(2 * p.hw) * c;
     const long long base = which == 0 ? -p.hw : jw.nprime - p.hw;
     const bool own = which == 0 ? jw.head != 0 : jw.tail != 0;
-    for (int idx = tid; idx < 2 * p.hw * p.c; idx += kFinThreads) {
-      const int r = idx / p.c, col = idx % p.c;
+    for (int idx = tid; idx < 2 * p.hw * c; idx += kFinThreads) {
+      const int r = idx / c, col = idx % c;
       const long long u = base + r;
-      dst[idx] = (own && u >= 0 && u < jw.valid) ? p.x[(jw.row0 + u) * p.ldx + col] : 0.f;
+      dst[idx] = (own && u >= 0 && u < jw.valid) ? src[(jw.row0 + u) * ld + col] : 0.f;
     }
   }
 }
@@ -589,6 +655,12 @@ inline bool stats_fusable(const td_stats* s) {
   return s->c2 == 0 && s->d >= 1 && s->d <= 4 && s->c1 <= 64 && s->l1 <= 32;
 }
 
+// CCA without context on either input and without targets: every moment is one Gram matrix of
+// [x | x2 | 1] (td_gram), whose reduction can overwrite fresh statistics as well.
+inline bool stats_one_pass(const td_stats* s) {
+  return s->c2 > 0 && s->d == 0 && s->l1 == 1 && s->l2 == 1 && s->c1 <= 64 && s->c2 <= 31;
+}
+
 // Writes a pending reset (see td_stats::fresh_*): the part of `g` nobody has overwritten yet is
 // zeroed on the handle's stream.  main = [0, off_gxo) + [off_n, g_len), targets = [off_gxo, off_n).
 int stats_materialize(td_handle* h, td_stats* s) {
@@ -697,7 +769,7 @@ int td_stats_destroy(td_handle* h, td_stats* s) {
 
 int td_stats_reset(td_handle* h, td_stats* s) {
   if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_reset: NULL argument");
-  if (stats_fusable(s)) {
+  if (stats_fusable(s) || stats_one_pass(s)) {
     // nothing is queued: the next accumulate call overwrites (td_stats::fresh_*)
     s->fresh_main = s->fresh_tgt = true;
   } else {
@@ -969,13 +1041,52 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
   TD_REQUIRE(h, first_slot >= 0, "td_stats_accumulate_parts: TARGETS before MAIN");
   // CCA without context on either input: every moment is one Gram matrix of [x | x2 | 1]
   // (td_gram), done by MAIN; TARGETS then has nothing left to add.
-  const bool one_pass = s->c2 > 0 && s->d == 0 && s->l1 == 1 && s->l2 == 1 && s->c1 <= 64 && s->c2 <= 31;
+  const bool one_pass = stats_one_pass(s);
 
   static const bool no_fuse = getenv("TD_ACC_UNFUSED") != nullptr;     // development: A/B runs
   if (stats_fusable(s) && new_frames > 0 && !no_fuse)
     return accumulate_fused(h, s, x_dev, ldx, y_dev, ldy, sxx, syx, j1, num_files, new_frames,
                             first_slot, do_main, do_targets);
-  TD_TRY(stats_materialize(h, s));
+  // (the one-pass Gram reduction overwrites fresh statistics itself)
+  const bool gram_fresh = one_pass && do_main && s->fresh_main && s->fresh_tgt && new_frames > 0;
+  if (!gram_fresh) TD_TRY(stats_materialize(h, s));
+
+  if (one_pass && do_main && new_frames > 0) {
+    // CCA without context: the Gram kernel + ONE finalize launch (its float64 reduction, the
+    // boundary windows of both views, the frame count) -- 2 launches for what was reset +
+    // 2 window gathers + Gram + reduction + an upload of the count.
+    TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
+    FinalizeParams fp;
+    memset(&fp, 0, sizeof(fp));
+    bool handled = false;
+    TD_TRY(td_gram(h, x_dev, ldx, s->c1, x2_dev, ldx2, s->c2, sxy, s->g + s->off_fxx,
+                   s->g + s->off_fyy, s->g + s->off_gxy, s->g + s->off_gxo, s->g + s->off_gyo,
+                   &handled, !gram_fresh, nullptr, 0.0, &fp.gram));
+    TD_REQUIRE(h, handled, "td_gram refused a shape the one-pass test accepted");
+    const size_t bytes = sizeof(WinJob) * num_files;
+    const void* d1 = nullptr;
+    const void* d2 = nullptr;
+    TD_TRY(td_table_upload(h, j1.data(), bytes, &d1));
+    TD_TRY(td_table_upload(h, j2.data(), bytes, &d2));
+    fp.jobs = reinterpret_cast<const WinJob*>(d1); fp.jobs2 = reinterpret_cast<const WinJob*>(d2);
+    fp.x = x_dev; fp.ldx = ldx; fp.c = s->c1; fp.x2 = x2_dev; fp.ldx2 = ldx2; fp.c2 = s->c2;
+    fp.n_files = num_files; fp.hw = s->hw; fp.first_slot = first_slot;
+    fp.win = s->win1; fp.win2 = s->win2;
+    // block ranges: [windows of x | windows of x2 | Gram reduction]; no reductions / bias jobs
+    fp.b_ysum = fp.b_ones = fp.b_win = 0;
+    fp.b_win2 = 2 * num_files;
+    fp.b_gram = 4 * num_files;
+    const int pairs = fp.gram.n_groups * (fp.gram.n_groups + 1) / 2;
+    fp.n_blocks = fp.b_gram + pairs * 256 / 64;
+    s->n_files += num_files;
+    s->frames += new_frames;
+    fp.n_dst = s->g + s->off_n;
+    fp.n_value = (double)s->frames;
+    s->fresh_main = s->fresh_tgt = false;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)fp.n_blocks), dim3(kFinThreads), 0, h->stream, fp);
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
 
   if (do_main) {
     // Boundary windows of the new files (also feed the all-ones rows below).
@@ -1001,8 +1112,9 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
       bool handled = false;
       TD_TRY(td_gram(h, x_dev, ldx, s->c1, x2_dev, ldx2, s->c2, sxy, s->g + s->off_fxx,
                      s->g + s->off_fyy, s->g + s->off_gxy, s->g + s->off_gxo, s->g + s->off_gyo,
-                     &handled));
+                     &handled, !gram_fresh, s->g + s->off_n, (double)(s->frames + new_frames)));
       TD_REQUIRE(h, handled, "td_gram refused a shape the one-pass test accepted");
+      if (gram_fresh) s->fresh_main = s->fresh_tgt = false;
     } else {
       TD_TRY(lagcov_auto(h, x_dev, ldx, s->c1, sxx, s->l1, s->g + s->off_fxx));
     }
@@ -1014,9 +1126,10 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
     }
     s->n_files += num_files;
     s->frames += new_frames;
-    // keep n on the device too (it travels in the all-reduce)
+    // keep n on the device too (it travels in the all-reduce); the one-pass Gram reduction
+    // has written it already
     const double nd = (double)s->frames;
-    TD_TRY(td_upload_async(h, &nd, sizeof(double), s->g + s->off_n));
+    if (!one_pass || new_frames == 0) TD_TRY(td_upload_async(h, &nd, sizeof(double), s->g + s->off_n));
   }
 
   if (do_targets && !one_pass) {

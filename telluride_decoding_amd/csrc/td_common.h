@@ -368,10 +368,21 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
                       int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
                       double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled);
 
-// CCA moments without context in one pass over z = [x | x2 | 1] (lagcov.hip); accumulates.
+// The float64 reduction of td_gram's partial blocks, as a job of the statistics' finalize launch.
+struct GramReduceJob {
+  const float* partial;   // [n_slabs][pairs][16][16]
+  int n_slabs, n_groups, c1, c2, accumulate;
+  double *fxx, *fyy, *gxy, *sx, *sx2;
+};
+
+// CCA moments without context in one pass over z = [x | x2 | 1] (lagcov.hip); accumulates, or
+// (accumulate = false) overwrites every number it owns: fxx, fyy, gxy, sx, sx2.
 int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, int64_t ldx2, int c2,
             const std::vector<LagSeg>& segs, double* fxx, double* fyy, double* gxy, double* sx,
-            double* sx2, bool* handled);
+            double* sx2, bool* handled, bool accumulate = true, double* n_dst = nullptr,
+            double n_value = 0.0, GramReduceJob* defer = nullptr);
+// (defer: the matrix kernel only; the caller runs the reduction it describes.  Its scratch stays
+// untouched until then.)
 
 // Column sums in float64 of rows [r0, r1) per segment (lagcov.hip).
 int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vector<LagSeg>& segs,
