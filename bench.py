@@ -264,6 +264,9 @@ def cca_leg(h, device, eeg):
   t_acc2 = timed(acc2, 20)
   t_solve2 = timed(lambda: st2.cca_solve(m - 1, 0.1, 5), 5)
   sweeps = st2.cca_solve(m - 1, 0.1, 5)[5]
+  # the class default of BrainModelCCA is regularization_lambda = 0 (cca.py:172)
+  t_solve2_r0 = timed(lambda: st2.cca_solve(m - 1, 0.0, 5), 5)
+  route_r0 = st2.last_cca_route
   return {
       'workload': 'C3: CCA, 64-ch EEG vs 8-band envelope, 1e6 samples, no context, 5 components',
       'fit_ms': (t_acc + t_solve) * 1e3, 'accumulate_ms': t_acc * 1e3,
@@ -283,7 +286,8 @@ def cca_leg(h, device, eeg):
       'codelab_shape': {
           'workload': 'K1 = 69 ch x 37 lags = 2553, K2 = 31 lags of one envelope, 200k samples',
           'fit_ms': (t_acc2 + t_solve2) * 1e3, 'accumulate_ms': t_acc2 * 1e3,
-          'solve_ms': t_solve2 * 1e3, 'jacobi_sweeps_eig_xx_yy_svd': list(sweeps)},
+          'solve_ms': t_solve2 * 1e3, 'jacobi_sweeps_eig_xx_yy_svd': list(sweeps),
+          'solve_ms_reg0': t_solve2_r0 * 1e3, 'reg0_whitening': route_r0},
       'note': 'the dense stage (whitening, SVD, rotations) runs on the device in float64 '
               '(td_cca_solve): with reg > 0 the large side is whitened by its Cholesky factor '
               '(blocked MFMA Cholesky), the small side -- and everything when reg = 0 -- by the '

@@ -963,27 +963,38 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   int sweeps[3] = {0, 0, 0};
   // The whitening of the x side.  The reference takes the symmetric inverse square root of
   // cov_xx + reg I from its eigen-decomposition, dropping eigenvalues <= eps_eig (cca.py:337-352).
-  // When nothing can be dropped -- reg > 2 eps_eig on a positive semi-definite covariance, and
-  // the Cholesky factorisation finds every pivot positive -- ANY whitening W (W C W^T = I) gives
+  // When nothing can be dropped (proofs below) ANY whitening W (W C W^T = I) gives
   // the same canonical directions W^T u, so the O(n^3 * sweeps) Jacobi eigen-decomposition of
   // the large side is replaced by its Cholesky factor: T = L^-1 cov_xy K22 (the forward
   // substitution rides along the factorisation), rot_x = L^-T u (backward substitution).
   // Codelab shape (K1 = 2553): 290 ms -> a few ms.  The small side keeps the eigen route.
   td_chol_state chol;
-  // Positive semi-definiteness is what makes "nothing can be dropped" true: S / denom - m^T m
-  // = (frames / denom) (S / frames) - m^T m  >=  S / frames - m^T m  >=  0 needs denom <= frames
-  // (the reference's denom = minibatches x rows of the LAST minibatch - 1, cca.py:339-343, exceeds
-  // the frame count for iterables with uneven batches; the covariance can then be indefinite and
-  // still pass a Cholesky with eigenvalues in (0, eps_eig] that the reference drops).
+  // "Nothing can be dropped" has two proofs.  (1) reg > 2 eps_eig on a positive semi-definite
+  // covariance: S / denom - m^T m = (frames / denom) (S / frames) - m^T m >= S / frames - m^T m >= 0
+  // needs denom <= frames (the reference's denom = minibatches x rows of the LAST minibatch - 1,
+  // cca.py:339-343, exceeds the frame count for iterables with uneven batches: the covariance can
+  // then be indefinite).  (2) Otherwise -- reg = 0, the class default of BrainModelCCA (cca.py:172),
+  // or uneven batches -- Sylvester's law of inertia: the eigenvalues of C that are <= eps_eig are
+  // as many as the non-positive pivots of C - eps_eig I, so if THAT matrix has a Cholesky factor
+  // (every pivot above the rounding tolerance of td_chol_factor) the reference's filter keeps
+  // every eigenvalue.  One extra factorisation (4 ms at K1 = 2553) instead of the Jacobi
+  // eigen-decomposition (0.2-0.3 s) -- which still decides whenever the certificate fails.
   // (development A/B switch, read per call so that one process can compare both routes; a
   // getenv is ~50 ns against a dense stage of >= 0.28 ms that ends in a stream synchronisation)
   const bool force_eig = getenv("TD_CCA_EIG") != nullptr;
-  bool use_chol = regularization > 2.0 * eps_eig && k2 <= 64 && cols && !force_eig &&
-                  denom <= (double)frames;
+  bool use_chol = k2 <= 64 && cols && !force_eig;
+  const bool psd_proof = regularization > 2.0 * eps_eig && denom <= (double)frames;
   if (use_chol) {
     // right-hand sides as rows: cov_xy^T [k2][k1] (m1 is free until T is formed)
     hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)k1 * k2)), dim3(256), 0, h->stream,
                        w.cxy, k1, k2, w.m1);
+    if (!psd_proof) {
+      const int rc = td_chol_factor(h, w.chol, w.cxx, k1, w.m1, 0, &chol, -eps_eig);
+      if (rc == TD_ERR_SINGULAR) use_chol = false;     // some eigenvalue is <= eps_eig (or too close to call)
+      else if (rc != TD_OK) return rc;
+    }
+  }
+  if (use_chol) {
     const int rc = td_chol_factor(h, w.chol, w.cxx, k1, w.m1, k2, &chol);
     if (rc == TD_ERR_SINGULAR) use_chol = false;       // not positive definite: the eigen route decides
     else if (rc != TD_OK) return rc;

@@ -956,8 +956,14 @@ size_t td_chol_ws_bytes(int n) {
   return sizeof(double) * (np * np + 64 * np + 2 * kMaxRhs * np + nblk * NB * NB + 64) + 1024;
 }
 
+__global__ void diag_add_kernel(double* __restrict__ a, int np, int n, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[(size_t)i * np + i] += v;
+}
+
+// diag_shift: factor C + diag_shift I instead (the inertia test of td_cca_solve uses a negative one).
 int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const double* bt_dev, int nb,
-                   td_chol_state* st) {
+                   td_chol_state* st, double diag_shift) {
   TD_REQUIRE(h, n > 0 && nb >= 0 && nb <= 64, "td_chol_factor: bad sizes");
   const int np = (int)td_round_up(n, NB);
   char* p = reinterpret_cast<char*>(ws);
@@ -970,6 +976,9 @@ int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const dou
   st->tol = reinterpret_cast<double*>(p);
   hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), 1), dim3(256), 0, h->stream, c_dev, 0LL,
                      n, np, 1.0, (const double*)nullptr, st->a);
+  if (diag_shift != 0.0)
+    hipLaunchKernelGGL(diag_add_kernel, dim3((unsigned)td_ceil_div(n, 256)), dim3(256), 0, h->stream, st->a,
+                       np, n, diag_shift);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(64), dim3(256), 0, h->stream, bt_dev, nb, n, 64, np, st->rt);
   TD_TRY(chol_factor_forward(h, st->a, st->rt, st->sol, st->linv, st->tol, np, nb > 0 ? nb : 1, 1,
                              nullptr, 64, n));

@@ -209,7 +209,8 @@ def test_cca_solve_matches_float64_lapack(dev, c1, l1, c2, l2, n, reg):
 def test_cholesky_and_eigen_whitening_agree(dev, monkeypatch):
   """With reg > 0 nothing can be filtered and td_cca_solve whitens the x side with its Cholesky
   factor (no Jacobi sweeps on cov_xx); TD_CCA_EIG forces the reference's eigen route: same
-  canonical correlations and rotations.  With reg = 0 the eigen route is taken by itself."""
+  canonical correlations and rotations.  With reg = 0 the shortcut is taken only with a proof that
+  nothing would be filtered."""
   rng = np.random.default_rng(77)
   h = dev.default_handle()
   n, c1, l1, c2, l2 = 8000, 20, 7, 2, 5             # K1 = 140 (block Jacobi on the eigen route), K2 = 10
@@ -230,8 +231,26 @@ def test_cholesky_and_eigen_whitening_agree(dev, monkeypatch):
                   ra2.cpu().numpy().astype(np.float64), rb2.cpu().numpy().astype(np.float64))
   np.testing.assert_allclose(a, ra2.cpu().numpy(), atol=2e-5 * np.max(np.abs(a)))
   np.testing.assert_allclose(b, rb2.cpu().numpy(), atol=2e-5 * np.max(np.abs(b)))
-  _, _, _, _, _, sweeps0 = st.cca_solve(n - 1, 0.0, dim)
-  assert sweeps0[0] > 0, 'reg = 0 must take the eigen route'
+  # reg = 0 (the class default of BrainModelCCA, cca.py:172): the shortcut needs a PROOF that the
+  # reference's eigenvalue filter drops nothing -- Sylvester's law of inertia: C - 1e-12 I has a
+  # Cholesky factor iff every eigenvalue of C exceeds 1e-12.  Full-rank data: certified, no Jacobi
+  # sweeps on cov_xx, same answer as the eigen route ...
+  ra0, rb0, _, _, e0, sweeps0 = st.cca_solve(n - 1, 0.0, dim)
+  assert st.last_cca_route == 'cholesky' and sweeps0[0] == 0
+  monkeypatch.setenv('TD_CCA_EIG', '1')
+  ra1, rb1, _, _, e1, _ = st.cca_solve(n - 1, 0.0, dim)
+  monkeypatch.delenv('TD_CCA_EIG')
+  np.testing.assert_allclose(e0.cpu().numpy(), e1.cpu().numpy(), rtol=1e-6)
+  a, b = _aligned(ra0.cpu().numpy().astype(np.float64), rb0.cpu().numpy().astype(np.float64),
+                  ra1.cpu().numpy().astype(np.float64), rb1.cpu().numpy().astype(np.float64))
+  np.testing.assert_allclose(a, ra1.cpu().numpy(), atol=2e-5 * np.max(np.abs(a)))
+  # ... an exactly collinear channel (an eigenvalue of ~0 that the reference drops): no certificate,
+  # the eigen route decides
+  x[:, -1] = x[:, 0]
+  st2 = dev.LagStats(c1, 0, l1 - 1, c2, 0, l2 - 1)
+  st2.accumulate(h.to_device(x), h.to_device(x2), None, [0, n])
+  st2.cca_solve(n - 1, 0.0, dim)
+  assert st2.last_cca_route == 'eigen', 'a rank-deficient covariance must not take the Cholesky shortcut'
 
 
 def test_uneven_batches_denominator_takes_the_eigen_route(dev):
