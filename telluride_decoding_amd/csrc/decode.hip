@@ -1412,6 +1412,190 @@ __global__ __launch_bounds__(64 * kProjWaves, 3) void cca_project_kernel(ProjPar
   }
 }
 
+// ---- one-output FIR prediction without workgroup barriers ---------------------------------------
+//   out[t] = b + sum_l sum_c x~[t + l - pre][c] W[l][c]                       (brain_model.py:335-341)
+// P[u][l] = sum_c x[u][c] W[l][c] is a product with M = time, N = lag (<= 32), K = channel (<= 64),
+// and out[t] is the sum of the diagonal P[t + l - pre][l].  predict_fir_mfma_kernel above stages a
+// P tile in LDS and walks its diagonals (~300 non-matrix instructions per 32 rows that ADD to its
+// matrix and memory time: 73 us at C4, 4.2 TB/s).  Here, as in gram_bf16x3_kernel / cca_project_kernel:
+//   * a WAVE owns a strip of outputs and walks 16-row tiles of x; it loads them with whole-line
+//     float4s two tiles ahead, writes them row-major into a wave-private LDS tile (row stride 68
+//     floats: the b128 operand reads of 16 rows hit 64 different banks), reads back 8 consecutive
+//     channels of ITS row per lane -- the A operand of v_mfma_f32_16x16x32_bf16 after the exact
+//     three-way bf16 split -- against the weights held split in registers;
+//   * the diagonal sums stay in registers: a C register of lane (lag l, row quarter q) belongs to
+//     output u0 + 4 q + r - l, the (at most four) lanes of a diagonal are 20 lanes apart -- two
+//     shuffle-and-add steps -- and one more shuffle hands the sum to the lane that owns that
+//     output in a 64-lane ring of running sums (lane D <-> output u0 + D - 31 + pre).  After a
+//     tile the 16 oldest outputs are final, leave with the bias, and the ring moves down 16 lanes.
+// No workgroup barrier, no LDS atomics, 24 MFMAs + ~25 shuffles per 16 rows.
+constexpr int kFir16Ld = 68;
+#ifndef TD_FIR16_ABL
+#define TD_FIR16_ABL 0      // development: 1 no diagonal shuffles, 2 no split / MFMA, 3 no streaming loads
+#endif
+
+struct Fir16Params {
+  const float* x;
+  long long ldx;
+  const FileDesc* files;
+  int n_files;
+  long long n_strips;
+  int strip, c, pre, post;
+  const float* w;        // [nl * c][d]
+  const float* bias;     // [d] or null
+  int d, q0;             // outputs per weight row; which one this launch computes
+  float* out;
+  long long ldout;
+};
+
+__global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) {
+  __shared__ __attribute__((aligned(16))) float lds[(kThreads / 64) * 16 * kFir16Ld];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long sidx = blockIdx.x * (long long)(kThreads / 64) + wave;
+  if (sidx >= p.n_strips) return;
+  const FileDesc st = p.files[find_file(p.files, p.n_files, sidx)];
+  const long long s0 = (sidx - st.first) * p.strip;             // first output of the strip
+  const int st_len = (int)(st.nrows - s0 < p.strip ? st.nrows - s0 : p.strip);
+  const int nl = p.pre + 1 + p.post;
+  float* tile = lds + wave * 16 * kFir16Ld;
+  const int li = lane & 15, kq = lane >> 4;
+
+  // weights as the B operand: lane (lag n = li of n tile nt, k quarter kq): channels 32 s + 8 kq + kk
+  pj_u32x4 wh[2][2], wm[2][2], wl[2][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float v[8];
+      const int l = 16 * nt + li;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int ch = 32 * s2 + 8 * kq + kk;
+        v[kk] = (l < nl && ch < p.c) ? p.w[((size_t)l * p.c + ch) * p.d + p.q0] : 0.f;
+      }
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        unsigned a, b, c3;
+        td_split3(v[2 * dd], v[2 * dd + 1], a, b, c3);
+        wh[nt][s2][dd] = a; wm[nt][s2][dd] = b; wl[nt][s2][dd] = c3;
+      }
+    }
+  const float bq = p.bias ? p.bias[p.q0] : 0.f;
+
+  // diagonal bookkeeping (lane constants).  C register r of n tile nt in lane (l, q) is
+  // P[u0 + 4 q + r][16 nt + l], ring slot D = (4 q + r) - (16 nt + l) + 31.
+  //   step 1: + the lane 40 up (l + 8, q + 2), step 2: + the lane 20 up (l + 4, q + 1);
+  //   the lowest lane of a diagonal (l < 4 or q = 0) then holds its sum.
+  const bool up40 = li + 8 <= 15 && kq + 2 <= 3, up20 = li + 4 <= 15 && kq + 1 <= 3;
+  // for ring slot D = lane and (nt, r): the diagonal e = 4 q - l = D - 31 - r + 16 nt; its lowest
+  // lane is q = max(0, ceil(e / 4)), l = 4 q - e (valid for -15 <= e <= 12)
+  int src[2][4];
+  bool src_ok[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane - 31 - r + 16 * nt;
+      const int q = e > 0 ? (e + 3) >> 2 : 0;
+      const int l = 4 * q - e;
+      src_ok[nt][r] = e >= -15 && e <= 12 && l <= 15 && q <= 3;
+      src[nt][r] = src_ok[nt][r] ? l + 16 * q : 0;
+    }
+
+  // tiles: x rows u0 = s0 - pre + 16 k; the last one that matters holds row s0 + st_len - 1 + post
+  const long long u_first = s0 - p.pre;
+  const int n_tiles = (st_len + nl - 1 + 15) / 16;
+  const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+  const bool col_ok = c4 < p.c;
+  const float* xb = p.x + st.row0 * p.ldx + (col_ok ? c4 : 0);
+  auto load_tile = [&](int k, float4 (&pf)[4]) {
+    const long long u0 = u_first + 16LL * k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long u = u0 + r0 + 4 * j;
+      u = u < 0 ? 0 : (u >= st.nrows ? st.nrows - 1 : u);           // clamped: masked when stored
+      pf[j] = *reinterpret_cast<const float4*>(xb + u * p.ldx);
+    }
+  };
+  auto store_tile = [&](int k, const float4 (&pf)[4]) {
+    const long long u0 = u_first + 16LL * k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long u = u0 + r0 + 4 * j;
+      const bool ok = col_ok && u >= 0 && u < st.nrows;              // x~ is zero outside the trial
+      float4 v = pf[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(tile + (r0 + 4 * j) * kFir16Ld + c4) = v;
+    }
+  };
+  float ring = 0.f;                                    // lane D: running sum of output u0 + D - 31 + pre
+  auto emit = [&](long long u0) {
+    // lanes 0..15 hold final outputs t = u0 + D - 31 + pre
+    const long long t = u0 + lane - 31 + p.pre;
+    if (lane < 16 && t >= s0 && t < s0 + st_len) p.out[(st.out0 + t) * p.ldout + p.q0] = ring + bq;
+    const float up = __shfl_down(ring, 16, 64);
+    ring = lane < 48 ? up : 0.f;
+  };
+  float4 pfa[4], pfb[4];                               // tiles k (even) / k + 1 (odd) in flight
+  load_tile(0, pfa);
+  if (n_tiles > 1) load_tile(1, pfb);
+#define TD_FIR16_TILE(K, PF)                                                                    \
+  {                                                                                             \
+    const int k_ = (K);                                                                         \
+    store_tile(k_, PF);                                                                         \
+    if (k_ + 2 < n_tiles && TD_FIR16_ABL != 3) load_tile(k_ + 2, PF);                           \
+    __builtin_amdgcn_wave_barrier();                                                            \
+    pj_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};                              \
+    const float* row = tile + li * kFir16Ld + 8 * kq;                                           \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                          \
+      const float4 v0 = *reinterpret_cast<const float4*>(row + 32 * s2);                        \
+      const float4 v1 = *reinterpret_cast<const float4*>(row + 32 * s2 + 4);                    \
+      pj_u32x4 zh, zm, zl;                                                                      \
+      unsigned a_, b_, c_;                                                                      \
+      td_split3(v0.x, v0.y, a_, b_, c_); zh[0] = a_; zm[0] = b_; zl[0] = c_;                    \
+      td_split3(v0.z, v0.w, a_, b_, c_); zh[1] = a_; zm[1] = b_; zl[1] = c_;                    \
+      td_split3(v1.x, v1.y, a_, b_, c_); zh[2] = a_; zm[2] = b_; zl[2] = c_;                    \
+      td_split3(v1.z, v1.w, a_, b_, c_); zh[3] = a_; zm[3] = b_; zl[3] = c_;                    \
+      if (TD_FIR16_ABL == 2) { c0[0] += v0.x * v1.y; c1[1] += v0.z * v1.w; continue; }         \
+      TD_FIR16_MFMA(c0, zl, wh[0][s2]); TD_FIR16_MFMA(c1, zl, wh[1][s2]);                       \
+      TD_FIR16_MFMA(c0, zh, wl[0][s2]); TD_FIR16_MFMA(c1, zh, wl[1][s2]);                       \
+      TD_FIR16_MFMA(c0, zm, wm[0][s2]); TD_FIR16_MFMA(c1, zm, wm[1][s2]);                       \
+      TD_FIR16_MFMA(c0, zm, wh[0][s2]); TD_FIR16_MFMA(c1, zm, wh[1][s2]);                       \
+      TD_FIR16_MFMA(c0, zh, wm[0][s2]); TD_FIR16_MFMA(c1, zh, wm[1][s2]);                       \
+      TD_FIR16_MFMA(c0, zh, wh[0][s2]); TD_FIR16_MFMA(c1, zh, wh[1][s2]);                       \
+    }                                                                                           \
+    __builtin_amdgcn_wave_barrier();                   /* the tile may be overwritten */        \
+    float add = 0.f;                                                                            \
+    if (TD_FIR16_ABL == 1) add = c0[0] + c1[1] + c0[2] + c1[3];                                 \
+    else                                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                             \
+      float v0 = c0[r], v1 = c1[r];                                                             \
+      const float a0 = __shfl_down(v0, 40, 64), a1 = __shfl_down(v1, 40, 64);                   \
+      v0 += up40 ? a0 : 0.f; v1 += up40 ? a1 : 0.f;                                             \
+      const float b0 = __shfl_down(v0, 20, 64), b1 = __shfl_down(v1, 20, 64);                   \
+      v0 += up20 ? b0 : 0.f; v1 += up20 ? b1 : 0.f;                                             \
+      const float g0 = __shfl(v0, src[0][r], 64), g1 = __shfl(v1, src[1][r], 64);               \
+      add += (src_ok[0][r] ? g0 : 0.f) + (src_ok[1][r] ? g1 : 0.f);                             \
+    }                                                                                           \
+    ring += add;                                                                                \
+    emit(u_first + 16LL * k_);                                                                  \
+  }
+#define TD_FIR16_MFMA(C, A, B) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+      __builtin_bit_cast(td_bf16x8, A), __builtin_bit_cast(td_bf16x8, B), C, 0, 0, 0)
+  int k = 0;
+  for (; k + 1 < n_tiles; k += 2) {
+    TD_FIR16_TILE(k, pfa)
+    TD_FIR16_TILE(k + 1, pfb)
+  }
+  if (k < n_tiles) TD_FIR16_TILE(k, pfa)
+#undef TD_FIR16_TILE
+#undef TD_FIR16_MFMA
+  // the ring still holds the outputs of the last 31 rows: two more emissions flush them
+  emit(u_first + 16LL * n_tiles);
+  emit(u_first + 16LL * (n_tiles + 1));
+}
+
 // The per-file descriptor table goes through the handle's content-cached table slots
 // (td_table_upload): no td_scratch use, and no upload at all when the layout repeats.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
@@ -1469,6 +1653,36 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
                      num_files, n_strips, (int)strip, c, w, bias, d, out, (long long)ldout)
     if (c <= 8) TD_PROJ(4); else if (c <= 16) TD_PROJ(8); else if (c <= 32) TD_PROJ(16); else TD_PROJ(32);
 #undef TD_PROJ
+    TD_HIP(h, hipGetLastError());
+    return TD_OK;
+  }
+  // (Measured at C4, decode step: 90.1 us with fir_tile16_kernel against 86.3 us with
+  // predict_fir_mfma_kernel -- its split + MFMA cost 26 us and its loads 19 us that overlap only
+  // partly (ablations: DESIGN 8) -- so the P-tile kernel stays the default and this one is opt-in.)
+  static const bool tile16 = getenv("TD_FIR_TILE16") != nullptr;          // development: A/B runs
+  if (d == 1 && nl <= 32 && c >= 4 && c <= 64 && vec4 && tile16 && h->acc_mode != TD_ACC_F32) {
+    // one output: the barrier-free 16-row kernel (fir_tile16_kernel); 12 waves per CU, one round
+    const int cus = h->cu_count > 0 ? h->cu_count : 256;
+    int64_t strip = td_round_up(td_ceil_div(total, (int64_t)cus * 12), 16);
+    if (strip < 256) strip = 256;
+    std::vector<FileDesc> files(num_files);
+    long long n_strips = 0;
+    for (int f = 0; f < num_files; ++f) {
+      const int64_t n = offs[f + 1] - offs[f] - shift;
+      files[f].row0 = offs[f] + shift;
+      files[f].nrows = n > 0 ? n : 0;
+      files[f].out0 = offs[f];
+      files[f].first = n_strips;
+      if (n > 0) n_strips += td_ceil_div(n, strip);
+    }
+    TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(FileDesc), &table_dev));
+    Fir16Params fp;
+    fp.x = x; fp.ldx = ldx; fp.files = reinterpret_cast<const FileDesc*>(table_dev);
+    fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = (int)strip;
+    fp.c = c; fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
+    fp.out = out; fp.ldout = ldout;
+    hipLaunchKernelGGL(fir_tile16_kernel, dim3((unsigned)td_ceil_div(n_strips, kThreads / 64)),
+                       dim3(kThreads), 0, h->stream, fp);
     TD_HIP(h, hipGetLastError());
     return TD_OK;
   }

@@ -18,12 +18,16 @@ def counter(path, kernel, name):
 
 out = {}
 for key, kernel, algo, note in (
-    ('lagcov', 'lagcov_bf16x3_kernel<true, 83>', 256000000,
+    ('lagcov', 'lagcov_split_kernel<true, 83, true, false>', 256000000,
      'reads the 256 MB of input (the four lag-group workgroups of a time slab share one XCD L2); '
      'writes ~100 MB = 192 float32 partial slabs of 512 KB (one per <= 8192-sample slab; the count '
-     'fills whole rounds of the CUs), summed in float64 by lagcov_reduce_kernel'),
-    ('gram', 'gram_mfma_kernel<true, 5>', 288000000,
-     'C3 one-pass CCA moments: every input byte read once; 505 partial slabs of 15 KB')):
+     'fills whole rounds of the CUs), summed in float64 by stats_finalize_kernel'),
+    ('targets', 'lagcov_targets_mfma_kernel<true>', 260000000,
+     'the second read of x (+ y): y^T x~, column sums and the channel maxima of the float16 kernel'),
+    ('gram', 'gram_bf16x3_kernel<5>', 288000000,
+     'C3 one-pass CCA moments: every input byte read once; 512 partial slabs of 15 KB'),
+    ('project', 'cca_project_kernel<76>', 328000000,
+     'C3 transform: x and x2 read once, 40 MB of outputs written')):
   name, fetch = counter(os.path.join(root, tag + '_hotkernels_pmc1.txt'), kernel, 'FETCH_SIZE')
   _, write = counter(os.path.join(root, tag + '_hotkernels_pmc2.txt'), kernel, 'WRITE_SIZE')
   out[key] = {
@@ -37,6 +41,8 @@ doc['source'] = ('profiles/%s_hotkernels_pmc1.txt (FETCH_SIZE) and profiles/%s_h
                  % (tag, tag))
 doc['correction'] = ('gfx950: FETCH_SIZE counts 128-B read requests at 64 B -> x2 '
                      '(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16-B-per-lane streaming stores')
-doc['gram_mfma_kernel'] = out['gram']
+doc['lagcov_targets_mfma_kernel'] = out['targets']
+doc['gram_bf16x3_kernel'] = out['gram']
+doc['cca_project_kernel'] = out['project']
 json.dump(doc, open(os.path.join(root, tag + '_lagcov_pmc.json'), 'w'), indent=1)
 print(json.dumps(doc, indent=1))

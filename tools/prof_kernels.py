@@ -27,6 +27,9 @@ if 'cca' in what:
   for rep in range(3):
     st.reset(); st.accumulate(x, x2, None, offs)
   m = st.moments(want_cca=True)
+  rot_x, rot_y, mean_x, mean_y, e, _ = st.cca_solve(n - 1, 0.1, 5)
+  for rep in range(3):
+    out = device.cca_transform(x, x2, offs, mean_x, rot_x, mean_y, rot_y, 0, 0, 0, 0, handle=h)
   torch.cuda.synchronize()
 if 'ccasolve' in what:
   # CCA dense stage (td_cca_solve): C3 and a lagged shape that takes the block-Jacobi path
