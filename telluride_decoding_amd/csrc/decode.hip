@@ -1487,11 +1487,11 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
   // P[u0 + 4 q + r][16 nt + l], ring slot D = (4 q + r) - (16 nt + l) + 31.
   //   step 1: + the lane 40 up (l + 8, q + 2), step 2: + the lane 20 up (l + 4, q + 1);
   //   the lowest lane of a diagonal (l < 4 or q = 0) then holds its sum.
-  const bool up40 = li + 8 <= 15 && kq + 2 <= 3, up20 = li + 4 <= 15 && kq + 1 <= 3;
+  const float m40 = (li + 8 <= 15 && kq + 2 <= 3) ? 1.f : 0.f, m20 = (li + 4 <= 15 && kq + 1 <= 3) ? 1.f : 0.f;
   // for ring slot D = lane and (nt, r): the diagonal e = 4 q - l = D - 31 - r + 16 nt; its lowest
   // lane is q = max(0, ceil(e / 4)), l = 4 q - e (valid for -15 <= e <= 12)
   int src[2][4];
-  bool src_ok[2][4];
+  float msrc[2][4];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -1499,8 +1499,9 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
       const int e = lane - 31 - r + 16 * nt;
       const int q = e > 0 ? (e + 3) >> 2 : 0;
       const int l = 4 * q - e;
-      src_ok[nt][r] = e >= -15 && e <= 12 && l <= 15 && q <= 3;
-      src[nt][r] = src_ok[nt][r] ? l + 16 * q : 0;
+      const bool ok = e >= -15 && e <= 12 && l <= 15 && q <= 3;
+      msrc[nt][r] = ok ? 1.f : 0.f;
+      src[nt][r] = ok ? l + 16 * q : 0;
     }
 
   // tiles: x rows u0 = s0 - pre + 16 k; the last one that matters holds row s0 + st_len - 1 + post
@@ -1509,8 +1510,17 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
   const int c4 = (lane & 15) * 4, r0 = lane >> 4;
   const bool col_ok = c4 < p.c;
   const float* xb = p.x + st.row0 * p.ldx + (col_ok ? c4 : 0);
+  // a tile wholly inside the trial, 64 real channels: no clamps, no masks
+  auto interior = [&](long long u0) -> bool { return p.c == 64 && u0 >= 0 && u0 + 16 <= st.nrows; };
+  const int ldx32 = (int)p.ldx;
   auto load_tile = [&](int k, float4 (&pf)[4]) {
     const long long u0 = u_first + 16LL * k;
+    if (interior(u0)) {
+      const float* tb = xb + u0 * p.ldx;               // wave-uniform base + 32-bit lane offsets
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pf[j] = *reinterpret_cast<const float4*>(tb + (r0 + 4 * j) * ldx32);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       long long u = u0 + r0 + 4 * j;
@@ -1520,6 +1530,11 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
   };
   auto store_tile = [&](int k, const float4 (&pf)[4]) {
     const long long u0 = u_first + 16LL * k;
+    if (interior(u0)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(tile + (r0 + 4 * j) * kFir16Ld + c4) = pf[j];
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long u = u0 + r0 + 4 * j;
@@ -1568,15 +1583,18 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
     __builtin_amdgcn_wave_barrier();                   /* the tile may be overwritten */        \
     float add = 0.f;                                                                            \
     if (TD_FIR16_ABL == 1) add = c0[0] + c1[1] + c0[2] + c1[3];                                 \
-    else                                                                                        \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                             \
-      float v0 = c0[r], v1 = c1[r];                                                             \
-      const float a0 = __shfl_down(v0, 40, 64), a1 = __shfl_down(v1, 40, 64);                   \
-      v0 += up40 ? a0 : 0.f; v1 += up40 ? a1 : 0.f;                                             \
-      const float b0 = __shfl_down(v0, 20, 64), b1 = __shfl_down(v1, 20, 64);                   \
-      v0 += up20 ? b0 : 0.f; v1 += up20 ? b1 : 0.f;                                             \
-      const float g0 = __shfl(v0, src[0][r], 64), g1 = __shfl(v1, src[1][r], 64);               \
-      add += (src_ok[0][r] ? g0 : 0.f) + (src_ok[1][r] ? g1 : 0.f);                             \
+    else {                                                                                      \
+      /* the three shuffle levels of the eight (n tile, register) chains, level by level: the  \
+         eight shuffles of a level are in flight together (one LDS round trip per level, not   \
+         per shuffle); masks as 0/1 factors (one fma instead of select + add) */                \
+      float v_[8], t_[8];                                                                       \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) { v_[r] = c0[r]; v_[4 + r] = c1[r]; }       \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) t_[i] = __shfl_down(v_[i], 40, 64);         \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) v_[i] = fmaf(t_[i], m40, v_[i]);            \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) t_[i] = __shfl_down(v_[i], 20, 64);         \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) v_[i] = fmaf(t_[i], m20, v_[i]);            \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) t_[i] = __shfl(v_[i], src[i >> 2][i & 3], 64); \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) add = fmaf(t_[i], msrc[i >> 2][i & 3], add); \
     }                                                                                           \
     ring += add;                                                                                \
     emit(u_first + 16LL * k_);                                                                  \
