@@ -253,7 +253,10 @@ def cca_leg(h, device, eeg):
                                             handle=h))
   # codelab shape on 200k samples
   m = 200000
-  xc = h.to_device(np.concatenate((eeg[:m], eeg[:m, :5]), axis=1))
+  # (69 channels: the 64 + five mixtures with their own noise -- exact copies would make the
+  # covariance rank-deficient, which sends reg = 0 down the eigen route by design)
+  extra = (0.5 * eeg[:m, :5] + rng.standard_normal((m, 5))).astype(np.float32)
+  xc = h.to_device(np.concatenate((eeg[:m], extra), axis=1))
   yc = h.to_device(bands[:m, :1])
   st2 = device.LagStats(69, 0, 36, 1, 15, 15, 0, handle=h)
 

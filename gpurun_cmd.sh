@@ -1,4 +1,6 @@
-timeout 300 python -m pytest tests/test_gpu_decode.py tests/test_gpu_decoder_train.py -m gpu -x -q 2>&1 | tail -3
-echo "--- old"; timeout 120 python tools/time_decode.py 2>&1 | grep "W 1000 hop  100"
-echo "--- tile16"; TD_FIR_TILE16=1 timeout 120 python tools/time_decode.py 2>&1 | grep "W 1000 hop  100"
-TD_FIR_TILE16=1 timeout 300 python -m pytest tests/test_gpu_decode.py tests/test_gpu_decoder_train.py -m gpu -x -q 2>&1 | tail -3
+rm -f gpurun_out/parity.jsonl
+timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 900 python bench.py > gpurun_out/bench_stdout.log 2>gpurun_out/bench_stderr.log; tail -1 gpurun_out/bench_stdout.log > gpurun_out/r03_bench_line.json
+timeout 120 python tools/time_strong_share.py 1 2 4 8 2>&1 | tail -4
+timeout 120 python tools/time_solve.py 1 20 160 2>&1 | tail -3
+timeout 120 python tools/bias_probe.py 2>&1 | tail -1
