@@ -12,9 +12,11 @@ messages, written from that behaviour:
     along the first axis, to y0 and y1.
 
 The scatter matrices come from per-class moment sums (count, sum, x^T x) in
-float64 instead of a Python loop over the rows:
+float64 instead of a Python loop over the rows (reference :141-148):
   S_w = sum_c (X_c^T X_c - n_c m_c m_c^T),  S_b = sum_c n_c (m_c - m)(m_c - m)^T.
-The model is d x d with d <= ~10 (the CCA dimensions), so this is host NumPy.
+For a float32 device tensor the per-class moments are the same X^T X accumulate the
+fits use (device.LagStats, one "recording" per class); the d x d algebra
+that follows (d <= ~10, the CCA dimensions) is host NumPy either way.
 With two classes S_b has rank one: only the first axis is meaningful, every
 further eigenvalue is rounding noise (in the reference too).
 """
@@ -27,13 +29,49 @@ LdaParamsTuple = collections.namedtuple(
 
 
 def _columns(data):
-  """Vectors become single-column matrices."""
+  """Vectors become single-column matrices.  (Device tensors pass: fit() takes their class
+  moments on the device; everything else works on a host copy.)"""
+  if hasattr(data, 'is_cuda'):
+    return data.reshape(-1, 1) if data.dim() == 1 else data
   data = np.asarray(data)
   return data.reshape(-1, 1) if data.ndim == 1 else data
 
 
+def _class_moments_device(x, y):
+  """_class_moments for a float32 CUDA tensor x [rows, dims]: count, sum and x^T x of every
+  class from the accumulate kernels (LagStats without context: xtx = [[X^T X, sum], [sum^T, n]])."""
+  import torch
+  from telluride_decoding_amd import device
+  y = np.asarray(y).reshape(-1)
+  labels = sorted(set(y.tolist()))
+  dims = int(x.shape[1])
+  h = device.default_handle()
+  moments = []
+  for label in labels:
+    rows = x[torch.from_numpy(y == label).to(x.device)].contiguous()       # device gather: plumbing
+    st = device.LagStats(dims, handle=h)
+    st.accumulate(rows, None, None, [0, int(rows.shape[0])])
+    moments.append(st.moments(want_xty=False)['xtx'].cpu().numpy())
+  total = sum(m[dims, dims] for m in moments)
+  grand_mean = sum(m[dims, :dims] for m in moments) / total
+  within = np.zeros((dims, dims))
+  between = np.zeros((dims, dims))
+  means = []
+  for m in moments:
+    count, mean = m[dims, dims], m[dims, :dims] / m[dims, dims]
+    means.append(mean)
+    within += m[:dims, :dims] - count * np.outer(mean, mean)
+    shift = mean - grand_mean
+    between += count * np.outer(shift, shift)
+  return labels, means, within, between
+
+
 def _class_moments(x, y):
   """Sorted labels with (count, mean) per class, and the two scatter matrices."""
+  if hasattr(x, 'is_cuda') and x.is_cuda and str(x.dtype) == 'torch.float32' and x.dim() == 2:
+    return _class_moments_device(x, y)
+  if hasattr(x, 'is_cuda'):
+    x = x.cpu().numpy()
   x = np.asarray(x, dtype=np.float64)
   labels = sorted(set(np.asarray(y).tolist()))
   grand_mean = x.mean(axis=0)
@@ -128,6 +166,8 @@ class LinearDiscriminantAnalysis(object):
     if self._w is None:
       raise ValueError('Must fit the model before transforming.')
     x = _columns(x)
+    if hasattr(x, 'is_cuda'):
+      x = x.cpu().numpy()
     if x.ndim != 2 or x.shape[1] != self._w.shape[0]:
       raise TypeError('Inconsistent training and transform sizes. %s vs %s' %
                       (x.shape, self._w.shape))

@@ -256,3 +256,27 @@ def test_regression_without_offset_column(use_ridge, lamb):
   np.testing.assert_allclose(w, w64, rtol=1e-4, atol=1e-5)
   np.testing.assert_allclose(cov_x, cx, rtol=1e-4, atol=1e-5)
   np.testing.assert_allclose(cov_xy, cxy, rtol=1e-4, atol=1e-5)
+
+
+def test_lda_scatter_on_the_device():
+  """SURVEY F1 / VERDICT r2 missing #6: the LDA class moments (count, sum, x^T x per class:
+  the reference's per-row loop, scaled_lda.py:141-148) through the accumulate kernels for a
+  float32 device tensor -- same model as from the host array (golden G8 fixture data)."""
+  from telluride_decoding_amd import device as dev, scaled_lda
+  rng = np.random.default_rng(21)
+  n, d = 4000, 6
+  x = rng.standard_normal((n, d)).astype(np.float32)
+  labels = (rng.random(n) < 0.4).astype(np.float64)
+  x[labels == 1] += np.linspace(0.2, 1.5, d).astype(np.float32)
+  host = scaled_lda.ScaledLinearDiscriminantAnalysis()
+  host.fit(x, labels)
+  h = dev.default_handle()
+  devm = scaled_lda.ScaledLinearDiscriminantAnalysis()
+  devm.fit(h.to_device(x), labels)
+  w_h, w_d = np.real(host.coef_array[:, 0]), np.real(devm.coef_array[:, 0])
+  w_d = w_d * np.sign(np.dot(w_h, w_d))
+  np.testing.assert_allclose(w_d, w_h, rtol=1e-5, atol=1e-7)
+  np.testing.assert_allclose(np.abs(devm.slope), np.abs(host.slope), rtol=1e-5)
+  np.testing.assert_allclose(devm.transform(x)[:, 0], host.transform(x)[:, 0], rtol=1e-4, atol=1e-5)
+  for a, b in zip(devm.mean_vectors, host.mean_vectors):
+    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
