@@ -254,6 +254,20 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats_host, int n_stats,
                          const double* lambdas_host, int n_lambda, float* w_dev, float* b_dev,
                          const int** singular_flag_host);
 
+/* The same systems for a leave-one-out sweep (regression.jackknife_over_regularizations,
+ * regression.py:326-420: fold f = every recording but f, all lambdas) WITHOUT factoring each of
+ * them: one Cholesky factor per lambda of the TOTAL covariance + lambda I preconditions a
+ * conjugate-gradient solve of every fold's system (the folds' matrices differ from the total's
+ * by 1 / folds), all systems in lock step: a [lambda x n] . [n x n] product per fold on the float64
+ * MFMA and two blocked triangular substitutions per iteration.  total = statistics of all
+ * recordings, folds[f] = training statistics of fold f.  Synchronous.  *status_host = 0: every
+ * system converged to the relative residual `tol` (outputs as td_ridge_solve_multi);
+ * 1: the preconditioner is not positive definite or max_iter was not enough -- use
+ * td_ridge_solve_multi.  iterations_host (may be NULL) receives the iteration count. */
+int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, int n_folds,
+                        const double* lambdas_host, int n_lambda, int max_iter, double tol,
+                        float* w_dev, float* b_dev, int* status_host, int* iterations_host);
+
 /* Generic SPD solve used by the above and by the shrinkage branch
  * (brain_model.py:456-477): a_dev [batch, n, n] float64 (destroyed),
  * rhs_dev [batch, n, nrhs] float64 (overwritten with the solution). */

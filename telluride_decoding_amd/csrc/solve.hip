@@ -945,6 +945,283 @@ __global__ void unpad_rows_kernel(const double* __restrict__ src, int nb, int n,
     dst[i] = src[(size_t)(i / n) * np + (i % n)];
 }
 
+
+// ---- the (fold x lambda) systems of a leave-one-out sweep by preconditioned CG ------------------
+// regression.jackknife_over_regularizations (regression.py:326-420) solves F x Lambda ridge
+// systems whose matrices differ little: fold f's is A_f + lambda I with A_f = M_f / n_f, M_f the
+// moments of all recordings but one -- within 1 / F of P = M_total / N.  So ONE Cholesky factor
+// per lambda, of P + lambda I (Lambda factorisations instead of F x Lambda), preconditions a
+// conjugate-gradient solve of every fold's system with that lambda: the preconditioned spectrum
+// sits in a narrow band below 1 + 1 / (F - 1) when the recordings are alike, and CG reaches
+// float64 accuracy in a handful of iterations.  An iteration is
+//   q = A_f p        one pass over the F dense matrices (a [Lambda d x n] x [n x n] product per fold
+//                    on the float64 MFMA: every matrix byte read once for all lambdas),
+//   z = (P + lambda I)^-1 r   two blocked triangular substitutions with F d right-hand sides each,
+//   a few row-wise dot products / axpys.
+// At C5 (32 folds x 20 lambdas, n = 2049): 20 factorisations + ~10 iterations instead of 640
+// factorisations.  Convergence is checked (relative residual of every system); the caller
+// falls back to the direct batched solve if it is not reached.
+//
+// Vectors are ROWS of np doubles in the order [lambda][output q][fold]: the rows of a lambda are
+// contiguous (the triangular solves), the rows of a fold a constant stride apart (the products).
+constexpr int kLosoRows = 32;      // right-hand-side rows per workgroup
+
+// C[32 x 64] (+)= As[32 x 64] . Bs^T (kNT) or As . Bs (!kNT); As rows r, Bs 64 x 64, both LDS with
+// stride LS.  4 waves: wave w owns output columns 16 w .. 16 w + 15, both 16-row tiles.
+template <bool kNT>
+__device__ __forceinline__ void gemm_32x64(const double* __restrict__ as, const double* __restrict__ bs,
+                                           int wave, int lane, f64x4 (&acc)[2]) {
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < NB / 4; ++s) {
+    const int k = 4 * s + lk;
+    const double b = kNT ? bs[(16 * wave + li) * LS + k] : bs[k * LS + 16 * wave + li];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[li * LS + k], b, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[(16 + li) * LS + k], b, acc[1], 0, 0, 0);
+  }
+}
+
+// rows [r0, r0 + 32) x columns [c0, c0 + 64) of a row array (row stride ld doubles) -> LDS
+// (stride LS); rows beyond rows_valid / columns beyond cols_valid read as zero
+__device__ __forceinline__ void rows_to_lds(double* lds, const double* __restrict__ g, long long ld,
+                                            int rows_valid, int cols_valid, int tid) {
+  for (int idx = tid; idx < kLosoRows * NB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    lds[r * LS + c] = (r < rows_valid && c < cols_valid) ? g[(long long)r * ld + c] : 0.0;
+  }
+}
+
+struct LosoMatvec {
+  const double* a;        // [folds][n][n] dense moments (unpadded, symmetric)
+  const double* p;        // rows
+  double* q;              // rows
+  const double* inv_n;    // [folds] 1 / frames of the fold
+  const double* lams;     // [n_lambda]
+  int n, np, folds, n_lambda, d;
+};
+
+// q_row = inv_n[f] * (p_row . A_f) + lambda * p_row for the rows (lambda, q) of fold f.
+// grid: (np / 64 column tiles, folds, ceil(n_lambda * d / 32))
+__global__ __launch_bounds__(256) void loso_matvec_kernel(LosoMatvec m) {
+  __shared__ double as[kLosoRows * LS];
+  __shared__ double bs[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = blockIdx.x, f = blockIdx.y, chunk = blockIdx.z;
+  const int rows_f = m.n_lambda * m.d;                 // rows of this fold: index j = lambda * d + q
+  const int j0 = chunk * kLosoRows;
+  const int rows_valid = rows_f - j0 < kLosoRows ? rows_f - j0 : kLosoRows;
+  const long long row_stride = (long long)m.folds * m.np;        // between rows j and j + 1 of a fold
+  const double* pf = m.p + ((long long)j0 * m.folds + f) * m.np;
+  const double* af = m.a + (size_t)f * m.n * m.n;
+  const int c0 = ct * NB;
+  const int cols_valid = m.n - c0 < NB ? m.n - c0 : NB;
+  f64x4 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+  for (int kt = 0; kt < m.np / NB; ++kt) {
+    const int k0 = kt * NB;
+    const int k_valid = m.n - k0 < NB ? (m.n - k0 > 0 ? m.n - k0 : 0) : NB;
+    rows_to_lds(as, pf + k0, row_stride, rows_valid, k_valid, tid);
+    // A_f[k0 + r][c0 + c] (zero outside the matrix)
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      bs[r * LS + c] = (r < k_valid && c < cols_valid) ? af[(size_t)(k0 + r) * m.n + c0 + c] : 0.0;
+    }
+    __syncthreads();
+    gemm_32x64<false>(as, bs, wave, lane, acc);
+    __syncthreads();
+  }
+  // C/D map: col = lane & 15, row = (lane >> 4) + 4 reg
+  const int col = c0 + 16 * wave + (lane & 15);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * t + (lane >> 4) + 4 * r;
+      if (row < rows_valid) {
+        const int j = j0 + row;
+        const long long off = ((long long)j * m.folds + f) * m.np + col;
+        const double lam = m.lams[j / m.d];
+        m.q[off] = col < m.n ? acc[t][r] * m.inv_n[f] + lam * m.p[off] : 0.0;
+      }
+    }
+}
+
+struct LosoTrsm {
+  const double* l;        // [n_lambda][np][np] Cholesky factors (lower)
+  const double* linv;     // [n_lambda][nblk][64][64] inverses of the diagonal blocks
+  double* v;              // rows, updated in place (the not-yet-solved blocks)
+  double* out;            // rows: the solved blocks
+  int np, nblk, k, rows_per_lambda;
+};
+
+// One block step of a triangular substitution with many right-hand-side rows.
+//   forward (L y = b, k ascending):   y_k = b_k Linv_kk^T ; b_i -= y_k L_ik^T   for i > k
+//   backward (L^T w = y, k descending): w_k = y_k Linv_kk ; y_m -= w_k L_km     for m < k
+// grid: (blocks still to update + 1, n_lambda, row chunks); workgroup 0 publishes the solved
+// block to `out`, the others update their block in `v` (every workgroup forms the solved block
+// itself: one 32 x 64 x 64 product).
+template <bool kBack>
+__global__ __launch_bounds__(256) void loso_trsm_kernel(LosoTrsm t) {
+  __shared__ double as[kLosoRows * LS];
+  __shared__ double ys[kLosoRows * LS];
+  __shared__ double bs[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lam = blockIdx.y, chunk = blockIdx.z;
+  const int r0 = chunk * kLosoRows;
+  const int rows_valid = t.rows_per_lambda - r0 < kLosoRows ? t.rows_per_lambda - r0 : kLosoRows;
+  double* vrows = t.v + ((long long)lam * t.rows_per_lambda + r0) * t.np;
+  double* orows = t.out + ((long long)lam * t.rows_per_lambda + r0) * t.np;
+  const double* lmat = t.l + (size_t)lam * t.np * t.np;
+  const int k0 = t.k * NB;
+  rows_to_lds(as, vrows + k0, t.np, rows_valid, NB, tid);
+  tile_to_lds(bs, t.linv + ((size_t)lam * t.nblk + t.k) * NB * NB, NB, NB, tid);
+  __syncthreads();
+  f64x4 acc[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
+  gemm_32x64<!kBack>(as, bs, wave, lane, acc);           // forward: . Linv^T ; backward: . Linv
+  const int ccol = 16 * wave + (lane & 15);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ys[(16 * s + (lane >> 4) + 4 * r) * LS + ccol] = acc[s][r];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int idx = tid; idx < kLosoRows * NB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      if (r < rows_valid) orows[(long long)r * t.np + k0 + c] = ys[r * LS + c];
+    }
+    return;
+  }
+  // the block this workgroup updates: forward i = k + blockIdx.x, backward m = k - blockIdx.x
+  const int bi = kBack ? t.k - (int)blockIdx.x : t.k + (int)blockIdx.x;
+  // forward: tile L[bi][k] (rows of block bi, columns of block k), used as . L_ik^T  (NT)
+  // backward: tile L[k][bi], used as . L_km (NN)
+  const double* tile = kBack ? lmat + (size_t)k0 * t.np + (size_t)bi * NB
+                             : lmat + (size_t)bi * NB * t.np + k0;
+  tile_to_lds(bs, tile, t.np, NB, tid);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
+  gemm_32x64<!kBack>(ys, bs, wave, lane, acc);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * s + (lane >> 4) + 4 * r;
+      if (row < rows_valid) vrows[(long long)row * t.np + (size_t)bi * NB + ccol] -= acc[s][r];
+    }
+}
+
+// Row-wise pieces of the CG iteration.  One workgroup per row.
+//   stage 0 (start):  x = 0 ; r = b ; bb = b . b
+//   stage 1:          rz = r . z ; p = z                        (first direction)
+//   stage 2:          alpha = rz / (p . q) ; x += alpha p ; r -= alpha q
+//   stage 3:          rz' = r . z ; beta = rz' / rz ; p = z + beta p ; rz = rz'
+//   stage 4 (end):    flag |= (r . r > tol^2 bb)
+struct LosoVec {
+  double *x, *r, *z, *p, *q;
+  const double* b;
+  double *rz, *bb;
+  int np, stage;
+  double tol2;
+  int* flag;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const double s = red[0];
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(256) void loso_vec_kernel(LosoVec v) {
+  __shared__ double red[256];
+  const long long row = blockIdx.x;
+  const long long o = row * v.np;
+  const int tid = threadIdx.x;
+  if (v.stage == 0) {
+    double s = 0.0;
+    for (int i = tid; i < v.np; i += 256) {
+      const double bi = v.b[o + i];
+      v.x[o + i] = 0.0; v.r[o + i] = bi; s += bi * bi;
+    }
+    s = block_sum(s, red);
+    if (tid == 0) v.bb[row] = s;
+  } else if (v.stage == 1) {
+    double s = 0.0;
+    for (int i = tid; i < v.np; i += 256) { const double zi = v.z[o + i]; s += v.r[o + i] * zi; v.p[o + i] = zi; }
+    s = block_sum(s, red);
+    if (tid == 0) v.rz[row] = s;
+  } else if (v.stage == 2) {
+    double s = 0.0;
+    for (int i = tid; i < v.np; i += 256) s += v.p[o + i] * v.q[o + i];
+    s = block_sum(s, red);
+    // (a converged or empty system: p . q = 0 -> leave it alone)
+    const double alpha = s > 0.0 ? v.rz[row] / s : 0.0;
+    for (int i = tid; i < v.np; i += 256) { v.x[o + i] += alpha * v.p[o + i]; v.r[o + i] -= alpha * v.q[o + i]; }
+  } else if (v.stage == 3) {
+    double s = 0.0;
+    for (int i = tid; i < v.np; i += 256) s += v.r[o + i] * v.z[o + i];
+    s = block_sum(s, red);
+    const double old = v.rz[row];
+    const double beta = old > 0.0 ? s / old : 0.0;
+    for (int i = tid; i < v.np; i += 256) v.p[o + i] = v.z[o + i] + beta * v.p[o + i];
+    __syncthreads();
+    if (tid == 0) v.rz[row] = s;
+  } else {
+    double s = 0.0;
+    for (int i = tid; i < v.np; i += 256) s += v.r[o + i] * v.r[o + i];
+    s = block_sum(s, red);
+    if (tid == 0 && !(s <= v.tol2 * v.bb[row])) atomicExch(v.flag, 1);
+  }
+}
+
+// b rows [lambda][q][fold][np] = xty_f[:, q] / n_f (the same for every lambda), zero padded
+__global__ void loso_rhs_kernel(const double* __restrict__ xty, const double* __restrict__ inv_n, int n,
+                                int d, int np, int folds, int n_lambda, double* __restrict__ b) {
+  const long long total = (long long)n_lambda * d * folds * np;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % np);
+    const long long row = i / np;
+    const int f = (int)(row % folds);
+    const int q = (int)((row / folds) % d);
+    b[i] = c < n ? xty[((size_t)f * n + c) * d + q] * inv_n[f] : 0.0;
+  }
+}
+
+// w [fold][lambda][k1][d], bias [fold][lambda][d] (float32) from the solution rows
+__global__ void loso_emit_kernel(const double* __restrict__ x, int k1, int d, int np, int folds,
+                                 int n_lambda, float* __restrict__ w, float* __restrict__ bias) {
+  const long long total = (long long)folds * n_lambda * (k1 + 1) * d;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % d);
+    const int r = (int)((i / d) % (k1 + 1));
+    const int lam = (int)((i / ((long long)d * (k1 + 1))) % n_lambda);
+    const int f = (int)(i / ((long long)d * (k1 + 1) * n_lambda));
+    const float v = (float)x[(((long long)lam * d + q) * folds + f) * np + r];
+    const long long sys = (long long)f * n_lambda + lam;
+    if (r < k1) w[((size_t)sys * k1 + r) * d + q] = v;
+    else bias[(size_t)sys * d + q] = v;
+  }
+}
+
 }  // namespace
 
 // ---- Cholesky whitening for the CCA dense stage (eig.hip: td_cca_solve) -------------------------
@@ -1145,6 +1422,137 @@ int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, 
   TD_HIP(h, hipMemcpyAsync(h->host_flags + slot, h->dev_flags + slot, sizeof(int),
                            hipMemcpyDeviceToHost, h->stream));
   *singular_flag_host = h->host_flags + slot;
+  return TD_OK;
+}
+
+
+// The (fold x lambda) systems of a leave-one-out sweep by preconditioned conjugate gradients
+// (kernels and rationale above: loso_matvec_kernel).  Synchronous; *status_host = 0 when every
+// system reached the relative residual `tol`, 1 when the preconditioner was not positive
+// definite or some system did not converge in max_iter iterations (the outputs are then not to
+// be used: the caller falls back to td_ridge_solve_multi).
+int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, int n_folds,
+                        const double* lambdas_host, int n_lambda, int max_iter, double tol,
+                        float* w_dev, float* b_dev, int* status_host, int* iterations_host) {
+  if (!h || !total || !folds || !lambdas_host || !w_dev || !b_dev || !status_host)
+    return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_loso: NULL argument");
+  TD_REQUIRE(h, n_folds > 0 && n_lambda > 0 && max_iter > 0 && tol > 0.0, "td_ridge_solve_loso: bad sizes");
+  int k1 = 0, d = 0;
+  int64_t frames_total = 0;
+  td_stats_layout(total, &k1, &d, &frames_total);
+  TD_REQUIRE(h, d > 0 && d <= kMaxRhs, "td_ridge_solve_loso: outputs per solve must be in [1, %d]", kMaxRhs);
+  if (frames_total <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve_loso: no data accumulated");
+  std::vector<double> inv_n((size_t)n_folds);
+  for (int f = 0; f < n_folds; ++f) {
+    int kf = 0, df = 0;
+    int64_t ff = 0;
+    TD_REQUIRE(h, folds[f], "td_ridge_solve_loso: NULL statistics");
+    td_stats_layout(folds[f], &kf, &df, &ff);
+    TD_REQUIRE(h, kf == k1 && df == d, "td_ridge_solve_loso: layouts differ");
+    if (ff <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve_loso: a fold has no data");
+    inv_n[f] = 1.0 / (double)ff;
+  }
+  const int n = k1 + 1, np = (int)td_round_up(n, NB), nblk = np / NB;
+  const size_t nn = (size_t)n * n;
+  const long long rows = (long long)n_lambda * d * n_folds;
+  const int rows_per_lambda = d * n_folds;
+  // workspace
+  auto carve_all = [&](char* base, double** af, double** xty, double** mt, double** invn, double** lams,
+                       double** pa, double** linv, double** tolv, double** rt, double** sol,
+                       double* (*vec)[9], double** rz, double** bb) -> size_t {
+    char* p = base;
+    auto take = [&](size_t count) { double* q = reinterpret_cast<double*>(p); p += td_round_up((int64_t)(sizeof(double) * count), 256); return q; };
+    *af = take(nn * n_folds); *xty = take((size_t)n * d * n_folds); *mt = take(nn);
+    *invn = take(n_folds); *lams = take(n_lambda);
+    *pa = take((size_t)n_lambda * np * np); *linv = take((size_t)n_lambda * nblk * NB * NB);
+    *tolv = take(td_round_up(n_lambda, 32)); *rt = take((size_t)n_lambda * kMaxRhs * np);
+    *sol = take((size_t)n_lambda * kMaxRhs * np);
+    for (int i = 0; i < 9; ++i) (*vec)[i] = take((size_t)rows * np);
+    *rz = take(rows); *bb = take(rows);
+    return (size_t)(p - base);
+  };
+  double *af, *xty, *mt, *invn, *lams, *pa, *linv, *tolv, *rt, *sol, *rz, *bb;
+  double* vec[9];
+  void* base = nullptr;
+  TD_TRY(td_workspace(h, carve_all(nullptr, &af, &xty, &mt, &invn, &lams, &pa, &linv, &tolv, &rt, &sol,
+                                   &vec, &rz, &bb), &base));
+  carve_all(reinterpret_cast<char*>(base), &af, &xty, &mt, &invn, &lams, &pa, &linv, &tolv, &rt, &sol, &vec,
+            &rz, &bb);
+  double *X = vec[0], *R = vec[1], *Z = vec[2], *P = vec[3], *Q = vec[4], *B = vec[5], *V = vec[6], *Y = vec[7];
+  TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, lams));
+  TD_TRY(td_upload_async(h, inv_n.data(), sizeof(double) * n_folds, invn));
+  // the preconditioners: Cholesky factors of M_total / N + lambda I
+  TD_TRY(td_stats_moments(h, total, mt, nullptr, nullptr, nullptr, nullptr));
+  hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), (unsigned)n_lambda), dim3(256), 0, h->stream, mt,
+                     0LL, n, np, 1.0 / (double)frames_total, lams, pa);
+  TD_HIP(h, hipMemsetAsync(rt, 0, sizeof(double) * (size_t)n_lambda * kMaxRhs * np, h->stream));
+  TD_TRY(chol_factor_forward(h, pa, rt, sol, linv, tolv, np, 1, n_lambda, nullptr, kMaxRhs, n));
+  // the folds' dense moments and right-hand sides
+  for (int f = 0; f < n_folds; ++f)
+    TD_TRY(td_stats_moments(h, folds[f], af + (size_t)f * nn, xty + (size_t)f * n * d, nullptr, nullptr, nullptr));
+  hipLaunchKernelGGL(loso_rhs_kernel, dim3(1024), dim3(256), 0, h->stream, xty, invn, n, d, np, n_folds,
+                     n_lambda, B);
+  LosoVec lv;
+  lv.x = X; lv.r = R; lv.z = Z; lv.p = P; lv.q = Q; lv.b = B; lv.rz = rz; lv.bb = bb; lv.np = np;
+  lv.tol2 = tol * tol; lv.flag = h->dev_flag;
+  auto vec_stage = [&](int stage) {
+    lv.stage = stage;
+    hipLaunchKernelGGL(loso_vec_kernel, dim3((unsigned)rows), dim3(256), 0, h->stream, lv);
+  };
+  const unsigned chunks = (unsigned)td_ceil_div(rows_per_lambda, kLosoRows);
+  auto precondition = [&]() -> int {        // Z = (P + lambda I)^-1 R
+    TD_HIP(h, hipMemcpyAsync(V, R, sizeof(double) * (size_t)rows * np, hipMemcpyDeviceToDevice, h->stream));
+    LosoTrsm t;
+    t.l = pa; t.linv = linv; t.np = np; t.nblk = nblk; t.rows_per_lambda = rows_per_lambda;
+    t.v = V; t.out = Y;
+    for (int k = 0; k < nblk; ++k) {
+      t.k = k;
+      hipLaunchKernelGGL(loso_trsm_kernel<false>, dim3((unsigned)(nblk - k), (unsigned)n_lambda, chunks),
+                         dim3(256), 0, h->stream, t);
+    }
+    t.v = Y; t.out = Z;
+    for (int k = nblk - 1; k >= 0; --k) {
+      t.k = k;
+      hipLaunchKernelGGL(loso_trsm_kernel<true>, dim3((unsigned)(k + 1), (unsigned)n_lambda, chunks),
+                         dim3(256), 0, h->stream, t);
+    }
+    return TD_OK;
+  };
+  LosoMatvec mv;
+  mv.a = af; mv.p = P; mv.q = Q; mv.inv_n = invn; mv.lams = lams;
+  mv.n = n; mv.np = np; mv.folds = n_folds; mv.n_lambda = n_lambda; mv.d = d;
+  const dim3 mv_grid((unsigned)nblk, (unsigned)n_folds, (unsigned)td_ceil_div(n_lambda * d, kLosoRows));
+  vec_stage(0);
+  TD_TRY(precondition());
+  vec_stage(1);
+  // Convergence is looked at every `check` iterations (a device-to-host read: the only
+  // synchronisation of the solve).
+  const int check = 4;
+  int it = 0, flag = 1;
+  while (it < max_iter) {
+    const int upto = it + check < max_iter ? it + check : max_iter;
+    for (; it < upto; ++it) {
+      hipLaunchKernelGGL(loso_matvec_kernel, mv_grid, dim3(256), 0, h->stream, mv);
+      vec_stage(2);
+      TD_TRY(precondition());
+      vec_stage(3);
+    }
+    // (the flag also carries "preconditioner not positive definite" from the factorisation)
+    int pd_flag = 0;
+    TD_HIP(h, hipMemcpyAsync(&pd_flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+    if (pd_flag) { flag = 1; break; }
+    vec_stage(4);
+    TD_HIP(h, hipMemcpyAsync(&flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+    if (!flag) break;
+    if (it < max_iter) TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
+  }
+  hipLaunchKernelGGL(loso_emit_kernel, dim3(1024), dim3(256), 0, h->stream, X, k1, d, np, n_folds, n_lambda,
+                     w_dev, b_dev);
+  TD_HIP(h, hipGetLastError());
+  *status_host = flag ? 1 : 0;
+  if (iterations_host) *iterations_host = it;
   return TD_OK;
 }
 

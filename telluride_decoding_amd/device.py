@@ -314,6 +314,26 @@ class LagStats(object):
                                        _ptr(b), ctypes.byref(ptr)))
     return w, b, (lambda: int(ptr[0]))
 
+  @staticmethod
+  def ridge_solve_loso(total, folds, lambdas, max_iter=40, tol=1e-12, handle=None):
+    """The (fold x lambda) systems of a leave-one-out sweep by preconditioned conjugate gradients
+    (td_ridge_solve_loso): `total` = statistics of all recordings, folds[f] = training statistics
+    of fold f.  Returns (W [n_folds, n_lambda, k1, d], b [n_folds, n_lambda, d], iterations), or
+    None when the solver reports that it did not converge / the preconditioner is not positive
+    definite (the caller then takes the direct batched solve)."""
+    h = handle or total.h
+    lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
+    w = h.empty((len(folds), len(lam), total.k1, total.d), 'float32')
+    b = h.empty((len(folds), len(lam), total.d), 'float32')
+    arr = (ctypes.c_void_p * len(folds))(*[s.ptr for s in folds])
+    status, iters = ctypes.c_int(0), ctypes.c_int(0)
+    h.check(h.lib.td_ridge_solve_loso(h.ptr, total.ptr, arr, len(folds), lam_p, len(lam), int(max_iter),
+                                      float(tol), _ptr(w), _ptr(b), ctypes.byref(status),
+                                      ctypes.byref(iters)))
+    if status.value:
+      return None
+    return w, b, int(iters.value)
+
   def cca_solve(self, denom, regularization, dim, eps_eig=1e-12, handle=None):
     """CCA dense stage on the device (td_cca_solve; reference cca.py:337-367): returns float32
     device tensors (rot_x [k1, dim], rot_y [k2, dim], mean_x [1, k1], mean_y [1, k2], e [dim])

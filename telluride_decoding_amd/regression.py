@@ -45,6 +45,9 @@ def calculate_stats(values):
 
 # Workspace budget of one batched solve (bytes).  288 GB of HBM make a few GB free; the budget
 # keeps wide configurations (more channels x lags) from asking for tens of GB.
+# The preconditioned-CG solve of the whole sweep (td_ridge_solve_loso); False = always the direct
+# batched Cholesky.
+USE_PCG = True
 SOLVE_WORKSPACE_BYTES = 6 << 30
 MAX_SYSTEMS_PER_SOLVE = 160
 
@@ -176,15 +179,54 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
       g -= 1
     train.combine(parts)
 
-  # Folds go through the solver in chunks: (folds in the chunk) x (lambdas) systems in ONE
-  # batched Cholesky -- the late block steps of the factorisation cannot fill the chip with the
+  def evaluate(f, w, b):
+    """Held-out scores of fold f for its n_lam weight sets w [n_lam, K, d], b [n_lam, d]."""
+    u = held_used[f]
+    if u == 0:
+      scores.append(h.zeros((n_lam,), 'float64') + float('nan'))
+      return
+    k = int(w.shape[1])
+    w_all = w.permute(1, 0, 2).reshape(k, n_lam * d).contiguous()
+    xf, yf = file_arrays(f)
+    pred = dev.predict_fir(xf, [0, int(xf.shape[0])], w_all, b.reshape(-1).contiguous(),
+                           dataset.pre, dataset.post, handle=h, input_offset=off)
+    # columns = (lambda, output); the truth repeats per lambda.  pearson_correlation_first =
+    # output 0 of each model, with the zero rule taken over that model's d outputs
+    p_all = pred[:u] if pred.shape[0] != u else pred
+    y_all = yf[dy:dy + u].repeat(1, n_lam)
+    sums = dev.window_sums(y_all, p_all, [0, u], bsz, bsz, handle=h)
+    r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)   # [minibatches, Lambda * d]
+    scores.append(r[:, ::d].mean(dim=0))
+
+  # (1) All (fold, lambda) systems at once by preconditioned conjugate gradients: the folds'
+  # covariances differ from the total's by 1 / folds, so ONE Cholesky factor per lambda (of the
+  # total covariance) preconditions every fold's system with that lambda -- Lambda factorisations
+  # and ~10 iterations of [products with the folds' matrices + triangular substitutions] instead
+  # of folds x Lambda factorisations (td_ridge_solve_loso; C5: the 4 batched solves were 60 of the
+  # sweep's 95 ms).  Falls through to (2) when the solver reports no convergence.
+  done = False
+  if hasattr(dev.LagStats, 'ridge_solve_loso') and my_folds and USE_PCG:
+    trains_all = [proto.like() for _ in my_folds]
+    for train, f in zip(trains_all, my_folds):
+      fold_statistics(f, train)
+    total = proto.like().combine(stats)
+    out = dev.LagStats.ridge_solve_loso(total, trains_all, lambdas, handle=h)
+    if out is not None:
+      w_all_folds, b_all_folds, _ = out
+      for fi, f in enumerate(my_folds):
+        evaluate(f, w_all_folds[fi], b_all_folds[fi])
+      done = True
+    del trains_all
+
+  # (2) Folds go through the direct solver in chunks: (folds in the chunk) x (lambdas) systems in
+  # ONE batched Cholesky -- the late block steps of the factorisation cannot fill the chip with the
   # 20 systems of a single fold (measured at C5: 32 solves of 20 systems 110 ms).  The chunk is
   # sized by BYTES: a system takes an identity-padded (ceil(n / 64) * 64)^2 float64 workspace
   # that the handle keeps (grow-only), so ~160 systems of n = 2049 are 5.7 GB, but the same
   # count at 64 ch x 64 lags would be 23 GB.
   chunk = _fold_chunk(len(my_folds), n_lam, proto.k1 + 1)
-  trains = [proto.like() for _ in range(chunk)]
-  c0 = 0
+  trains = [] if done else [proto.like() for _ in range(chunk)]
+  c0 = len(my_folds) if done else 0
   while c0 < len(my_folds):
     folds = my_folds[c0:c0 + chunk]
     for train, f in zip(trains, folds):
@@ -201,23 +243,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     outstanding.append((h.record_event(), flag, folds[0]))
     check(keep=4)
     for fi, f in enumerate(folds):
-      w, b = w_all_folds[fi], b_all_folds[fi]
-      u = held_used[f]
-      if u == 0:
-        scores.append(h.zeros((n_lam,), 'float64') + float('nan'))
-        continue
-      k = int(w.shape[1])
-      w_all = w.permute(1, 0, 2).reshape(k, n_lam * d).contiguous()
-      xf, yf = file_arrays(f)
-      pred = dev.predict_fir(xf, [0, int(xf.shape[0])], w_all, b.reshape(-1).contiguous(),
-                             dataset.pre, dataset.post, handle=h, input_offset=off)
-      # columns = (lambda, output); the truth repeats per lambda.  pearson_correlation_first =
-      # output 0 of each model, with the zero rule taken over that model's d outputs
-      p_all = pred[:u] if pred.shape[0] != u else pred
-      y_all = yf[dy:dy + u].repeat(1, n_lam)
-      sums = dev.window_sums(y_all, p_all, [0, u], bsz, bsz, handle=h)
-      r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)   # [minibatches, Lambda * d]
-      scores.append(r[:, ::d].mean(dim=0))
+      evaluate(f, w_all_folds[fi], b_all_folds[fi])
   check(keep=0)
   rows = (np.stack([s.cpu().numpy() for s in scores]) if scores else np.zeros((0, n_lam)))
   # 5. gather
