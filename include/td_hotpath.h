@@ -125,6 +125,8 @@ int td_probe_bf16_mfma(td_handle* h, int split_shaped, double* tflops);
  */
 int td_stats_create(td_handle* h, int c1, int pre1, int post1, int c2, int pre2,
                     int post2, int d, td_stats** out);
+/* Stream-ordered and non-blocking: the memory returns to the device's pool after the work
+ * queued so far on h's stream and on the streams of the process's other handles. */
 int td_stats_destroy(td_handle* h, td_stats* s);
 int td_stats_reset(td_handle* h, td_stats* s);
 

@@ -1,6 +1,9 @@
 // Handle lifecycle, error reporting, memory and timing helpers of the C-ABI.
 #include "td_common.h"
 
+#include <algorithm>
+#include <mutex>
+
 thread_local std::string td_global_error;
 
 int td_fail(td_handle* h, int code, const char* fmt, ...) {
@@ -12,6 +15,48 @@ int td_fail(td_handle* h, int code, const char* fmt, ...) {
   td_global_error = buf;
   if (h) h->error = buf;
   return code;
+}
+
+namespace {
+std::mutex g_handles_mu;
+std::vector<td_handle*> g_handles;      // live handles of the process (td_create / td_destroy)
+}
+
+int td_order_after_others(td_handle* h) {
+  std::lock_guard<std::mutex> lock(g_handles_mu);
+  for (td_handle* o : g_handles) {
+    if (o == h || o->device != h->device || o->stream == h->stream || !o->order_event) continue;
+    TD_HIP(h, hipEventRecord(o->order_event, o->stream));
+    TD_HIP(h, hipStreamWaitEvent(h->stream, o->order_event, 0));
+  }
+  return TD_OK;
+}
+
+int td_alloc_async(td_handle* h, size_t bytes, void** out) {
+  static std::once_flag once[64];
+  std::call_once(once[h->device & 63], [&]() {
+    // keep freed blocks in the pool (the default threshold of 0 hands them back to the driver
+    // at the next synchronisation, which is the cost this allocator is here to avoid)
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, h->device) == hipSuccess && pool) {
+      uint64_t keep = ~0ull;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+  });
+  *out = nullptr;
+  const hipError_t e = hipMallocAsync(out, bytes, h->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return td_fail(h, TD_ERR_NOMEM, "hipMallocAsync(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return TD_OK;
+}
+
+int td_free_async(td_handle* h, void* p) {
+  if (!p) return TD_OK;
+  TD_TRY(td_order_after_others(h));
+  TD_HIP(h, hipFreeAsync(p, h->stream));
+  return TD_OK;
 }
 
 int td_scratch(td_handle* h, size_t bytes, void** out) {
@@ -181,14 +226,23 @@ int td_create(int device_id, td_handle** out) {
   h->stream = h->own_stream;
   TD_HIP(h, hipEventCreate(&h->ev_start));
   TD_HIP(h, hipEventCreate(&h->ev_stop));
+  TD_HIP(h, hipEventCreateWithFlags(&h->order_event, hipEventDisableTiming));
   TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flag), sizeof(int) * 64));
   TD_HIP(h, hipMemset(h->dev_flag, 0, sizeof(int) * 64));
+  {
+    std::lock_guard<std::mutex> lock(g_handles_mu);
+    g_handles.push_back(h);
+  }
   *out = h;
   return TD_OK;
 }
 
 int td_destroy(td_handle* h) {
   if (!h) return TD_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_handles_mu);
+    g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), h), g_handles.end());
+  }
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   if (h->scratch) hipFree(h->scratch);
@@ -205,6 +259,7 @@ int td_destroy(td_handle* h) {
   if (h->host_flags) hipHostFree(h->host_flags);
   if (h->ev_start) hipEventDestroy(h->ev_start);
   if (h->ev_stop) hipEventDestroy(h->ev_stop);
+  if (h->order_event) hipEventDestroy(h->order_event);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return TD_OK;

@@ -631,20 +631,21 @@ int ensure_window_capacity(td_handle* h, td_stats* s, int64_t need) {
   while (cap < need) cap *= 2;
   const size_t per1 = (size_t)2 * 2 * s->hw * s->c1 * sizeof(float);
   const size_t per2 = (size_t)2 * 2 * s->hw * s->c2 * sizeof(float);
-  float* n1 = nullptr;
-  float* n2 = nullptr;
-  TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&n1), per1 * cap));
-  if (s->c2) TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&n2), per2 * cap));
+  void* n1 = nullptr;
+  void* n2 = nullptr;
+  TD_TRY(td_alloc_async(h, per1 * cap, &n1));
+  if (s->c2) TD_TRY(td_alloc_async(h, per2 * cap, &n2));
   if (s->n_files) {
+    // (the old windows may have been written from another handle's stream)
+    TD_TRY(td_order_after_others(h));
     TD_HIP(h, hipMemcpyAsync(n1, s->win1, per1 * s->n_files, hipMemcpyDeviceToDevice, h->stream));
     if (s->c2)
       TD_HIP(h, hipMemcpyAsync(n2, s->win2, per2 * s->n_files, hipMemcpyDeviceToDevice, h->stream));
   }
-  TD_HIP(h, hipStreamSynchronize(h->stream));
-  if (s->win1) TD_HIP(h, hipFree(s->win1));
-  if (s->win2) TD_HIP(h, hipFree(s->win2));
-  s->win1 = n1;
-  s->win2 = n2;
+  TD_TRY(td_free_async(h, s->win1));
+  TD_TRY(td_free_async(h, s->win2));
+  s->win1 = reinterpret_cast<float*>(n1);
+  s->win2 = reinterpret_cast<float*>(n2);
   s->cap_files = cap;
   return TD_OK;
 }
@@ -747,11 +748,13 @@ int td_stats_create(td_handle* h, int c1, int pre1, int post1, int c2, int pre2,
   s->off_gxy = o; o += c2 ? (int64_t)(s->l1 + s->l2 - 1) * c1 * c2 : 0;
   s->off_gyo = o; o += (int64_t)s->l2 * c2;
   s->g_len = o;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->g), sizeof(double) * s->g_len);
-  if (e != hipSuccess) {
+  void* g = nullptr;
+  const int rc = td_alloc_async(h, sizeof(double) * s->g_len, &g);
+  if (rc != TD_OK) {
     delete s;
-    return td_fail(h, TD_ERR_NOMEM, "statistics allocation failed: %s", hipGetErrorString(e));
+    return rc;
   }
+  s->g = reinterpret_cast<double*>(g);
   TD_HIP(h, hipMemsetAsync(s->g, 0, sizeof(double) * s->g_len, h->stream));
   *out = s;
   return TD_OK;
@@ -759,10 +762,19 @@ int td_stats_create(td_handle* h, int c1, int pre1, int post1, int c2, int pre2,
 
 int td_stats_destroy(td_handle* h, td_stats* s) {
   if (!s) return TD_OK;
-  if (h) hipStreamSynchronize(h->stream);
-  if (s->g) hipFree(s->g);
-  if (s->win1) hipFree(s->win1);
-  if (s->win2) hipFree(s->win2);
+  if (h) {
+    // stream-ordered: after everything queued so far on this and the other handles' streams;
+    // nothing waits (td_free_async)
+    td_order_after_others(h);
+    if (s->g) hipFreeAsync(s->g, h->stream);
+    if (s->win1) hipFreeAsync(s->win1, h->stream);
+    if (s->win2) hipFreeAsync(s->win2, h->stream);
+  } else {
+    hipDeviceSynchronize();
+    if (s->g) hipFree(s->g);
+    if (s->win1) hipFree(s->win1);
+    if (s->win2) hipFree(s->win2);
+  }
   delete s;
   return TD_OK;
 }
