@@ -139,12 +139,16 @@ template <int NCH, bool kVec4>
 __global__ __launch_bounds__(kThreads, 2) void predict_fir_mfma_kernel(
     const float* __restrict__ x, long long ldx, const FileDesc* __restrict__ files, int n_files,
     long long n_strips, int strip_len, int c, int pre, int post, const float* __restrict__ w,
-    const float* __restrict__ bias, int d_total, int q0, int dq, int tpq, int ring,
+    const float* __restrict__ bias, int d_total, int dq_max, int tpq, int ring,
     float* __restrict__ out, long long ldout) {
   extern __shared__ __attribute__((aligned(16))) float fir_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = pre + 1 + post;
+  // blockIdx.y: the group of <= dq_max outputs this workgroup computes (the 20 lambdas of a
+  // held-out recording were 7 launches of 62 workgroups, one after the other)
+  const int q0 = (int)blockIdx.y * dq_max;
+  const int dq = d_total - q0 < dq_max ? d_total - q0 : dq_max;
   const int nt_count = dq * tpq;
 
   // ---- weights, split into bf16 pieces, in MFMA B-operand order:
@@ -1734,13 +1738,11 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     // of a held-out recording: 7 launches of ~120 workgroups -- took a lone call from 245 to
     // 163 us but made the leave-one-out sweep inside a process with many live streams 20 % slower
     // (0.097 -> 0.117 s in bench.py): one stream.)
-    for (int q0 = 0; q0 < d; q0 += dq_max) {
-      const int dq = d - q0 < dq_max ? d - q0 : dq_max;
-      hipLaunchKernelGGL((predict_fir_mfma_kernel<1, true>), dim3(blocks), dim3(kThreads),
-                         lds_for(dq), h->stream, x, (long long)ldx, df, num_files, n_strips,
-                         (int)strip, c, pre, post, w, bias, d, q0, dq, tpq, ring, out,
-                         (long long)ldout);
-    }
+    hipLaunchKernelGGL((predict_fir_mfma_kernel<1, true>),
+                       dim3(blocks, (unsigned)td_ceil_div(d, dq_max)), dim3(kThreads),
+                       lds_for(dq_max), h->stream, x, (long long)ldx, df, num_files, n_strips,
+                       (int)strip, c, pre, post, w, bias, d, dq_max, tpq, ring, out,
+                       (long long)ldout);
     TD_HIP(h, hipGetLastError());
     return TD_OK;
   }

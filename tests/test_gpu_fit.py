@@ -967,6 +967,82 @@ def test_ridge_solve_multi_equals_single_solves(dev):
     dev.LagStats.ridge_solve_multi(sts[:2] + [zero], [0.0])
 
 
+def _loso_case(dev, rng, n_files, c, pre, post, d, alike=True, frames=1200):
+  """Per-file statistics, the folds' training sums and the total for a leave-one-out sweep."""
+  h = dev.default_handle()
+  mix = rng.standard_normal((c, c)) * 0.3 + np.eye(c)
+  files = []
+  for i in range(n_files):
+    n = frames + 37 * i
+    x = (rng.standard_normal((n, c)) @ (mix if alike else mix * (1 + 3 * (i % 2)))).astype(np.float32)
+    y = (x[:, :d] * 0.5 + 0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    st = dev.LagStats(c, pre, post, d=d)
+    st.accumulate(h.to_device(x), None, h.to_device(y))
+    files.append(st)
+  proto = files[0]
+  folds = [proto.like().combine([s for g, s in enumerate(files) if g != f]) for f in range(n_files)]
+  total = proto.like().combine(files)
+  return files, folds, total
+
+
+@pytest.mark.parametrize('c,pre,post,d,n_files,frames', [
+    (8, 0, 7, 1, 5, 1200), (12, 2, 3, 2, 4, 1200), (64, 0, 31, 1, 6, 6000)])
+def test_loso_pcg_solver_equals_the_direct_solves(dev, c, pre, post, d, n_files, frames):
+  """td_ridge_solve_loso (preconditioned CG over all folds x lambdas, one Cholesky factor per
+  lambda of the total covariance) against td_ridge_solve_multi (one factorisation per system):
+  the same float32 weights up to the last bits, for well and badly conditioned lambdas, ragged
+  file lengths, several outputs, and n = 2049 (padding to 2112)."""
+  rng = np.random.default_rng(31)
+  _, folds, total = _loso_case(dev, rng, n_files, c, pre, post, d, frames=frames)
+  lams = [1e-6, 1e-2, 1.0, 1e3]
+  out = dev.LagStats.ridge_solve_loso(total, folds, lams)
+  assert out is not None, 'the PCG solver reported no convergence on a well-posed sweep'
+  w, b, iters = out
+  assert 1 <= iters <= 40
+  w0, b0 = dev.LagStats.ridge_solve_multi(folds, lams)
+  assert tuple(w.shape) == tuple(w0.shape) and tuple(b.shape) == tuple(b0.shape)
+  w, w0, b, b0 = (t.cpu().numpy().astype(np.float64) for t in (w, w0, b, b0))
+  for li in range(len(lams)):
+    scale = np.abs(w0[:, li]).max()
+    assert np.abs(w[:, li] - w0[:, li]).max() <= 2e-6 * scale, (lams[li], iters)
+    assert np.abs(b[:, li] - b0[:, li]).max() <= 2e-6 * max(scale, np.abs(b0[:, li]).max())
+
+
+def test_loso_pcg_solver_reports_when_it_cannot_converge(dev):
+  """One iteration is not enough: status 1 -> None, and regression.jackknife_over_regularizations
+  then takes the direct batched solve (same results as with the solver switched off)."""
+  from telluride_decoding_amd import brain_data, regression
+  rng = np.random.default_rng(32)
+  _, folds, total = _loso_case(dev, rng, 4, 8, 0, 7, 1, alike=False)
+  assert dev.LagStats.ridge_solve_loso(total, folds, [1e-6, 1.0], max_iter=1, tol=1e-14) is None
+  # a preconditioner that is not positive definite (all-zero data, lambda = 0) is reported too
+  h = dev.default_handle()
+  zeros = []
+  for _ in range(3):
+    st = dev.LagStats(8, 0, 3, d=1)
+    st.accumulate(h.to_device(np.zeros((400, 8), np.float32)), None, h.to_device(np.zeros((400, 1), np.float32)))
+    zeros.append(st)
+  zf = [zeros[0].like().combine([s for g, s in enumerate(zeros) if g != f]) for f in range(3)]
+  assert dev.LagStats.ridge_solve_loso(zeros[0].like().combine(zeros), zf, [0.0]) is None
+  # the sweep end to end with and without the solver
+  c, n = 6, 900
+  trials = []
+  for i in range(5):
+    x = rng.standard_normal((n + 10 * i, c)).astype(np.float32)
+    y = (x[:, :1] + 0.2 * rng.standard_normal((x.shape[0], 1))).astype(np.float32)
+    trials.append((x, y, y, np.zeros((x.shape[0], 1), np.float32)))
+  ds = brain_data.Dataset(trials, 100, pre_context=0, post_context=3)
+  lams = [1e-4, 1e-1, 10.0]
+  with_pcg = regression.jackknife_over_regularizations(ds, lams)
+  old = regression.USE_PCG
+  regression.USE_PCG = False
+  try:
+    direct = regression.jackknife_over_regularizations(ds, lams)
+  finally:
+    regression.USE_PCG = old
+  np.testing.assert_allclose(with_pcg['all_runs'], direct['all_runs'], rtol=0, atol=2e-6)
+
+
 def test_bf16_mfma_probe_reports_a_rate(dev):
   """td_probe_bf16_mfma (bench.py's sustained-pipe figure): a plausible rate, below the nominal
   2516.6 TFLOP/s, for both kinds of operands (which of the two is faster depends on how warm
