@@ -332,6 +332,9 @@ def loso_leg(eeg, env):
       'workload': 'C5: LOSO x 20 lambdas, 32 subjects x 31 250 samples x 64 ch, 32 lags, one GPU',
       'seconds': best, 'fits': n_subj * len(lams), 'fits_per_s': n_subj * len(lams) / best,
       'best_lambda': float(top[1]), 'best_mean_r': float(top[0]),
+      'solver': dict(regression.LAST_SWEEP,
+                     what='pcg = td_ridge_solve_loso (one Cholesky factor per lambda of the total '
+                          'covariance preconditions CG on every fold); direct = batched Cholesky'),
       'inputs': 'resident in HBM (best of 3 sweeps)',
       'seconds_with_upload': with_upload, 'seconds_first_sweep': first,
       'upload': 'host->device copy of the recordings (264 MB, pageable) inside the timed region',

@@ -765,10 +765,9 @@ int td_stats_destroy(td_handle* h, td_stats* s) {
   if (h) {
     // stream-ordered: after everything queued so far on this and the other handles' streams;
     // nothing waits (td_free_async)
-    td_order_after_others(h);
-    if (s->g) hipFreeAsync(s->g, h->stream);
-    if (s->win1) hipFreeAsync(s->win1, h->stream);
-    if (s->win2) hipFreeAsync(s->win2, h->stream);
+    td_free_async(h, s->g);
+    td_free_async(h, s->win1);
+    td_free_async(h, s->win2);
   } else {
     hipDeviceSynchronize();
     if (s->g) hipFree(s->g);

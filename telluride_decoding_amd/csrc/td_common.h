@@ -114,10 +114,11 @@ int td_scratch(td_handle* h, size_t bytes, void** out);
 int td_workspace(td_handle* h, size_t bytes, void** out);
 // Stream-ordered device memory for objects that come and go inside a fit (the statistics of a
 // leave-one-out sweep: 67 hipFree calls were 20 ms of a 64 ms sweep, each one a device-wide
-// wait).  td_alloc_async returns memory usable by work queued on h->stream after the call;
-// td_free_async first orders h->stream after everything queued so far on the streams of the
+// wait).  td_free_async orders h->stream after everything queued so far on the streams of the
 // process's OTHER handles (td_order_after_others: the statistics of a pipelined fit are used
-// from two streams), then returns the block to HIP's pool in stream order.  Nothing waits.
+// from two streams), records an event there and keeps the block in a process-wide pool;
+// td_alloc_async hands a pooled block of the same size to a stream that first waits for that
+// event, else calls hipMalloc.  Neither waits on the host.
 int td_alloc_async(td_handle* h, size_t bytes, void** out);
 int td_free_async(td_handle* h, void* p);
 int td_order_after_others(td_handle* h);

@@ -48,6 +48,8 @@ def calculate_stats(values):
 # The preconditioned-CG solve of the whole sweep (td_ridge_solve_loso); False = always the direct
 # batched Cholesky.
 USE_PCG = True
+# How the last sweep of this process was solved: {'solver': 'pcg' | 'direct', 'iterations': n}
+LAST_SWEEP = {}
 SOLVE_WORKSPACE_BYTES = 6 << 30
 MAX_SYSTEMS_PER_SOLVE = 160
 
@@ -212,7 +214,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     total = proto.like().combine(stats)
     out = dev.LagStats.ridge_solve_loso(total, trains_all, lambdas, handle=h)
     if out is not None:
-      w_all_folds, b_all_folds, _ = out
+      w_all_folds, b_all_folds, iters = out
+      LAST_SWEEP.update(solver='pcg', iterations=int(iters))
       for fi, f in enumerate(my_folds):
         evaluate(f, w_all_folds[fi], b_all_folds[fi])
       done = True
@@ -226,6 +229,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   # count at 64 ch x 64 lags would be 23 GB.
   chunk = _fold_chunk(len(my_folds), n_lam, proto.k1 + 1)
   trains = [] if done else [proto.like() for _ in range(chunk)]
+  if not done:
+    LAST_SWEEP.update(solver='direct', iterations=0)
   c0 = len(my_folds) if done else 0
   while c0 < len(my_folds):
     folds = my_folds[c0:c0 + chunk]
@@ -245,7 +250,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     for fi, f in enumerate(folds):
       evaluate(f, w_all_folds[fi], b_all_folds[fi])
   check(keep=0)
-  rows = (np.stack([s.cpu().numpy() for s in scores]) if scores else np.zeros((0, n_lam)))
+  import torch
+  rows = (torch.stack(scores).cpu().numpy() if scores else np.zeros((0, n_lam)))   # one copy
   # 5. gather
   all_folds = distributed.gather_rows(rows, n_files, my_folds, group)     # [F, Lambda]
   results = collections.OrderedDict()
