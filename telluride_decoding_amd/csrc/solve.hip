@@ -1002,6 +1002,9 @@ struct LosoMatvec {
 
 // q_row = inv_n[f] * (p_row . A_f) + lambda * p_row for the rows (lambda, q) of fold f.
 // grid: (np / 64 column tiles, folds, ceil(n_lambda * d / 32))
+// The pass is HBM traffic (every A_f byte once: 1.07 GB at C5): the next 64 x 64 tile of A_f and
+// the next 32 x 64 piece of the rows are fetched into registers while the matrix cores work on
+// the current ones (load - barrier - product - barrier without that: 0.79 ms, 1.4 TB/s).
 __global__ __launch_bounds__(256) void loso_matvec_kernel(LosoMatvec m) {
   __shared__ double as[kLosoRows * LS];
   __shared__ double bs[NB * LS];
@@ -1021,16 +1024,33 @@ __global__ __launch_bounds__(256) void loso_matvec_kernel(LosoMatvec m) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
-  for (int kt = 0; kt < m.np / NB; ++kt) {
+  // thread (c = tid & 63, r0 = tid >> 6): rows r0 + 4 i of the A tile (16), rows r0 + 4 i of the
+  // row piece (8); a wave instruction reads one 512-byte row of the tile
+  const int c = tid & 63, r0 = tid >> 6;
+  double ta[16], tp[8];
+  auto fetch = [&](int kt) {
     const int k0 = kt * NB;
     const int k_valid = m.n - k0 < NB ? (m.n - k0 > 0 ? m.n - k0 : 0) : NB;
-    rows_to_lds(as, pf + k0, row_stride, rows_valid, k_valid, tid);
-    // A_f[k0 + r][c0 + c] (zero outside the matrix)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      bs[r * LS + c] = (r < k_valid && c < cols_valid) ? af[(size_t)(k0 + r) * m.n + c0 + c] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + 4 * i;
+      ta[i] = (r < k_valid && c < cols_valid) ? af[(size_t)(k0 + r) * m.n + c0 + c] : 0.0;
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + 4 * i;
+      tp[i] = (r < rows_valid && c < k_valid) ? pf[(long long)r * row_stride + k0 + c] : 0.0;
+    }
+  };
+  const int n_kt = m.np / NB;
+  fetch(0);
+  for (int kt = 0; kt < n_kt; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bs[(r0 + 4 * i) * LS + c] = ta[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) as[(r0 + 4 * i) * LS + c] = tp[i];
     __syncthreads();
+    if (kt + 1 < n_kt) fetch(kt + 1);
     gemm_32x64<false>(as, bs, wave, lane, acc);
     __syncthreads();
   }
