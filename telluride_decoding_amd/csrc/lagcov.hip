@@ -475,10 +475,14 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
   for (int pc = 0; pc < kP; ++pc)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+#ifdef TD_ABL_NOALIGN   // timing ablations (wrong sums; tools/README.md): no operand VALU
+      b[0][pc][i] = d[pc][i]; b[1][pc][i] = a[pc][i]; b[2][pc][i] = d[pc][i + 2]; b[3][pc][i] = a[kP - 1 - pc][i];
+#else
       b[0][pc][i] = d[pc][i];
       b[1][pc][i] = __builtin_amdgcn_alignbit(d[pc][i + 1], d[pc][i], 16);
       b[2][pc][i] = d[pc][i + 1];
       b[3][pc][i] = __builtin_amdgcn_alignbit(d[pc][i + 2], d[pc][i + 1], 16);
+#endif
     }
   f32x16 c[4];
 #pragma unroll
@@ -516,8 +520,13 @@ __device__ __forceinline__ void bf_ksteps(const unsigned* __restrict__ ap,
                                           f32x16 (&total)[4]) {
 #pragma unroll
   for (int s = kFrom; s < kTo; ++s) {
-    if (s % kChain == 0) bf_kstep<true, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc);
-    else                 bf_kstep<false, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+#ifdef TD_ABL_NOLDS      // timing ablation: the same operand words for every k-step of a tile
+#define TD_KOFF(s) 0
+#else
+#define TD_KOFF(s) (8 * (s))
+#endif
+    if (s % kChain == 0) bf_kstep<true, kBfPieceDw, kF16>(ap + TD_KOFF(s), bp + TD_KOFF(s), nullptr, acc);
+    else                 bf_kstep<false, kBfPieceDw, kF16>(ap + TD_KOFF(s), bp + TD_KOFF(s), nullptr, acc);
     if ((s + 1) % kChain == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) total[r] += acc[r];
@@ -689,6 +698,9 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     return kVec4 && p.ca == 64 && ut >= 0 && ut + kBfRows <= w.a_valid;
   };
   auto prefetch = [&](long long ut) {
+#ifdef TD_ABL_NOSTAGE
+    return;
+#endif
     if (interior(ut)) {
       const float* base = p.a + (w.a_row0 + ut) * p.lda + c4;
       const int ld = (int)p.lda;
@@ -711,6 +723,9 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     }
   };
   auto store = [&](long long ut, unsigned* buf) {
+#ifdef TD_ABL_NOSTAGE    // timing ablation: no staging at all (with prefetch below)
+    return;
+#endif
     float4 v[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) v[s] = pf[s];
@@ -730,7 +745,11 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
         unsigned h[2], l[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d)
+#ifdef TD_ABL_NOSPLIT    // timing ablation: no split arithmetic
+        { h[d] = __builtin_bit_cast(unsigned, comp4(v[2 * d], q)); l[d] = __builtin_bit_cast(unsigned, comp4(v[2 * d + 1], q)); }
+#else
           td_split2_f16(comp4(v[2 * d], q) * sc[q], comp4(v[2 * d + 1], q) * sc[q], h[d], l[d]);
+#endif
         dst[0] = h[0]; dst[1] = h[1];
         dst[kBfPieceDw] = l[0]; dst[kBfPieceDw + 1] = l[1];
       } else {
@@ -828,7 +847,9 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
         tgt_tile<kBfPieceDw, kYDw>(ap, tl, left < kBfTile ? (int)left : kBfTile,
                                    !more && w.u_end == tw.seg_end, group, p.n_groups, wi, lg);
     }
+#ifndef TD_ABL_NOBAR      // timing ablation: no barrier per tile
     if (more) __syncthreads();
+#endif
   }
 
   // Epilogue: the wave's 32 x 32 block of its four lags in the workgroup's partial slab.
