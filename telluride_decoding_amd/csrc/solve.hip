@@ -1098,6 +1098,16 @@ __global__ __launch_bounds__(256) void loso_trsm_kernel(LosoTrsm t) {
   double* orows = t.out + ((long long)lam * t.rows_per_lambda + r0) * t.np;
   const double* lmat = t.l + (size_t)lam * t.np * t.np;
   const int k0 = t.k * NB;
+  // the block this workgroup updates: forward i = k + blockIdx.x, backward m = k - blockIdx.x
+  const int bi = kBack ? t.k - (int)blockIdx.x : t.k + (int)blockIdx.x;
+  // forward: tile L[bi][k] (rows of block bi, columns of block k), used as . L_ik^T  (NT)
+  // backward: tile L[k][bi], used as . L_km (NN)
+  const double* tile = kBack ? lmat + (size_t)k0 * t.np + (size_t)bi * NB
+                             : lmat + (size_t)bi * NB * t.np + k0;
+  // (its loads leave now and arrive under the first product: the step was two dependent round
+  // trips to memory)
+  f64x2 lt[8];
+  if (blockIdx.x != 0) tile_to_regs(lt, tile, t.np, NB, tid);
   rows_to_lds(as, vrows + k0, t.np, rows_valid, NB, tid);
   tile_to_lds(bs, t.linv + ((size_t)lam * t.nblk + t.k) * NB * NB, NB, NB, tid);
   __syncthreads();
@@ -1120,13 +1130,7 @@ __global__ __launch_bounds__(256) void loso_trsm_kernel(LosoTrsm t) {
     }
     return;
   }
-  // the block this workgroup updates: forward i = k + blockIdx.x, backward m = k - blockIdx.x
-  const int bi = kBack ? t.k - (int)blockIdx.x : t.k + (int)blockIdx.x;
-  // forward: tile L[bi][k] (rows of block bi, columns of block k), used as . L_ik^T  (NT)
-  // backward: tile L[k][bi], used as . L_km (NN)
-  const double* tile = kBack ? lmat + (size_t)k0 * t.np + (size_t)bi * NB
-                             : lmat + (size_t)bi * NB * t.np + k0;
-  tile_to_lds(bs, tile, t.np, NB, tid);
+  regs_to_lds(bs, lt, tid);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 2; ++s)
