@@ -2195,7 +2195,9 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   if (total == 0) return TD_OK;
   // the LDS-tiled VALU kernel only serves skinny [y | 1] operands that the streaming targets
   // kernel does not take; narrow real operands (an 8-band envelope) go to the matrix cores
-  const bool small = a_ones && ca_eff <= 8;
+  // (... unless the caller says so: the cross-covariance of a wide view with a 1-column one runs
+  // with the operands swapped -- force_small -- instead of as padded 64 x 64 tiles)
+  const bool small = (a_ones || plan->force_small) && ca_eff <= 8;
   // matrix-core path: 8 lags per workgroup, or 4 / 2 / 1 when fewer are asked for (the 8
   // (wave, le) slots then split the tile's rows: mfma_tile_few)
   const int few_g = e_count >= 5 ? 8 : e_count >= 3 ? 4 : e_count;
@@ -2493,12 +2495,33 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
   return TD_OK;
 }
 
+__global__ void add_reversed_transposed_kernel(const double* __restrict__ src, int e_count, int ca,
+                                               int cb, double* __restrict__ dst) {
+  const long long total = (long long)e_count * ca * cb;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int jb = (int)(i % cb), ia = (int)((i / cb) % ca), e = (int)(i / ((long long)ca * cb));
+    dst[i] += src[((long long)(e_count - 1 - e) * cb + jb) * ca + ia];
+  }
+}
+
+int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst) {
+  const long long total = (long long)e_count * ca * cb;
+  if (total == 0) return TD_OK;
+  const long long blocks = td_ceil_div(total, 256);
+  hipLaunchKernelGGL(add_reversed_transposed_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256),
+                     0, h->stream, src, e_count, ca, cb, dst);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate, int ldg, int rows_dst) {
+              double* g_dev, bool accumulate, int ldg, int rows_dst, bool skinny) {
   // (ldg / rows_dst: g_dev is a sub-block of lag matrices of rows_dst rows of ldg numbers --
   // the channel-tile decomposition of td_lagcov_auto; 0 = dense [e][ca_eff][cb])
   LagcovPlan plan;
+  plan.force_small = skinny;
   TD_TRY(td_lagcov_plan(h, a, lda, ca, a_ones, b, ldb, cb, segs, e_min, e_count, &plan));
   const int ca_eff = plan.ca_eff;
   if (ldg <= 0) ldg = cb;

@@ -298,6 +298,7 @@ struct LagReduceJob {
 // reduce them in one launch: the plan fixes the work list and the scratch bytes, the launch
 // queues the matrix kernel only and describes the reduction it leaves to the caller.
 struct LagcovPlan {
+  bool force_small = false;   // IN: skinny real A (<= 8 columns) on the LDS-tiled VALU kernel
   LagParams p;
   std::vector<LagWork> works;
   bool small = false, few = false, split = false, aligned = false;
@@ -369,7 +370,10 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
 
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate, int ldg = 0, int rows_dst = 0);
+              double* g_dev, bool accumulate, int ldg = 0, int rows_dst = 0, bool skinny = false);
+// dst [e_count][ca][cb] += src [e_count][cb][ca] with the lag order reversed and every block
+// transposed (the cross-covariance from a call with the operands swapped).
+int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst);
 int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld);
 
 // [y]^T x~ per signed lag on the lane-per-channel kernel, plus the per-segment column sums

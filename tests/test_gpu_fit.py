@@ -78,6 +78,14 @@ def _rel(a, b):
     (100, 2, 9, 0, 0, 0, 2, 1, (1800, 129, 640), 13),
     (128, 0, 31, 0, 0, 0, 1, 0, (3000,), 0),
     (65, 1, 2, 0, 0, 0, 1, 0, (900, 901), 0),
+    # lagged CCA with a narrow second view (<= 8 columns) against a wide first one: the
+    # cross-covariance runs with the operands swapped (skinny kernel + reversed, transposed add);
+    # offsets of either sign, a dropped remainder, recordings shorter than the lag span, the
+    # codelab's 69 x 1 channels
+    (69, 0, 36, 1, 0, 30, 0, 0, (2500, 700), 0),
+    (12, 2, 3, 3, 4, 1, 0, 2, (900, 40, 1300), 57),
+    (33, 0, 8, 8, 3, 3, 2, -3, (1500, 5, 700), 11),
+    (20, 5, 0, 2, 0, 6, 0, 0, (64, 3000), 0),
     # 33 .. 64 lags: the 192-row geometry of the same kernel
     (64, 40, 20, 0, 0, 0, 1, 0, (3000, 260, 129), 0),
     (44, 0, 32, 0, 0, 0, 1, 3, (2500, 2049), 17),
