@@ -742,7 +742,62 @@ __global__ __launch_bounds__(256) void svd_small_kernel(const double* __restrict
   if (tid == 0 && sweeps_out) *sweeps_out = sweep;
 }
 
-size_t svd_ws_bytes(int k) { return sizeof(double) * ((size_t)k * k + k) + 256; }
+size_t svd_ws_bytes(int k) { return sizeof(double) * (2 * (size_t)k * k + 2 * k) + 512; }
+
+// ---- k <= 64 long vectors: the SVD through the k x k Gram matrix ------------------------------
+// One-sided Jacobi on k = 31 vectors of length 2553 (the codelab's whitened cross-covariance) is
+// 8 sweeps x 31 rounds = 248 launches and 8 host round trips: 1.9 of the 4.0 ms dense stage.  The
+// k x k matrix G = g g^T has the squared singular values as eigenvalues and the rotation side as
+// eigenvectors: one launch for G, one for its Jacobi eigen-decomposition in LDS (jacobi64_kernel),
+// one for the `dim` leading triplets (the g side = combinations of the rows).  The squaring costs
+// relative accuracy on SMALL singular values only, ~eps (s_1 / s_i)^2: used when the dim-th
+// eigenvalue is above 1e-10 of the first (singular values within 1e-5: 1e-6 relative at worst,
+// in float64, for float32 outputs), else the rounds below.
+__global__ __launch_bounds__(256) void gram_rows_kernel(const double* __restrict__ g, int ldg, int k, int m,
+                                                        double* __restrict__ gg) {
+  __shared__ double red[4];
+  const int i = blockIdx.x, j = blockIdx.y;
+  if (j < i) return;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < m; t += 256) s += g[(size_t)i * ldg + t] * g[(size_t)j * ldg + t];
+  s = block_sum(s, red, threadIdx.x);
+  if (threadIdx.x == 0) { gg[(size_t)i * k + j] = s; gg[(size_t)j * k + i] = s; }
+}
+
+// vals [k], vecs [k][k] (eigenvectors as columns) of G -> the `dim` leading singular triplets
+__global__ __launch_bounds__(256) void svd_from_eig_kernel(const double* __restrict__ g, int ldg, int k, int m,
+                                                           const double* __restrict__ vals,
+                                                           const double* __restrict__ vecs,
+                                                           double* __restrict__ sig, double* __restrict__ gn,
+                                                           double* __restrict__ vn) {
+  __shared__ double col[64];
+  __shared__ int pick_s;
+  const int want = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int pick = 0;
+    for (int i = 0; i < k; ++i) {
+      const double si = vals[i];
+      int rank = 0;
+      for (int j = 0; j < k; ++j) rank += (vals[j] > si || (vals[j] == si && j < i)) ? 1 : 0;
+      if (rank == want) pick = i;
+    }
+    pick_s = pick;
+  }
+  __syncthreads();
+  const int pick = pick_s;
+  if (tid < k) col[tid] = vecs[(size_t)tid * k + pick];
+  __syncthreads();
+  const double lam = vals[pick];
+  const double sv = lam > 0.0 ? sqrt(lam) : 0.0;
+  const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
+  if (tid == 0) sig[want] = sv;
+  for (int t = tid; t < k; t += 256) vn[(size_t)want * k + t] = col[t];
+  for (int r = tid; r < m; r += 256) {
+    double acc = 0.0;
+    for (int t = 0; t < k; ++t) acc += col[t] * g[(size_t)t * ldg + r];
+    gn[(size_t)want * m + r] = acc * inv;
+  }
+}
 
 // g [k][ldg] (overwritten), k <= m: top `dim` singular triplets as rows sig [dim], gn [dim][m]
 // (unit vectors along the g side), vn [dim][k] (rotation side).
@@ -759,6 +814,25 @@ int jacobi_svd(td_handle* h, double* g, int ldg, int k, int m, int dim, double* 
     TD_HIP(h, hipGetLastError());
     if (sweeps_out) *sweeps_out = 0;
     return TD_OK;
+  }
+  static const bool no_gram = getenv("TD_SVD_JACOBI") != nullptr;         // development: A/B runs
+  if (k <= NB && k > 1 && m >= 4 * k && !no_gram) {
+    double* gg = norms + k;                              // [k][k]
+    double* vals = gg + (size_t)k * k;                   // [k]; eigenvectors -> vt
+    void* eig_ws = reinterpret_cast<char*>(vals + k);    // the eigen-solver's counter (256 bytes)
+    hipLaunchKernelGGL(gram_rows_kernel, dim3((unsigned)k, (unsigned)k), dim3(256), 0, h->stream, g, ldg, k, m, gg);
+    TD_TRY(sym_eig(h, gg, k, k, vals, vt, eig_ws, nullptr));
+    std::vector<double> lam((size_t)k);
+    TD_HIP(h, hipMemcpyAsync(lam.data(), vals, sizeof(double) * k, hipMemcpyDeviceToHost, h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+    std::sort(lam.begin(), lam.end(), [](double a, double b) { return a > b; });
+    if (lam[0] > 0.0 && lam[dim - 1] > 1e-10 * lam[0]) {
+      hipLaunchKernelGGL(svd_from_eig_kernel, dim3((unsigned)dim), dim3(256), 0, h->stream, g, ldg, k, m, vals,
+                         vt, sig, gn, vn);
+      TD_HIP(h, hipGetLastError());
+      if (sweeps_out) *sweeps_out = 0;
+      return TD_OK;
+    }
   }
   hipLaunchKernelGGL(identity_kernel, dim3(grid_for((long long)k * k)), dim3(256), 0, h->stream, vt, k);
   SvdParams P;

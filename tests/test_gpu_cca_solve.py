@@ -66,7 +66,11 @@ def test_sym_eigh_keeps_small_eigenvalues_relatively_accurate(dev):
 
 
 @pytest.mark.parametrize('m,n,dim', [(64, 8, 8), (8, 64, 5), (300, 31, 31), (5, 5, 5), (1, 3, 1),
-                                     (3, 1, 1), (700, 130, 10), (40, 10, 3), (9, 9, 2)])
+                                     (3, 1, 1), (700, 130, 10), (40, 10, 3), (9, 9, 2),
+                                     # k <= 64 long vectors: the Gram-matrix route (leading triplets
+                                     # well above the cut) and its fall-back to the rounds (300 x 31
+                                     # with all 31: the last eigenvalue is 1e-12 of the first)
+                                     (2553, 31, 5), (500, 64, 6), (31, 2553, 5)])
 def test_jacobi_svd_matches_lapack(dev, m, n, dim):
   rng = np.random.default_rng(m * 1000 + n)
   t = rng.standard_normal((m, n)) * np.logspace(0, -6, n)[None, :]
