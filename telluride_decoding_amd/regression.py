@@ -64,6 +64,16 @@ def _fold_chunk(n_folds, n_lambda, n):
   return int(max(1, min(n_folds, by_bytes, by_count)))
 
 
+def _pcg_chunk(n_folds, n_lambda, n, d):
+  """Folds per td_ridge_solve_loso call: its workspace holds a dense n x n float64 matrix per
+  fold, a padded factor per lambda (fixed) and 9 row vectors per (fold, lambda, output); what is
+  left of SOLVE_WORKSPACE_BYTES after the fixed part decides (at least one fold)."""
+  n_pad = (int(n) + 63) // 64 * 64
+  fixed = max(1, int(n_lambda)) * (n_pad * n_pad + n_pad * 64) * 8 + n * n * 8
+  per_fold = n * n * 8 + 9 * max(1, int(n_lambda)) * max(1, int(d)) * n_pad * 8
+  return int(max(1, min(n_folds, (SOLVE_WORKSPACE_BYTES - fixed) // per_fold)))
+
+
 def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, world_size=1,
                                    group=None, device=None):
   """dataset: brain_data.Dataset whose files are the jackknife units (subjects).
@@ -206,20 +216,34 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   # and ~10 iterations of [products with the folds' matrices + triangular substitutions] instead
   # of folds x Lambda factorisations (td_ridge_solve_loso; C5: the 4 batched solves were 60 of the
   # sweep's 95 ms).  Falls through to (2) when the solver reports no convergence.
-  done = False
+  # The folds go through it in chunks sized by its workspace (a dense matrix per fold: all 32
+  # folds of C5 are 1.1 GB; _pcg_chunk); a chunk that does not converge, or does not fit after
+  # all, sends the REST of the sweep to (2).
+  n_done = 0
   if hasattr(dev.LagStats, 'ridge_solve_loso') and my_folds and USE_PCG:
-    trains_all = [proto.like() for _ in my_folds]
-    for train, f in zip(trains_all, my_folds):
-      fold_statistics(f, train)
+    per_call = _pcg_chunk(len(my_folds), n_lam, proto.k1 + 1, d)
     total = proto.like().combine(stats)
-    out = dev.LagStats.ridge_solve_loso(total, trains_all, lambdas, handle=h)
-    if out is not None:
+    trains_all = [proto.like() for _ in range(per_call)]
+    iters_max = 0
+    while n_done < len(my_folds):
+      folds = my_folds[n_done:n_done + per_call]
+      for train, f in zip(trains_all, folds):
+        fold_statistics(f, train)
+      try:
+        out = dev.LagStats.ridge_solve_loso(total, trains_all[:len(folds)], lambdas, handle=h)
+      except MemoryError:
+        out = None
+      if out is None:
+        break
       w_all_folds, b_all_folds, iters = out
-      LAST_SWEEP.update(solver='pcg', iterations=int(iters))
-      for fi, f in enumerate(my_folds):
+      iters_max = max(iters_max, int(iters))
+      for fi, f in enumerate(folds):
         evaluate(f, w_all_folds[fi], b_all_folds[fi])
-      done = True
+      n_done += len(folds)
+    if n_done:
+      LAST_SWEEP.update(solver='pcg' if n_done == len(my_folds) else 'pcg+direct', iterations=iters_max)
     del trains_all
+  done = n_done == len(my_folds)
 
   # (2) Folds go through the direct solver in chunks: (folds in the chunk) x (lambdas) systems in
   # ONE batched Cholesky -- the late block steps of the factorisation cannot fill the chip with the
@@ -229,9 +253,9 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   # count at 64 ch x 64 lags would be 23 GB.
   chunk = _fold_chunk(len(my_folds), n_lam, proto.k1 + 1)
   trains = [] if done else [proto.like() for _ in range(chunk)]
-  if not done:
+  if not n_done:
     LAST_SWEEP.update(solver='direct', iterations=0)
-  c0 = len(my_folds) if done else 0
+  c0 = n_done
   while c0 < len(my_folds):
     folds = my_folds[c0:c0 + chunk]
     for train, f in zip(trains, folds):

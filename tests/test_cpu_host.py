@@ -436,6 +436,18 @@ def test_fold_chunk_is_sized_by_bytes():
   assert r._fold_chunk(3, 2, 17) == 3
 
 
+def test_pcg_chunk_is_sized_by_bytes():
+  """The preconditioned-CG sweep solver keeps a dense n x n matrix per fold: the folds per call
+  follow SOLVE_WORKSPACE_BYTES too (all 32 folds at C5; one at a time when nothing else fits)."""
+  from telluride_decoding_amd import regression as r
+  assert r._pcg_chunk(32, 20, 2049, 1) == 32                     # C5: 1.1 GB of fold matrices
+  assert 1 <= r._pcg_chunk(500, 20, 2049, 1) < 500
+  for n_folds, n_lam, n, d in ((32, 20, 2554, 1), (32, 20, 4097, 2), (64, 7, 8193, 1), (3, 2, 17, 1)):
+    c = r._pcg_chunk(n_folds, n_lam, n, d)
+    assert 1 <= c <= n_folds
+    assert c == 1 or c * n * n * 8 <= r.SOLVE_WORKSPACE_BYTES
+
+
 def test_time_shard_halo_must_cover_the_context():
   """a halo shorter than the context would zero-extend at interior cuts and the
   all-reduced moments would be silently wrong."""

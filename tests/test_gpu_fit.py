@@ -1049,6 +1049,20 @@ def test_loso_pcg_solver_reports_when_it_cannot_converge(dev):
   finally:
     regression.USE_PCG = old
   np.testing.assert_allclose(with_pcg['all_runs'], direct['all_runs'], rtol=0, atol=2e-6)
+  assert regression.LAST_SWEEP['solver'] == 'direct'
+  # ... and in chunks of two folds (a workspace budget that small)
+  old_bytes = regression.SOLVE_WORKSPACE_BYTES
+  n1 = c * 4 + 1
+  n_pad = 64
+  regression.SOLVE_WORKSPACE_BYTES = len(lams) * (n_pad * n_pad + n_pad * 64) * 8 + n1 * n1 * 8 + \
+      2 * (n1 * n1 * 8 + 9 * len(lams) * n_pad * 8) + 8
+  try:
+    assert regression._pcg_chunk(5, len(lams), n1, 1) == 2
+    chunked = regression.jackknife_over_regularizations(ds, lams)
+  finally:
+    regression.SOLVE_WORKSPACE_BYTES = old_bytes
+  assert regression.LAST_SWEEP['solver'] == 'pcg'
+  np.testing.assert_allclose(chunked['all_runs'], with_pcg['all_runs'], rtol=0, atol=1e-9)
 
 
 def test_bf16_mfma_probe_reports_a_rate(dev):
