@@ -1065,6 +1065,33 @@ def test_loso_pcg_solver_reports_when_it_cannot_converge(dev):
   np.testing.assert_allclose(chunked['all_runs'], with_pcg['all_runs'], rtol=0, atol=1e-9)
 
 
+def test_loso_sweep_at_c5_size_pcg_equals_direct(dev):
+  """BASELINE config C5 at full size (32 subjects x 31 250 samples x 64 ch, 32 lags, 20 lambdas =
+  640 fits): the preconditioned-CG sweep against the direct batched Cholesky sweep -- the same
+  held-out correlations to 2e-6 for every (lambda, subject), the same best lambda; every subject
+  decodes (mean r > 0.9 at the best lambda: the synthetic EEG is a filtered envelope + noise)."""
+  from telluride_decoding_amd import brain_data, regression, synth
+  n_subj, n, c = 32, 31250, 64
+  trials = synth.make_trials(5, n_subj, n, c)
+  files = [(eeg, env, env[:, 0:1].astype(np.float32), att) for eeg, env, att in trials]
+  ds = brain_data.Dataset(files, 1000, pre_context=0, post_context=31)
+  lams = list(np.logspace(-6, 3, 20))
+  got = regression.jackknife_over_regularizations(ds, lams)
+  assert regression.LAST_SWEEP['solver'] == 'pcg' and 1 <= regression.LAST_SWEEP['iterations'] <= 20
+  old = regression.USE_PCG
+  regression.USE_PCG = False
+  try:
+    want = regression.jackknife_over_regularizations(ds, lams)
+  finally:
+    regression.USE_PCG = old
+  assert got['all_runs'].shape == (20, n_subj)
+  assert np.all(np.isfinite(got['all_runs']))
+  np.testing.assert_allclose(got['all_runs'], want['all_runs'], rtol=0, atol=2e-6)
+  best = max((v[0], k) for k, v in got.items() if k != 'all_runs')
+  best_direct = max((v[0], k) for k, v in want.items() if k != 'all_runs')
+  assert best[1] == best_direct[1] and best[0] > 0.9
+
+
 def test_bf16_mfma_probe_reports_a_rate(dev):
   """td_probe_bf16_mfma (bench.py's sustained-pipe figure): a plausible rate, below the nominal
   2516.6 TFLOP/s, for both kinds of operands (which of the two is faster depends on how warm
