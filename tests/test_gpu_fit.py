@@ -1092,6 +1092,34 @@ def test_loso_sweep_at_c5_size_pcg_equals_direct(dev):
   assert best[1] == best_direct[1] and best[0] > 0.9
 
 
+def test_pooled_statistics_memory_comes_back_fresh(dev):
+  """td_stats_destroy hands the device memory to a pool inside the library (an event marks when
+  it is free) and td_stats_create takes blocks of the same size from it: a recycled block must
+  read as new statistics, also when the old object was destroyed with work still queued on it and
+  when the new one lives on another handle (another stream)."""
+  rng = np.random.default_rng(77)
+  h = dev.default_handle()
+  x = h.to_device(rng.standard_normal((20000, 64)).astype(np.float32))
+  y = h.to_device(rng.standard_normal((20000, 1)).astype(np.float32))
+  ref = dev.LagStats(64, 0, 31, d=1)
+  ref.accumulate(x, None, y)
+  want = {k: v.cpu().numpy() for k, v in ref.moments().items() if v is not None}
+  h2 = dev.Handle()
+  for rep in range(6):
+    a = dev.LagStats(64, 0, 31, d=1)
+    for _ in range(3):
+      a.accumulate(x, None, y)               # queued work ...
+    del a                                    # ... and the object goes while it runs
+    b = dev.LagStats(64, 0, 31, d=1, handle=h2 if rep % 2 else h)
+    frames, nfiles = b.counts()
+    assert frames == 0 and nfiles == 0
+    b.accumulate(x, None, y)
+    got = b.moments()
+    for k, v in want.items():
+      np.testing.assert_array_equal(got[k].cpu().numpy(), v)
+    del b
+
+
 def test_bf16_mfma_probe_reports_a_rate(dev):
   """td_probe_bf16_mfma (bench.py's sustained-pipe figure): a plausible rate, below the nominal
   2516.6 TFLOP/s, for both kinds of operands (which of the two is faster depends on how warm
