@@ -1146,6 +1146,201 @@ __global__ __launch_bounds__(256) void loso_trsm_kernel(LosoTrsm t) {
     }
 }
 
+// ---- the same substitutions in steps of FOUR block columns (256 unknowns) -----------------------
+// A substitution above is a chain of 33 dependent launches (n = 2049), ~17 us each whatever they
+// compute: 1.1 ms per application of the preconditioner, 8 of the C5 sweep's 24 ms.  With the
+// inverse of every 256 x 256 diagonal block of L at hand (four 64-blocks: X_ii = Linv_ii,
+// X_ij = -Linv_ii sum_{j <= p < i} L_ip X_pj, built once per factorisation: loso_binv_kernel) a
+// step solves 256 unknowns at a time -- one launch for the solved block (a sum of <= 4 products
+// per 64-column tile), one for the updates of the tiles beyond (4 products each) -- and the chain
+// is 9 x 2 launches per direction.
+constexpr int kBig = 4;                    // 64-blocks per step
+
+struct LosoBig {
+  const double* l;        // [n_lambda][np][np]
+  const double* xinv;     // [n_lambda][nbig][4][4][64][64] inverses of the 256-blocks (lower tiles)
+  double* v;              // rows, updated in place
+  double* out;            // rows: the solved blocks
+  int np, nblk, nbig, kb, m, rows_per_lambda;     // kb: big block; m: its 64-blocks (<= 4)
+};
+
+__device__ __forceinline__ void rows_to_regs(double (&r)[8], const double* __restrict__ g, long long ld,
+                                             int rows_valid, int tid) {
+  // thread (c = tid & 63, r0 = tid >> 6): rows r0 + 4 i of a 32 x 64 piece
+  const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = r0 + 4 * i;
+    r[i] = row < rows_valid ? g[(long long)row * ld + c] : 0.0;
+  }
+}
+__device__ __forceinline__ void rows_regs_to_lds(double* lds, const double (&r)[8], int tid) {
+  const int c = tid & 63, r0 = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lds[(r0 + 4 * i) * LS + c] = r[i];
+}
+
+// X = (L_KK)^-1 of one 256-block, block column j of it per workgroup.  grid: (nbig, n_lambda, 4)
+__global__ __launch_bounds__(256) void loso_binv_kernel(const double* __restrict__ l,
+                                                        const double* __restrict__ linv,
+                                                        double* __restrict__ xinv, int np, int nblk, int nbig) {
+  __shared__ double as[NB * LS];
+  __shared__ double bs[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = blockIdx.x, lam = blockIdx.y, j = blockIdx.z;
+  const int m = nblk - kBig * kb < kBig ? nblk - kBig * kb : kBig;
+  if (j >= m) return;
+  const double* lmat = l + (size_t)lam * np * np;
+  const double* li = linv + ((size_t)lam * nblk + (size_t)kBig * kb) * NB * NB;
+  double* x = xinv + ((size_t)lam * nbig + kb) * 16 * NB * NB;          // tile (r, c) at (4 r + c) * 4096
+  const int col = 16 * wave + (lane & 15);
+  // X_jj = Linv_jj
+  for (int idx = tid; idx < NB * NB; idx += 256) x[(size_t)(4 * j + j) * NB * NB + idx] = li[(size_t)j * NB * NB + idx];
+  for (int i = j + 1; i < m; ++i) {
+    __syncthreads();                                   // (X tiles written above are read below)
+    f64x4 acc[2][2];                                   // [row half][16-row tile] of the 64 x 64 sum
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[hf][t][r] = 0.0;
+    for (int p = j; p < i; ++p) {
+      // A = L[4 kb + i][4 kb + p], B = X_pj
+      tile_to_lds(as, lmat + (size_t)(kBig * kb + i) * NB * np + (size_t)(kBig * kb + p) * NB, np, NB, tid);
+      tile_to_lds(bs, x + (size_t)(4 * p + j) * NB * NB, NB, NB, tid);
+      __syncthreads();
+      gemm_32x64<false>(as, bs, wave, lane, acc[0]);
+      gemm_32x64<false>(as + 32 * LS, bs, wave, lane, acc[1]);
+      __syncthreads();
+    }
+    // the sum -> LDS (as B), times -Linv_ii from the left
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[(32 * hf + 16 * t + (lane >> 4) + 4 * r) * LS + col] = acc[hf][t][r];
+    tile_to_lds(as, li + (size_t)i * NB * NB, NB, NB, tid);
+    __syncthreads();
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[hf][t][r] = 0.0;
+    gemm_32x64<false>(as, bs, wave, lane, acc[0]);
+    gemm_32x64<false>(as + 32 * LS, bs, wave, lane, acc[1]);
+    double* xt = x + (size_t)(4 * i + j) * NB * NB;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xt[(32 * hf + 16 * t + (lane >> 4) + 4 * r) * NB + col] = -acc[hf][t][r];
+    __threadfence_block();
+  }
+}
+
+// The solved 256-block: tile c of it = sum over p of (rows of block 4 kb + p) x (a tile of X).
+//   forward:  y_c = sum_{p <= c} b_p X_cp^T          backward: w_c = sum_{p >= c} y_p X_pc
+// grid: (m, n_lambda, row chunks)
+template <bool kBack>
+__global__ __launch_bounds__(256) void loso_big_solve_kernel(LosoBig t) {
+  __shared__ double as[kLosoRows * LS];
+  __shared__ double bs[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.x, lam = blockIdx.y, chunk = blockIdx.z;
+  const int r0 = chunk * kLosoRows;
+  const int rows_valid = t.rows_per_lambda - r0 < kLosoRows ? t.rows_per_lambda - r0 : kLosoRows;
+  const double* vrows = t.v + ((long long)lam * t.rows_per_lambda + r0) * t.np + (size_t)kBig * t.kb * NB;
+  double* orows = t.out + ((long long)lam * t.rows_per_lambda + r0) * t.np + (size_t)kBig * t.kb * NB;
+  const double* x = t.xinv + ((size_t)lam * t.nbig + t.kb) * 16 * NB * NB;
+  const int p_lo = kBack ? c : 0, p_hi = kBack ? t.m - 1 : c;
+  auto xtile = [&](int p) { return x + (size_t)(kBack ? 4 * p + c : 4 * c + p) * NB * NB; };
+  f64x4 acc[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
+  double ra[8];
+  f64x2 rt[8];
+  rows_to_regs(ra, vrows + (size_t)p_lo * NB, t.np, rows_valid, tid);
+  tile_to_regs(rt, xtile(p_lo), NB, NB, tid);
+  for (int p = p_lo; p <= p_hi; ++p) {
+    rows_regs_to_lds(as, ra, tid);
+    regs_to_lds(bs, rt, tid);
+    __syncthreads();
+    if (p < p_hi) {
+      rows_to_regs(ra, vrows + (size_t)(p + 1) * NB, t.np, rows_valid, tid);
+      tile_to_regs(rt, xtile(p + 1), NB, NB, tid);
+    }
+    gemm_32x64<!kBack>(as, bs, wave, lane, acc);       // forward: . X_cp^T ; backward: . X_pc
+    __syncthreads();
+  }
+  const int ccol = 16 * wave + (lane & 15);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * s + (lane >> 4) + 4 * r;
+      if (row < rows_valid) orows[(long long)row * t.np + (size_t)c * NB + ccol] = acc[s][r];
+    }
+}
+
+// The tiles beyond take the solved 256-block's update.
+//   forward (tile i > the block):   b_i -= sum_p y_p L[i][4 kb + p]^T
+//   backward (tile mm < the block): y_mm -= sum_p w_p L[4 kb + p][mm]
+// grid: (tiles to update, n_lambda, row chunks)
+template <bool kBack>
+__global__ __launch_bounds__(256) void loso_big_update_kernel(LosoBig t) {
+  __shared__ double as[kLosoRows * LS];
+  __shared__ double bs[NB * LS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lam = blockIdx.y, chunk = blockIdx.z;
+  const int bi = kBack ? (int)blockIdx.x : kBig * t.kb + t.m + (int)blockIdx.x;
+  const int r0 = chunk * kLosoRows;
+  const int rows_valid = t.rows_per_lambda - r0 < kLosoRows ? t.rows_per_lambda - r0 : kLosoRows;
+  double* vrows = t.v + ((long long)lam * t.rows_per_lambda + r0) * t.np;
+  const double* srows = t.out + ((long long)lam * t.rows_per_lambda + r0) * t.np + (size_t)kBig * t.kb * NB;
+  const double* lmat = t.l + (size_t)lam * t.np * t.np;
+  auto ltile = [&](int p) {
+    const int kk = kBig * t.kb + p;
+    return kBack ? lmat + (size_t)kk * NB * t.np + (size_t)bi * NB : lmat + (size_t)bi * NB * t.np + (size_t)kk * NB;
+  };
+  f64x4 acc[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[s][r] = 0.0;
+  double ra[8];
+  f64x2 rt[8];
+  rows_to_regs(ra, srows, t.np, rows_valid, tid);
+  tile_to_regs(rt, ltile(0), t.np, NB, tid);
+  for (int p = 0; p < t.m; ++p) {
+    rows_regs_to_lds(as, ra, tid);
+    regs_to_lds(bs, rt, tid);
+    __syncthreads();
+    if (p + 1 < t.m) {
+      rows_to_regs(ra, srows + (size_t)(p + 1) * NB, t.np, rows_valid, tid);
+      tile_to_regs(rt, ltile(p + 1), t.np, NB, tid);
+    }
+    gemm_32x64<!kBack>(as, bs, wave, lane, acc);
+    __syncthreads();
+  }
+  const int ccol = 16 * wave + (lane & 15);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * s + (lane >> 4) + 4 * r;
+      if (row < rows_valid) vrows[(long long)row * t.np + (size_t)bi * NB + ccol] -= acc[s][r];
+    }
+}
+
 // Row-wise pieces of the CG iteration.  One workgroup per row.
 //   stage 0 (start):  x = 0 ; r = b ; bb = b . b
 //   stage 1:          rz = r . z ; p = z                        (first direction)
@@ -1481,6 +1676,8 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
   const long long rows = (long long)n_lambda * d * n_folds;
   const int rows_per_lambda = d * n_folds;
   // workspace
+  const int nbig = (int)td_ceil_div(nblk, kBig);
+  double* xinv = nullptr;
   auto carve_all = [&](char* base, double** af, double** xty, double** mt, double** invn, double** lams,
                        double** pa, double** linv, double** tolv, double** rt, double** sol,
                        double* (*vec)[9], double** rz, double** bb) -> size_t {
@@ -1493,6 +1690,7 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
     *sol = take((size_t)n_lambda * kMaxRhs * np);
     for (int i = 0; i < 9; ++i) (*vec)[i] = take((size_t)rows * np);
     *rz = take(rows); *bb = take(rows);
+    xinv = take((size_t)n_lambda * nbig * 16 * NB * NB);
     return (size_t)(p - base);
   };
   double *af, *xty, *mt, *invn, *lams, *pa, *linv, *tolv, *rt, *sol, *rz, *bb;
@@ -1511,6 +1709,10 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
                      0LL, n, np, 1.0 / (double)frames_total, lams, pa);
   TD_HIP(h, hipMemsetAsync(rt, 0, sizeof(double) * (size_t)n_lambda * kMaxRhs * np, h->stream));
   TD_TRY(chol_factor_forward(h, pa, rt, sol, linv, tolv, np, 1, n_lambda, nullptr, kMaxRhs, n));
+  static const bool trsm64 = getenv("TD_LOSO_TRSM64") != nullptr;        // development: A/B runs
+  if (!trsm64)
+    hipLaunchKernelGGL(loso_binv_kernel, dim3((unsigned)nbig, (unsigned)n_lambda, kBig), dim3(256), 0, h->stream,
+                       pa, linv, xinv, np, nblk, nbig);
   // the folds' dense moments and right-hand sides
   for (int f = 0; f < n_folds; ++f)
     TD_TRY(td_stats_moments(h, folds[f], af + (size_t)f * nn, xty + (size_t)f * n * d, nullptr, nullptr, nullptr));
@@ -1526,6 +1728,30 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
   const unsigned chunks = (unsigned)td_ceil_div(rows_per_lambda, kLosoRows);
   auto precondition = [&]() -> int {        // Z = (P + lambda I)^-1 R
     TD_HIP(h, hipMemcpyAsync(V, R, sizeof(double) * (size_t)rows * np, hipMemcpyDeviceToDevice, h->stream));
+    if (!trsm64) {
+      LosoBig b;
+      b.l = pa; b.xinv = xinv; b.np = np; b.nblk = nblk; b.nbig = nbig; b.rows_per_lambda = rows_per_lambda;
+      b.v = V; b.out = Y;
+      for (int kb = 0; kb < nbig; ++kb) {
+        b.kb = kb; b.m = nblk - kBig * kb < kBig ? nblk - kBig * kb : kBig;
+        hipLaunchKernelGGL(loso_big_solve_kernel<false>, dim3((unsigned)b.m, (unsigned)n_lambda, chunks), dim3(256), 0,
+                           h->stream, b);
+        const int beyond = nblk - kBig * kb - b.m;
+        if (beyond > 0)
+          hipLaunchKernelGGL(loso_big_update_kernel<false>, dim3((unsigned)beyond, (unsigned)n_lambda, chunks),
+                             dim3(256), 0, h->stream, b);
+      }
+      b.v = Y; b.out = Z;
+      for (int kb = nbig - 1; kb >= 0; --kb) {
+        b.kb = kb; b.m = nblk - kBig * kb < kBig ? nblk - kBig * kb : kBig;
+        hipLaunchKernelGGL(loso_big_solve_kernel<true>, dim3((unsigned)b.m, (unsigned)n_lambda, chunks), dim3(256), 0,
+                           h->stream, b);
+        if (kb > 0)
+          hipLaunchKernelGGL(loso_big_update_kernel<true>, dim3((unsigned)(kBig * kb), (unsigned)n_lambda, chunks),
+                             dim3(256), 0, h->stream, b);
+      }
+      return TD_OK;
+    }
     LosoTrsm t;
     t.l = pa; t.linv = linv; t.np = np; t.nblk = nblk; t.rows_per_lambda = rows_per_lambda;
     t.v = V; t.out = Y;
