@@ -520,6 +520,8 @@ __global__ __launch_bounds__(256) void edge_outer_kernel(ExpandParams p) {
     }
 }
 
+constexpr int kExpandSeg = 8;
+
 __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
   __shared__ double tr[32][33];
   const int e = p.e_min + blockIdx.x;
@@ -564,18 +566,28 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
       if (row_ok && j0 + q < p.cb) v[q] += d[(long long)i * p.cb + j0 + q];
   };
 
+  // The lag diagonal is walked in segments of kExpandSeg steps, one workgroup (blockIdx.z) each:
+  // steps 0 .. posta - 1 are a = 1 .. posta, steps posta .. posta + prea - 1 are a = -1 .. -prea;
+  // the running sum at a segment's first step is the prefix of D over the steps of its side
+  // before it (a few independent loads).  (One workgroup walking all 31 steps of C2, a load, an
+  // add and a barrier-fenced transposing store per step, was a 40 us serial chain per launch.)
+  const int n_steps = p.posta + p.prea;
+  const int s0 = (int)blockIdx.z * kExpandSeg;
+  const int s1 = s0 + kExpandSeg < n_steps ? s0 + kExpandSeg : n_steps;
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = base[q];
-  emit(0);
-  for (int a = 1; a <= p.posta; ++a) {
-    add_step(a - 1);
-    emit(a);
-  }
+  if (blockIdx.z == 0) emit(0);
+  if (s0 < s1) {
+    const int side0 = s0 < p.posta ? 0 : p.posta;      // first step of the side s0 is on
+    for (int sp = side0; sp < s0; ++sp) add_step(sp);
+    for (int st = s0; st < s1; ++st) {
+      if (st == p.posta) {                             // the negative side starts from the base again
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = base[q];
-  for (int a = -1; a >= -p.prea; --a) {
-    add_step(p.posta + (-a - 1));
-    emit(a);
+        for (int q = 0; q < 4; ++q) v[q] = base[q];
+      }
+      add_step(st);
+      emit(st < p.posta ? st + 1 : -(st - p.posta + 1));
+    }
   }
 }
 
@@ -697,7 +709,8 @@ int expand_block(td_handle* h, const double* g, int e_min, int e_count, int ca, 
     hipLaunchKernelGGL(edge_outer_kernel, grid1, dim3(256), 0, h->stream, p);
   }
   p.n_tj = (int)td_ceil_div(cb, 32);
-  dim3 grid((unsigned)e_count, (unsigned)(td_ceil_div(ca, 32) * p.n_tj));
+  const int segs = n_steps > 0 ? (int)td_ceil_div(n_steps, kExpandSeg) : 1;
+  dim3 grid((unsigned)e_count, (unsigned)(td_ceil_div(ca, 32) * p.n_tj), (unsigned)segs);
   hipLaunchKernelGGL(expand_kernel, grid, dim3(256), 0, h->stream, p);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
