@@ -846,8 +846,8 @@ int spd_check_flag(td_handle* h) {
 // copy is pure HBM traffic (33 MB per system at n = 2049: 2.1 ms for the 160 systems of one
 // batch of a leave-one-out sweep when the whole square was written).  Workgroup = one tile.
 __global__ __launch_bounds__(256) void pad_matrix_kernel(const double* __restrict__ src,
-                                                         long long src_batch_stride, int n, int np,
-                                                         double scale,
+                                                         long long src_batch_stride, int src_ld, int n,
+                                                         int np, double scale,
                                                          const double* __restrict__ lambdas,
                                                          double* __restrict__ dst) {
   const int b = blockIdx.y;
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void pad_matrix_kernel(const double* __restric
   for (int i = 0; i < 16; ++i) {
     const int r = bi * NB + (threadIdx.x >> 6) + 4 * i;
     double v = (r == c) ? 1.0 : 0.0;
-    if (r < n && c < n) v = s[(size_t)r * n + c] * scale + (r == c ? lam : 0.0);
+    if (r < n && c < n) v = s[(size_t)r * src_ld + c] * scale + (r == c ? lam : 0.0);
     d[(size_t)r * np + c] = v;
   }
 }
@@ -992,7 +992,7 @@ __device__ __forceinline__ void rows_to_lds(double* lds, const double* __restric
 }
 
 struct LosoMatvec {
-  const double* a;        // [folds][n][n] dense moments (unpadded, symmetric)
+  const double* a;        // [folds][n][np] dense moments (symmetric; rows np numbers apart)
   const double* p;        // rows
   double* q;              // rows
   const double* inv_n;    // [folds] 1 / frames of the fold
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void loso_matvec_kernel(LosoMatvec m) {
   const int rows_valid = rows_f - j0 < kLosoRows ? rows_f - j0 : kLosoRows;
   const long long row_stride = (long long)m.folds * m.np;        // between rows j and j + 1 of a fold
   const double* pf = m.p + ((long long)j0 * m.folds + f) * m.np;
-  const double* af = m.a + (size_t)f * m.n * m.n;
+  const double* af = m.a + (size_t)f * m.n * m.np;     // rows np numbers apart (aligned)
   const int c0 = ct * NB;
   const int cols_valid = m.n - c0 < NB ? m.n - c0 : NB;
   f64x4 acc[2];
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void loso_matvec_kernel(LosoMatvec m) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = r0 + 4 * i;
-      ta[i] = (r < k_valid && c < cols_valid) ? af[(size_t)(k0 + r) * m.n + c0 + c] : 0.0;
+      ta[i] = (r < k_valid && c < cols_valid) ? af[(size_t)(k0 + r) * m.np + c0 + c] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1471,7 +1471,7 @@ int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const dou
   st->linv = reinterpret_cast<double*>(p);  p += sizeof(double) * (size_t)(np / NB) * NB * NB;
   st->tol = reinterpret_cast<double*>(p);
   hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), 1), dim3(256), 0, h->stream, c_dev, 0LL,
-                     n, np, 1.0, (const double*)nullptr, st->a);
+                     n, n, np, 1.0, (const double*)nullptr, st->a);
   if (diag_shift != 0.0)
     hipLaunchKernelGGL(diag_add_kernel, dim3((unsigned)td_ceil_div(n, 256)), dim3(256), 0, h->stream, st->a,
                        np, n, diag_shift);
@@ -1506,7 +1506,7 @@ int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, 
   TD_TRY(td_workspace(h, carve(nullptr, np, batch).bytes, &base));
   const SolveWs w = carve(base, np, batch);
   hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), (unsigned)batch), dim3(256), 0, h->stream, a_dev,
-                     (long long)n * n, n, np, 1.0, (const double*)nullptr, w.a);
+                     (long long)n * n, n, n, np, 1.0, (const double*)nullptr, w.a);
   hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)batch), dim3(256), 0, h->stream, rhs_dev,
                      (long long)n * nrhs, n, nrhs, np, 1.0, w.rt);
   TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, n, nrhs, batch));
@@ -1531,7 +1531,7 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
   if (frames <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve: no data accumulated");
   const int n = k1 + 1;
   const int np = (int)td_round_up(n, NB);
-  const size_t nn = (size_t)n * n;
+  const size_t nn = (size_t)n * np;             // dense moments with the padded row stride (aligned rows)
   // workspace (grow-only, owned by the handle): [xtx nn][xty n*d][padded systems ...]
   const size_t head = td_round_up((int64_t)(sizeof(double) * (nn + (size_t)n * d)), 256);
   void* base = nullptr;
@@ -1539,12 +1539,12 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
   double* xtx = reinterpret_cast<double*>(base);
   double* xty = xtx + nn;
   const SolveWs w = carve(reinterpret_cast<char*>(base) + head, np, n_lambda);
-  TD_TRY(td_stats_moments(h, s, xtx, xty, nullptr, nullptr, nullptr));
+  TD_TRY(td_stats_moments_ld(h, s, xtx, np, xty, nullptr, nullptr, nullptr));
   TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, w.lams));
   const double inv = 1.0 / (double)frames;
   // cov = M / n + lambda I for each lambda (same xtx for the whole batch: stride 0); rhs = xty / n
   hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), (unsigned)n_lambda), dim3(256), 0, h->stream, xtx,
-                     0LL, n, np, inv, w.lams, w.a);
+                     0LL, np, n, np, inv, w.lams, w.a);
   hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)n_lambda), dim3(256), 0, h->stream, xty, 0LL,
                      n, d, np, inv, w.rt);
   TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, n, d, n_lambda, flag_dev));
@@ -1584,7 +1584,7 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
   }
   const int n = k1 + 1;
   const int np = (int)td_round_up(n, NB);
-  const size_t nn = (size_t)n * n;
+  const size_t nn = (size_t)n * np;             // (padded row stride: td_stats_moments_ld)
   const int batch = n_stats * n_lambda;
   const size_t head = td_round_up((int64_t)(sizeof(double) * (nn + (size_t)n * d)), 256);
   void* base = nullptr;
@@ -1595,10 +1595,10 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
   TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, w.lams));
   for (int i = 0; i < n_stats; ++i) {
     td_stats_layout(stats[i], &k1, &d, &frames);
-    TD_TRY(td_stats_moments(h, stats[i], xtx, xty, nullptr, nullptr, nullptr));
+    TD_TRY(td_stats_moments_ld(h, stats[i], xtx, np, xty, nullptr, nullptr, nullptr));
     const double inv = 1.0 / (double)frames;
     hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), (unsigned)n_lambda), dim3(256), 0, h->stream, xtx,
-                       0LL, n, np, inv, w.lams, w.a + (size_t)i * n_lambda * np * np);
+                       0LL, np, n, np, inv, w.lams, w.a + (size_t)i * n_lambda * np * np);
     hipLaunchKernelGGL(pad_rhs_kernel, dim3(16, (unsigned)n_lambda), dim3(256), 0, h->stream, xty,
                        0LL, n, d, np, inv, w.rt + (size_t)i * n_lambda * kMaxRhs * np);
   }
@@ -1672,7 +1672,7 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
     inv_n[f] = 1.0 / (double)ff;
   }
   const int n = k1 + 1, np = (int)td_round_up(n, NB), nblk = np / NB;
-  const size_t nn = (size_t)n * n;
+  const size_t nn = (size_t)n * np;             // (padded row stride: td_stats_moments_ld)
   const long long rows = (long long)n_lambda * d * n_folds;
   const int rows_per_lambda = d * n_folds;
   // workspace
@@ -1704,9 +1704,9 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
   TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, lams));
   TD_TRY(td_upload_async(h, inv_n.data(), sizeof(double) * n_folds, invn));
   // the preconditioners: Cholesky factors of M_total / N + lambda I
-  TD_TRY(td_stats_moments(h, total, mt, nullptr, nullptr, nullptr, nullptr));
+  TD_TRY(td_stats_moments_ld(h, total, mt, np, nullptr, nullptr, nullptr, nullptr));
   hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), (unsigned)n_lambda), dim3(256), 0, h->stream, mt,
-                     0LL, n, np, 1.0 / (double)frames_total, lams, pa);
+                     0LL, np, n, np, 1.0 / (double)frames_total, lams, pa);
   TD_HIP(h, hipMemsetAsync(rt, 0, sizeof(double) * (size_t)n_lambda * kMaxRhs * np, h->stream));
   TD_TRY(chol_factor_forward(h, pa, rt, sol, linv, tolv, np, 1, n_lambda, nullptr, kMaxRhs, n));
   static const bool trsm64 = getenv("TD_LOSO_TRSM64") != nullptr;        // development: A/B runs
@@ -1715,7 +1715,7 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
                        pa, linv, xinv, np, nblk, nbig);
   // the folds' dense moments and right-hand sides
   for (int f = 0; f < n_folds; ++f)
-    TD_TRY(td_stats_moments(h, folds[f], af + (size_t)f * nn, xty + (size_t)f * n * d, nullptr, nullptr, nullptr));
+    TD_TRY(td_stats_moments_ld(h, folds[f], af + (size_t)f * nn, np, xty + (size_t)f * n * d, nullptr, nullptr, nullptr));
   hipLaunchKernelGGL(loso_rhs_kernel, dim3(1024), dim3(256), 0, h->stream, xty, invn, n, d, np, n_folds,
                      n_lambda, B);
   LosoVec lv;

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
 // Fills the bias row/column of XtX and the whole XtY from gxo / sy / n.
 __global__ void bias_fill_kernel(const double* __restrict__ gxo, const double* __restrict__ sy,
                                  const double* __restrict__ n, int l1, int c1, int d,
-                                 double* __restrict__ xtx, double* __restrict__ xty) {
+                                 double* __restrict__ xtx, long long ld, double* __restrict__ xty) {
   const int k1 = l1 * c1;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < k1) {
@@ -602,13 +602,13 @@ __global__ void bias_fill_kernel(const double* __restrict__ gxo, const double* _
     const double* row = gxo + (long long)l * (d + 1) * c1;
     if (xtx) {
       const double s = row[(long long)d * c1 + c];   // ones row of A = [y | 1]
-      xtx[(long long)idx * (k1 + 1) + k1] = s;
-      xtx[(long long)k1 * (k1 + 1) + idx] = s;
+      xtx[(long long)idx * ld + k1] = s;
+      xtx[(long long)k1 * ld + idx] = s;
     }
     if (xty)
       for (int dd = 0; dd < d; ++dd) xty[(long long)idx * d + dd] = row[(long long)dd * c1 + c];
   } else if (idx == k1) {
-    if (xtx) xtx[(long long)k1 * (k1 + 1) + k1] = n[0];
+    if (xtx) xtx[(long long)k1 * ld + k1] = n[0];
     if (xty)
       for (int dd = 0; dd < d; ++dd) xty[(long long)k1 * d + dd] = sy[dd];
   }
@@ -1385,15 +1385,25 @@ int td_stats_unpack(td_handle* h, td_stats* s, const double* buf_dev, int64_t to
 
 int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev,
                      double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev) {
+  return td_stats_moments_ld(h, s, xtx_dev, s ? s->k1 + 1 : 0, xty_dev, x2tx2_dev, xtx2_dev, sum_x2_dev);
+}
+
+}  // extern "C"
+
+// The same with the rows of XtX `ld_xtx` numbers apart (the solvers ask for their padded stride,
+// a multiple of 64: with the dense stride n = 2049 every 256-byte piece of a row straddles cache
+// lines and the 34 MB of the C2 matrix took 42 us to write).
+int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_xtx, double* xty_dev,
+                        double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev) {
   if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_moments: NULL argument");
   TD_TRY(stats_materialize(h, s));
   if (xtx_dev)
     TD_TRY(expand_block(h, s->g + s->off_fxx, 0, s->l1, s->c1, s->pre1, s->post1, s->c1, s->pre1,
-                        s->post1, s->win1, s->win1, s->hw, s->n_files, xtx_dev, s->k1 + 1, true));
+                        s->post1, s->win1, s->win1, s->hw, s->n_files, xtx_dev, ld_xtx, true));
   if (xtx_dev || xty_dev) {
     hipLaunchKernelGGL(bias_fill_kernel, dim3((unsigned)td_ceil_div(s->k1 + 1, 256)), dim3(256), 0,
                        h->stream, s->g + s->off_gxo, s->g + s->off_sy, s->g + s->off_n, s->l1,
-                       s->c1, s->d, xtx_dev, s->d ? xty_dev : nullptr);
+                       s->c1, s->d, xtx_dev, (long long)ld_xtx, s->d ? xty_dev : nullptr);
     TD_HIP(h, hipGetLastError());
   }
   if (s->c2) {
@@ -1410,5 +1420,3 @@ int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev
   }
   return TD_OK;
 }
-
-}  // extern "C"

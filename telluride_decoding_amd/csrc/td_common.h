@@ -373,6 +373,8 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
               double* g_dev, bool accumulate, int ldg = 0, int rows_dst = 0, bool skinny = false);
 // dst [e_count][ca][cb] += src [e_count][cb][ca] with the lag order reversed and every block
 // transposed (the cross-covariance from a call with the operands swapped).
+int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_xtx, double* xty_dev,
+                        double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev);
 int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst);
 int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld);
 

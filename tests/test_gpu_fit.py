@@ -1054,8 +1054,8 @@ def test_loso_pcg_solver_reports_when_it_cannot_converge(dev):
   old_bytes = regression.SOLVE_WORKSPACE_BYTES
   n1 = c * 4 + 1
   n_pad = 64
-  regression.SOLVE_WORKSPACE_BYTES = len(lams) * (n_pad * n_pad + n_pad * 64) * 8 + n1 * n1 * 8 + \
-      2 * (n1 * n1 * 8 + 9 * len(lams) * n_pad * 8) + 8
+  regression.SOLVE_WORKSPACE_BYTES = len(lams) * (n_pad * n_pad + n_pad * 64) * 8 + n1 * n_pad * 8 + \
+      2 * (n1 * n_pad * 8 + 9 * len(lams) * n_pad * 8) + 8
   try:
     assert regression._pcg_chunk(5, len(lams), n1, 1) == 2
     chunked = regression.jackknife_over_regularizations(ds, lams)
