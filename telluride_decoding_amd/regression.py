@@ -69,7 +69,8 @@ def _pcg_chunk(n_folds, n_lambda, n, d):
   fold, a padded factor per lambda (fixed) and 9 row vectors per (fold, lambda, output); what is
   left of SOLVE_WORKSPACE_BYTES after the fixed part decides (at least one fold)."""
   n_pad = (int(n) + 63) // 64 * 64
-  fixed = max(1, int(n_lambda)) * (n_pad * n_pad + n_pad * 64) * 8 + n * n_pad * 8
+  # per lambda: the padded factor, the 64-block inverses and the 256-block inverses (16 tiles each)
+  fixed = max(1, int(n_lambda)) * (n_pad * n_pad + n_pad * 64 + ((n_pad + 255) // 256) * 16 * 4096) * 8 + n * n_pad * 8
   per_fold = n * n_pad * 8 + 9 * max(1, int(n_lambda)) * max(1, int(d)) * n_pad * 8
   return int(max(1, min(n_folds, (SOLVE_WORKSPACE_BYTES - fixed) // per_fold)))
 

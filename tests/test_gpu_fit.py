@@ -1054,7 +1054,7 @@ def test_loso_pcg_solver_reports_when_it_cannot_converge(dev):
   old_bytes = regression.SOLVE_WORKSPACE_BYTES
   n1 = c * 4 + 1
   n_pad = 64
-  regression.SOLVE_WORKSPACE_BYTES = len(lams) * (n_pad * n_pad + n_pad * 64) * 8 + n1 * n_pad * 8 + \
+  regression.SOLVE_WORKSPACE_BYTES = len(lams) * (n_pad * n_pad + n_pad * 64 + 16 * 4096) * 8 + n1 * n_pad * 8 + \
       2 * (n1 * n_pad * 8 + 9 * len(lams) * n_pad * 8) + 8
   try:
     assert regression._pcg_chunk(5, len(lams), n1, 1) == 2
