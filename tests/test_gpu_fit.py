@@ -1127,3 +1127,82 @@ def test_bf16_mfma_probe_reports_a_rate(dev):
   h = dev.default_handle()
   for split_shaped in (False, True):
     assert 300.0 < h.probe_bf16_mfma(split_shaped) < 2600.0
+
+
+_TWO_RANK_GPU_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from telluride_decoding_amd import brain_data, device, distributed, regression
+from tests.test_cpu_host import _loso_case
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)                      # both ranks on the one GPU of the box: gloo, not RCCL
+dist.init_process_group('gloo')
+files = _loso_case()
+lens = [f[0].shape[0] for f in files]
+pre, post, batch = 1, 2, 100
+h = device.default_handle()
+
+def stats_of(idx):
+  st = device.LagStats(4, pre, post, d=2)
+  offs = np.concatenate(([0], np.cumsum([lens[i] for i in idx])))
+  st.accumulate(h.to_device(np.concatenate([files[i][0] for i in idx])), None,
+                h.to_device(np.concatenate([files[i][2] for i in idx])), offs)
+  return st
+
+whole = stats_of(range(len(files)))
+want = {k: v.cpu().numpy() for k, v in whole.moments().items() if v is not None}
+# (a) recordings dealt to ranks: the real device statistics through pack -> all-reduce -> unpack
+plan = distributed.ShardPlan(lens, world)
+mine = stats_of(plan.files_of(rank))
+distributed.allreduce_stats(mine, plan, rank, total_frames=sum(lens))
+assert mine.counts() == whole.counts()
+got = mine.moments()
+for k, v in want.items():
+  np.testing.assert_allclose(got[k].cpu().numpy(), v, rtol=1e-12, atol=1e-9)
+# (b) the leave-one-out x lambda sweep on two ranks equals the one-rank sweep (the sweep's
+#     solver included: each rank's folds against the total of ALL recordings)
+ds = brain_data.Dataset(files, batch, pre, post, input_offset=2)
+lams = [1e-3, 0.1, 10.0]
+two = regression.jackknife_over_regularizations(ds, lams, rank=rank, world_size=world)
+assert regression.LAST_SWEEP['solver'] in ('pcg', 'direct')
+solo = [dist.new_group([r]) for r in range(world)][rank]
+one = regression.jackknife_over_regularizations(ds, lams, rank=0, world_size=1, group=solo)
+np.testing.assert_allclose(two['all_runs'], one['all_runs'], rtol=0, atol=2e-6)
+dist.barrier()
+dist.destroy_process_group()
+print('rank %%d ok (%%s)' %% (rank, regression.LAST_SWEEP['solver']))
+'''
+
+
+def test_two_ranks_on_one_gpu_allreduce_and_loso_sweep(dev, tmp_path):
+  """The multi-rank paths on the REAL device layer: two processes share the box's one GPU
+  (gloo rendezvous on 127.0.0.1 -- RCCL needs a GPU per rank): allreduce_stats over file shards
+  (pack / unpack kernels, slot layout) and jackknife_over_regularizations(world_size=2) -- table
+  all-reduce, folds dealt round-robin, each rank's systems through the sweep solver, gather."""
+  import os, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = tmp_path / 'worker_gpu.py'
+  script.write_text(_TWO_RANK_GPU_WORKER % {'root': root})
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+  port = 30500 + (os.getpid() % 2000)
+  procs = []
+  for r in range(2):
+    e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+             MASTER_PORT=str(port))
+    procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True))
+  outs = []
+  for p in procs:
+    try:
+      out, _ = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+      p.kill()
+      out, _ = p.communicate()
+    outs.append(out)
+  for r, (p, out) in enumerate(zip(procs, outs)):
+    assert p.returncode == 0, 'rank %d:\n%s' % (r, out[-3000:])
+    assert 'rank %d ok' % r in out
