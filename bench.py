@@ -353,7 +353,7 @@ def launch_ranks(args, argv):
   if not args.dry_launch:
     import torch                                        # device_count() does not initialise HIP
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not (args.share_gpu and have >= 1):
       sys.stderr.write('bench.py: --gpus %d but this node shows %d GPU(s); refusing to run fewer '
                        'ranks than asked for\n' % (n, have))
       return 2
@@ -469,6 +469,9 @@ def main():
                   help='run the N > 1 code path (RCCL all-reduce of the statistics) on one rank')
   ap.add_argument('--serial', action='store_true',
                   help='one stream, fits back to back (no accumulate/solve overlap)')
+  ap.add_argument('--share-gpu', action='store_true',
+                  help='development: all N ranks on GPU 0 over gloo (RCCL needs a GPU per rank) -- '
+                       'runs the N > 1 logic of this file on a one-GPU box; the numbers mean nothing')
   ap.add_argument('--dry-launch', action='store_true',
                   help='launch the ranks, rendezvous (gloo, CPU) and print the line without any '
                        'compute: checks the multi-rank plumbing where there is no GPU')
@@ -488,6 +491,8 @@ def main():
   if args.dry_launch:
     sys.exit(dry_launch(args, rank, local_rank, world))
   import torch
+  if args.share_gpu:
+    local_rank = 0
   if torch.cuda.device_count() <= local_rank:
     raise SystemExit('rank %d: no GPU %d on this node (%d visible)'
                      % (rank, local_rank, torch.cuda.device_count()))
@@ -501,6 +506,8 @@ def main():
       os.environ['TD_ALLREDUCE_ALWAYS'] = '1'
       dist.init_process_group('nccl', rank=0, world_size=1,
                               device_id=torch.device('cuda', local_rank))
+    elif args.share_gpu:
+      dist.init_process_group('gloo')
     else:
       dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
   # what the communicator itself reports (RCCL's world size), counted once more by a collective

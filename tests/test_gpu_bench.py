@@ -1,0 +1,30 @@
+"""bench.py's N > 1 logic on the real device layer of a one-GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_share_the_gpu():
+  """`bench.py --gpus 2 --share-gpu`: the launcher starts two ranks, both on GPU 0 over gloo (RCCL
+  needs a GPU per rank), and the whole N > 1 path of the file runs on the device: recordings dealt
+  to ranks, FitPipeline with the statistics all-reduce on its solve streams, one solver rank per
+  fit, the barrier / max-over-ranks timing, the strong-scaling leg by time ranges + halo.  Only
+  the plumbing is judged here (the timings of two ranks on one GPU through gloo mean nothing)."""
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+  res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-gpu',
+                        '--steps', '3', '--warmup', '1', '--no-cpu', '--no-extra', '--no-decode'],
+                       env=env, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+  line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+  assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launcher'] == 'self'
+  assert line['steps'] == 3 and line['value'] > 0 and line['scaling'] == 'weak'
+  assert line['strong']['fit_ms_per_step'] > 0
+  assert line['roofline']['launches'] == 3
