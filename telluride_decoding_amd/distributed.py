@@ -202,20 +202,56 @@ def native_comm(handle, group=None):
     return None
   key = (id(group) if group is not None else 0, handle.device_id)
   if key not in _comms:
+    import ctypes
+    import sys
     import torch
+
+    def agree(ok):
+      """True only if every rank of the group says so (the ranks must take the same route)."""
+      t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=handle.device)
+      dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+      return bool(t.item())
 
     def exchange(ident):
       t = torch.tensor(list(ident), dtype=torch.uint8, device=handle.device)
       dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
       return bytes(t.cpu().tolist())
-    _comms[key] = RcclComm(handle, dist.get_rank(group), world, exchange)
+
+    # (1) can every rank bind librccl at all?  (a throw-away id: no collective inside)
+    probe = (ctypes.c_char * 128)()
+    usable = handle.lib.td_rccl_unique_id(handle.ptr, probe) == _lib_ok()
+    comm = None
+    if agree(usable):
+      # (2) the communicator itself (ncclCommInitRank: a collective of its own), then agree again
+      err = None
+      try:
+        comm = RcclComm(handle, dist.get_rank(group), world, exchange)
+      except Exception as e:            # pylint: disable=broad-except
+        err = e
+      if not agree(comm is not None):
+        if comm is not None:
+          comm.close()
+        comm = None
+        if err is not None:
+          sys.stderr.write('telluride_decoding_amd: C-ABI communicator not created (%s); the '
+                           'statistics all-reduce goes through torch.distributed\n' % err)
+    else:
+      sys.stderr.write('telluride_decoding_amd: librccl could not be bound on every rank; the '
+                       'statistics all-reduce goes through torch.distributed\n')
+    _comms[key] = comm
   return _comms[key]
+
+
+def _lib_ok():
+  from telluride_decoding_amd import _lib
+  return _lib.TD_OK
 
 
 def close_native_comms():
   """Destroys the C-ABI communicators (before torch.distributed.destroy_process_group)."""
   for c in _comms.values():
-    c.close()
+    if c is not None:
+      c.close()
   _comms.clear()
 
 
