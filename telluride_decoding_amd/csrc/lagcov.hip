@@ -626,9 +626,14 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int quad = wave & 1, mt = (wave >> 1) & 1, nt = wave >> 2;
 
+  // One workgroup = one lag group of the work items part, part + n_part, ... (n_part = n_work:
+  // one item each; n_part = workgroups / n_groups: a workgroup per CU that walks its share of
+  // the slabs and leaves ONE partial slab -- a third of the partial-slab traffic and of the
+  // finalize launch's reads at C2, where the plan gives every CU three slabs).
   int id = xcd_remap(blockIdx.x, gridDim.x);
   const int group = id % p.n_groups; id /= p.n_groups;
-  const LagWork w = p.works[id];
+  const int part = id;
+  LagWork w = p.works[id];
   const int e0 = group * kLagsPerWg;                   // e_min == 0
 
   f32x16 total[4];                                     // [lag], the slab's sums
@@ -800,6 +805,11 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   f32x16 acc[4];
   unsigned* const buf0 = ldsu;
   unsigned* const buf1 = ldsu + kP * kBfPieceDw;
+  for (; id < p.n_work; id += p.n_part) {
+  if (id != part) {
+    __syncthreads();                                   // every wave is done with the last tile
+    w = p.works[id];
+  }
   prefetch(w.u_begin);
   prefetch_y(w.u_begin);
   store(w.u_begin, buf0);
@@ -851,9 +861,10 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     if (more) __syncthreads();
 #endif
   }
+  }   // work items of this workgroup
 
   // Epilogue: the wave's 32 x 32 block of its four lags in the workgroup's partial slab.
-  float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
+  float* slab = p.partial + (size_t)part * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float* pe = slab + (size_t)(e0 + 4 * quad + r) * p.ca_pad * p.cb_pad;
@@ -872,7 +883,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     // 4 lk = q + 8 k4 + 4 lk of channel mt * 32 + col.
     __syncthreads();
     const float* all = reinterpret_cast<const float*>(ybuf + 4 * kYDw);     // [8 waves][1024]
-    float* tp = p.tpartial + ((size_t)id * p.n_groups + group) * 32 * 64;
+    float* tp = p.tpartial + ((size_t)part * p.n_groups + group) * 32 * 64;
 #pragma unroll
     for (int o = tid; o < 32 * 64; o += kBfThreads) {
       const int e = o >> 6, ch = o & 63;
@@ -2300,6 +2311,7 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
       (lda % 4 == 0) && (ca % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
   // the skinny-A kernel reads A with scalar loads: only B's alignment matters
   plan->aligned = small ? b_aligned : (a_aligned && b_aligned);
+  p.n_part = p.n_work;
   plan->nwg = (long long)p.n_work * per_item_wgs;
   TD_REQUIRE(h, plan->nwg < (1LL << 31), "lagcov: too many workgroups");
   return TD_OK;
@@ -2446,8 +2458,20 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
 #undef TD_BF_OPT
         h->lds_opt_lagcov = true;
       }
+      // More work items than CUs (the C2 plan: three slabs per CU): one workgroup per CU walks its
+      // share and leaves one partial slab (LagParams::n_part).  Not with the riding target column.
+      long long grid_wgs = nwg;
+      static const bool no_persist = getenv("TD_LAG_ONE_ITEM") != nullptr;   // development: A/B runs
+      {
+        const int cus = h->cu_count > 0 ? h->cu_count : 256;
+        const long long per_round = (long long)(cus / p.n_groups) * p.n_groups;
+        if (!(plan->f16 && p.ty) && !no_persist && per_round > 0 && nwg > per_round) {
+          grid_wgs = per_round;
+          p.n_part = (int)(per_round / p.n_groups);
+        }
+      }
 #define TD_BF_LAUNCH(V, R, F, T)                                                                   \
-      hipLaunchKernelGGL((lagcov_split_kernel<V, R, F, T>), dim3((unsigned)nwg), dim3(kBfThreads),   \
+      hipLaunchKernelGGL((lagcov_split_kernel<V, R, F, T>), dim3((unsigned)grid_wgs), dim3(kBfThreads), \
                          (BfGeom<R, ((F) ? 2 : 3)>::kLdsBytes), h->stream, p)
       if (plan->f16 && p.ty) {   // (one target column rides along: <= 32 lags)
         if (aligned) TD_BF_LAUNCH(true, 83, true, true); else TD_BF_LAUNCH(false, 83, true, true);
@@ -2472,7 +2496,7 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
   *job = LagReduceJob{};
   job->partial = p.partial; job->is_f64 = 0;
   // few: [work][phase][n_groups * G lags]: S = 8 / G slabs per work item
-  job->n_work = few ? p.n_work * (8 / few_g) : p.n_work;
+  job->n_work = few ? p.n_work * (8 / few_g) : p.n_part;
   job->e_pad = few ? p.n_groups * few_g : p.e_pad;
   job->ca_pad = p.ca_pad; job->cb_pad = p.cb_pad;
   job->e_count = e_count; job->ca_eff = ca_eff; job->cb = cb;

@@ -257,7 +257,9 @@ struct LagParams {
   const LagWork* works;
   int n_work, n_groups, n_cat, n_cbt;
   int e_min, e_count;
-  float* partial;    // [n_work][e_pad][ca_pad][cb_pad]
+  float* partial;    // [n_part][e_pad][ca_pad][cb_pad]
+  int n_part;        // partial slabs: n_work, or fewer when a workgroup of the split kernel walks
+                     // several work items (work items part, part + n_part, ... into slab `part`)
   int e_pad, ca_pad, cb_pad;
   int lag_g, lag_lg;   // lags per workgroup (8, or 4/2/1 with the 8 wave slots split over time) and log2
   const unsigned* chan_max;   // float16 form: largest magnitude of each channel, float bits [64]

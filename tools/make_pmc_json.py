@@ -20,8 +20,9 @@ out = {}
 for key, kernel, algo, note in (
     ('lagcov', 'lagcov_split_kernel<true, 83, true, false>', 256000000,
      'reads the 256 MB of input (the four lag-group workgroups of a time slab share one XCD L2); '
-     'writes ~100 MB = 192 float32 partial slabs of 512 KB (one per <= 8192-sample slab; the count '
-     'fills whole rounds of the CUs), summed in float64 by stats_finalize_kernel'),
+     'writes 33 MB = 64 float32 partial slabs of 512 KB (one workgroup per CU and lag group walks '
+     'three <= 8192-sample slabs and leaves one partial slab), summed in float64 by '
+     'stats_finalize_kernel'),
     ('targets', 'lagcov_targets_mfma_kernel<true>', 260000000,
      'the second read of x (+ y): y^T x~, column sums and the channel maxima of the float16 kernel'),
     ('gram', 'gram_bf16x3_kernel<5>', 288000000,
