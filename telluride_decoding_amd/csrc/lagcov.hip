@@ -2069,7 +2069,8 @@ __global__ __launch_bounds__(256) void ysum_reduce_kernel(const double* __restri
 template <typename T, int Q>
 __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     const T* __restrict__ partial, int n_work, int e_pad, int ca_pad, int cb_pad, int e_count,
-    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst, int ldg) {
+    int ca_eff, int cb, double* __restrict__ g, int accumulate, int ca_dst, int ldg,
+    const unsigned* __restrict__ scale_a, const unsigned* __restrict__ scale_b) {
   __shared__ double part[Q][64];
   const long long total = (long long)e_count * ca_eff * cb;
   const size_t slab = (size_t)e_pad * ca_pad * cb_pad;
@@ -2099,6 +2100,12 @@ __global__ __launch_bounds__(64 * Q) void lagcov_reduce_kernel(
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < Q; ++k) t += part[k][ol];
+    // float16 kernel: the sums carry the two channels' power-of-two scales (as in the finalize
+    // launch, stats.hip)
+    if (scale_a) {
+      t = ldexp(t, -(td_f16_scale_exp(scale_a[i]) + td_f16_scale_exp(scale_b[j])));
+      if (td_chan_not_finite(scale_a[i]) || td_chan_not_finite(scale_b[j])) t = __builtin_nan("");
+    }
     double* dst = g + ((long long)e * ca_dst + i) * ldg + j;  // ca_dst >= ca_eff rows of ldg per lag
     *dst = accumulate ? *dst + t : t;
   }
@@ -2115,18 +2122,19 @@ __global__ void mirror_upper_kernel(double* __restrict__ g, int c, int ld) {
 template <typename T>
 void launch_lagcov_reduce(td_handle* h, const T* partial, int n_work, int e_pad, int ca_pad,
                           int cb_pad, int e_count, int ca_eff, int cb, double* g, bool accumulate,
-                          int ca_dst, int ldg = 0) {
+                          int ca_dst, int ldg = 0, const unsigned* scale_a = nullptr,
+                          const unsigned* scale_b = nullptr) {
   if (ldg <= 0) ldg = cb;
   const long long outs = (long long)e_count * ca_eff * cb;
   const unsigned blocks = (unsigned)td_ceil_div(outs, 64);
   if (outs < 32768)
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 16>), dim3(blocks), dim3(1024), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst, ldg);
+                       ca_dst, ldg, scale_a, scale_b);
   else
     hipLaunchKernelGGL((lagcov_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 0, h->stream, partial,
                        n_work, e_pad, ca_pad, cb_pad, e_count, ca_eff, cb, g, accumulate ? 1 : 0,
-                       ca_dst, ldg);
+                       ca_dst, ldg, scale_a, scale_b);
 }
 
 // ---- float64 column sums (sum of y over the rows that enter the fit) --------
@@ -2541,11 +2549,12 @@ int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int
 
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate, int ldg, int rows_dst, bool skinny) {
+              double* g_dev, bool accumulate, int ldg, int rows_dst, bool skinny, bool allow_f16) {
   // (ldg / rows_dst: g_dev is a sub-block of lag matrices of rows_dst rows of ldg numbers --
   // the channel-tile decomposition of td_lagcov_auto; 0 = dense [e][ca_eff][cb])
   LagcovPlan plan;
   plan.force_small = skinny;
+  plan.allow_f16 = allow_f16;    // (the reduction below divides the channel scales out)
   TD_TRY(td_lagcov_plan(h, a, lda, ca, a_ones, b, ldb, cb, segs, e_min, e_count, &plan));
   const int ca_eff = plan.ca_eff;
   if (ldg <= 0) ldg = cb;
@@ -2563,7 +2572,7 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
   TD_TRY(td_lagcov_launch(h, &plan, scratch, g_dev, accumulate, ldg, rows_dst, &job));
   launch_lagcov_reduce<float>(h, reinterpret_cast<const float*>(job.partial), job.n_work, job.e_pad,
                               job.ca_pad, job.cb_pad, e_count, ca_eff, cb, g_dev, accumulate, rows_dst,
-                              ldg);
+                              ldg, job.scale_a, job.scale_b);
   if (job.mirror)
     hipLaunchKernelGGL(mirror_upper_kernel, dim3((unsigned)td_ceil_div((long long)ca * cb, 256)),
                        dim3(256), 0, h->stream, g_dev, ca, ldg);
@@ -2575,15 +2584,27 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
 // y_i^T x~ (accumulated), row d (the all-ones row) is left to the caller, who gets the
 // per-segment column sums of B over [u_begin, u_end) in colsum_seg_dev [n_segs][cb]
 // (overwritten) and, if sy_dev, the accumulated column sums of Y.  Returns TD_ERR_STATE-free
-// false in *handled when the shape needs the generic kernel (more than 32 lags / 4 targets).
+// false in *handled when the shape needs the generic kernel (targets with more than 32 lags,
+// more than 4 targets, column sums alone with more than 31 past lags).
 int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, const float* b,
                            int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min,
-                           int e_count, TargetsPlan* plan) {
+                           int e_count, TargetsPlan* plan, bool any_lag_window) {
   plan->handled = false;
   plan->scratch_bytes = 0;
   plan->works.clear();
   plan->seg_work0.clear();
-  if (e_count > 32 || d > 4 || e_min > 0 || e_min + e_count - 1 < 0) return TD_OK;
+  if (any_lag_window) {
+    // td_lagcov_column: a window of lags that need not contain lag 0.  The products are right for
+    // any window (targets are zero outside their rows, the stream is masked by its own validity);
+    // the column sums the kernel leaves are not (they assume the rows [u_begin, u_end) lie inside
+    // what a strip streams) and the caller must not use them.
+    if (d != 1 || e_count > 32) return TD_OK;
+  } else {
+    if (d > 4 || e_min > 0 || e_min + e_count - 1 < 0) return TD_OK;
+    // with targets at most 32 lags; without (column sums only: the lag count plays no part) the
+    // wave kernel streams a strip from row u_begin + e_min on and covers it when e_min >= -31
+    if (d > 0 ? e_count > 32 : -e_min > 31) return TD_OK;
+  }
   plan->handled = true;
   const int n_segs = (int)segs.size();
   plan->d = d; plan->cb = cb; plan->e_count = e_count; plan->n_segs = n_segs;
@@ -2708,6 +2729,29 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
   hipLaunchKernelGGL(colsum_file_reduce_kernel, dim3((unsigned)n_segs, (unsigned)plan.p.n_cbt),
                      dim3(1024), 0, h->stream, out.csum, plan.p.cb_pad, cb,
                      reinterpret_cast<const int*>(seg_dev), colsum_seg_dev);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_lagcov_column(td_handle* h, const float* y, int64_t ldy, const float* b, int64_t ldb, int cb,
+                     const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev) {
+  if (segs.empty()) return TD_OK;
+  for (int k0 = 0; k0 < e_count; k0 += 32) {
+    const int cnt = e_count - k0 < 32 ? e_count - k0 : 32;
+    TargetsPlan plan;
+    TD_TRY(td_lagcov_targets_plan(h, y, ldy, 1, b, ldb, cb, segs, e_min + k0, cnt, &plan, true));
+    TD_REQUIRE(h, plan.handled, "lagcov_column: the targets kernel refused the shape");
+    if (plan.n_work == 0) continue;
+    void* scratch = nullptr;
+    TD_TRY(td_scratch(h, plan.scratch_bytes, &scratch));
+    TargetsOutputs out;
+    out.maxtab = nullptr;
+    double* dst = g_dev + (size_t)k0 * cb;
+    TD_TRY(td_lagcov_targets_launch(h, &plan, scratch, dst, true, &out));
+    const LagReduceJob& job = out.jobs[0];
+    launch_lagcov_reduce<double>(h, reinterpret_cast<const double*>(job.partial), job.n_work, job.e_pad,
+                                 job.ca_pad, job.cb_pad, cnt, 1, cb, dst, true, 1);
+  }
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

@@ -830,16 +830,48 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
 }
 
 // Auto-covariance G[e] = x~^T shift_e(x~), e = 0 .. l-1, accumulated into g [l][c][c].  Up to
-// 64 channels it is one td_lagcov call.  65 .. 128 channels are cut into two channel tiles
-// [0, 64) and [64, c): the two diagonal blocks are the same-stream case again (the bf16x3 kernel
-// for a tile of more than 32 channels), the two off-diagonal blocks go through the general
-// kernel with A and B pointing at different channels of the same rows -- instead of four padded
-// 64 x 64 tiles through the general kernel (the codelab's 69 channels: 3.4 -> 1.x ms).
+// 64 channels it is one td_lagcov call (the split kernel, float16 form).
+//
+// 65 .. 128 channels (the codelab's 69): the fast kernel wants ONE 64-channel tile with 16-byte
+// rows on both sides of the product, and 69 floats per row are neither.  The channels are cut
+// into tiles of 32; every unordered PAIR of tiles (i < j) is gathered into a dense [rows][64]
+// copy (tile i | tile j, zeros past channel c) and goes through the split kernel as a 64-channel
+// stream of its own: its lag matrices hold the blocks (i,i) (i,j) (j,i) (j,j), which are added
+// into g where they belong -- a diagonal block from one pass only.  3 passes for <= 96 channels,
+// 6 for <= 128, each at the speed of the aligned 64-channel case; the copies cost a read and a
+// write of the input per pass.  (Before: two diagonal 64-channel blocks on the unaligned bf16x3
+// path and two off-diagonal ones on the float32 matrix kernel with A and B at different
+// channels of the same rows -- 1.15 ms of the codelab accumulate's 2.0; `TD_AUTO_BLOCKS` keeps it.)
 namespace {
-int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
-                int l, double* g) {
-  if (c <= 64 || c > 128)
-    return td_lagcov(h, x, ldx, c, false, x, ldx, c, segs, 0, l, g, true);
+// out[r][k] = x[row_lo + r][32 (k < 32 ? ti : tj) + (k & 31)], zero past channel c
+__global__ __launch_bounds__(256) void gather_tile_pair_kernel(const float* __restrict__ x, long long ldx,
+                                                               int c, long long row_lo, long long rows,
+                                                               int ti, int tj, float* __restrict__ out) {
+  const int k = threadIdx.x & 63;
+  const int ch = 32 * (k < 32 ? ti : tj) + (k & 31);
+  const bool ok = ch < c;
+  for (long long r = blockIdx.x * 4LL + (threadIdx.x >> 6); r < rows; r += 4LL * gridDim.x)
+    out[r * 64 + k] = ok ? x[(row_lo + r) * ldx + ch] : 0.f;
+}
+
+// g [l][c][c] += the blocks of tmp [l][64][64] (a pass over tiles ti | tj); diag bit 0 / 1: the
+// pass owns the diagonal block of ti / tj
+__global__ __launch_bounds__(256) void scatter_tile_pair_kernel(const double* __restrict__ tmp, int l, int c,
+                                                                int ti, int tj, int diag,
+                                                                double* __restrict__ g) {
+  const long long total = (long long)l * 64 * 64;
+  for (long long o = blockIdx.x * 256LL + threadIdx.x; o < total; o += 256LL * gridDim.x) {
+    const int j = (int)(o & 63), i = (int)((o >> 6) & 63), e = (int)(o >> 12);
+    const int bi = i >> 5, bj = j >> 5;
+    if (bi == bj && !((diag >> bi) & 1)) continue;
+    const int ci = 32 * (bi ? tj : ti) + (i & 31), cj = 32 * (bj ? tj : ti) + (j & 31);
+    if (ci >= c || cj >= c) continue;
+    g[((long long)e * c + ci) * c + cj] += tmp[o];
+  }
+}
+
+int lagcov_auto_blocks(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
+                       int l, double* g) {
   const int c1 = c - 64;
   TD_TRY(td_lagcov(h, x, ldx, 64, false, x, ldx, 64, segs, 0, l, g, true, c, c));
   TD_TRY(td_lagcov(h, x + 64, ldx, c1, false, x + 64, ldx, c1, segs, 0, l, g + (size_t)64 * c + 64, true,
@@ -849,6 +881,53 @@ int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vec
   // (the lag-0 matrix is promised exactly symmetric: its two off-diagonal blocks come from two
   // launches)
   return td_mirror_upper(h, g, c, c);
+}
+
+int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
+                int l, double* g) {
+  if (c <= 64 || c > 128)
+    return td_lagcov(h, x, ldx, c, false, x, ldx, c, segs, 0, l, g, true, 0, 0, false, true);
+  static const bool blocks = getenv("TD_AUTO_BLOCKS") != nullptr;          // development: A/B runs
+  long long lo = 0, hi = 0;
+  bool any = false, same = true;
+  for (const LagSeg& sg : segs) {
+    if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) same = false;
+    if (sg.a_valid <= 0) continue;
+    if (!any || sg.a_row0 < lo) lo = sg.a_row0;
+    if (!any || sg.a_row0 + sg.a_valid > hi) hi = sg.a_row0 + sg.a_valid;
+    any = true;
+  }
+  // (more than 64 lags: not the split kernel's case; > 2^33 bytes of copy: the caller's arrays
+  // of that size are cut into calls anyway)
+  if (blocks || !any || !same || l > 64 || (hi - lo) > (1LL << 25)) return lagcov_auto_blocks(h, x, ldx, c, segs, l, g);
+  const long long rows = hi - lo;
+  std::vector<LagSeg> rel(segs);
+  for (LagSeg& sg : rel) { sg.a_row0 -= lo; sg.b_row0 -= lo; }
+  void* copy = nullptr;
+  void* tmp = nullptr;
+  TD_TRY(td_alloc_async(h, sizeof(float) * 64 * (size_t)rows, &copy));
+  int rc = td_alloc_async(h, sizeof(double) * (size_t)l * 64 * 64, &tmp);
+  if (rc != TD_OK) { td_free_async(h, copy); return rc; }
+  const int nt = (c + 31) / 32;
+  const unsigned gb = (unsigned)(td_ceil_div(rows, 4) > 4096 ? 4096 : td_ceil_div(rows, 4));
+  for (int ti = 0; ti < nt && rc == TD_OK; ++ti)
+    for (int tj = ti + 1; tj < nt && rc == TD_OK; ++tj) {
+      const int diag = (tj == ti + 1 ? 1 : 0) | (ti == nt - 2 && tj == nt - 1 ? 2 : 0);
+      hipLaunchKernelGGL(gather_tile_pair_kernel, dim3(gb), dim3(256), 0, h->stream, x, (long long)ldx, c,
+                         lo, rows, ti, tj, reinterpret_cast<float*>(copy));
+      const float* xc = reinterpret_cast<const float*>(copy);
+      rc = td_lagcov(h, xc, 64, 64, false, xc, 64, 64, rel, 0, l, reinterpret_cast<double*>(tmp), false,
+                     0, 0, false, true);
+      if (rc != TD_OK) break;
+      hipLaunchKernelGGL(scatter_tile_pair_kernel, dim3((unsigned)td_ceil_div((long long)l * 4096, 256)),
+                         dim3(256), 0, h->stream, reinterpret_cast<const double*>(tmp), l, c, ti, tj, diag,
+                         g);
+    }
+  td_free_async(h, copy);
+  td_free_async(h, tmp);
+  TD_TRY(rc);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
 }
 }  // namespace
 
@@ -1143,8 +1222,17 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
       TD_TRY(lagcov_auto(h, x_dev, ldx, s->c1, sxx, s->l1, s->g + s->off_fxx));
     }
     if (s->c2 && !one_pass) {
-      TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
-                       s->g + s->off_fyy, true));
+      // (a one-column view -- an envelope -- is a "target column" against itself / against x: the
+      // matrix-core targets kernel in windows of 32 lags, td_lagcov_column, instead of a padded
+      // 64-channel tile for its auto-covariance (0.14 ms at the codelab's shape) and the skinny
+      // VALU kernel for the cross-covariance (0.28 ms); `TD_LAG_NO_COLUMN` keeps those)
+      static const bool no_column = getenv("TD_LAG_NO_COLUMN") != nullptr;
+      const bool column = s->c2 == 1 && !no_column;
+      if (column)
+        TD_TRY(td_lagcov_column(h, x2_dev, ldx2, x2_dev, ldx2, 1, syy, 0, s->l2, s->g + s->off_fyy));
+      else
+        TD_TRY(td_lagcov(h, x2_dev, ldx2, s->c2, false, x2_dev, ldx2, s->c2, syy, 0, s->l2,
+                         s->g + s->off_fyy, true, 0, 0, false, true));
       // Cross-covariance [e][c1][c2].  A narrow second view (an envelope: c2 <= 8) against a wide
       // first one would run as padded 64 x 64 tiles of the matrix kernel (the codelab's 69 x 1
       // channels, 67 lags: 1.1 ms of a 2.7 ms accumulate for 69 numbers per lag): with the
@@ -1174,8 +1262,10 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
         const size_t tmp_bytes = sizeof(double) * (size_t)e_cnt_xy * s->c1 * s->c2;
         TD_TRY(td_alloc_async(h, tmp_bytes, &tmp));
         TD_HIP(h, hipMemsetAsync(tmp, 0, tmp_bytes, h->stream));
-        int rc = td_lagcov(h, x2_dev, ldx2, s->c2, false, x_dev, ldx, s->c1, sw, -e_max_xy, e_cnt_xy,
-                           reinterpret_cast<double*>(tmp), true, 0, 0, true);
+        int rc = column ? td_lagcov_column(h, x2_dev, ldx2, x_dev, ldx, s->c1, sw, -e_max_xy, e_cnt_xy,
+                                           reinterpret_cast<double*>(tmp))
+                        : td_lagcov(h, x2_dev, ldx2, s->c2, false, x_dev, ldx, s->c1, sw, -e_max_xy,
+                                    e_cnt_xy, reinterpret_cast<double*>(tmp), true, 0, 0, true);
         if (rc == TD_OK)
           rc = td_add_reversed_transposed(h, reinterpret_cast<const double*>(tmp), e_cnt_xy, s->c1, s->c2,
                                           s->g + s->off_gxy);

@@ -357,7 +357,7 @@ struct TargetsPlan {
 };
 int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, const float* b,
                            int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min,
-                           int e_count, TargetsPlan* plan);
+                           int e_count, TargetsPlan* plan, bool any_lag_window = false);
 // Queues the d kernels; jobs[i] reduces target column i into row i of g_dev [e][d + 1][cb];
 // csum [n_work][cb_pad] holds the per-slab column sums of B, ysum[i] [n_work] those of y_i.
 struct TargetsOutputs {
@@ -372,7 +372,8 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
 
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate, int ldg = 0, int rows_dst = 0, bool skinny = false);
+              double* g_dev, bool accumulate, int ldg = 0, int rows_dst = 0, bool skinny = false,
+              bool allow_f16 = false);
 // dst [e_count][ca][cb] += src [e_count][cb][ca] with the lag order reversed and every block
 // transposed (the cross-covariance from a call with the operands swapped).
 int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_xtx, double* xty_dev,
@@ -383,6 +384,11 @@ int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld);
 // [y]^T x~ per signed lag on the lane-per-channel kernel, plus the per-segment column sums
 // of B over [u_begin, u_end) and the column sums of Y (lagcov.hip).  *handled = false when
 // the shape is outside that kernel's range (nothing was done).
+// g_dev [e_count][cb] += sum_u y~[u] b~[u + e], e = e_min .. e_min + e_count - 1, for ONE column y
+// (zero outside the rows [u_begin, u_end) of a segment) against a view of any width, any lag
+// range: the matrix-core targets kernel in windows of 32 lags.
+int td_lagcov_column(td_handle* h, const float* y, int64_t ldy, const float* b, int64_t ldb, int cb,
+                     const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev);
 int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
                       int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
                       double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled);

@@ -72,9 +72,11 @@ def _rel(a, b):
     (40, 0, 20, 0, 0, 0, 1, 2, (130, 129, 2050, 131), 77),
     (64, 0, 31, 0, 0, 0, 1, -3, (4097, 640), 5),
     (57, 0, 31, 0, 0, 0, 1, 0, (17, 9000, 400), 130),
-    # 65 .. 128 channels: two channel tiles (diagonal blocks on the same-stream kernels, the
-    # off-diagonal ones on the general kernel)
+    # 65 .. 128 channels: every pair of 32-channel tiles gathered into a 64-channel copy of its
+    # own for the split kernel (3 passes up to 96 channels, 6 up to 128)
     (69, 0, 36, 0, 0, 0, 1, 0, (2500, 700), 0),
+    (90, 10, 30, 0, 0, 0, 1, 2, (700, 129, 2500), 9),
+    (97, 0, 3, 0, 0, 0, 1, -2, (300, 5, 1400), 0),
     (100, 2, 9, 0, 0, 0, 2, 1, (1800, 129, 640), 13),
     (128, 0, 31, 0, 0, 0, 1, 0, (3000,), 0),
     (65, 1, 2, 0, 0, 0, 1, 0, (900, 901), 0),
@@ -86,6 +88,12 @@ def _rel(a, b):
     (12, 2, 3, 3, 4, 1, 0, 2, (900, 40, 1300), 57),
     (33, 0, 8, 8, 3, 3, 2, -3, (1500, 5, 700), 11),
     (20, 5, 0, 2, 0, 6, 0, 0, (64, 3000), 0),
+    # a one-column second view: its auto- and cross-covariance as a "target column" on the
+    # matrix-core targets kernel in windows of 32 lags (td_lagcov_column), windows without lag 0
+    (20, 3, 4, 1, 5, 40, 0, 2, (900, 40, 1300), 57),
+    (33, 0, 8, 1, 3, 3, 1, -3, (1500, 5, 700), 11),
+    (64, 0, 63, 1, 31, 0, 0, 0, (4000, 129), 0),
+    (9, 0, 0, 1, 0, 33, 0, 0, (2600,), 0),
     # 33 .. 64 lags: the 192-row geometry of the same kernel
     (64, 40, 20, 0, 0, 0, 1, 0, (3000, 260, 129), 0),
     (44, 0, 32, 0, 0, 0, 1, 3, (2500, 2049), 17),
