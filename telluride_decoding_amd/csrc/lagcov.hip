@@ -1847,9 +1847,8 @@ __device__ __forceinline__ void tgt_stage_targets(const LagParams& p, const LagW
 template <bool kVec2>
 __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams p,
                                                                        double* __restrict__ part64,
-                                                                       double* __restrict__ csum,
-                                                                       double* __restrict__ ysum,
-                                                                       unsigned* __restrict__ maxtab) {
+                                                                       double* csum, double* ysum,
+                                                                       unsigned* maxtab) {
   constexpr int E = 32, P = kTgtPrefetch, kPad = 32, kRowsBody = 2 * kTgtBody;
   constexpr int kBodiesMax = (kTgtStrip + E - 1 + kRowsBody - 1) / kRowsBody;
   __shared__ float ya[kPad + kBodiesMax * kRowsBody];
@@ -1859,6 +1858,11 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   const int cbt = (int)(blockIdx.x % p.n_cbt);
   const int wi = (int)(blockIdx.x / p.n_cbt);          // strip = slab
   const LagWork w = p.works[wi];
+  // blockIdx.y: window of 32 lags (td_lagcov_column: lags e_min + 32 y ..; otherwise one window).
+  // A strip's slab holds all its windows; the column sums are window 0's business.
+  const int e_lo = 32 * (int)blockIdx.y;
+  p.e_min += e_lo;
+  if (e_lo) { csum = nullptr; ysum = nullptr; maxtab = nullptr; }
   const TgtStrip ts = tgt_strip(p, w);
   const int slab_i = wi;
   tgt_stage_targets(p, w, ts.len, ts.n_body, kPad, ya, tid);
@@ -2004,13 +2008,13 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   double* slab = part64 + (size_t)slab_i * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int k = (r & 3) + 8 * (r >> 2) + 4 * g;
+    const int k = e_lo + (r & 3) + 8 * (r >> 2) + 4 * g;
     if (k < p.e_count) {
       slab[(size_t)k * p.ca_pad * p.cb_pad + c0] = big0[r];
       slab[(size_t)k * p.ca_pad * p.cb_pad + c0 + 1] = big1[r];
     }
   }
-  if (g == 0) {
+  if (g == 0 && csum) {
     csum[(size_t)slab_i * p.cb_pad + c0] = cs0;
     csum[(size_t)slab_i * p.cb_pad + c0 + 1] = cs1;
   }
@@ -2327,10 +2331,21 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
 
 int td_chan_tab(td_handle* h, unsigned** tab) {
   if (!h->chan_max) {
-    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->chan_max), sizeof(unsigned) * 2 * kChanTab));
-    TD_HIP(h, hipMemsetAsync(h->chan_max, 0, sizeof(unsigned) * 2 * kChanTab, h->stream));
+    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->chan_max), sizeof(unsigned) * 3 * kChanTab));
+    TD_HIP(h, hipMemsetAsync(h->chan_max, 0, sizeof(unsigned) * 3 * kChanTab, h->stream));
   }
   *tab = h->chan_max + kChanTab * (h->chan_phase & 1);
+  return TD_OK;
+}
+
+// The table of a stand-alone td_lagcov call (the first two alternate between the accumulate calls
+// of the regression statistics, whose finalize launch clears the one the next call will use):
+// zeroed here, on the stream, for the measuring kernel that follows.
+int td_chan_tab_scratch(td_handle* h, unsigned** tab) {
+  unsigned* first = nullptr;
+  TD_TRY(td_chan_tab(h, &first));
+  *tab = h->chan_max + 2 * kChanTab;
+  TD_HIP(h, hipMemsetAsync(*tab, 0, sizeof(unsigned) * kChanTab, h->stream));
   return TD_OK;
 }
 
@@ -2429,7 +2444,7 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
       // channel scales of the float16 form: largest magnitude of every channel over the rows
       // of the array that hold this call's recordings (a superset of what the kernel reads)
       unsigned* tab = nullptr;
-      TD_TRY(td_chan_tab(h, &tab));
+      TD_TRY(td_chan_tab_scratch(h, &tab));
       long long lo = plan->works[0].a_row0, hi = lo;
       for (const LagWork& wk : plan->works) {
         lo = wk.a_row0 < lo ? wk.a_row0 : lo;
@@ -2549,12 +2564,14 @@ int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int
 
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-              double* g_dev, bool accumulate, int ldg, int rows_dst, bool skinny, bool allow_f16) {
+              double* g_dev, bool accumulate, int ldg, int rows_dst, bool skinny, bool allow_f16,
+              unsigned* chan_tab) {
   // (ldg / rows_dst: g_dev is a sub-block of lag matrices of rows_dst rows of ldg numbers --
   // the channel-tile decomposition of td_lagcov_auto; 0 = dense [e][ca_eff][cb])
   LagcovPlan plan;
   plan.force_small = skinny;
   plan.allow_f16 = allow_f16;    // (the reduction below divides the channel scales out)
+  plan.tab = chan_tab;           // (the caller measured the channels' maxima: td_chan_tab_scratch)
   TD_TRY(td_lagcov_plan(h, a, lda, ca, a_ones, b, ldb, cb, segs, e_min, e_count, &plan));
   const int ca_eff = plan.ca_eff;
   if (ldg <= 0) ldg = cb;
@@ -2598,7 +2615,7 @@ int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, con
     // any window (targets are zero outside their rows, the stream is masked by its own validity);
     // the column sums the kernel leaves are not (they assume the rows [u_begin, u_end) lie inside
     // what a strip streams) and the caller must not use them.
-    if (d != 1 || e_count > 32) return TD_OK;
+    if (d != 1 || e_count > 32 * 8) return TD_OK;
   } else {
     if (d > 4 || e_min > 0 || e_min + e_count - 1 < 0) return TD_OK;
     // with targets at most 32 lags; without (column sums only: the lag count plays no part) the
@@ -2622,11 +2639,16 @@ int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, con
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
   long long t_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, 4 * cus), 32);
   t_strip = t_strip < 512 ? 512 : (t_strip > kTgtStrip ? kTgtStrip : t_strip);
+  // strips of the column-sum kernel (one WAVE each): <= kWaveStrip rows, shorter when the call is
+  // short, down to 128 (a strip streams 31 .. 62 rows more than it sums) -- 200k rows in strips of
+  // 512 were 391 waves on 1024 SIMDs: 52 us for a 55 MB read
+  long long w_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, 8 * cus), 32);
+  w_strip = w_strip < 128 ? 128 : (w_strip > kWaveStrip ? kWaveStrip : w_strip);
   plan->seg_work0.assign(n_segs + 1, 0);
   for (int f = 0; f < n_segs; ++f) {
     plan->seg_work0[f] = (int)plan->works.size() * slabs_per_strip;
     std::vector<LagSeg> one(1, segs[f]);
-    std::vector<LagWork> ws = split_work(one, ni > 0 ? t_strip : kWaveStrip);
+    std::vector<LagWork> ws = split_work(one, ni > 0 ? t_strip : w_strip);
     plan->works.insert(plan->works.end(), ws.begin(), ws.end());
   }
   plan->seg_work0[n_segs] = (int)plan->works.size() * slabs_per_strip;
@@ -2669,7 +2691,8 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
   } else {
     const float* y = p.a;
     const bool vec2 = (p.ldb % 2 == 0) && (cb % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 7) == 0);
-    const dim3 grid((unsigned)(plan->n_strips * p.n_cbt));
+    // (td_lagcov_column: windows of 32 lags in grid.y)
+    const dim3 grid((unsigned)(plan->n_strips * p.n_cbt), (unsigned)td_ceil_div(e_count, 32));
     for (int i = 0; i < cols; ++i) {
       // target column i: A = y + i (one column), output row i of every lag
       LagParams pi = p;
@@ -2736,8 +2759,8 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
 int td_lagcov_column(td_handle* h, const float* y, int64_t ldy, const float* b, int64_t ldb, int cb,
                      const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev) {
   if (segs.empty()) return TD_OK;
-  for (int k0 = 0; k0 < e_count; k0 += 32) {
-    const int cnt = e_count - k0 < 32 ? e_count - k0 : 32;
+  for (int k0 = 0; k0 < e_count; k0 += 32 * 8) {       // (one launch covers 8 windows = 256 lags)
+    const int cnt = e_count - k0 < 32 * 8 ? e_count - k0 : 32 * 8;
     TargetsPlan plan;
     TD_TRY(td_lagcov_targets_plan(h, y, ldy, 1, b, ldb, cb, segs, e_min + k0, cnt, &plan, true));
     TD_REQUIRE(h, plan.handled, "lagcov_column: the targets kernel refused the shape");

@@ -843,15 +843,42 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
 // path and two off-diagonal ones on the float32 matrix kernel with A and B at different
 // channels of the same rows -- 1.15 ms of the codelab accumulate's 2.0; `TD_AUTO_BLOCKS` keeps it.)
 namespace {
-// out[r][k] = x[row_lo + r][32 (k < 32 ? ti : tj) + (k & 31)], zero past channel c
+// out[r][k] = x[row_lo + r][32 (k < 32 ? ti : tj) + (k & 31)], zero past channel c; the largest
+// magnitude of every column of the copy goes into tab (the float16 kernel's channel scales:
+// chan_max_kernel's table, lagcov.hip)
 __global__ __launch_bounds__(256) void gather_tile_pair_kernel(const float* __restrict__ x, long long ldx,
                                                                int c, long long row_lo, long long rows,
-                                                               int ti, int tj, float* __restrict__ out) {
-  const int k = threadIdx.x & 63;
+                                                               int ti, int tj, float* __restrict__ out,
+                                                               unsigned* __restrict__ tab) {
+  __shared__ unsigned red[4][64];
+  const int k = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int ch = 32 * (k < 32 ? ti : tj) + (k & 31);
   const bool ok = ch < c;
-  for (long long r = blockIdx.x * 4LL + (threadIdx.x >> 6); r < rows; r += 4LL * gridDim.x)
-    out[r * 64 + k] = ok ? x[(row_lo + r) * ldx + ch] : 0.f;
+  unsigned m = 0u;
+  long long r = blockIdx.x * 4LL + rg;
+  const long long stride = 4LL * gridDim.x;
+  for (; r + 3 * stride < rows; r += 4 * stride) {       // four rows in flight per thread
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = ok ? x[(row_lo + r + q * stride) * ldx + ch] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      out[(r + q * stride) * 64 + k] = v[q];
+      m = max(m, __float_as_uint(v[q]) & 0x7fffffffu);
+    }
+  }
+  for (; r < rows; r += stride) {
+    const float v = ok ? x[(row_lo + r) * ldx + ch] : 0.f;
+    out[r * 64 + k] = v;
+    m = max(m, __float_as_uint(v) & 0x7fffffffu);
+  }
+  if (!tab) return;
+  red[rg][k] = m;
+  __syncthreads();
+  if (rg == 0) {
+    m = max(max(red[0][k], red[1][k]), max(red[2][k], red[3][k]));
+    if (m) atomicMax(tab + (blockIdx.x % kChanShards) * 128 + k, m);
+  }
 }
 
 // g [l][c][c] += the blocks of tmp [l][64][64] (a pass over tiles ti | tj); diag bit 0 / 1: the
@@ -909,15 +936,19 @@ int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vec
   int rc = td_alloc_async(h, sizeof(double) * (size_t)l * 64 * 64, &tmp);
   if (rc != TD_OK) { td_free_async(h, copy); return rc; }
   const int nt = (c + 31) / 32;
-  const unsigned gb = (unsigned)(td_ceil_div(rows, 4) > 4096 ? 4096 : td_ceil_div(rows, 4));
+  const unsigned gb = (unsigned)(td_ceil_div(rows, 16) > 2048 ? 2048 : td_ceil_div(rows, 16));
   for (int ti = 0; ti < nt && rc == TD_OK; ++ti)
     for (int tj = ti + 1; tj < nt && rc == TD_OK; ++tj) {
       const int diag = (tj == ti + 1 ? 1 : 0) | (ti == nt - 2 && tj == nt - 1 ? 2 : 0);
+      // (the copy's channel maxima ride along: a table the float32 / bf16x3 forms simply ignore)
+      unsigned* tab = nullptr;
+      rc = td_chan_tab_scratch(h, &tab);
+      if (rc != TD_OK) break;
       hipLaunchKernelGGL(gather_tile_pair_kernel, dim3(gb), dim3(256), 0, h->stream, x, (long long)ldx, c,
-                         lo, rows, ti, tj, reinterpret_cast<float*>(copy));
+                         lo, rows, ti, tj, reinterpret_cast<float*>(copy), tab);
       const float* xc = reinterpret_cast<const float*>(copy);
       rc = td_lagcov(h, xc, 64, 64, false, xc, 64, 64, rel, 0, l, reinterpret_cast<double*>(tmp), false,
-                     0, 0, false, true);
+                     0, 0, false, true, tab);
       if (rc != TD_OK) break;
       hipLaunchKernelGGL(scatter_tile_pair_kernel, dim3((unsigned)td_ceil_div((long long)l * 4096, 256)),
                          dim3(256), 0, h->stream, reinterpret_cast<const double*>(tmp), l, c, ti, tj, diag,

@@ -373,7 +373,10 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
               double* g_dev, bool accumulate, int ldg = 0, int rows_dst = 0, bool skinny = false,
-              bool allow_f16 = false);
+              bool allow_f16 = false, unsigned* chan_tab = nullptr);
+// A zeroed channel-maximum table (kChanTab numbers; row = workgroup % kChanShards, 128 per row)
+// for a caller that measures the maxima of a stand-alone td_lagcov call's input itself.
+int td_chan_tab_scratch(td_handle* h, unsigned** tab);
 // dst [e_count][ca][cb] += src [e_count][cb][ca] with the lag order reversed and every block
 // transposed (the cross-covariance from a call with the operands swapped).
 int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_xtx, double* xty_dev,

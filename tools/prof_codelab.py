@@ -1,7 +1,7 @@
-"""Kernel trace target: the accumulate of the codelab-shape CCA fit (69 ch x 37 lags against 31 lags
-of one envelope, 200k samples), a few calls.
+"""Kernel trace target: the accumulate (default) or the dense stage (`solve` / `solve0` = reg 0) of
+the codelab-shape CCA fit (69 ch x 37 lags against 31 lags of one envelope, 200k samples).
 
-    tools/prof.sh codelab -- tools/prof_codelab.py
+    tools/prof.sh codelab -- tools/prof_codelab.py [solve|solve0]
 """
 import os
 import sys
@@ -24,6 +24,14 @@ def main():
     st.reset()
     st.accumulate(xc, yc, None, [0, m])
   h.synchronize()
+  if len(sys.argv) > 1 and sys.argv[1].startswith('solve'):
+    reg = 0.0 if sys.argv[1] == 'solve0' else 0.1
+    st.cca_solve(m - 1, reg, 5)
+    h.timer_start()
+    for _ in range(5):
+      st.cca_solve(m - 1, reg, 5)
+    print('cca_solve(reg=%g) %.3f ms' % (reg, h.timer_stop() / 5))
+    return
   h.timer_start()
   for _ in range(20):
     st.reset()
