@@ -27,6 +27,10 @@ int td_order_after_others(td_handle* h) {
   std::lock_guard<std::mutex> lock(g_handles_mu);
   for (td_handle* o : g_handles) {
     if (o == h || o->device != h->device || o->stream == h->stream || !o->order_event) continue;
+    // nothing outstanding there: nothing to order after (a record + wait on an idle CU-masked
+    // stream cost ~50 us of stream time each: its queue has to be scheduled to signal the event)
+    if (hipStreamQuery(o->stream) == hipSuccess) continue;
+    (void)hipGetLastError();                 // (hipErrorNotReady is the other expected answer)
     TD_HIP(h, hipEventRecord(o->order_event, o->stream));
     TD_HIP(h, hipStreamWaitEvent(h->stream, o->order_event, 0));
   }
@@ -103,9 +107,9 @@ int td_alloc_async(td_handle* h, size_t bytes, void** out) {
   return TD_OK;
 }
 
-int td_free_async(td_handle* h, void* p) {
+int td_free_async(td_handle* h, void* p, bool own_stream_only) {
   if (!p) return TD_OK;
-  TD_TRY(td_order_after_others(h));
+  if (!own_stream_only) TD_TRY(td_order_after_others(h));
   std::unique_lock<std::mutex> lock(g_pool_mu);
   const auto it = g_pool_sizes.find(p);
   if (it == g_pool_sizes.end()) {                    // not from td_alloc_async

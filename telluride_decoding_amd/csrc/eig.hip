@@ -292,12 +292,15 @@ __global__ __launch_bounds__(256) void jacobi64_kernel(JacParams P) {
                 S[qi * LS + qj] = si * b01 + ci * b11;
               }
             }
+            // (rows >= players of J stay rows of the identity: nothing to rotate there)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               const int row = (tid >> 5) + 8 * i;
-              const double jp = J[row * LS + pj], jq = J[row * LS + qj];
-              J[row * LS + pj] = cj * jp - sj * jq;
-              J[row * LS + qj] = sj * jp + cj * jq;
+              if (row < players) {
+                const double jp = J[row * LS + pj], jq = J[row * LS + qj];
+                J[row * LS + pj] = cj * jp - sj * jq;
+                J[row * LS + qj] = sj * jp + cj * jq;
+              }
             }
           }
         }
@@ -990,7 +993,7 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   struct Ws {
     double *xtx, *x2tx2, *xtx2, *sum2, *cxx, *cyy, *cxy, *vals1, *vecs1, *vals2, *vecs2, *m1, *g,
         *sig, *gn, *vn, *rt;
-    void *eig, *svd, *chol;
+    void *eig, *svd, *chol, *chol2;
   } w;
   auto carve = [&](void* base) {
     Carver cv(base);
@@ -1014,6 +1017,7 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
     w.eig = cv.take<char>(eig_ws_bytes(std::max(k1, k2)));
     w.svd = cv.take<char>(svd_ws_bytes(k));
     w.chol = cv.take<char>(td_chol_ws_bytes(k1));
+    w.chol2 = cv.take<char>(td_chol_ws_bytes(k2 <= 64 ? k2 : 1));
     return (size_t)(cv.p - reinterpret_cast<char*>(base));
   };
   void* base = nullptr;
@@ -1081,19 +1085,48 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
                        w.vecs1, w.vals1, k1, eps_eig, w.cxx);
     TD_TRY(gemm(h, w.cxx, k1, false, w.cxx, k1, true, k11, k1, k1, k1, k1));
   }
-  TD_TRY(sym_eig(h, w.cyy, k2, k2, w.vals2, w.vecs2, w.eig, &sweeps[1]));
-  hipLaunchKernelGGL(whiten_scale_kernel, dim3(grid_for((long long)k2 * k2)), dim3(256), 0, h->stream,
-                     w.vecs2, w.vals2, k2, eps_eig, w.cyy);
-  double* k22 = w.vecs2;
-  TD_TRY(gemm(h, w.cyy, k2, false, w.cyy, k2, true, k22, k2, k2, k2, k2));
-  // T = W_x cov_xy K22, laid out with the vectors to orthogonalise as rows
-  if (use_chol) {   // g = T^T [k2][k1] = K22 (L^-1 cov_xy)^T; the rows of (L^-1 cov_xy)^T are in chol.rt
-    TD_TRY(gemm(h, k22, k2, false, chol.rt, chol.np, false, w.g, k1, k2, k1, k2));
-  } else if (cols) {   // g = T^T [k2][k1] = K22 (cov_xy^T K11)
+  // The whitening W_y of the other side (T = W_x cov_xy W_y^T, rot_y = W_y^T v): the same argument.
+  // 17 .. 64 columns (the codelab's 31 lags of an envelope) take W_y = L2^-1 from the Cholesky
+  // factor of cov_yy + reg I -- its transpose comes out of the factorisation as the forward
+  // substitution of the identity's rows -- when the same two proofs hold; the Jacobi
+  // eigen-decomposition of a 31 x 31 matrix in one workgroup was 0.29 of the 2.6 ms dense stage.
+  // (Up to 16 columns the eigen route is as fast as the factorisation's launches.)
+  td_chol_state chol2;
+  bool use_chol2 = k2 > 16 && k2 <= 64 && !force_eig;
+  if (use_chol2) {
+    hipLaunchKernelGGL(identity_kernel, dim3(grid_for((long long)k2 * k2)), dim3(256), 0, h->stream,
+                       w.vecs2, k2);
+    if (!psd_proof) {
+      const int rc = td_chol_factor(h, w.chol2, w.cyy, k2, w.vecs2, 0, &chol2, -eps_eig);
+      if (rc == TD_ERR_SINGULAR) use_chol2 = false;
+      else if (rc != TD_OK) return rc;
+    }
+  }
+  if (use_chol2) {
+    const int rc = td_chol_factor(h, w.chol2, w.cyy, k2, w.vecs2, k2, &chol2);
+    if (rc == TD_ERR_SINGULAR) use_chol2 = false;
+    else if (rc != TD_OK) return rc;
+  }
+  // wy: W_y (symmetric K22, eigen route) or W_y^T = (L2^-1)^T (rows of chol2.rt); wy_t: which
+  const double* wy = w.vecs2;
+  int ldwy = k2;
+  const bool wy_t = use_chol2;
+  if (use_chol2) {
+    wy = chol2.rt; ldwy = chol2.np;
+  } else {
+    TD_TRY(sym_eig(h, w.cyy, k2, k2, w.vals2, w.vecs2, w.eig, &sweeps[1]));
+    hipLaunchKernelGGL(whiten_scale_kernel, dim3(grid_for((long long)k2 * k2)), dim3(256), 0, h->stream,
+                       w.vecs2, w.vals2, k2, eps_eig, w.cyy);
+    TD_TRY(gemm(h, w.cyy, k2, false, w.cyy, k2, true, w.vecs2, k2, k2, k2, k2));
+  }
+  // T = W_x cov_xy W_y^T, laid out with the vectors to orthogonalise as rows
+  if (use_chol) {   // g = T^T [k2][k1] = W_y (L^-1 cov_xy)^T; the rows of (L^-1 cov_xy)^T are in chol.rt
+    TD_TRY(gemm(h, wy, ldwy, wy_t, chol.rt, chol.np, false, w.g, k1, k2, k1, k2));
+  } else if (cols) {   // g = T^T [k2][k1] = W_y (cov_xy^T K11)
     TD_TRY(gemm(h, w.cxy, k2, true, k11, k1, false, w.m1, k1, k2, k1, k1));
-    TD_TRY(gemm(h, k22, k2, false, w.m1, k1, false, w.g, k1, k2, k1, k2));
-  } else {      // g = T [k1][k2] = K11 (cov_xy K22)
-    TD_TRY(gemm(h, w.cxy, k2, false, k22, k2, false, w.m1, k2, k1, k2, k2));
+    TD_TRY(gemm(h, wy, ldwy, wy_t, w.m1, k1, false, w.g, k1, k2, k1, k2));
+  } else {      // g = T [k1][k2] = K11 (cov_xy W_y^T)
+    TD_TRY(gemm(h, w.cxy, k2, false, wy, ldwy, !wy_t, w.m1, k2, k1, k2, k2));
     TD_TRY(gemm(h, k11, k1, false, w.m1, k2, false, w.g, k2, k1, k2, k1));
   }
   TD_TRY(jacobi_svd(h, w.g, len, k, len, dim, w.sig, w.gn, w.vn, w.svd, &sweeps[2]));
@@ -1104,7 +1137,7 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   else TD_TRY(gemm(h, u_rows, k1, false, k11, k1, false, w.rt, k1, dim, k1, k1));
   hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(grid_for((long long)dim * k1)), dim3(256), 0,
                      h->stream, w.rt, dim, k1, rot_x_dev);
-  TD_TRY(gemm(h, v_rows, k2, false, k22, k2, false, w.rt, k2, dim, k2, k2));
+  TD_TRY(gemm(h, v_rows, k2, false, wy, ldwy, wy_t, w.rt, k2, dim, k2, k2));   // v^T W_y
   hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(grid_for((long long)dim * k2)), dim3(256), 0,
                      h->stream, w.rt, dim, k2, rot_y_dev);
   hipLaunchKernelGGL(scale_to_f32_kernel, dim3(1), dim3(256), 0, h->stream, w.sig, 1.0, (long long)dim,
@@ -1113,7 +1146,7 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   TD_HIP(h, hipStreamSynchronize(h->stream));
   if (info_host) {
     info_host[0] = sweeps[0]; info_host[1] = sweeps[1]; info_host[2] = sweeps[2];
-    info_host[3] = use_chol ? 1 : 0;      // which whitening the x side took
+    info_host[3] = (use_chol ? 1 : 0) | (use_chol2 ? 2 : 0);      // which sides took the Cholesky whitening
   }
   return TD_OK;
 }

@@ -934,7 +934,7 @@ int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vec
   void* tmp = nullptr;
   TD_TRY(td_alloc_async(h, sizeof(float) * 64 * (size_t)rows, &copy));
   int rc = td_alloc_async(h, sizeof(double) * (size_t)l * 64 * 64, &tmp);
-  if (rc != TD_OK) { td_free_async(h, copy); return rc; }
+  if (rc != TD_OK) { td_free_async(h, copy, true); return rc; }
   const int nt = (c + 31) / 32;
   const unsigned gb = (unsigned)(td_ceil_div(rows, 16) > 2048 ? 2048 : td_ceil_div(rows, 16));
   for (int ti = 0; ti < nt && rc == TD_OK; ++ti)
@@ -954,8 +954,8 @@ int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vec
                          dim3(256), 0, h->stream, reinterpret_cast<const double*>(tmp), l, c, ti, tj, diag,
                          g);
     }
-  td_free_async(h, copy);
-  td_free_async(h, tmp);
+  td_free_async(h, copy, true);
+  td_free_async(h, tmp, true);
   TD_TRY(rc);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
@@ -1300,7 +1300,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
         if (rc == TD_OK)
           rc = td_add_reversed_transposed(h, reinterpret_cast<const double*>(tmp), e_cnt_xy, s->c1, s->c2,
                                           s->g + s->off_gxy);
-        td_free_async(h, tmp);
+        td_free_async(h, tmp, true);
         TD_TRY(rc);
       } else {
         TD_TRY(td_lagcov(h, x_dev, ldx, s->c1, false, x2_dev, ldx2, s->c2, sxy, e_min_xy, e_cnt_xy,

@@ -348,7 +348,8 @@ class LagStats(object):
     h.check(h.lib.td_cca_solve(h.ptr, self.ptr, float(denom), float(regularization),
                                float(eps_eig), int(dim), _ptr(rot_x), _ptr(rot_y), _ptr(mean_x),
                                _ptr(mean_y), _ptr(e), info))
-    self.last_cca_route = 'cholesky' if info[3] else 'eigen'     # whitening of the x side
+    self.last_cca_route = 'cholesky' if info[3] & 1 else 'eigen'     # whitening of the x side
+    self.last_cca_route_y = 'cholesky' if info[3] & 2 else 'eigen'   # ... of the other side
     return rot_x, rot_y, mean_x, mean_y, e, tuple(info[:3])
 
   def __del__(self):

@@ -14,10 +14,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
   from telluride_decoding_amd import device
   h = device.default_handle()
+  # TD_EXTRA_HANDLES=n: n more handles (streams) alive in the process, as in bench.py after its
+  # pipelined leg (td_free_async orders a freed block after every handle's stream)
+  extra = [device.Handle() for _ in range(int(os.environ.get('TD_EXTRA_HANDLES', '0')))]
   rng = np.random.default_rng(0)
   m = 200000
-  x = rng.standard_normal((m, 69)).astype(np.float32)
-  y = rng.standard_normal((m, 1)).astype(np.float32)
+  if os.environ.get('TD_BENCH_DATA'):      # the data of bench.py's codelab leg
+    import bench
+    eeg, _, _ = bench.make_workload(0)
+    bands = (eeg[:, :8] * 0.5 + np.random.default_rng(3).standard_normal((eeg.shape[0], 8))).astype(np.float32)
+    extra_ch = (0.5 * eeg[:m, :5] + rng.standard_normal((m, 5))).astype(np.float32)
+    x = np.concatenate((eeg[:m], extra_ch), axis=1)
+    y = bands[:m, :1]
+  else:
+    x = rng.standard_normal((m, 69)).astype(np.float32)
+    y = rng.standard_normal((m, 1)).astype(np.float32)
   xc, yc = h.to_device(x), h.to_device(y)
   st = device.LagStats(69, 0, 36, 1, 15, 15, 0, handle=h)
   for _ in range(5):

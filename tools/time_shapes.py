@@ -14,7 +14,8 @@ def timed(fn, reps=5):
   return (time.perf_counter() - t0) / reps * 1e3
 for (c, pre, post, d, n) in [(64, 0, 31, 1, 1000000), (128, 0, 31, 1, 1000000), (32, 0, 31, 1, 1000000),
                              (16, 0, 3, 1, 1000000), (64, 8, 8, 2, 1000000), (64, 0, 63, 1, 1000000),
-                             (21, 0, 31, 1, 1000000)]:
+                             (21, 0, 31, 1, 1000000), (69, 0, 36, 1, 1000000), (96, 0, 31, 1, 1000000),
+                             (64, 0, 31, 4, 1000000), (8, 0, 31, 1, 1000000), (48, 16, 16, 1, 1000000)]:
   x = torch.randn(n, c, device='cuda'); y = torch.randn(n, d, device='cuda')
   offs = np.array([0, n], np.int64)
   st = device.LagStats(c, pre, post, d=d)
