@@ -234,7 +234,9 @@ int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev
  * diagonal entries incl. the bias (brain_model.py:447-455), then
  * solve(cov_x, cov_xy) (:477).  Float64 Cholesky on the device.
  *   w_dev [n_lambda, k1, d] float32, b_dev [n_lambda, d] float32.
- * TD_ERR_SINGULAR when cov_x is not positive definite. */
+ * Any number of outputs d (up to 8 ride in the batched factorisation; wider targets -- a forward
+ * model whose targets are the EEG channels -- are solved one lambda at a time, 64 columns per
+ * factorisation).  TD_ERR_SINGULAR when cov_x is not positive definite. */
 int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
                    float* w_dev, float* b_dev);
 /* The same without waiting for the device.  *singular_flag_host points at a pinned host int
@@ -324,7 +326,9 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
  *   float32 on the device, the dtype the reference returns for float32 inputs.
  *   dim <= min(k1, k2) (the caller clips, as the reference's slicing does).
  *   info_host (may be NULL, else int[4]) receives the Jacobi sweep counts {eig xx, eig yy, svd}
- *   and in [3] which whitening the x side took: 1 = Cholesky factor, 0 = eigen-decomposition.
+ *   and in [3] which sides were whitened by a Cholesky factor instead of the eigen-decomposition
+ *   (any whitening gives the same canonical directions when no eigenvalue is dropped): bit 0 the
+ *   x side, bit 1 the other side (17 .. 64 columns).
  * Singular vectors are defined up to a joint sign of (rot_x[:, i], rot_y[:, i]). */
 int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization, double eps_eig,
                  int dim, float* rot_x_dev, float* rot_y_dev, float* mean_x_dev, float* mean_y_dev,

@@ -587,7 +587,9 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(CholParams p, int n
                        (wave & 1) * 32 + 16 * nn) * 8);
   };
   auto load_operands = [&](const UpdTile& u, int q, f64x2 (&va)[8], f64x2 (&vb)[8]) {
-    if (u.rows_valid == NB) load_tile(va, u.bi, q);
+    // (a matrix tile goes through the matrix's buffer descriptor; the right-hand-side rows live
+    // in another buffer -- also when there are exactly 64 of them)
+    if (u.bi != p.nblk) load_tile(va, u.bi, q);
     else tile_to_regs(va, u.rows_i + (p.kf + q) * NB, n, u.rows_valid, tid);
     load_tile(vb, u.bj, q);
   };
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(CholParams p, int n
     UpdTile nxt = cur;
     if (more) nxt = upd_tile(p, sys, a_b, tn, n_tri);
     double* dst = cur.rows_i + (size_t)cur.bj * NB;
-    const bool full = cur.rows_valid == NB;         // every tile but the right-hand-side rows
+    const bool full = cur.bi != p.nblk;             // every tile but the right-hand-side rows
     f64x4 acc[2][2];
     double cold[2][2][4];
 #pragma unroll
@@ -1457,9 +1459,10 @@ __global__ void diag_add_kernel(double* __restrict__ a, int np, int n, double v)
   if (i < n) a[(size_t)i * np + i] += v;
 }
 
-// diag_shift: factor C + diag_shift I instead (the inertia test of td_cca_solve uses a negative one).
+// Factors scale * C + diag_shift I (the inertia test of td_cca_solve uses a negative shift; the wide
+// ridge solve below scale = 1 / frames and shift = lambda).
 int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const double* bt_dev, int nb,
-                   td_chol_state* st, double diag_shift) {
+                   td_chol_state* st, double diag_shift, double scale) {
   TD_REQUIRE(h, n > 0 && nb >= 0 && nb <= 64, "td_chol_factor: bad sizes");
   const int np = (int)td_round_up(n, NB);
   char* p = reinterpret_cast<char*>(ws);
@@ -1471,7 +1474,7 @@ int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const dou
   st->linv = reinterpret_cast<double*>(p);  p += sizeof(double) * (size_t)(np / NB) * NB * NB;
   st->tol = reinterpret_cast<double*>(p);
   hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), 1), dim3(256), 0, h->stream, c_dev, 0LL,
-                     n, n, np, 1.0, (const double*)nullptr, st->a);
+                     n, n, np, scale, (const double*)nullptr, st->a);
   if (diag_shift != 0.0)
     hipLaunchKernelGGL(diag_add_kernel, dim3((unsigned)td_ceil_div(n, 256)), dim3(256), 0, h->stream, st->a,
                        np, n, diag_shift);
@@ -1493,6 +1496,69 @@ int td_chol_back(td_handle* h, const td_chol_state* st, const double* ut_dev, in
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
+
+// ---- ridge solve with more than kMaxRhs outputs (a forward model: D = EEG channels) --------------
+// The batched solver carries at most kMaxRhs right-hand-side rows per system (they ride in its
+// panel and update kernels).  Wider targets go through the Cholesky helpers above, one lambda at
+// a time: factor cov + lambda I with up to 64 columns of cov_xy riding along (forward
+// substitution), backward substitution 8 rows at a time; more than 64 outputs factor again per
+// 64 columns.  Same arithmetic (float64 Cholesky), same failure (TD_ERR_SINGULAR), synchronous.
+namespace {
+// out [nb][n]: column c0 + q of xty [n][d], scaled
+__global__ void xty_rows_kernel(const double* __restrict__ xty, int n, int d, int c0, int nb, double inv,
+                                double* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * n; i += gridDim.x * blockDim.x)
+    out[i] = xty[(size_t)(i % n) * d + c0 + i / n] * inv;
+}
+
+// sol [nb][n] (row q = output c0 + q; entry k1 = the bias) -> W [k1][d], b [d]
+__global__ void ridge_emit_rows_kernel(const double* __restrict__ sol, int k1, int d, int c0, int nb,
+                                       float* __restrict__ w, float* __restrict__ bias) {
+  const int n = k1 + 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * n; i += gridDim.x * blockDim.x) {
+    const int q = i / n, r = i % n;
+    const float v = (float)sol[i];
+    if (r < k1) w[(size_t)r * d + c0 + q] = v;
+    else bias[c0 + q] = v;
+  }
+}
+
+int ridge_solve_wide(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda, float* w_dev,
+                     float* b_dev) {
+  int k1 = 0, d = 0;
+  int64_t frames = 0;
+  td_stats_layout(s, &k1, &d, &frames);
+  const int n = k1 + 1;
+  const size_t off_xty = (size_t)n * n, off_bt = off_xty + (size_t)n * d, off_z = off_bt + (size_t)64 * n,
+               off_sol = off_z + (size_t)64 * n, off_ws = off_sol + (size_t)64 * n;
+  void* base = nullptr;
+  TD_TRY(td_workspace(h, sizeof(double) * off_ws + td_chol_ws_bytes(n) + 256, &base));
+  double* xtx = reinterpret_cast<double*>(base);
+  double* xty = xtx + off_xty;
+  double* bt = xtx + off_bt;
+  double* z = xtx + off_z;
+  double* sol = xtx + off_sol;
+  void* cws = reinterpret_cast<char*>(base) + td_round_up((int64_t)(sizeof(double) * off_ws), 256);
+  TD_TRY(td_stats_moments_ld(h, s, xtx, n, xty, nullptr, nullptr, nullptr));
+  const double inv = 1.0 / (double)frames;
+  for (int li = 0; li < n_lambda; ++li) {
+    float* w_l = w_dev + (size_t)li * k1 * d;
+    float* b_l = b_dev + (size_t)li * d;
+    for (int c0 = 0; c0 < d; c0 += 64) {
+      const int nb = d - c0 < 64 ? d - c0 : 64;
+      hipLaunchKernelGGL(xty_rows_kernel, dim3(64), dim3(256), 0, h->stream, xty, n, d, c0, nb, inv, bt);
+      td_chol_state st;
+      TD_TRY(td_chol_factor(h, cws, xtx, n, bt, nb, &st, lambdas_host[li], inv));
+      hipLaunchKernelGGL(unpad_rows_kernel, dim3(64), dim3(256), 0, h->stream, st.rt, nb, n, st.np, z);
+      TD_TRY(td_chol_back(h, &st, z, nb, sol));
+      hipLaunchKernelGGL(ridge_emit_rows_kernel, dim3(64), dim3(256), 0, h->stream, sol, k1, d, c0, nb,
+                         w_l, b_l);
+    }
+  }
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -1527,8 +1593,14 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
   td_stats_layout(s, &k1, &d, &frames);
   TD_REQUIRE(h, n_lambda > 0, "td_ridge_solve: need at least one lambda");
   TD_REQUIRE(h, d > 0, "td_ridge_solve: statistics were created without a target (d = 0)");
-  TD_REQUIRE(h, d <= kMaxRhs, "td_ridge_solve: at most %d outputs per solve, not %d", kMaxRhs, d);
   if (frames <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve: no data accumulated");
+  if (d > kMaxRhs) {
+    // wide targets: synchronous; an asynchronous caller gets its flag written behind the solve
+    const int rc = ridge_solve_wide(h, s, lambdas_host, n_lambda, w_dev, b_dev);
+    if (!flag_dev || (rc != TD_OK && rc != TD_ERR_SINGULAR)) return rc;
+    const int flag = rc == TD_ERR_SINGULAR ? 1 : 0;
+    return td_upload_async(h, &flag, sizeof(int), flag_dev);
+  }
   const int n = k1 + 1;
   const int np = (int)td_round_up(n, NB);
   const size_t nn = (size_t)n * np;             // dense moments with the padded row stride (aligned rows)
@@ -1572,8 +1644,7 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
   int k1 = 0, d = 0;
   int64_t frames = 0;
   td_stats_layout(stats[0], &k1, &d, &frames);
-  TD_REQUIRE(h, d > 0 && d <= kMaxRhs, "td_ridge_solve_multi: outputs per solve must be in [1, %d]",
-             kMaxRhs);
+  TD_REQUIRE(h, d > 0, "td_ridge_solve_multi: statistics were created without a target (d = 0)");
   for (int i = 0; i < n_stats; ++i) {
     int ki = 0, di = 0;
     int64_t fi = 0;
@@ -1581,6 +1652,29 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
     td_stats_layout(stats[i], &ki, &di, &fi);
     TD_REQUIRE(h, ki == k1 && di == d, "td_ridge_solve_multi: layouts differ");
     if (fi <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve_multi: no data accumulated");
+  }
+  if (d > kMaxRhs) {
+    // wide targets: one statistics object at a time (ridge_solve_wide), synchronous
+    int singular = 0;
+    for (int i = 0; i < n_stats; ++i) {
+      const int rc = ridge_solve_wide(h, stats[i], lambdas_host, n_lambda,
+                                      w_dev + (size_t)i * n_lambda * k1 * d, b_dev + (size_t)i * n_lambda * d);
+      if (rc == TD_ERR_SINGULAR) singular = 1;
+      else if (rc != TD_OK) return rc;
+    }
+    if (!singular_flag_host)
+      return singular ? td_fail(h, TD_ERR_SINGULAR, "Singular matrix: covariance is not positive definite")
+                      : TD_OK;
+    if (!h->dev_flags) {
+      TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flags), sizeof(int) * td_handle::kAsyncFlags));
+      TD_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags),
+                              sizeof(int) * td_handle::kAsyncFlags, hipHostMallocDefault));
+    }
+    const int slot = h->async_next;
+    h->async_next = (h->async_next + 1) % td_handle::kAsyncFlags;
+    h->host_flags[slot] = singular;       // (everything above has finished: the solves are synchronous)
+    *singular_flag_host = h->host_flags + slot;
+    return TD_OK;
   }
   const int n = k1 + 1;
   const int np = (int)td_round_up(n, NB);

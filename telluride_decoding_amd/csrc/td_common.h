@@ -427,5 +427,5 @@ struct td_chol_state {
 };
 size_t td_chol_ws_bytes(int n);
 int td_chol_factor(td_handle* h, void* ws, const double* c_dev, int n, const double* bt_dev, int nb,
-                   td_chol_state* st, double diag_shift = 0.0);
+                   td_chol_state* st, double diag_shift = 0.0, double scale = 1.0);
 int td_chol_back(td_handle* h, const td_chol_state* st, const double* ut_dev, int nu, double* xt_dev);

@@ -221,7 +221,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   # folds of C5 are 1.1 GB; _pcg_chunk); a chunk that does not converge, or does not fit after
   # all, sends the REST of the sweep to (2).
   n_done = 0
-  if hasattr(dev.LagStats, 'ridge_solve_loso') and my_folds and USE_PCG:
+  # (the CG solver carries at most 8 outputs per system; wider targets take the direct solves)
+  if hasattr(dev.LagStats, 'ridge_solve_loso') and my_folds and USE_PCG and d <= 8:
     per_call = _pcg_chunk(len(my_folds), n_lam, proto.k1 + 1, d)
     total = proto.like().combine(stats)
     trains_all = [proto.like() for _ in range(per_call)]

@@ -174,6 +174,9 @@ def _numpy_dense_stage(cxx, cyy, cxy, dim, eps=1e-12):
     (23, 9, 1, 31, 6000, 0.1),        # block Jacobi (207 x 207), narrow second view
     (69, 37, 1, 31, 6000, 0.1),       # the codelab shape: K1 = 2553, K2 = 31
     (6, 3, 40, 3, 3000, 0.0),         # K1 < K2 (rows of T are orthogonalised), reg = 0
+    (50, 3, 64, 1, 6000, 0.1),        # K2 = 64 exactly: a full tile of right-hand-side rows rides in
+                                      # the factorisation (it was mistaken for a matrix tile)
+    (40, 2, 20, 2, 5000, 0.05),       # both sides whitened by Cholesky factors (17 <= K2 <= 64)
 ])
 def test_cca_solve_matches_float64_lapack(dev, c1, l1, c2, l2, n, reg):
   """Moments -> rotations on the device vs the same dense stage through LAPACK's symmetric

@@ -253,6 +253,42 @@ def test_ridge_lambda_batch_and_spd_failure(dev):
     st.ridge_solve([0.0])
 
 
+@pytest.mark.parametrize('c,pre,post,d,n', [(7, 1, 3, 12, 2500), (3, 0, 4, 70, 3000), (20, 0, 5, 64, 4000)])
+def test_ridge_with_wide_targets(dev, c, pre, post, d, n):
+  """More outputs than the batched solver's 8 right-hand sides (a forward model: the targets are
+  the EEG channels; the reference has no limit, brain_model.py:384-481): the same float64 Cholesky
+  through td_chol_factor / td_chol_back, against the reference algorithm on the dense lag matrix."""
+  rng = np.random.default_rng(100 + d)
+  x = rng.standard_normal((n, c)).astype(np.float32)
+  mix = rng.standard_normal((c, d))
+  y = (x @ mix + 0.3 * rng.standard_normal((n, d)) + rng.standard_normal((1, d))).astype(np.float32)
+  h = dev.default_handle()
+  st = dev.LagStats(c, pre, post, d=d)
+  st.accumulate(h.to_device(x), None, h.to_device(y))
+  lams = [1e-3, 0.1]
+  w, b = st.ridge_solve(lams)
+  k = c * (pre + 1 + post)
+  assert tuple(w.shape) == (2, k, d) and tuple(b.shape) == (2, d)
+  batches = list(o_lag.minibatches([(x.astype(np.float64), x[:, :1], y.astype(np.float64),
+                                     np.zeros((n, 1)))], n, pre=pre, post=post))
+  for i, lam in enumerate(lams):
+    wr, br, _, _, _ = o_reg.linear_regressor_from_batches(batches, lamb=lam)
+    np.testing.assert_allclose(w[i].cpu().numpy(), wr, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(b[i].cpu().numpy(), br[0], rtol=2e-4, atol=2e-5)
+  # the asynchronous and the batched entry points take the same route
+  w2, b2, flag = st.ridge_solve_async(lams)
+  h.synchronize()
+  assert flag() == 0
+  np.testing.assert_array_equal(w2.cpu().numpy(), w.cpu().numpy())
+  w3, b3 = dev.LagStats.ridge_solve_multi([st, st], lams)
+  np.testing.assert_array_equal(w3[1].cpu().numpy(), w.cpu().numpy())
+  np.testing.assert_array_equal(b3[0].cpu().numpy(), b.cpu().numpy())
+  zero = dev.LagStats(c, pre, post, d=d)
+  zero.accumulate(h.to_device(np.zeros((400, c), np.float32)), None, h.to_device(np.zeros((400, d), np.float32)))
+  with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
+    zero.ridge_solve([0.0])
+
+
 def test_spd_solve_sizes(dev):
   """Blocked Cholesky across partial panels, several right-hand sides, batch."""
   import ctypes
