@@ -454,10 +454,21 @@ def spd_solve(a, rhs, handle=None):
   """Solution of a x = rhs for a symmetric positive definite float64 device matrix a [n, n]
   and rhs [n, nrhs] (td_spd_solve, blocked Cholesky); inputs untouched."""
   h = handle or default_handle()
-  a = a.clone().contiguous()
-  x = rhs.clone().contiguous()
-  h.check(h.lib.td_spd_solve(h.ptr, _ptr(a), _ptr(x), int(a.shape[0]), int(x.shape[1]), 1))
-  return x
+  n, nrhs = int(a.shape[0]), int(rhs.shape[1])
+  if nrhs <= 8:
+    a = a.clone().contiguous()
+    x = rhs.clone().contiguous()
+    h.check(h.lib.td_spd_solve(h.ptr, _ptr(a), _ptr(x), n, nrhs, 1))
+    return x
+  # td_spd_solve carries at most 8 right-hand sides through its factorisation (and overwrites
+  # the matrix): wider ones go 8 columns at a time
+  out = rhs.clone().contiguous()
+  for c0 in range(0, nrhs, 8):
+    x = rhs[:, c0:c0 + 8].clone().contiguous()
+    m = a.clone().contiguous()
+    h.check(h.lib.td_spd_solve(h.ptr, _ptr(m), _ptr(x), n, int(x.shape[1]), 1))
+    out[:, c0:c0 + 8] = x
+  return out
 
 
 def shrinkage_moment(x, file_offsets, pre, post, batch_rows, input_offset=0, rows_used=None,

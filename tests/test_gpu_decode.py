@@ -585,6 +585,15 @@ def test_forward_model_with_many_outputs(dev):
   np.testing.assert_allclose(pred, cov @ sol, rtol=1e-4, atol=2e-4)
   ev = model.evaluate(ds)
   assert ev['pearson_correlation_first'] > 0.9
+  # the shrinkage branch (use_ridge=False) solves through td_spd_solve, 8 columns at a time
+  from oracle import regression as o_reg
+  batches = [({'input_1': lagged[i:i + 500].astype(np.float32)}, y[i:i + 500]) for i in range(0, n, 500)]
+  ws, bs, _, _, sh = brain_model.calculate_linear_regressor_parameters_from_dataset(
+      batches, lamb=0.3, use_ridge=False)
+  wr, br, _, _, shr = o_reg.linear_regressor_from_batches(batches, lamb=0.3, use_ridge=False)
+  assert sh == shr
+  np.testing.assert_allclose(ws, wr, rtol=1e-3, atol=2e-5)
+  np.testing.assert_allclose(np.ravel(bs), np.ravel(br), rtol=1e-3, atol=2e-5)
 
 
 def test_decoder_streaming_api_and_persistence(dev, tmp_path):
