@@ -1855,12 +1855,20 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   __shared__ double comb[3][16][64];                   // waves 1-3 -> wave 0, 16 registers at a time
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cbt = (int)(blockIdx.x % p.n_cbt);
-  const int wi = (int)(blockIdx.x / p.n_cbt);          // strip = slab
-  const LagWork w = p.works[wi];
-  // blockIdx.y: window of 32 lags (td_lagcov_column: lags e_min + 32 y ..; otherwise one window).
+  // Work item = (strip, 64-channel tile); td_lagcov_column adds windows of 32 lags (p.n_groups of
+  // them: lags e_min + 32 win ..; otherwise one).  The windows of an item read the same rows of x:
+  // they are dealt to ONE XCD, next to each other in dispatch order (workgroup g runs on XCD g % 8),
+  // so that the second and third read hit its L2 -- with the windows in blockIdx.y a strip's
+  // windows ran a whole grid apart and x came from HBM once per window.
   // A strip's slab holds all its windows; the column sums are window 0's business.
-  const int e_lo = 32 * (int)blockIdx.y;
+  const int n_win = p.n_groups;
+  const int slot = (int)(blockIdx.x >> 3);
+  const int item = (slot / n_win) * 8 + (int)(blockIdx.x & 7);
+  if (item >= p.n_work * p.n_cbt) return;              // (the grid is padded to whole XCD rounds)
+  const int cbt = item % p.n_cbt;
+  const int wi = item / p.n_cbt;                       // strip = slab
+  const LagWork w = p.works[wi];
+  const int e_lo = 32 * (slot % n_win);
   p.e_min += e_lo;
   if (e_lo) { csum = nullptr; ysum = nullptr; maxtab = nullptr; }
   const TgtStrip ts = tgt_strip(p, w);
@@ -2691,8 +2699,10 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
   } else {
     const float* y = p.a;
     const bool vec2 = (p.ldb % 2 == 0) && (cb % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 7) == 0);
-    // (td_lagcov_column: windows of 32 lags in grid.y)
-    const dim3 grid((unsigned)(plan->n_strips * p.n_cbt), (unsigned)td_ceil_div(e_count, 32));
+    // (td_lagcov_column: several windows of 32 lags per work item, see the kernel)
+    const int n_win = (int)td_ceil_div(e_count, 32);
+    p.n_groups = n_win;
+    const dim3 grid((unsigned)(td_ceil_div((int64_t)plan->n_strips * p.n_cbt, 8) * 8 * n_win));
     for (int i = 0; i < cols; ++i) {
       // target column i: A = y + i (one column), output row i of every lag
       LagParams pi = p;

@@ -177,6 +177,9 @@ def _numpy_dense_stage(cxx, cyy, cxy, dim, eps=1e-12):
     (50, 3, 64, 1, 6000, 0.1),        # K2 = 64 exactly: a full tile of right-hand-side rows rides in
                                       # the factorisation (it was mistaken for a matrix tile)
     (40, 2, 20, 2, 5000, 0.05),       # both sides whitened by Cholesky factors (17 <= K2 <= 64)
+    (30, 2, 16, 1, 4000, 0.1),        # K2 = 16 / 17: either side of the second Cholesky's threshold
+    (30, 2, 17, 1, 4000, 0.1),
+    (70, 1, 65, 1, 4000, 0.1),        # K2 = 65: no Cholesky shortcut on either side (k2 > 64)
 ])
 def test_cca_solve_matches_float64_lapack(dev, c1, l1, c2, l2, n, reg):
   """Moments -> rotations on the device vs the same dense stage through LAPACK's symmetric

@@ -94,6 +94,12 @@ def _rel(a, b):
     (33, 0, 8, 1, 3, 3, 1, -3, (1500, 5, 700), 11),
     (64, 0, 63, 1, 31, 0, 0, 0, (4000, 129), 0),
     (9, 0, 0, 1, 0, 33, 0, 0, (2600,), 0),
+    # boundaries: 129 channels (three 64-channel tiles of the general kernels), 96 channels exactly,
+    # 65 lags (one past the split kernel's 64), K + 1 a multiple of 64
+    (129, 0, 2, 0, 0, 0, 1, 0, (700, 300), 0),
+    (96, 1, 1, 0, 0, 0, 2, -1, (900, 200), 0),
+    (34, 32, 32, 0, 0, 0, 1, 0, (1500, 400), 0),
+    (21, 0, 2, 0, 0, 0, 1, 0, (800,), 0),
     # 33 .. 64 lags: the 192-row geometry of the same kernel
     (64, 40, 20, 0, 0, 0, 1, 0, (3000, 260, 129), 0),
     (44, 0, 32, 0, 0, 0, 1, 3, (2500, 2049), 17),
@@ -287,6 +293,26 @@ def test_ridge_with_wide_targets(dev, c, pre, post, d, n):
   zero.accumulate(h.to_device(np.zeros((400, c), np.float32)), None, h.to_device(np.zeros((400, d), np.float32)))
   with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
     zero.ridge_solve([0.0])
+
+
+@pytest.mark.parametrize('c,post,d', [(21, 2, 1), (9, 6, 8), (9, 6, 9), (127, 0, 3), (64, 1, 2), (3, 20, 16)])
+def test_ridge_at_size_boundaries(dev, c, post, d):
+  """K + 1 at and next to multiples of the solver's 64-wide blocks, 8 and 9 outputs (the batched
+  solver's limit and the first wide case): against a float64 solve of the dense system."""
+  rng = np.random.default_rng(c * 100 + post * 10 + d)
+  n = 3000
+  x = rng.standard_normal((n, c)).astype(np.float32)
+  xp = np.vstack([x.astype(np.float64), np.zeros((post, c))])
+  lagged = np.hstack([xp[l:l + n] for l in range(post + 1)])
+  y = (lagged[:, :d] * 0.7 + 0.2 * rng.standard_normal((n, d)) + 1.0).astype(np.float32)
+  h = dev.default_handle()
+  st = dev.LagStats(c, 0, post, d=d)
+  st.accumulate(h.to_device(x), None, h.to_device(y))
+  w, b = st.ridge_solve([0.05])
+  x1 = np.hstack([lagged, np.ones((n, 1))])
+  sol = np.linalg.solve(x1.T @ x1 / n + 0.05 * np.eye(x1.shape[1]), x1.T @ y.astype(np.float64) / n)
+  np.testing.assert_allclose(w[0].cpu().numpy(), sol[:-1], rtol=2e-4, atol=2e-5)
+  np.testing.assert_allclose(b[0].cpu().numpy(), sol[-1], rtol=2e-4, atol=2e-5)
 
 
 def test_spd_solve_sizes(dev):
