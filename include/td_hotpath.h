@@ -305,6 +305,16 @@ int td_predict_fir(td_handle* h, const float* x_dev, int64_t ldx,
  * context is added (brain_data.py:466-475).  Output row file_offsets[f] + t is
  * frame t of the zipped streams of file f. */
 
+/* The same forward with EVERY FILE UNDER ITS OWN MODEL: w_dev [num_files, K, d], b_dev
+ * [num_files, d] (may be NULL).  This is the evaluation half of the leave-one-out sweep
+ * (regression.jackknife_one_model, regression.py:197-214: the model fitted without recording f
+ * predicts recording f; with the lambdas of a sweep as the d output columns) as ONE launch over
+ * all held-out recordings instead of one per fold. */
+int td_predict_fir_per_file(td_handle* h, const float* x_dev, int64_t ldx,
+                            const int64_t* file_offsets_host, int num_files, int c, int pre,
+                            int post, int input_offset, const float* w_dev, const float* b_dev,
+                            int d, float* out_dev, int64_t ldout);
+
 /* CCA transform [(x - mean1).rot1 | (x2 - mean2).rot2] on lagged views
  * (cca.BrainCcaLayer.call, cca.py:150-161).  out_dev [rows, 2*dims]. */
 int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int pre1,

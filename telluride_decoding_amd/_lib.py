@@ -91,6 +91,7 @@ SIGNATURES = {
     'td_general_solve': [_vp, _vp, _vp, _i, _i],
     'td_shrinkage_moment': [_vp, _vp, _i64, _i, _i, _i, _pi64, _i, _i, _pi64, _i64, _vp],
     'td_predict_fir': [_vp, _vp, _i64, _pi64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64],
+    'td_predict_fir_per_file': [_vp, _vp, _i64, _pi64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64],
     'td_cca_transform': [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i, _i, _pi64, _i, _i,
                          _vp, _vp, _vp, _vp, _i, _vp, _i64],
     'td_cca_solve': [_vp, _vp, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i)],

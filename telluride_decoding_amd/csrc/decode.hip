@@ -140,11 +140,21 @@ __global__ __launch_bounds__(kThreads, 2) void predict_fir_mfma_kernel(
     const float* __restrict__ x, long long ldx, const FileDesc* __restrict__ files, int n_files,
     long long n_strips, int strip_len, int c, int pre, int post, const float* __restrict__ w,
     const float* __restrict__ bias, int d_total, int dq_max, int tpq, int ring,
-    float* __restrict__ out, long long ldout) {
+    float* __restrict__ out, long long ldout, long long w_file_stride, long long b_file_stride) {
   extern __shared__ __attribute__((aligned(16))) float fir_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = pre + 1 + post;
+  // every recording its own weights (td_predict_fir_per_file: the held-out recordings of a
+  // leave-one-out sweep, each under its own fold's models): the host gives every recording whole
+  // workgroups of strips, so the weights a workgroup stages are those of its first strip's file
+  if (w_file_stride) {
+    long long s0 = blockIdx.x * (long long)(kThreads / 64);
+    s0 = s0 < n_strips ? s0 : n_strips - 1;
+    const int f0 = find_file(files, n_files, s0);
+    w += f0 * w_file_stride;
+    if (bias) bias += f0 * b_file_stride;
+  }
   // blockIdx.y: the group of <= dq_max outputs this workgroup computes (the 20 lambdas of a
   // held-out recording were 7 launches of 62 workgroups, one after the other)
   const int q0 = (int)blockIdx.y * dq_max;
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(kThreads, 2) void predict_fir_mfma_kernel(
   const FileDesc st = files[find_file(files, n_files, sidx)];
   const long long ts = (sidx - st.first) * strip_len;
   const int st_len = (int)(st.nrows - ts < strip_len ? st.nrows - ts : strip_len);
+  if (st_len <= 0) return;                     // (a strip that pads a recording to whole workgroups)
   const long long rb = ts - pre;
   const int nb = (st_len + nl - 1 + 31) / 32;
   const int li = lane & 31, lh = lane >> 5;
@@ -1624,7 +1635,7 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
 // (td_table_upload): no td_scratch use, and no upload at all when the layout repeats.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
                int c, int pre, int post, const float* w, const float* bias, int d, float* out,
-               int64_t ldout, int64_t shift = 0) {
+               int64_t ldout, int64_t shift = 0, int64_t w_file_stride = 0, int64_t b_file_stride = 0) {
   // `shift` leading rows of every file are dropped from this input stream BEFORE
   // context is added (brain_data.py:466-475); output row offs[f] + t is frame t of
   // the shifted stream, i.e. the index of the zipped streams.
@@ -1655,7 +1666,14 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   // (16-byte aligned rows of at most 64 channels; everything else takes the lane-per-channel path)
   const bool vec4 = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const bool mfma_ok = c <= 64 && vec4 && lds_for(dq_max) <= kFirLdsMax;
-  if (nl == 1 && c >= 4 && c <= 64 && vec4 && d <= 32) {
+  if (w_file_stride && !mfma_ok) {
+    // per-file weights outside the matrix-core kernel's shapes: one call per recording
+    for (int f = 0; f < num_files; ++f)
+      TD_TRY(launch_fir(h, x, ldx, offs + f, 1, c, pre, post, w + f * w_file_stride,
+                        bias ? bias + f * b_file_stride : nullptr, d, out, ldout, shift));
+    return TD_OK;
+  }
+  if (!w_file_stride && nl == 1 && c >= 4 && c <= 64 && vec4 && d <= 32) {
     // no context: one MFMA tile holds all outputs (project_mfma_kernel)
     int64_t strip = td_round_up(td_ceil_div(total, 256 * kProjWavesPerCu), 64);
     if (strip < 128) strip = 128;
@@ -1684,7 +1702,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   // predict_fir_mfma_kernel -- its split + MFMA cost 26 us and its loads 19 us that overlap only
   // partly (ablations: DESIGN 8) -- so the P-tile kernel stays the default and this one is opt-in.)
   static const bool tile16 = getenv("TD_FIR_TILE16") != nullptr;          // development: A/B runs
-  if (d == 1 && nl <= 32 && c >= 4 && c <= 64 && vec4 && tile16 && h->acc_mode != TD_ACC_F32) {
+  if (!w_file_stride && d == 1 && nl <= 32 && c >= 4 && c <= 64 && vec4 && tile16 && h->acc_mode != TD_ACC_F32) {
     // one output: the barrier-free 16-row kernel (fir_tile16_kernel); 12 waves per CU, one round
     const int cus = h->cu_count > 0 ? h->cu_count : 256;
     int64_t strip = td_round_up(td_ceil_div(total, (int64_t)cus * 12), 16);
@@ -1726,7 +1744,9 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       files[f].nrows = n > 0 ? n : 0;
       files[f].out0 = offs[f];
       files[f].first = n_strips;
-      if (n > 0) n_strips += td_ceil_div(n, strip);
+      // (per-file weights: whole workgroups of strips per recording, the kernel skips the padding)
+      if (n > 0) n_strips += w_file_stride ? td_round_up(td_ceil_div(n, strip), kThreads / 64)
+                                           : td_ceil_div(n, strip);
     }
     TD_TRY(td_table_upload(h, files.data(), files.size() * sizeof(FileDesc), &table_dev));
     const FileDesc* df = reinterpret_cast<const FileDesc*>(table_dev);
@@ -1744,7 +1764,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
                        dim3(blocks, (unsigned)td_ceil_div(d, dq_max)), dim3(kThreads),
                        lds_for(dq_max), h->stream, x, (long long)ldx, df, num_files, n_strips,
                        (int)strip, c, pre, post, w, bias, d, dq_max, tpq, ring, out,
-                       (long long)ldout);
+                       (long long)ldout, (long long)w_file_stride, (long long)b_file_stride);
     TD_HIP(h, hipGetLastError());
     return TD_OK;
   }
@@ -1842,6 +1862,21 @@ int td_predict_fir(td_handle* h, const float* x_dev, int64_t ldx,
   TD_REQUIRE(h, ldx >= c && ldout >= d, "td_predict_fir: leading dimension too small");
   return launch_fir(h, x_dev, ldx, file_offsets_host, num_files, c, pre, post, w_dev, b_dev, d,
                     out_dev, ldout, input_offset > 0 ? input_offset : 0);
+}
+
+int td_predict_fir_per_file(td_handle* h, const float* x_dev, int64_t ldx,
+                            const int64_t* file_offsets_host, int num_files, int c, int pre, int post,
+                            int input_offset, const float* w_dev, const float* b_dev, int d,
+                            float* out_dev, int64_t ldout) {
+  if (!h || !x_dev || !file_offsets_host || !w_dev || !out_dev)
+    return td_fail(h, TD_ERR_INVALID, "td_predict_fir_per_file: NULL argument");
+  TD_REQUIRE(h, c > 0 && pre >= 0 && post >= 0 && d > 0 && num_files >= 0,
+             "td_predict_fir_per_file: bad sizes");
+  TD_REQUIRE(h, ldx >= c && ldout >= d, "td_predict_fir_per_file: leading dimension too small");
+  if (num_files == 0) return TD_OK;
+  return launch_fir(h, x_dev, ldx, file_offsets_host, num_files, c, pre, post, w_dev, b_dev, d,
+                    out_dev, ldout, input_offset > 0 ? input_offset : 0,
+                    (int64_t)c * (pre + 1 + post) * d, (int64_t)d);
 }
 
 int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int pre1, int post1,

@@ -385,6 +385,26 @@ def predict_fir(x, file_offsets, w, b, pre, post, out=None, handle=None, input_o
   return out
 
 
+def predict_fir_per_file(x, file_offsets, w, b, pre, post, out=None, handle=None, input_offset=0):
+  """predict_fir with every file under its own model (td_predict_fir_per_file): w [files, K, D],
+  b [files, D] device float32 -- the held-out recordings of a leave-one-out sweep in one launch."""
+  h = handle or default_handle()
+  rows, c = int(x.shape[0]), int(x.shape[1])
+  offs, offs_p = _lib.i64_array(file_offsets)
+  n_files, d = len(offs) - 1, int(w.shape[2])
+  if int(w.shape[0]) != n_files or int(w.shape[1]) != c * (pre + 1 + post):
+    raise ValueError('weights are %s, expected (%d, %d, D)' %
+                     (tuple(w.shape), n_files, c * (pre + 1 + post)))
+  if out is None:
+    out = h.empty((rows, d), 'float32')
+  w = w.contiguous()
+  b = b.contiguous()
+  h.check(h.lib.td_predict_fir_per_file(h.ptr, _ptr(x), x.stride(0), offs_p, n_files, c, pre, post,
+                                        int(input_offset), _ptr(w), _ptr(b), d, _ptr(out),
+                                        out.stride(0)))
+  return out
+
+
 def cca_transform(x, x2, file_offsets, mean1, rot1, mean2, rot2, pre1, post1, pre2, post2,
                   handle=None, input_offset=0):
   h = handle or default_handle()

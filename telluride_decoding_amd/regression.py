@@ -211,6 +211,42 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)   # [minibatches, Lambda * d]
     scores.append(r[:, ::d].mean(dim=0))
 
+  def evaluate_folds(folds, w_all, b_all):
+    """evaluate() for the folds of one solver call, w_all [folds, n_lam, K, d].  A run of
+    consecutive recordings of a single-rank sweep without input offset is ONE prediction launch
+    with every recording under its own models (td_predict_fir_per_file), one window-sums and
+    one scores launch (32 + 32 + 32 launches of ~120 workgroups at C5: 2 of the sweep's 19 ms);
+    anything else goes fold by fold."""
+    batched = (whole is not None and off == 0 and len(folds) > 1 and
+               hasattr(dev, 'predict_fir_per_file') and
+               all(b == a + 1 for a, b in zip(folds, folds[1:])) and
+               all(held_used[f] > 0 for f in folds))
+    if not batched:
+      for fi, f in enumerate(folds):
+        evaluate(f, w_all[fi], b_all[fi])
+      return
+    import torch
+    x_all, _, y_all, offs = whole
+    r0, r1 = int(offs[folds[0]]), int(offs[folds[-1] + 1])
+    sub = [int(offs[f]) - r0 for f in folds] + [r1 - r0]
+    k = int(w_all.shape[2])
+    w_f = w_all.permute(0, 2, 1, 3).reshape(len(folds), k, n_lam * d).contiguous()
+    b_f = b_all.reshape(len(folds), n_lam * d).contiguous()
+    pred = dev.predict_fir_per_file(x_all[r0:r1], sub, w_f, b_f, dataset.pre, dataset.post, handle=h)
+    truth = y_all[r0:r1].repeat(1, n_lam)
+    # minibatches = the full windows of every recording (no offset: a recording's zipped stream
+    # is the recording), each model scored on its own (groups of d columns)
+    sums = dev.window_sums(truth, pred, sub, bsz, bsz, handle=h)
+    r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)[:, ::d]    # [minibatches, Lambda]
+    counts = [held_used[f] // bsz for f in folds]
+    if all(cnt == counts[0] for cnt in counts):            # equal recordings: one mean launch
+      scores.extend(r.reshape(len(folds), counts[0], n_lam).mean(dim=1).unbind(0))
+      return
+    start = 0
+    for cnt in counts:
+      scores.append(r[start:start + cnt].mean(dim=0))
+      start += cnt
+
   # (1) All (fold, lambda) systems at once by preconditioned conjugate gradients: the folds'
   # covariances differ from the total's by 1 / folds, so ONE Cholesky factor per lambda (of the
   # total covariance) preconditions every fold's system with that lambda -- Lambda factorisations
@@ -239,8 +275,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
         break
       w_all_folds, b_all_folds, iters = out
       iters_max = max(iters_max, int(iters))
-      for fi, f in enumerate(folds):
-        evaluate(f, w_all_folds[fi], b_all_folds[fi])
+      evaluate_folds(folds, w_all_folds, b_all_folds)
       n_done += len(folds)
     if n_done:
       LAST_SWEEP.update(solver='pcg' if n_done == len(my_folds) else 'pcg+direct', iterations=iters_max)

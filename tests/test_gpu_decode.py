@@ -560,6 +560,28 @@ def test_linear_regression_model_api(dev):
     brain_model.calculate_linear_regressor_parameters_from_dataset(ds, lamb=2.0, use_ridge=False)
 
 
+@pytest.mark.parametrize('c,pre,post,d,lens', [
+    (64, 0, 31, 20, (3000, 129, 31250, 64)),     # the sweep's shape: 20 lambdas as output columns
+    (16, 2, 5, 3, (500, 500, 7)),                # narrow, a recording shorter than the context
+    (70, 0, 3, 2, (900, 300)),                   # not the matrix-core kernel's shape: one call per recording
+])
+def test_predict_fir_per_file_equals_one_call_per_file(dev, c, pre, post, d, lens):
+  """td_predict_fir_per_file (every recording under its own weights, one launch) against
+  td_predict_fir recording by recording: the same kernel and arithmetic, bit for bit."""
+  rng = np.random.default_rng(c + d)
+  h = dev.default_handle()
+  offs = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+  x = h.to_device(rng.standard_normal((int(offs[-1]), c)).astype(np.float32))
+  k = c * (pre + 1 + post)
+  w = h.to_device(rng.standard_normal((len(lens), k, d)).astype(np.float32))
+  b = h.to_device(rng.standard_normal((len(lens), d)).astype(np.float32))
+  got = dev.predict_fir_per_file(x, offs, w, b, pre, post).cpu().numpy()
+  for f in range(len(lens)):
+    one = dev.predict_fir(x[int(offs[f]):int(offs[f + 1])], [0, lens[f]], w[f].contiguous(),
+                          b[f].contiguous(), pre, post).cpu().numpy()
+    np.testing.assert_array_equal(got[int(offs[f]):int(offs[f + 1])], one)
+
+
 def test_forward_model_with_many_outputs(dev):
   """A forward model (one envelope with context -> 20 EEG channels): more outputs than the
   batched solver's right-hand sides, through fit / predict / evaluate of the model class."""
