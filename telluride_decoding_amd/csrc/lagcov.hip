@@ -1095,10 +1095,12 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__
 // ---- skinny-A variant (ca_eff <= 8: regression targets [y | 1]) -------------
 // VALU kernel: thread = (B channel j, lag phase q); 8 lags x NI A-columns of f32
 // accumulators per thread; A rows are LDS broadcasts.
-constexpr int kSmallLags = 32;  // lags per workgroup
-
-template <int NI, bool kAligned>
+// kLpt lags per thread (q + 4 m, m < kLpt): 4 kLpt lags per workgroup.  8 is the regression
+// targets' case (<= 32 lags); the swapped cross-covariance of a lagged CCA asks for other counts
+// (36 lags as 2 x 32 spent 44 % of a VALU-bound kernel on lags nobody asked for: 4 x 10 now).
+template <int NI, bool kAligned, int kLpt>
 __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
+  constexpr int kSmallLags = 4 * kLpt;  // lags per workgroup
   __shared__ __attribute__((aligned(16))) float as[kTile * 8];
   __shared__ __attribute__((aligned(16))) float bs[(kTile + kSmallLags) * 64];
   const int tid = threadIdx.x;
@@ -1110,9 +1112,9 @@ __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
   const LagWork w = p.works[id];
   const int e0 = p.e_min + group * kSmallLags;
 
-  float acc[8][NI];
+  float acc[kLpt][NI];
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
+  for (int m = 0; m < kLpt; ++m)
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[m][i] = 0.f;
 
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[i] = as[r * 8 + i];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
+      for (int m = 0; m < kLpt; ++m) {
         const float b = bs[(r + q + 4 * m) * 64 + j];
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[m][i] = fmaf(a[i], b, acc[m][i]);
@@ -1150,7 +1152,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
   }
   float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
+  for (int m = 0; m < kLpt; ++m) {
     const int e_idx = group * kSmallLags + q + 4 * m;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -2233,7 +2235,17 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   // (wave, le) slots then split the tile's rows: mfma_tile_few)
   const int few_g = e_count >= 5 ? 8 : e_count >= 3 ? 4 : e_count;
   const bool few = !small && few_g < 8;
-  const int lags_per_wg = small ? kSmallLags : few_g;
+  // skinny kernel: 4 x lpt lags per workgroup, lpt in {8, 10, 12, 16} -- the one that pads least
+  int small_lpt = 8;
+  if (small) {
+    long long best = -1;
+    for (int lpt : {8, 10, 12, 16}) {
+      const long long padded = td_ceil_div(e_count, 4 * lpt) * 4 * lpt;
+      if (best < 0 || padded < best) { best = padded; small_lpt = lpt; }
+    }
+  }
+  plan->small_lpt = small_lpt;
+  const int lags_per_wg = small ? 4 * small_lpt : few_g;
   LagParams& p = plan->p;
   p.lag_g = few_g;
   p.lag_lg = few_g == 8 ? 3 : few_g == 4 ? 2 : few_g == 2 ? 1 : 0;
@@ -2251,7 +2263,7 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
     if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) split = false;
   p.n_cat = small ? 1 : (int)td_ceil_div(ca_eff, 64);
   p.n_cbt = (int)td_ceil_div(cb, 64);
-  p.e_pad = p.n_groups * (small ? kSmallLags : kLagsPerWg);   // slab entries per work item
+  p.e_pad = p.n_groups * (small ? 4 * small_lpt : kLagsPerWg);   // slab entries per work item
   p.ca_pad = small ? 8 : p.n_cat * 64;
   p.cb_pad = p.n_cbt * 64;
   plan->small = small; plan->few = few; plan->split = split; plan->few_g = few_g;
@@ -2413,20 +2425,28 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
   const int e_min = p.e_min;
   if (small) {
     const int ni = ca_eff <= 1 ? 1 : ca_eff <= 2 ? 2 : ca_eff <= 4 ? 4 : 8;
-#define TD_LAUNCH_SMALL(NI)                                                              \
+#define TD_LAUNCH_SMALL2(NI, LPT)                                                        \
   do {                                                                                   \
     if (aligned)                                                                         \
-      hipLaunchKernelGGL((lagcov_small_kernel<NI, true>), dim3((unsigned)nwg),           \
+      hipLaunchKernelGGL((lagcov_small_kernel<NI, true, LPT>), dim3((unsigned)nwg),      \
                          dim3(kThreads), 0, h->stream, p);                               \
     else                                                                                 \
-      hipLaunchKernelGGL((lagcov_small_kernel<NI, false>), dim3((unsigned)nwg),          \
+      hipLaunchKernelGGL((lagcov_small_kernel<NI, false, LPT>), dim3((unsigned)nwg),     \
                          dim3(kThreads), 0, h->stream, p);                               \
+  } while (0)
+#define TD_LAUNCH_SMALL(NI)                                                              \
+  do {                                                                                   \
+    if (plan->small_lpt == 8) TD_LAUNCH_SMALL2(NI, 8);                                   \
+    else if (plan->small_lpt == 10) TD_LAUNCH_SMALL2(NI, 10);                            \
+    else if (plan->small_lpt == 12) TD_LAUNCH_SMALL2(NI, 12);                            \
+    else TD_LAUNCH_SMALL2(NI, 16);                                                       \
   } while (0)
     if (ni == 1) TD_LAUNCH_SMALL(1);
     else if (ni == 2) TD_LAUNCH_SMALL(2);
     else if (ni == 4) TD_LAUNCH_SMALL(4);
     else TD_LAUNCH_SMALL(8);
 #undef TD_LAUNCH_SMALL
+#undef TD_LAUNCH_SMALL2
   } else {
     // Unified mode: both operands are the same stream and channel tile.
     const int rows_u = kTile + kHalo + e_min + (p.n_groups - 1) * few_g;

@@ -319,6 +319,7 @@ struct LagcovPlan {
   std::vector<TgtWork> tsegs;    // per SEGMENT: where its targets are
   size_t tpartial_bytes = 0;     // (set by td_lagcov_plan_targets) scratch behind the Gram slabs
   int few_g = 8, ca_eff = 0, cb = 0, e_count = 0;
+  int small_lpt = 8;             // skinny kernel: lags per thread (4 x that per workgroup)
   long long total = 0, nwg = 0;
   size_t scratch_bytes = 0;      // the float partial slabs
 };
