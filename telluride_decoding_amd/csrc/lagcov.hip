@@ -1160,6 +1160,61 @@ __global__ __launch_bounds__(kThreads) void lagcov_small_kernel(LagParams p) {
   }
 }
 
+// ---- both operands narrow (<= 8 channels each): the second view of a lagged CCA (an 8-band
+// envelope), a forward model's stimulus features ------------------------------------------------
+// The matrix kernels spend a 32 x 32 tile per lag on at most 8 x 8 numbers (8 bands x 16 lags at
+// 1e6 samples: 0.34 ms on the float32 matrix kernel).  Here thread (lag e, A channel i) keeps the
+// row of <= 8 outputs (e, i, 0..7) in registers: per sample one broadcast read of A[r][i] and
+// two 16-byte reads of B[r + e][0..7] -- conflict-free, the 8 lags of a wave read 8 consecutive
+// rows -- for 8 FMAs: VALU-bound.  32 lags per workgroup, float32 chains of one slab (<= 2048
+// samples), partial slabs in the skinny kernel's layout [e][8][64].
+__global__ __launch_bounds__(kThreads) void lagcov_narrow_kernel(LagParams p) {
+  constexpr int kLags = 32;
+  __shared__ __attribute__((aligned(16))) float as[kTile * 8];
+  __shared__ __attribute__((aligned(16))) float bs[(kTile + kLags) * 8];
+  const int tid = threadIdx.x;
+  const int i = tid & 7, el = tid >> 3;
+  int id = blockIdx.x;
+  const int group = id % p.n_groups; id /= p.n_groups;
+  const LagWork w = p.works[id];
+  const int e0 = p.e_min + group * kLags;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (long long ut = w.u_begin; ut < w.u_end; ut += kTile) {
+    for (int idx = tid; idx < kTile * 8; idx += kThreads) {
+      const int r = idx >> 3, c = idx & 7;
+      const long long u = ut + r;
+      float v = 0.f;
+      if (u < w.u_end && u >= 0 && u < w.a_valid && c < p.ca) v = p.a[(w.a_row0 + u) * p.lda + c];
+      as[idx] = v;
+    }
+    for (int idx = tid; idx < (kTile + kLags) * 8; idx += kThreads) {
+      const int r = idx >> 3, c = idx & 7;
+      const long long v_row = ut + e0 + r;
+      float v = 0.f;
+      if (v_row >= 0 && v_row < w.b_valid && c < p.cb) v = p.b[(w.b_row0 + v_row) * p.ldb + c];
+      bs[idx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < kTile; ++r) {
+      const float a = as[r * 8 + i];
+      const float4 b0 = *reinterpret_cast<const float4*>(bs + (r + el) * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(bs + (r + el) * 8 + 4);
+      acc[0] = fmaf(a, b0.x, acc[0]); acc[1] = fmaf(a, b0.y, acc[1]);
+      acc[2] = fmaf(a, b0.z, acc[2]); acc[3] = fmaf(a, b0.w, acc[3]);
+      acc[4] = fmaf(a, b1.x, acc[4]); acc[5] = fmaf(a, b1.y, acc[5]);
+      acc[6] = fmaf(a, b1.z, acc[6]); acc[7] = fmaf(a, b1.w, acc[7]);
+    }
+    __syncthreads();
+  }
+  float* slab = p.partial + (size_t)id * p.e_pad * p.ca_pad * p.cb_pad;
+  float* dst = slab + ((size_t)(group * kLags + el) * p.ca_pad + i) * p.cb_pad;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j] = acc[j];
+}
+
 // ---- CCA without context: every moment in ONE pass ---------------------------------------
 // With no lags on either input (cca.py:272-369 on raw streams; BASELINE config C3) the whole
 // set of CCA moments is the Gram matrix of z = [x (<= 64 ch) | x2 (<= 31 ch) | 1]: x^T x,
@@ -2230,14 +2285,19 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   // kernel does not take; narrow real operands (an 8-band envelope) go to the matrix cores
   // (... unless the caller says so: the cross-covariance of a wide view with a 1-column one runs
   // with the operands swapped -- force_small -- instead of as padded 64 x 64 tiles)
-  const bool small = (a_ones || plan->force_small) && ca_eff <= 8;
+  // both operands narrow and enough lags to fill a workgroup's 32: the VALU kernel with a row of
+  // outputs per thread (lagcov_narrow_kernel); it shares the skinny kernel's slab layout
+  static const bool no_narrow = getenv("TD_LAG_NO_NARROW") != nullptr;     // development: A/B runs
+  const bool narrow = !a_ones && ca <= 8 && cb <= 8 && e_count >= 8 && !no_narrow;
+  plan->narrow = narrow;
+  const bool small = narrow || ((a_ones || plan->force_small) && ca_eff <= 8);
   // matrix-core path: 8 lags per workgroup, or 4 / 2 / 1 when fewer are asked for (the 8
   // (wave, le) slots then split the tile's rows: mfma_tile_few)
   const int few_g = e_count >= 5 ? 8 : e_count >= 3 ? 4 : e_count;
   const bool few = !small && few_g < 8;
   // skinny kernel: 4 x lpt lags per workgroup, lpt in {8, 10, 12, 16} -- the one that pads least
   int small_lpt = 8;
-  if (small) {
+  if (small && !narrow) {
     long long best = -1;
     for (int lpt : {8, 10, 12, 16}) {
       const long long padded = td_ceil_div(e_count, 4 * lpt) * 4 * lpt;
@@ -2423,7 +2483,9 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
   p.partial = reinterpret_cast<float*>(scratch);
   const float* a = p.a; const float* b = p.b;
   const int e_min = p.e_min;
-  if (small) {
+  if (plan->narrow) {
+    hipLaunchKernelGGL(lagcov_narrow_kernel, dim3((unsigned)nwg), dim3(kThreads), 0, h->stream, p);
+  } else if (small) {
     const int ni = ca_eff <= 1 ? 1 : ca_eff <= 2 ? 2 : ca_eff <= 4 ? 4 : 8;
 #define TD_LAUNCH_SMALL2(NI, LPT)                                                        \
   do {                                                                                   \
@@ -2670,7 +2732,9 @@ int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, con
   // strips of the column-sum kernel (one WAVE each): <= kWaveStrip rows, shorter when the call is
   // short, down to 128 (a strip streams 31 .. 62 rows more than it sums) -- 200k rows in strips of
   // 512 were 391 waves on 1024 SIMDs: 52 us for a 55 MB read
-  long long w_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, 8 * cus), 32);
+  // (narrow rows: a wave moves 32 .. 64 bytes per load and is latency-bound whatever it does --
+  // four times the waves; the extra rows a short strip streams cost little there)
+  long long w_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, (cb <= 16 ? 32 : 8) * cus), 32);
   w_strip = w_strip < 128 ? 128 : (w_strip > kWaveStrip ? kWaveStrip : w_strip);
   plan->seg_work0.assign(n_segs + 1, 0);
   for (int f = 0; f < n_segs; ++f) {

@@ -94,6 +94,12 @@ def _rel(a, b):
     (33, 0, 8, 1, 3, 3, 1, -3, (1500, 5, 700), 11),
     (64, 0, 63, 1, 31, 0, 0, 0, (4000, 129), 0),
     (9, 0, 0, 1, 0, 33, 0, 0, (2600,), 0),
+    # both operands narrow (<= 8 channels, >= 8 lags): the VALU kernel with a row of outputs per
+    # thread -- auto- and cross-covariances of a lagged CCA's narrow views, a narrow regression
+    (8, 3, 12, 8, 7, 8, 2, 1, (900, 40, 1300), 57),
+    (6, 0, 40, 0, 0, 0, 1, 0, (3000, 64), 0),
+    (3, 0, 7, 2, 9, 0, 0, -2, (500, 700), 0),
+    (64, 0, 20, 8, 7, 8, 0, 0, (2500, 2049), 0),
     # boundaries: 129 channels (three 64-channel tiles of the general kernels), 96 channels exactly,
     # 65 lags (one past the split kernel's 64), K + 1 a multiple of 64
     (129, 0, 2, 0, 0, 0, 1, 0, (700, 300), 0),
