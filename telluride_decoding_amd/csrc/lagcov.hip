@@ -2207,35 +2207,69 @@ void launch_lagcov_reduce(td_handle* h, const T* partial, int n_work, int e_pad,
 }
 
 // ---- float64 column sums (sum of y over the rows that enter the fit) --------
-__global__ void colsum_kernel(const float* __restrict__ a, long long lda, int ca,
-                              const LagWork* __restrict__ works, int n_work,
-                              double* __restrict__ partial) {
-  // block b handles work item b; thread t handles column t % ca over rows t / ca + k*stride
+__global__ __launch_bounds__(kThreads) void colsum_kernel(const float* __restrict__ a, long long lda, int ca,
+                                                          const LagWork* __restrict__ works, int n_work,
+                                                          double* __restrict__ partial) {
+  // block b handles work item b.  Thread = (column cl of a tile of cp <= 64 columns, row phase rp):
+  // cp = the column count rounded up to a power of two, so that narrow inputs spread their rows
+  // over the lanes (one column: 256 row phases) and wide ones read whole rows: coalesced either
+  // way.  (The first version took one column per pass -- every pass read every row's cache line
+  // for 4 bytes: 1.1 ms for the 64 targets of a forward model.)
   __shared__ double red[kThreads];
   const LagWork w = works[blockIdx.x];
   const int tid = threadIdx.x;
-  for (int c = 0; c < ca; ++c) {
-    double s = 0.0;
-    for (long long u = w.u_begin + tid; u < w.u_end; u += kThreads)
-      if (u >= 0 && u < w.a_valid) s += (double)a[(w.a_row0 + u) * lda + c];
-    red[tid] = s;
+  int cp = 1;
+  while (cp < ca && cp < 64) cp <<= 1;
+  const int cl = tid & (cp - 1), rp = tid / cp, n_rp = kThreads / cp;
+  for (int c0 = 0; c0 < ca; c0 += cp) {
+    const int c = c0 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < ca) {
+      long long u = w.u_begin + rp;
+      for (; u + n_rp < w.u_end; u += 2 * n_rp) {
+        const bool ok0 = u >= 0 && u < w.a_valid, ok1 = u + n_rp >= 0 && u + n_rp < w.a_valid;
+        const float v0 = ok0 ? a[(w.a_row0 + u) * lda + c] : 0.f;
+        const float v1 = ok1 ? a[(w.a_row0 + u + n_rp) * lda + c] : 0.f;
+        s0 += (double)v0; s1 += (double)v1;
+      }
+      for (; u < w.u_end; u += n_rp)
+        if (u >= 0 && u < w.a_valid) s0 += (double)a[(w.a_row0 + u) * lda + c];
+    }
+    red[tid] = s0 + s1;
     __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
-      if (tid < off) red[tid] += red[tid + off];
+    // fixed order: halve the row phases until one is left
+    for (int off = n_rp / 2; off > 0; off >>= 1) {
+      if (rp < off) red[tid] += red[tid + off * cp];
       __syncthreads();
     }
-    if (tid == 0) partial[(size_t)blockIdx.x * ca + c] = red[0];
+    if (rp == 0 && c < ca) partial[(size_t)blockIdx.x * ca + c] = red[tid];
     __syncthreads();
   }
 }
 
-__global__ void colsum_reduce_kernel(const double* __restrict__ partial, int n_work, int ca,
-                                     double* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ca) return;
-  double s = 0.0;
-  for (int w = 0; w < n_work; ++w) s += partial[(size_t)w * ca + c];
-  out[c] = accumulate ? out[c] + s : s;
+// out[c] (+)= sum over the work items; 16 phases x 64 columns per workgroup, fixed order
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const double* __restrict__ partial, int n_work,
+                                                             int ca, double* __restrict__ out, int accumulate) {
+  __shared__ double part[16][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < ca) {
+    int w = q;
+    for (; w + 16 < n_work; w += 32) {
+      s0 += partial[(size_t)w * ca + c];
+      s1 += partial[(size_t)(w + 16) * ca + c];
+    }
+    if (w < n_work) s0 += partial[(size_t)w * ca + c];
+  }
+  part[q][cl] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && c < ca) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // Splits segments into slabs of at most `slab` samples (a multiple of kTile).
@@ -2633,21 +2667,23 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
 }
 
 __global__ void add_reversed_transposed_kernel(const double* __restrict__ src, int e_count, int ca,
-                                               int cb, double* __restrict__ dst) {
+                                               int cb, double* __restrict__ dst, int ca_dst) {
   const long long total = (long long)e_count * ca * cb;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int jb = (int)(i % cb), ia = (int)((i / cb) % ca), e = (int)(i / ((long long)ca * cb));
-    dst[i] += src[((long long)(e_count - 1 - e) * cb + jb) * ca + ia];
+    dst[((long long)e * ca_dst + ia) * cb + jb] += src[((long long)(e_count - 1 - e) * cb + jb) * ca + ia];
   }
 }
 
-int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst) {
+int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst,
+                               int ca_dst) {
   const long long total = (long long)e_count * ca * cb;
   if (total == 0) return TD_OK;
+  if (ca_dst <= 0) ca_dst = ca;
   const long long blocks = td_ceil_div(total, 256);
   hipLaunchKernelGGL(add_reversed_transposed_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256),
-                     0, h->stream, src, e_count, ca, cb, dst);
+                     0, h->stream, src, e_count, ca, cb, dst, ca_dst);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
@@ -2732,9 +2768,7 @@ int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, con
   // strips of the column-sum kernel (one WAVE each): <= kWaveStrip rows, shorter when the call is
   // short, down to 128 (a strip streams 31 .. 62 rows more than it sums) -- 200k rows in strips of
   // 512 were 391 waves on 1024 SIMDs: 52 us for a 55 MB read
-  // (narrow rows: a wave moves 32 .. 64 bytes per load and is latency-bound whatever it does --
-  // four times the waves; the extra rows a short strip streams cost little there)
-  long long w_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, (cb <= 16 ? 32 : 8) * cus), 32);
+  long long w_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, 8 * cus), 32);
   w_strip = w_strip < 128 ? 128 : (w_strip > kWaveStrip ? kWaveStrip : w_strip);
   plan->seg_work0.assign(n_segs + 1, 0);
   for (int f = 0; f < n_segs; ++f) {
@@ -2818,7 +2852,9 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
 
 int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
                       int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled) {
+                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled, int rows_dst) {
+  // (rows_dst: rows per lag of g_dev when the d columns are a slice of more targets; 0 = d + 1)
+  if (rows_dst <= 0) rows_dst = d + 1;
   TargetsPlan plan;
   TD_TRY(td_lagcov_targets_plan(h, y, ldy, d, b, ldb, cb, segs, e_min, e_count, &plan));
   *handled = plan.handled;
@@ -2836,7 +2872,7 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
   for (int i = 0; i < d; ++i) {
     const LagReduceJob& job = out.jobs[i];
     launch_lagcov_reduce<double>(h, reinterpret_cast<const double*>(job.partial), job.n_work, job.e_pad,
-                                 job.ca_pad, job.cb_pad, e_count, 1, cb, job.g, true, d + 1);
+                                 job.ca_pad, job.cb_pad, e_count, 1, cb, job.g, true, rows_dst);
     if (sy_dev)
       hipLaunchKernelGGL(ysum_reduce_kernel, dim3(1), dim3(256), 0, h->stream, out.ysum[i], job.n_work,
                          1, sy_dev + i, 1);
@@ -2947,7 +2983,7 @@ int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, 
 int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vector<LagSeg>& segs,
               double* out_dev, bool accumulate) {
   if (ca <= 0) return TD_OK;
-  std::vector<LagWork> works = split_work(segs, 1 << 12);
+  std::vector<LagWork> works = split_work(segs, 1 << 10);
   if (works.empty()) {
     if (!accumulate) TD_HIP(h, hipMemsetAsync(out_dev, 0, sizeof(double) * ca, h->stream));
     return TD_OK;
@@ -2960,7 +2996,7 @@ int td_colsum(td_handle* h, const float* a, int64_t lda, int ca, const std::vect
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)works.size()), dim3(kThreads), 0, h->stream,
                      a, (long long)lda, ca, reinterpret_cast<const LagWork*>(scratch),
                      (int)works.size(), partial);
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)td_ceil_div(ca, 64)), dim3(64), 0,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)td_ceil_div(ca, 64)), dim3(1024), 0,
                      h->stream, partial, (int)works.size(), ca, out_dev, accumulate ? 1 : 0);
   TD_HIP(h, hipGetLastError());
   return TD_OK;

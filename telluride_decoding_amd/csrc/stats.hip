@@ -1326,10 +1326,87 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
     double* colsum_seg = reinterpret_cast<double*>(ws);
     double* contrib = colsum_seg + (size_t)num_files * cmax;
     bool handled = false;
-    TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
-                             s->g + s->off_gxo, s->d ? s->g + s->off_sy : nullptr, colsum_seg,
-                             &handled));
-    if (handled) {
+    // More than four target columns (the fused path and one td_lagcov_targets call take up to four):
+    //  * a narrow x (<= 8 channels: a forward model, the targets are the EEG channels) -- the
+    //    product with the operands swapped, sum_v x[v] y[v - e]: x is the skinny operand of the
+    //    LDS-tiled VALU kernel, y restricted to the rows that are summed is the wide one, and the
+    //    result is added back transposed with the lags reversed (as the cross-covariance of a
+    //    lagged CCA above);
+    //  * otherwise, up to 32 lags and 16 columns: the matrix-core targets kernel, four columns a call.
+    // Both take the all-ones row from the column sums of x and sum y on its own.  (Before: the
+    // general float32 matrix kernel on [y | 1] padded to 128 rows -- 3.4 ms per 1e6 samples for
+    // 8 features x 32 lags against 64 targets, 1.3 ms for 64 channels against 8 targets -- and a
+    // column sum that read the targets once per column.)
+    static const bool wide_general = getenv("TD_TARGETS_GENERAL") != nullptr;   // development: A/B runs
+    bool wide_done = false;
+    if (s->d > 4 && !wide_general) {
+      bool from_start = true;
+      for (const LagSeg& sg : syx) if (sg.u_begin != 0) from_start = false;
+      const int e_min = -s->pre1, e_max = s->post1;
+      int rc = TD_OK;
+      if (s->c1 <= 8 && from_start) {
+        std::vector<LagSeg> sw(syx.size());
+        for (size_t f = 0; f < syx.size(); ++f) {
+          const LagSeg& sg = syx[f];          // a = y, b = x
+          LagSeg& o = sw[f];
+          o.a_row0 = sg.b_row0; o.a_valid = sg.b_valid;
+          o.b_row0 = sg.a_row0;
+          o.b_valid = sg.a_valid < sg.u_end ? sg.a_valid : sg.u_end;
+          if (o.b_valid < 0) o.b_valid = 0;
+          o.u_begin = 0;
+          o.u_end = sg.u_end + e_max < sg.b_valid ? sg.u_end + e_max : sg.b_valid;
+          if (o.u_end < 0 || sg.u_end <= 0) o.u_end = 0;
+        }
+        void* tmp = nullptr;
+        const size_t tmp_bytes = sizeof(double) * (size_t)s->l1 * s->c1 * s->d;
+        TD_TRY(td_alloc_async(h, tmp_bytes, &tmp));
+        TD_HIP(h, hipMemsetAsync(tmp, 0, tmp_bytes, h->stream));
+        rc = td_lagcov(h, x_dev, ldx, s->c1, false, y_dev, ldy, s->d, sw, -e_max, s->l1,
+                       reinterpret_cast<double*>(tmp), true, 0, 0, true);
+        // tmp [e'][c1][d] -> gxo [e][d + 1][c1] rows < d (e' runs backwards)
+        if (rc == TD_OK)
+          rc = td_add_reversed_transposed(h, reinterpret_cast<const double*>(tmp), s->l1, s->d, s->c1,
+                                          s->g + s->off_gxo, s->d + 1);
+        td_free_async(h, tmp, true);
+        TD_TRY(rc);
+        wide_done = true;
+      } else if (s->d <= 16 && s->l1 <= 32 && e_min <= 0 && e_max >= 0) {
+        for (int c0 = 0; c0 < s->d; c0 += 4) {
+          const int dc = s->d - c0 < 4 ? s->d - c0 : 4;
+          TD_TRY(td_lagcov_targets(h, y_dev + c0, ldy, dc, x_dev, ldx, s->c1, syx, e_min, s->l1,
+                                   s->g + s->off_gxo + (size_t)c0 * s->c1, s->g + s->off_sy + c0, colsum_seg,
+                                   &handled, s->d + 1));
+          TD_REQUIRE(h, handled, "accumulate: the targets kernel refused a column slice");
+        }
+        launch_ones_rows(h, s->g + s->off_gxo, s->d + 1, s->d, s->c1, s->l1, e_min, colsum_seg,
+                         s->win1, s->hw, (long long)first_slot, num_files, contrib);
+        TD_HIP(h, hipGetLastError());
+        wide_done = true;
+        handled = true;
+      }
+      if (wide_done && !handled) {
+        // the all-ones row from the column sums of x (the d = 0 form of the targets path), sum y
+        TD_TRY(td_lagcov_targets(h, nullptr, 0, 0, x_dev, ldx, s->c1, syx, e_min, s->l1,
+                                 s->g + s->off_gxo, nullptr, colsum_seg, &handled, s->d + 1));
+        if (handled) {
+          launch_ones_rows(h, s->g + s->off_gxo, s->d + 1, s->d, s->c1, s->l1, e_min, colsum_seg,
+                           s->win1, s->hw, (long long)first_slot, num_files, contrib);
+          TD_HIP(h, hipGetLastError());
+        } else {
+          // (column sums alone with more than 31 past lags: the all-ones column on the skinny kernel)
+          TD_TRY(td_lagcov(h, nullptr, 0, 0, true, x_dev, ldx, s->c1, syx, e_min, s->l1,
+                           s->g + s->off_gxo + (size_t)s->d * s->c1, true, s->c1, s->d + 1));
+        }
+        TD_TRY(td_colsum(h, y_dev, ldy, s->d, syx, s->g + s->off_sy, true));
+      }
+    }
+    if (!wide_done)
+      TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
+                               s->g + s->off_gxo, s->d ? s->g + s->off_sy : nullptr, colsum_seg,
+                               &handled));
+    if (wide_done) {
+      // done above
+    } else if (handled) {
       launch_ones_rows(h, s->g + s->off_gxo, s->d + 1, s->d, s->c1, s->l1, -s->pre1, colsum_seg,
                        s->win1, s->hw, (long long)first_slot, num_files, contrib);
       TD_HIP(h, hipGetLastError());

@@ -387,7 +387,8 @@ int td_chan_tab_scratch(td_handle* h, unsigned** tab);
 // transposed (the cross-covariance from a call with the operands swapped).
 int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_xtx, double* xty_dev,
                         double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev);
-int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst);
+int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst,
+                               int ca_dst = 0);
 int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld);
 
 // [y]^T x~ per signed lag on the lane-per-channel kernel, plus the per-segment column sums
@@ -400,7 +401,7 @@ int td_lagcov_column(td_handle* h, const float* y, int64_t ldy, const float* b, 
                      const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev);
 int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
                       int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
-                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled);
+                      double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled, int rows_dst = 0);
 
 // The float64 reduction of td_gram's partial blocks, as a job of the statistics' finalize launch.
 struct GramReduceJob {

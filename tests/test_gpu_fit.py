@@ -100,6 +100,14 @@ def _rel(a, b):
     (6, 0, 40, 0, 0, 0, 1, 0, (3000, 64), 0),
     (3, 0, 7, 2, 9, 0, 0, -2, (500, 700), 0),
     (64, 0, 20, 8, 7, 8, 0, 0, (2500, 2049), 0),
+    # more than four target columns: a narrow x against wide targets with the operands swapped
+    # (a forward model), 5 .. 16 columns on the matrix-core targets kernel four at a time, the
+    # general kernel beyond; offsets of either sign, dropped remainders, short recordings
+    (6, 2, 9, 0, 0, 0, 12, 1, (900, 40, 1300), 57),
+    (2, 0, 40, 0, 0, 0, 70, -3, (1500, 5, 700), 0),
+    (64, 0, 31, 0, 0, 0, 8, -2, (3000, 700), 0),
+    (40, 3, 8, 0, 0, 0, 16, 0, (500, 5, 2000), 13),
+    (12, 1, 1, 0, 0, 0, 20, 2, (800, 300), 0),
     # boundaries: 129 channels (three 64-channel tiles of the general kernels), 96 channels exactly,
     # 65 lags (one past the split kernel's 64), K + 1 a multiple of 64
     (129, 0, 2, 0, 0, 0, 1, 0, (700, 300), 0),
