@@ -2613,8 +2613,18 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
         const int cus = h->cu_count > 0 ? h->cu_count : 256;
         const long long per_round = (long long)(cus / p.n_groups) * p.n_groups;
         if (!(plan->f16 && p.ty) && !no_persist && per_round > 0 && nwg > per_round) {
-          grid_wgs = per_round;
-          p.n_part = (int)(per_round / p.n_groups);
+          // ... but a chain of float32 slab sums stays short: at most kMaxItemsPerChain items
+          // (~256 tiles) per partial slab -- 4e7 samples in one call gave every CU 76 items and the
+          // sums of squares came out 3e-7 off -- so very long inputs run several rounds of
+          // workgroups, each walking four items
+          constexpr long long kMaxItemsPerChain = 4;
+          long long chains = per_round / p.n_groups;
+          const long long min_chains = td_ceil_div(p.n_work, kMaxItemsPerChain);
+          if (min_chains > chains) chains = min_chains;
+          if (chains < p.n_work) {
+            grid_wgs = chains * p.n_groups;
+            p.n_part = (int)chains;
+          }
         }
       }
 #define TD_BF_LAUNCH(V, R, F, T)                                                                   \

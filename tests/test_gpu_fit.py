@@ -565,6 +565,27 @@ def test_c2_full_size_moments_properties(dev):
   assert float(res.abs().max()) / float((xty[:, 0] / n).abs().max()) < 1e-5    # f32 output rounding
 
 
+def test_long_recording_keeps_the_float32_chains_short(dev):
+  """3e6 samples in ONE recording: the lag kernel's workgroups walk their slabs, and a partial
+  slab is a float32 sum -- at most four work items long whatever the input's length (every CU
+  walking all of its items left the sums of squares of a 4e7-sample call 3e-7 off)."""
+  import torch
+  h = dev.default_handle()
+  torch.manual_seed(11)
+  n, c = 3000000, 64
+  x = torch.randn(n, c, device='cuda')
+  y = torch.randn(n, 1, device='cuda')
+  st = dev.LagStats(c, 0, 31, d=1)
+  st.accumulate(x, None, y, np.array([0, n], np.int64))
+  xtx = st.moments()['xtx']
+  want = (x.double() ** 2).sum(0)
+  got = torch.diagonal(xtx)[:c]
+  assert float(((got - want) / want).abs().max()) < 1.5e-7
+  lag5 = (x[:-5].double() * x[5:].double()).sum(0)             # diagonal of the lag-5 block
+  got5 = torch.diagonal(xtx[:c, 5 * c:6 * c])
+  assert float((got5 - lag5).abs().max()) / float(want.max()) < 2e-8
+
+
 def test_c3_full_size_cca_moments(dev):
   """BASELINE config C3 at full size (64-ch EEG vs 8-band envelope, 1e6 samples, no lags):
   every CCA moment against a direct float64 product."""
