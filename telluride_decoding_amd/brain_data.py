@@ -73,7 +73,18 @@ class Dataset(object):
     self.mixup_batch = bool(mixup_batch)
     self.mixup_seed = mixup_seed
     self.max_batches = max_batches
-    self._device_cache = None
+    # device copy of the recordings, shared with the datasets take() derives from this one (same
+    # files: BrainModelCCA.fit takes its minibatch count from a fresh take() on every call, and
+    # uploaded 290 MB each time)
+    self._cache_box = [None]
+
+  @property
+  def _device_cache(self):
+    return self._cache_box[0]
+
+  @_device_cache.setter
+  def _device_cache(self, value):
+    self._cache_box[0] = value
 
   # -- geometry --------------------------------------------------------------
   @property
@@ -138,7 +149,7 @@ class Dataset(object):
                  else min(count, self.max_batches))
     if count is None:
       ds.max_batches = self.max_batches
-    ds._device_cache = self._device_cache
+    ds._cache_box = self._cache_box
     return ds
 
   # -- host iteration (reference-compatible minibatches) ------------------------

@@ -75,6 +75,15 @@ def _dataset_stats(dataset, want_y=True, want_x2=False, handle=None):
   return st
 
 
+def rows_of_stream(per_frame, lengths, used):
+  """Host rows [offs[f], offs[f] + used[f]) of every file, concatenated -- the array itself when
+  nothing is dropped (no second copy of a 1e6-row result)."""
+  if all(int(u) == int(n) for u, n in zip(used, lengths)):
+    return per_frame
+  offs = np.concatenate(([0], np.cumsum(lengths)))
+  return np.concatenate([per_frame[offs[i]:offs[i] + u] for i, u in enumerate(used)])
+
+
 def zipped_rows(dataset, h, output, per_frame):
   """The rows of the final (zipped, drop-remainder) stream of a Dataset, concatenated over
   its files, as contiguous device tensors: `output` = the dataset's output tensor (its rows
@@ -118,7 +127,7 @@ def _iterable_stats(batches, key2=None, handle=None, keep=None):
 
 
 def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_offset=True,
-                                                       use_ridge=True):
+                                                       use_ridge=True, _want_cov=True):
   """Closed-form regression weights (reference brain_model.py:384-481).
 
   Returns (W [K, D], b [1, D], cov_x, cov_xy, shrinkage) as float32 arrays.  The
@@ -161,6 +170,11 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
   if use_ridge and use_offset:
     w, b = st.ridge_solve([lamb])
     w_np, b_np = w.cpu().numpy()[0], b.cpu().numpy()
+    if not _want_cov:
+      # BrainModelLinearRegression.fit keeps W and b only (brain_model.py:368-371): the dense
+      # (K+1)^2 covariance the function also returns is 34 MB to expand, copy and rescale on the
+      # host at C2 -- 27 of the 30 ms of a fit through the model class
+      return w_np, b_np.reshape(1, -1), None, None, lamb
     m = st.moments()
     cov_x = m['xtx'].cpu().numpy() / frames
     cov_x[np.diag_indices(k + 1)] += lamb
@@ -241,7 +255,7 @@ class BrainModelLinearRegression(object):
       raise TypeError('BrainModelLinearRegression.train must be called with '
                       'tf.data.Dataset, not %s.' % type(input_dataset))
     (self.w_estimate, b, _, _, _) = calculate_linear_regressor_parameters_from_dataset(
-        input_dataset, lamb=self._regularization_lambda)
+        input_dataset, lamb=self._regularization_lambda, _want_cov=False)
     self.b_estimate = np.reshape(b, (-1,))
     self._w_dev = self._b_dev = None
     return {}   # no training history (brain_model.py:377)
@@ -286,8 +300,7 @@ class BrainModelLinearRegression(object):
   def predict(self, dataset):
     used = dataset.rows_used()
     pred = self.predict_device(dataset).cpu().numpy()
-    offs = np.concatenate(([0], np.cumsum(dataset.file_lengths())))
-    return np.concatenate([pred[offs[i]:offs[i] + u] for i, u in enumerate(used)])
+    return rows_of_stream(pred, dataset.file_lengths(), used)
 
   def evaluate(self, dataset, **kwargs):
     """{'loss': mse, 'pearson_correlation_first': r} averaged over minibatches,

@@ -152,8 +152,7 @@ class BrainModelCCA(object):
   def predict(self, dataset):
     used = dataset.rows_used()
     out = self.transform_device(dataset).cpu().numpy()
-    offs = np.concatenate(([0], np.cumsum(dataset.file_lengths())))
-    return np.concatenate([out[offs[i]:offs[i] + u] for i, u in enumerate(used)])
+    return brain_model.rows_of_stream(out, dataset.file_lengths(), used)
 
   def evaluate(self, dataset, **kwargs):
     """Loss and metric are both cca_pearson_correlation_first (cca.py:196-199),
