@@ -91,15 +91,19 @@ def zipped_rows(dataset, h, output, per_frame):
   row file_offsets[f] + t already is frame t of file f (predictions, transforms).  Either
   may be None."""
   import torch
-  offs = dataset.device_arrays(h)[3]
-  used = dataset.rows_used()
+  offs = [int(v) for v in dataset.device_arrays(h)[3]]    # (NumPy integers index a tensor slowly)
+  used = [int(u) for u in dataset.rows_used()]
   dy = max(-dataset.input_offset, 0)
+  # nothing dropped anywhere: the tensors themselves
+  whole = dy == 0 and all(offs[i] + u == offs[i + 1] for i, u in enumerate(used))
   cat = lambda parts: torch.cat(parts).contiguous() if parts else None
   y_all = p_all = None
   if output is not None:
-    y_all = cat([output[offs[i] + dy:offs[i] + dy + u] for i, u in enumerate(used)])
+    y_all = (output.contiguous() if whole else
+             cat([output[offs[i] + dy:offs[i] + dy + u] for i, u in enumerate(used)]))
   if per_frame is not None:
-    p_all = cat([per_frame[offs[i]:offs[i] + u] for i, u in enumerate(used)])
+    p_all = (per_frame.contiguous() if whole else
+             cat([per_frame[offs[i]:offs[i] + u] for i, u in enumerate(used)]))
   return y_all, p_all
 
 

@@ -43,7 +43,7 @@ def _class_moments_device(x, y):
   import torch
   from telluride_decoding_amd import device
   y = np.asarray(y).reshape(-1)
-  labels = sorted(set(y.tolist()))
+  labels = np.unique(y).tolist()
   dims = int(x.shape[1])
   h = device.default_handle()
   moments = []
@@ -66,6 +66,19 @@ def _class_moments_device(x, y):
   return labels, means, within, between
 
 
+def _small_gram(m):
+  """m^T m for a tall matrix of a few columns, one sum of products per pair of columns.
+  (einsum, not BLAS: a threaded BLAS call on a tall-skinny operand costs milliseconds of thread
+  start-up -- 64 OpenBLAS threads on a 16-CPU share of the GPU host -- for microseconds of work,
+  and its spinning workers slow whatever the interpreter does next.)"""
+  cols = [np.ascontiguousarray(m[:, i]) for i in range(m.shape[1])]
+  g = np.empty((len(cols), len(cols)))
+  for i, a in enumerate(cols):
+    for j in range(i, len(cols)):
+      g[i, j] = g[j, i] = np.einsum('n,n->', a, cols[j])
+  return g
+
+
 def _class_moments(x, y):
   """Sorted labels with (count, mean) per class, and the two scatter matrices."""
   if hasattr(x, 'is_cuda') and x.is_cuda and str(x.dtype) == 'torch.float32' and x.dim() == 2:
@@ -73,18 +86,22 @@ def _class_moments(x, y):
   if hasattr(x, 'is_cuda'):
     x = x.cpu().numpy()
   x = np.asarray(x, dtype=np.float64)
-  labels = sorted(set(np.asarray(y).tolist()))
+  y = np.asarray(y)
+  labels = np.unique(y).tolist()         # (sorted; a Python set of 5e5 labels took 23 ms)
   grand_mean = x.mean(axis=0)
   dims = x.shape[1]
   within = np.zeros((dims, dims))
   between = np.zeros((dims, dims))
   means = []
   for label in labels:
-    members = x[np.asarray(y) == label]
+    members = x[y == label]
     count = members.shape[0]
     mean = members.sum(axis=0) / count
     means.append(mean)
-    within += members.T @ members - count * np.outer(mean, mean)
+    # (a [dims, rows] x [rows, dims] product with a handful of dims is a threaded BLAS call at its
+    # worst: 44 ms for 2.4e5 rows x 1 column against 0.2 ms for the same sum as a dot product)
+    gram = _small_gram(members) if dims <= 8 else members.T @ members
+    within += gram - count * np.outer(mean, mean)
     shift = mean - grand_mean
     between += count * np.outer(shift, shift)
   return labels, means, within, between
@@ -171,6 +188,8 @@ class LinearDiscriminantAnalysis(object):
     if x.ndim != 2 or x.shape[1] != self._w.shape[0]:
       raise TypeError('Inconsistent training and transform sizes. %s vs %s' %
                       (x.shape, self._w.shape))
+    if x.shape[1] <= 8:             # (tall and skinny: see _small_gram)
+      return np.real(np.einsum('nd,dk->nk', x, self._w))
     return np.real(x @ self._w)
 
   def transform(self, x):
