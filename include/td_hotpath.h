@@ -435,6 +435,17 @@ int td_decide_step(td_handle* h, const double* s1_dev, const double* s2_dev,
 int td_decode_ssd(td_handle* h, const double* s1_dev, const double* s2_dev,
                   const int64_t* window_offsets_host, int num_trials,
                   const double* params_host, const double* prior_host, double* out_dev);
+/* The same decoder fed as the windows arrive (the reference's object is stateful:
+ * attention_decoder.py:329-451 keeps mu_d, rho_d, z_k_k, the smoothed tails and the last
+ * k_w correlations between calls): state_dev [num_trials, td_ssd_state_doubles()] float64 on the
+ * device, all zeros for a fresh decoder, is read before the trial's windows of this call and
+ * written after them -- any split of a trial's windows over calls gives the outputs of one call.
+ * state_dev NULL = td_decode_ssd. */
+int td_ssd_state_doubles(void);
+int td_decode_ssd_stream(td_handle* h, const double* s1_dev, const double* s2_dev,
+                         const int64_t* window_offsets_host, int num_trials,
+                         const double* params_host, const double* prior_host, double* state_dev,
+                         double* out_dev);
 
 /* ------------------------------------------------------------------ fused decode
  * Raw EEG -> decisions in one pass: FIR predict, global-statistics correlation

@@ -107,6 +107,8 @@ SIGNATURES = {
     'td_decide_wta': [_vp, _vp, _vp, _i64, _vp],
     'td_decide_step': [_vp, _vp, _vp, _pi64, _i, _vp, _pd],
     'td_decode_ssd': [_vp, _vp, _vp, _pi64, _i, _pd, _pd, _vp],
+    'td_decode_ssd_stream': [_vp, _vp, _vp, _pi64, _i, _pd, _pd, _vp, _vp],
+    'td_ssd_state_doubles': [],
     'td_decode_fused': [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i64, _pi64, _i, _i,
                         _i, _pd, _vp, _vp],
 }

@@ -119,23 +119,34 @@ class StateSpaceAttentionDecoder(AttentionDecoder):
     self.rho_d, self.mu_d = [rho_a, rho_u], [mu_a, mu_u]
     self.mu_0 = [mu_a, mu_u]
     self._prior = ([rho_a, rho_u], [mu_a, mu_u])
+    if getattr(self, '_state', None) is not None:
+      # a streaming decoder tuned after it has seen windows: the reference overwrites its running
+      # rho_d / mu_d (attention_decoder.py:277-327); theirs sit behind the 8 arrays of the state
+      import torch
+      base = int(self._state.shape[1]) - 8
+      self._state[0, base + 1:base + 5] = torch.tensor([rho_a, rho_u, mu_a, mu_u], dtype=torch.float64,
+                                                        device=self._state.device)
 
-  def _run(self, s1, s2, window_offsets, h):
+  def _run(self, s1, s2, window_offsets, h, state=None):
     return device.decode_ssd(s1, s2, window_offsets, self.outer_iter, self.inner_iter,
                              self.newton_iter, self.k_f, self.k_b, self._offset, self._prior,
-                             handle=h)
+                             handle=h, state=state)
 
   def attention(self, r1, r2):
-    """Streaming call: the whole history of this decoder is replayed on the
-    device (one trial), the newest window's (p, lower, upper) is returned."""
+    """Streaming call: the decoder's state lives on the device (td_decode_ssd_stream) and one
+    window is decoded per call -- constant cost per window, like the reference's stateful object
+    (replaying the whole history, as the first version did, made the n-th call cost n windows).
+    Returns the newest window's (p, lower, upper)."""
     self.calls += 1
     self.r1.append(float(np.mean(r1)))
     self.r2.append(float(np.mean(r2)))
+    h = device.default_handle()
+    if getattr(self, '_state', None) is None:
+      self._state = device.ssd_state(1, handle=h)
+    out = self._run(_dev_f64(h, self.r1[-1:]), _dev_f64(h, self.r2[-1:]), [0, 1], h, state=self._state)
     if self.calls < self.k_w:
       return (0.5, 0.5, 0.5)
-    h = device.default_handle()
-    out = self._run(_dev_f64(h, self.r1), _dev_f64(h, self.r2), [0, len(self.r1)], h)
-    return tuple(float(v) for v in out[-1].cpu().numpy())
+    return tuple(float(v) for v in out[0].cpu().numpy())
 
   def attention_batch(self, r1, r2, window_offsets=None):
     h = device.default_handle()

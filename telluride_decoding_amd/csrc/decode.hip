@@ -963,9 +963,14 @@ __device__ double np_sum(const double* a, int n) {
   return res;
 }
 
+// Decoder state that survives from one window to the next (attention_decoder.py: mu_d, rho_d,
+// z_k_k, the smoothed tails, the last k_w correlations, the call count), for callers that feed
+// windows as they arrive: kSsdState doubles per trial, all zeros = a fresh decoder.
+constexpr int kSsdState = 8 * (kMaxKw + 1) + 8;
+
 __global__ void ssd_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
                            const long long* __restrict__ win_off, int n_trials, SsdParams sp,
-                           double* __restrict__ out) {
+                           double* __restrict__ out, double* __restrict__ state) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_trials) return;
   const int kw = sp.k_f + sp.k_b + 1;
@@ -993,6 +998,21 @@ __global__ void ssd_kernel(const double* __restrict__ s1, const double* __restri
   for (int i = 0; i <= kw; ++i) z_kk[i] = s_kk[i] = z_pred[i] = s_pred[i] = z_cap[i] = s_cap[i] = 0.0;
   for (int i = 0; i < kw; ++i) sm[i] = 0.0;
   int calls = 0;
+  double* st = state ? state + (size_t)t * kSsdState : nullptr;
+  constexpr int kA = kMaxKw + 1;
+  if (st && st[8 * kA] > 0.0) {            // a decoder that has seen windows: pick it up
+    for (int i = 0; i < kw; ++i) {
+      r1h[i] = st[0 * kA + i]; r2h[i] = st[1 * kA + i];
+      z_last[i] = st[2 * kA + i]; eta_last[i] = st[3 * kA + i];
+    }
+    for (int i = 0; i <= kw; ++i) {
+      z_kk[i] = st[4 * kA + i]; s_kk[i] = st[5 * kA + i];
+      z_cap[i] = st[6 * kA + i]; s_cap[i] = st[7 * kA + i];
+    }
+    calls = (int)st[8 * kA];
+    rho_d[0] = st[8 * kA + 1]; rho_d[1] = st[8 * kA + 2];
+    mu_d[0] = st[8 * kA + 3]; mu_d[1] = st[8 * kA + 4];
+  }
   for (long long w = win_off[t]; w < win_off[t + 1]; ++w) {
     ++calls;
     for (int i = 0; i + 1 < kw; ++i) { r1h[i] = r1h[i + 1]; r2h[i] = r2h[i + 1]; }
@@ -1070,6 +1090,19 @@ __global__ void ssd_kernel(const double* __restrict__ s1, const double* __restri
     out[w * 3 + 0] = 1.0 / (1 + exp(-zd));
     out[w * 3 + 1] = 1.0 / (1 + exp(-zd - c0 * sqrt(ed)));
     out[w * 3 + 2] = 1.0 / (1 + exp(-zd + c0 * sqrt(ed)));
+  }
+  if (st) {
+    for (int i = 0; i < kw; ++i) {
+      st[0 * kA + i] = r1h[i]; st[1 * kA + i] = r2h[i];
+      st[2 * kA + i] = z_last[i]; st[3 * kA + i] = eta_last[i];
+    }
+    for (int i = 0; i <= kw; ++i) {
+      st[4 * kA + i] = z_kk[i]; st[5 * kA + i] = s_kk[i];
+      st[6 * kA + i] = z_cap[i]; st[7 * kA + i] = s_cap[i];
+    }
+    st[8 * kA] = (double)calls;
+    st[8 * kA + 1] = rho_d[0]; st[8 * kA + 2] = rho_d[1];
+    st[8 * kA + 3] = mu_d[0]; st[8 * kA + 4] = mu_d[1];
   }
 }
 
@@ -2144,9 +2177,19 @@ int td_decide_step(td_handle* h, const double* s1_dev, const double* s2_dev,
   return TD_OK;
 }
 
+int td_ssd_state_doubles(void) { return kSsdState; }
+
 int td_decode_ssd(td_handle* h, const double* s1_dev, const double* s2_dev,
                   const int64_t* window_offsets_host, int num_trials, const double* params_host,
                   const double* prior_host, double* out_dev) {
+  return td_decode_ssd_stream(h, s1_dev, s2_dev, window_offsets_host, num_trials, params_host,
+                              prior_host, nullptr, out_dev);
+}
+
+int td_decode_ssd_stream(td_handle* h, const double* s1_dev, const double* s2_dev,
+                         const int64_t* window_offsets_host, int num_trials,
+                         const double* params_host, const double* prior_host, double* state_dev,
+                         double* out_dev) {
   if (!h || !s1_dev || !s2_dev || !window_offsets_host || !params_host || !out_dev)
     return td_fail(h, TD_ERR_INVALID, "td_decode_ssd: NULL");
   SsdParams sp;
@@ -2171,7 +2214,7 @@ int td_decode_ssd(td_handle* h, const double* s1_dev, const double* s2_dev,
   TD_TRY(td_upload_async(h, off.data(), sizeof(long long) * off.size(), scratch));
   hipLaunchKernelGGL(ssd_kernel, dim3((unsigned)td_ceil_div(num_trials, 64)), dim3(64), 0,
                      h->stream, s1_dev, s2_dev, reinterpret_cast<const long long*>(scratch),
-                     num_trials, sp, out_dev);
+                     num_trials, sp, out_dev, state_dev);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

@@ -592,9 +592,17 @@ def decide_step(s1, s2, window_offsets, state=None, handle=None):
   return out, st
 
 
+def ssd_state(num_trials, handle=None):
+  """Fresh state of `num_trials` state-space decoders for decode_ssd(..., state=): zeros
+  [num_trials, td_ssd_state_doubles()] float64 on the device."""
+  h = handle or default_handle()
+  return h.zeros((int(num_trials), int(h.lib.td_ssd_state_doubles())), 'float64')
+
+
 def decode_ssd(s1, s2, window_offsets, outer_iter=20, inner_iter=1, newton_iter=10,
-               forward_lag=0, backward_lag=13, offset=0.0, prior=None, handle=None):
-  """prior = (rho_d[2], mu_d[2]) from tune_log_normal_priors, or None."""
+               forward_lag=0, backward_lag=13, offset=0.0, prior=None, handle=None, state=None):
+  """prior = (rho_d[2], mu_d[2]) from tune_log_normal_priors, or None.  state (ssd_state): the
+  decoders pick up where the previous call with that state left them (td_decode_ssd_stream)."""
   h = handle or default_handle()
   out = h.zeros((int(s1.shape[0]), 3), 'float64')
   wo, wo_p = _lib.i64_array(window_offsets)
@@ -603,6 +611,10 @@ def decode_ssd(s1, s2, window_offsets, outer_iter=20, inner_iter=1, newton_iter=
   pr_p = None
   if prior is not None:
     pr, pr_p = _lib.f64_array(list(prior[0]) + list(prior[1]))
+  if state is not None:
+    h.check(h.lib.td_decode_ssd_stream(h.ptr, _ptr(s1), _ptr(s2), wo_p, len(wo) - 1, params_p, pr_p,
+                                       _ptr(state), _ptr(out)))
+    return out
   h.check(h.lib.td_decode_ssd(h.ptr, _ptr(s1), _ptr(s2), wo_p, len(wo) - 1, params_p, pr_p,
                               _ptr(out)))
   return out

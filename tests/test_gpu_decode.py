@@ -3,6 +3,8 @@
 HIP kernels through the C-ABI vs the CPU oracle on the same seeded inputs and
 vs the golden fixtures generated from the reference itself.
 """
+import time
+
 import numpy as np
 import pytest
 
@@ -210,6 +212,23 @@ def test_state_space_decoder_matches_reference_trajectory(dev, name, tune, offse
   np.testing.assert_array_equal(out3[:n], out)
   np.testing.assert_array_equal(out3[n + 40:], out)
   np.testing.assert_array_equal(out3[n:n + 40], out[:40])
+  # fed as the windows arrive (td_decode_ssd_stream): any split of the trial over calls gives the
+  # outputs of the single call, bit for bit -- one window at a time, then uneven chunks; two trials
+  # with their own states in one call
+  st = dev.ssd_state(1, handle=h)
+  pieces = [dev.decode_ssd(_d64(h, c[i:i + 1, 0]), _d64(h, c[i:i + 1, 1]), [0, 1], offset=offset,
+                           prior=prior, handle=h, state=st).cpu().numpy() for i in range(n)]
+  np.testing.assert_array_equal(np.concatenate(pieces), out)
+  st2 = dev.ssd_state(2, handle=h)
+  got = [[], []]
+  for a, b in ((0, 5), (5, 6), (6, 33), (33, n)):
+    s1 = np.concatenate((c[a:b, 0], c[a:b, 0]))
+    s2 = np.concatenate((c[a:b, 1], c[a:b, 1]))
+    o = dev.decode_ssd(_d64(h, s1), _d64(h, s2), [0, b - a, 2 * (b - a)], offset=offset, prior=prior,
+                       handle=h, state=st2).cpu().numpy()
+    got[0].append(o[:b - a]); got[1].append(o[b - a:])
+  np.testing.assert_array_equal(np.concatenate(got[0]), out)
+  np.testing.assert_array_equal(np.concatenate(got[1]), out)
 
 
 def test_attention_decoder_classes(dev):
@@ -229,6 +248,17 @@ def test_attention_decoder_classes(dev):
   np.testing.assert_allclose(ssd.mu_d, g['ssd_tuned_mu_d_tuned'], rtol=1e-12)
   stream = np.array([ssd.attention(a, b) for a, b in c[:40]])
   np.testing.assert_allclose(stream, g['ssd_tuned_traj'][:40], rtol=1e-7, atol=1e-9)
+  # (the streaming object keeps its state on the device: the 300th call costs what the 20th did)
+  t0 = time.perf_counter()
+  for a, b in c[40:60]:
+    ssd.attention(a, b)
+  early = time.perf_counter() - t0
+  for a, b in np.tile(c[60:100], (6, 1)):
+    ssd.attention(a, b)
+  t0 = time.perf_counter()
+  for a, b in c[100:120]:
+    ssd.attention(a, b)
+  assert time.perf_counter() - t0 < 5 * early + 0.05
   batch = ad.create_attention_decoder('ssd')
   batch.tune(c[:30, 0], c[:30, 1])
   p, lo, hi = batch.attention_batch(c[:, 0], c[:, 1])
