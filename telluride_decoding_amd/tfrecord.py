@@ -187,8 +187,99 @@ def discover_feature_shapes(tfrecord_file_name):
   return {}
 
 
+def _float_layout(record):
+  """[(feature name, byte offset of its packed float payload in the record, float count)] when
+  every feature of the Example is ONE packed FloatList (what the reference's ingest writes per
+  frame), else None."""
+  def fields_at(buf, base):
+    pos, end = 0, len(buf)
+    while pos < end:
+      key, pos = _varint(buf, pos)
+      num, wt = key >> 3, key & 7
+      if wt != 2:
+        raise ValueError('not a length-delimited field')
+      n, pos = _varint(buf, pos)
+      if pos + n > end:
+        raise ValueError('truncated')
+      yield num, buf[pos:pos + n], base + pos
+      pos += n
+  out = []
+  try:
+    buf = memoryview(record)
+    for num, features, f0 in fields_at(buf, 0):
+      if num != 1:
+        return None
+      for n2, entry, e0 in fields_at(features, f0):
+        if n2 != 1:
+          return None
+        key, payload = None, None
+        for n3, v3, v0 in fields_at(entry, e0):
+          if n3 == 1:
+            key = bytes(v3).decode('utf-8')
+          elif n3 == 2:
+            inner = list(fields_at(v3, v0))
+            if len(inner) != 1 or inner[0][0] != 2:          # exactly one FloatList
+              return None
+            lists = list(fields_at(inner[0][1], inner[0][2]))
+            if len(lists) != 1 or lists[0][0] != 1 or len(lists[0][1]) % 4:
+              return None
+            payload = (lists[0][2], len(lists[0][1]) // 4)
+          else:
+            return None
+        if key is None or payload is None:
+          return None
+        out.append((key, payload[0], payload[1]))
+  except (ValueError, IndexError, UnicodeDecodeError):
+    return None
+  return out or None
+
+
+def _read_file_regular(filename, fields):
+  """read_file for the regular case -- every record the same length and the same bytes outside
+  its float payloads (one Example per frame, fixed feature widths) -- as array slicing of the whole
+  file: no per-record Python (31 us a record through the generic parser: half a minute per 1e6
+  frames).  None when the file is not of that shape."""
+  with open(filename, 'rb') as f:
+    data = f.read()
+  if len(data) < 16:
+    return None
+  (length,) = struct.unpack_from('<Q', data, 0)
+  stride = length + 16
+  if length == 0 or len(data) % stride:
+    return None
+  layout = _float_layout(memoryview(data)[12:12 + length])
+  if layout is None:
+    return None
+  arr = np.frombuffer(data, np.uint8).reshape(-1, stride)
+  skeleton = np.ones(stride, bool)
+  skeleton[8:12] = False                       # (CRC of the length: equal anyway)
+  skeleton[12 + length:] = False               # CRC of the data
+  for _, start, count in layout:
+    skeleton[12 + start:12 + start + 4 * count] = False
+  if not (arr[:, skeleton] == arr[0, skeleton]).all():
+    return None
+  out = {}
+  for key, start, count in layout:
+    if fields is not None and key not in fields:
+      continue
+    if key in out:
+      return None
+    block = np.ascontiguousarray(arr[:, 12 + start:12 + start + 4 * count])
+    out[key] = block.view('<f4').astype(np.float32, copy=False)
+  return out
+
+
 def read_file(filename, fields=None, verify=False):
   """{feature: float32 [frames, width]} of the float / int features (one Example per frame)."""
+  if not verify:
+    out = _read_file_regular(filename, fields)
+    if out is not None:
+      if fields is not None:
+        missing = set(fields) - set(out)
+        if missing:
+          raise ValueError('Could not find all desired features (%s) in data (%s)' %
+                           (sorted(fields), sorted(out)))
+      return out
   cols = {}
   for rec in iter_records(filename, verify=verify):
     ex = parse_example(rec)

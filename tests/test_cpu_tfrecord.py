@@ -46,6 +46,47 @@ def test_round_trip_and_corruption(tmp_path):
   assert tfrecord.count_tfrecords(bad) == (36, True)
 
 
+def test_regular_files_are_read_without_a_loop_over_records(tmp_path):
+  """One Example per frame with fixed widths (what the reference's ingest writes) is read by
+  slicing the file as an array; anything else -- a record of another width, a corrupt skeleton
+  byte -- falls back to the record-by-record parser, and both agree."""
+  rng = np.random.default_rng(2)
+  data = {'eeg': rng.standard_normal((500, 7)).astype(np.float32),
+          'envelope': rng.standard_normal((500, 1)).astype(np.float32)}
+  name = str(tmp_path / 'regular.tfrecords')
+  tfrecord.write_file(name, data)
+  fast = tfrecord._read_file_regular(name, None)
+  assert fast is not None
+  slow = tfrecord.read_file(name, verify=True)            # (verification takes the generic path)
+  for k in data:
+    np.testing.assert_array_equal(fast[k], data[k])
+    np.testing.assert_array_equal(slow[k], data[k])
+    assert fast[k].dtype == np.float32 and fast[k].flags['C_CONTIGUOUS']
+  np.testing.assert_array_equal(tfrecord.read_file(name, fields=['eeg'])['eeg'], data['eeg'])
+  with pytest.raises(ValueError, match='Could not find all desired features'):
+    tfrecord.read_file(name, fields=['meg'])
+  here = os.path.join(os.path.dirname(__file__), 'golden', 'meg_subj01_400.tfrecords')
+  a, b = tfrecord.read_file(here), tfrecord.read_file(here, verify=True)
+  assert tfrecord._read_file_regular(here, None) is not None and set(a) == set(b)
+  for k in a:
+    np.testing.assert_array_equal(a[k], b[k])
+  # two files with different widths appended: not regular, the generic parser reports the change
+  other = str(tmp_path / 'other.tfrecords')
+  tfrecord.write_file(other, {'eeg': data['eeg'][:3, :5], 'envelope': data['envelope'][:3]})
+  mixed = str(tmp_path / 'mixed.tfrecords')
+  open(mixed, 'wb').write(open(name, 'rb').read() + open(other, 'rb').read())
+  assert tfrecord._read_file_regular(mixed, None) is None
+  with pytest.raises(ValueError, match='changes width'):
+    tfrecord.read_file(mixed)
+  # a feature renamed in ONE record (same length): the skeleton check sends the file to the parser
+  raw = bytearray(open(name, 'rb').read())
+  at = raw.find(b'envelope', len(raw) // 2)
+  raw[at] = ord('E')
+  odd = str(tmp_path / 'odd.tfrecords')
+  open(odd, 'wb').write(bytes(raw))
+  assert tfrecord._read_file_regular(odd, None) is None
+
+
 def test_field_selection_matches_reference_semantics(tmp_path):
   rng = np.random.default_rng(1)
   names = []
