@@ -454,6 +454,10 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--spinup-steps', type=int, default=40,
+                  help='untimed steps BEFORE the warm-up steps that bring the device out of idle: '
+                       'after seconds of host-side set-up the first ~25 launches run in a power / '
+                       'clock transient (tools/clock_transient.py); 0 = none')
   ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
   ap.add_argument('--no-decode', action='store_true', help='skip the informational decode leg')
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
@@ -529,15 +533,22 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
-  def time_region(run, steps, warmup):
+  def time_region(run, steps, warmup, after_warmup=None, collect=True):
     """The contract's timed region: warmup, barrier + sync, K steps, barrier + sync, MAX over
     ranks."""
-    out = run(warmup) if warmup > 0 else None
     # objects of earlier legs (pipelines, statistics, their 270 MB scratch arenas) that are only
     # reachable through reference cycles are freed by Python's cyclic collector at an arbitrary
     # later allocation -- hipFree waits for the device, a one-off ~35 ms stall inside whatever is
-    # being timed.  Collect them now.
-    gc.collect()
+    # being timed.  Collect them now -- BEFORE the warm-up steps: the collection takes tens of
+    # milliseconds of host time, and a device that idles that long between the warm-up and the
+    # timed steps answers the next burst with a power / clock transient (the lag kernel 0.76 ->
+    # 0.89 ms for the first ~25 launches, tools/clock_transient.py): a 20-step region then measured
+    # 1.12 ms per step where a 200-step one measures 0.93.
+    if collect:
+      gc.collect()
+    out = run(warmup) if warmup > 0 else None
+    if after_warmup is not None:
+      after_warmup()
     barrier()
     t0 = time.perf_counter()
     out = run(steps) or out
@@ -608,10 +619,13 @@ def main():
   host_data, shard, reduce_fn, solves, samples_per_step = (
       strong_setup() if args.scaling == 'strong' else weak_setup())
   run, h_prof, pipe = make_runner(shard, reduce_fn, solves, args.serial)
-  if args.warmup > 0:
-    run(args.warmup)
   h_prof.profile_enable(True)
-  elapsed, out = time_region(run, args.steps, 0)
+  gc.collect()
+  if args.spinup_steps > 0:
+    run(args.spinup_steps)
+  # (the warm-up steps' launches are read away, so that the profile covers the timed steps only)
+  elapsed, out = time_region(run, args.steps, args.warmup, after_warmup=h_prof.profile_read,
+                             collect=False)
   launches, kernel_ms, kernel_samples = h_prof.profile_read()
   h_prof.profile_enable(False)
   if out is not None:
@@ -636,6 +650,7 @@ def main():
     line = {
         'metric': 'TRF-fit samples/sec', 'value': value, 'unit': 'samples/s',
         'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
+        'spinup_steps': args.spinup_steps,
         'launcher': os.environ.get('TD_BENCH_LAUNCHER',
                                    'torch.distributed.run' if world > 1 else 'direct'),
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
@@ -690,9 +705,8 @@ def main():
   if not args.serial:
     # the same fits back to back on one stream, and the dominant kernel alone on the whole chip
     run_s, _, _ = make_runner(shard, reduce_fn, solves, True)
-    run_s(2)
     h.profile_enable(True)
-    e_s, _ = time_region(run_s, 10, 0)
+    e_s, _ = time_region(run_s, 10, 2, after_warmup=h.profile_read)
     l1, ms1, smp1 = h.profile_read()
     h.profile_enable(False)
     if rank == 0:
@@ -722,8 +736,7 @@ def main():
       for _ in range(kk):
         st.reset()
         st.accumulate(x, None, y, offs, **kw)
-    run_a(2)
-    e_a, _ = time_region(run_a, steps, 0)
+    e_a, _ = time_region(run_a, steps, 2)
     return e_a / steps * 1e3
 
   acc_ms = accumulate_only(shard)
@@ -733,8 +746,7 @@ def main():
     # informational strong-scaling leg: the ONE-GPU job cut into N time ranges
     _, shard2, reduce2, solves2, _ = strong_setup()
     run2, _, pipe2 = make_runner(shard2, reduce2, solves2, False)
-    run2(3)
-    e2, _ = time_region(run2, 50, 0)
+    e2, _ = time_region(run2, 50, 3)
     del pipe2, run2
     torch.cuda.synchronize()
     acc2 = accumulate_only(shard2)
