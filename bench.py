@@ -24,6 +24,11 @@ throughput-bound accumulate of fit i + 1.  All K fits, solves included, complete
 timed region.  --serial runs them back to back on one stream; the serial figure is also
 measured after the timed region and reported as `serial_ms_per_step`.
 
+Before the W warm-up steps, --spinup-steps (default 40, untimed, reported in the line) bring the
+device out of the idle of the set-up phase: after an idle moment the chip answers a burst of
+matrix work with a power / clock transient of ~25 launches, which W = 3 warm-up
+steps do not outlast.  The timed region is still exactly K steps between barrier + synchronise.
+
 The JSON line also carries
   roofline      the dominant kernel (lagcov MFMA accumulate) timed live with hipEvents on the
                 stream it runs on (td_profile_*); `traffic` is the HBM bytes per launch from
