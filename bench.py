@@ -40,7 +40,8 @@ The JSON line also carries
                 iterations, its HBM roofline, decision flips against the oracle, and the
                 reference harness' window sizes with hop = W // 2 (infer.py:376-378),
   cca, loso     configs C3 (CCA fit = accumulate + device solve, and transform; also at the
-                codelab's shape K1 = 2553) and C5 (LOSO x lambda sweep on one GPU)
+                codelab's shape K1 = 2553, with context on both views, and a forward model on
+                the same recording) and C5 (LOSO x lambda sweep on one GPU)
                 (N = 1; --no-extra skips them).
 """
 import argparse
@@ -275,7 +276,30 @@ def cca_leg(h, device, eeg):
   # the class default of BrainModelCCA is regularization_lambda = 0 (cca.py:172)
   t_solve2_r0 = timed(lambda: st2.cca_solve(m - 1, 0.0, 5), 5)
   route_r0 = st2.last_cca_route
+  # the same two views with context (21 lags on the EEG, 16 on the bands), and a forward model on the
+  # same recording (one band with 32 lags -> the 64 EEG channels as targets)
+  st3 = device.LagStats(C, 0, 20, 8, 7, 8, 0, handle=h)
+
+  def acc3():
+    st3.reset()
+    st3.accumulate(x, x2, None, offs)
+
+  t_acc3 = timed(acc3, 10)
+  x1 = x2[:, :1].contiguous()
+  st4 = device.LagStats(1, 0, 31, d=C, handle=h)
+
+  def acc4():
+    st4.reset()
+    st4.accumulate(x1, None, x, offs)
+
+  t_acc4 = timed(acc4, 10)
+  t_solve4 = timed(lambda: st4.ridge_solve([0.1]), 5)
+  del st3, st4
   return {
+      'lagged': {'workload': 'CCA accumulate with context: 64 ch x 21 lags vs 8 bands x 16 lags, 1e6 samples',
+                 'accumulate_ms': t_acc3 * 1e3},
+      'forward_model': {'workload': 'ridge TRF the other way round: 1 band x 32 lags -> 64 EEG channels, '
+                                    '1e6 samples', 'accumulate_ms': t_acc4 * 1e3, 'solve_ms': t_solve4 * 1e3},
       'workload': 'C3: CCA, 64-ch EEG vs 8-band envelope, 1e6 samples, no context, 5 components',
       'fit_ms': (t_acc + t_solve) * 1e3, 'accumulate_ms': t_acc * 1e3,
       'solve_ms': t_solve * 1e3, 'transform_ms': t_tr * 1e3,
