@@ -2229,7 +2229,20 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
   TD_REQUIRE(h, num_trials > 0 && width > 0 && hop > 0, "td_decode_fused: bad sizes");
   TD_REQUIRE(h, ldenv >= 2, "td_decode_fused: the envelope stream needs two columns");
   const int64_t rows = trial_offsets_host[num_trials];
-  const int g = window_block_size(width, hop);
+  int g = window_block_size(width, hop);
+  if (g == 0 && num_trials >= 16) {
+    // Short windows (W = 10 / hop 5 of the reference harness: gcd < 32): the per-trial tail kernel
+    // does not care how small a block is as long as a trial's blocks fit its LDS table -- blocks of
+    // gcd(W, hop) frames then, instead of the unfused chain below, whose per-window tables (240 000
+    // entries at C4) are built on the host three times per call (0.3 -> 0.7 ms a call against 0.09)
+    const int64_t gg = gcd64(width, hop);
+    bool fits = width / gg <= 64;
+    for (int t = 0; t < num_trials && fits; ++t) {
+      const int64_t n = trial_offsets_host[t + 1] - trial_offsets_host[t];
+      if (n >= width && (((n - width) / hop) * hop + width) / gg > kTrialBlocksMax) fits = false;
+    }
+    if (fits) g = (int)gg;
+  }
   if (g == 0) {
     // windows that do not share whole blocks (gcd(width, hop) < 32): unfused chain
     std::vector<long long> row0;

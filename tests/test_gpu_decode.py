@@ -378,7 +378,11 @@ def test_decode_fused_equals_unfused_at_scale(dev):
 
 
 @pytest.mark.parametrize('width,hop,pre,post', [(1000, 100, 0, 31), (1000, 500, 0, 31), (400, 200, 3, 20),
-                                                (256, 64, 0, 7), (96, 32, 0, 40)])
+                                                (256, 64, 0, 7), (96, 32, 0, 40),
+                                                # short windows: blocks of gcd(W, hop) < 32 frames in the
+                                                # per-trial tail kernel (the harness' W = 10), and a pair
+                                                # without a common divisor worth blocks (the unfused chain)
+                                                (10, 5, 0, 31), (30, 12, 2, 9), (37, 11, 0, 5)])
 def test_decode_fused_matches_oracle(dev, width, hop, pre, post):
   """td_decode_fused (FIR prediction -> block sums of both speakers -> window scores +
   winner-take-all) against the ORACLE chain: dense forward on the
