@@ -56,14 +56,16 @@ def _class_moments_device(x, y):
   grand_mean = sum(m[dims, :dims] for m in moments) / total
   within = np.zeros((dims, dims))
   between = np.zeros((dims, dims))
-  means = []
+  means, per_class = [], []
   for m in moments:
     count, mean = m[dims, dims], m[dims, :dims] / m[dims, dims]
     means.append(mean)
-    within += m[:dims, :dims] - count * np.outer(mean, mean)
+    scatter = m[:dims, :dims] - count * np.outer(mean, mean)
+    per_class.append((count, mean, scatter))
+    within += scatter
     shift = mean - grand_mean
     between += count * np.outer(shift, shift)
-  return labels, means, within, between
+  return labels, means, within, between, per_class
 
 
 def _small_gram(m):
@@ -92,7 +94,7 @@ def _class_moments(x, y):
   dims = x.shape[1]
   within = np.zeros((dims, dims))
   between = np.zeros((dims, dims))
-  means = []
+  means, per_class = [], []
   for label in labels:
     members = x[y == label]
     count = members.shape[0]
@@ -101,10 +103,12 @@ def _class_moments(x, y):
     # (a [dims, rows] x [rows, dims] product with a handful of dims is a threaded BLAS call at its
     # worst: 44 ms for 2.4e5 rows x 1 column against 0.2 ms for the same sum as a dot product)
     gram = _small_gram(members) if dims <= 8 else members.T @ members
-    within += gram - count * np.outer(mean, mean)
+    scatter = gram - count * np.outer(mean, mean)
+    per_class.append((count, mean, scatter))
+    within += scatter
     shift = mean - grand_mean
     between += count * np.outer(shift, shift)
-  return labels, means, within, between
+  return labels, means, within, between, per_class
 
 
 def _ranked_axes(within, between):
@@ -172,7 +176,7 @@ class LinearDiscriminantAnalysis(object):
   # ---- estimation ------------------------------------------------------------------
   def fit(self, x, y):
     x = _columns(x)
-    self._labels, self._mean_vectors, within, between = _class_moments(x, y)
+    self._labels, self._mean_vectors, within, between, self._per_class = _class_moments(x, y)
     self._strengths, axes = _ranked_axes(within, between)
     if len(axes) < 2:
       self._w = np.ones((1, 1))
@@ -258,3 +262,11 @@ class ScaledLinearDiscriminantAnalysis(LinearDiscriminantAnalysis):
 
   def transform(self, x):
     return np.real(self._slope * self._project(x) + self._intercept)
+
+  def projected_class_stats(self):
+    """[(mean, variance)] of transform(x)[:, 0] over the members of every class of the last fit,
+    from the class moments (the map is affine: mean = a . mu + b, variance = a^T (S / n) a with
+    a = slope * Re(w[:, 0])) -- what calculate_dprime needs, without projecting every row."""
+    a = np.real(self._slope * np.asarray(self._w)[:, 0])
+    return [(float(a @ mean + np.real(self._intercept)), float(a @ (scatter / count) @ a))
+            for count, mean, scatter in self._per_class]

@@ -22,7 +22,9 @@ def main():
   model.fit(train)
 
   def tm(name, fn, reps=3):
-    fn(); torch.cuda.synchronize()
+    for _ in range(4):          # (pools, table caches and scratch arenas settle over a few calls)
+      fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
       fn()
