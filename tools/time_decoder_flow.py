@@ -33,6 +33,8 @@ def main():
 
   dec = infer_decoder.LinearRegressionDecoder(model, reduction='first')
   dec2 = infer_decoder.LinearRegressionDecoder(model, reduction='lda')
+  for _ in range(10):           # (allocator caches of torch and of the library settle over the first calls)
+    dec.train(mixed, train)
   tm('model.fit (240k frames)', lambda: model.fit(train))
   tm("Decoder.train, reduction 'first'", lambda: dec.train(mixed, train))
   tm("Decoder.train, reduction 'lda'", lambda: dec2.train(mixed, train))
