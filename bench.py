@@ -27,7 +27,9 @@ measured after the timed region and reported as `serial_ms_per_step`.
 Before the W warm-up steps, --spinup-steps (default 40, untimed, reported in the line) bring the
 device out of the idle of the set-up phase: after an idle moment the chip answers a burst of
 matrix work with a power / clock transient of ~25 launches, which W = 3 warm-up
-steps do not outlast.  The timed region is still exactly K steps between barrier + synchronise.
+steps do not outlast; and --drain-fill (default 2, untimed, reported) accumulate-only calls run
+while the last warm-up solves drain, so that the barrier is reached under load.  The timed region
+is still exactly K steps between barrier + synchronise.
 
 The JSON line also carries
   roofline      the dominant kernel (lagcov MFMA accumulate) timed live with hipEvents on the
@@ -483,6 +485,10 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--drain-fill', type=int, default=2,
+                  help='untimed accumulate-only calls queued behind the warm-up steps while their last '
+                       'solves drain (pipelined runs), so that the device reaches the barrier under '
+                       'the load of the timed steps and not after 1.3 ms of solves alone; 0 = none')
   ap.add_argument('--spinup-steps', type=int, default=40,
                   help='untimed steps BEFORE the warm-up steps that bring the device out of idle: '
                        'after seconds of host-side set-up the first ~25 launches run in a power / '
@@ -575,7 +581,8 @@ def main():
     # 1.12 ms per step where a 200-step one measures 0.93.
     if collect:
       gc.collect()
-    out = run(warmup) if warmup > 0 else None
+    out = (run(warmup, args.drain_fill) if args.drain_fill and not args.serial and collect is False
+           else run(warmup)) if warmup > 0 else None
     if after_warmup is not None:
       after_warmup()
     barrier()
@@ -635,11 +642,20 @@ def main():
                                 targets_on_solve=args.targets_on_solve, allreduce=reduce_fn,
                                 solves=solves, solve_streams=args.solve_streams)
 
-    def run(k):
+    fill_stats = []
+
+    def run(k, fill=0):
       out = None
       for _ in range(k):
         r = pipe.submit(x, y, offs, lam, **kw)
         out = r if r is not None else out
+      if fill:
+        if not fill_stats:
+          fill_stats.append(device.LagStats(C, PRE, POST, d=D, handle=pipe.h_acc))
+        with torch.cuda.stream(pipe.s_acc):
+          for _ in range(fill):
+            fill_stats[0].reset()
+            fill_stats[0].accumulate(x, None, y, offs, **kw)
       for r in pipe.flush():                # every fit is solved before the clock stops
         out = r if r is not None else out
       return out
@@ -679,7 +695,7 @@ def main():
     line = {
         'metric': 'TRF-fit samples/sec', 'value': value, 'unit': 'samples/s',
         'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
-        'spinup_steps': args.spinup_steps,
+        'spinup_steps': args.spinup_steps, 'warmup_drain_fill': 0 if args.serial else args.drain_fill,
         'launcher': os.environ.get('TD_BENCH_LAUNCHER',
                                    'torch.distributed.run' if world > 1 else 'direct'),
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
