@@ -157,6 +157,7 @@ def decode_leg(h, device, iters=200):
   def timed(width, hop):
     for _ in range(3):
       out = device.decode_fused(xd, envd, offs, w, b, PRE, POST, width, hop, corr, handle=h)
+    gc.collect()           # (a collection inside the loop can free a device arena: a 40-70 ms stall)
     h.synchronize()
     h.timer_start()                                      # hipEvents on the launching stream
     for _ in range(iters):
