@@ -239,8 +239,27 @@ int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev
  * factorisation).  TD_ERR_SINGULAR when cov_x is not positive definite. */
 int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
                    float* w_dev, float* b_dev);
+/* How td_ridge_solve solves (brain_model.py:477 is one dense np.linalg.solve):
+ *   TD_SOLVER_AUTO (default) a synchronous call with at most 4 (lambda, output) systems, every lambda > 0, of
+ *                  at least 768 unknowns whose matrix fits the LDS of the CUs the handle runs on (td_set_cu_count;
+ *                  n = 2049 on the 256 CUs of an MI355X does) runs conjugate gradients in ONE persistent
+ *                  launch -- the matrix resident in LDS, one packet exchange per iteration -- and takes the
+ *                  blocked Cholesky only when that does not converge to a relative residual of 1e-12
+ *                  (checked on the TRUE residual), meets a non-positive curvature, or its workgroups are
+ *                  not all resident within 20 ms (another persistent grid on the device: the launch aborts
+ *                  itself and drains); everything else takes the Cholesky directly;
+ *   TD_SOLVER_CHOLESKY       always the blocked float64 Cholesky (~100 launches per system);
+ *   TD_SOLVER_CG             conjugate gradients first for any system count / size that fits (lambda > 0).
+ * td_last_solve_info: what the last td_ridge_solve on this handle did -- solver (TD_SOLVER_CHOLESKY or
+ * TD_SOLVER_CG), iterations of the slowest system, and the conjugate-gradient status (0 converged,
+ * 2 not converged / not positive definite, 3 aborted) when it was tried.  Any pointer may be NULL. */
+enum { TD_SOLVER_AUTO = 0, TD_SOLVER_CHOLESKY = 1, TD_SOLVER_CG = 2 };
+int td_set_solver(td_handle* h, int mode);
+int td_last_solve_info(td_handle* h, int* solver, int* iterations, int* cg_status);
 /* The same without waiting for the device.  *singular_flag_host points at a pinned host int
- * owned by the handle (a ring of 8: read it before the 8th later call) that becomes 0, or 1 if
+ * owned by the handle (a ring of 8: read it before the 8th later call; a call that would reuse a
+ * slot whose solve has not finished yet -- more than 8 solves outstanding, nobody can have read
+ * that flag -- returns TD_ERR_STATE instead of overwriting it) that becomes 0, or 1 if
  * some cov_x was not positive definite (w_dev / b_dev are then meaningless), once the work queued
  * by this call has completed -- wait for an event recorded after the call, then read it.  For
  * callers that pipeline fits: a host that waits for every solve cannot queue the next fit's

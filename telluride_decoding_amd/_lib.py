@@ -20,6 +20,7 @@ TD_ERR_HIP = -2
 TD_ERR_SINGULAR = -3
 TD_ERR_NOMEM = -4
 TD_ERR_STATE = -5
+TD_SOLVER_AUTO, TD_SOLVER_CHOLESKY, TD_SOLVER_CG = 0, 1, 2
 
 
 class HotPathUnavailable(RuntimeError):
@@ -83,6 +84,8 @@ SIGNATURES = {
     'td_rccl_comm_destroy': [_vp, _vp],
     'td_stats_moments': [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'td_ridge_solve': [_vp, _vp, _pd, _i, _vp, _vp],
+    'td_set_solver': [_vp, _i],
+    'td_last_solve_info': [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],
     'td_ridge_solve_async': [_vp, _vp, _pd, _i, _vp, _vp, _vp],
     'td_ridge_solve_multi': [_vp, _c.POINTER(_vp), _i, _pd, _i, _vp, _vp, _vp],
     'td_ridge_solve_loso': [_vp, _vp, _c.POINTER(_vp), _i, _pd, _i, _i, _d, _vp, _vp, _c.POINTER(_i),

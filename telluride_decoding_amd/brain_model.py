@@ -308,11 +308,16 @@ class BrainModelLinearRegression(object):
 
   def evaluate(self, dataset, **kwargs):
     """{'loss': mse, 'pearson_correlation_first': r} averaged over minibatches,
-    as Keras `evaluate` does (reference brain_model.py:206-253)."""
+    as Keras `evaluate` does (reference brain_model.py:206-253).  `dataset`: a brain_data.Dataset
+    (whole recordings in a few launches) or any iterable of (dict, y) minibatches whose 'input_1'
+    already carries its context (one prediction + one window-sums launch per minibatch)."""
     del kwargs
-    if not _is_dataset(dataset):
-      raise TypeError('BrainModel.evaluate must be called with tf.data.Dataset object.')
     h = device.default_handle()
+    if not _is_dataset(dataset):
+      if not hasattr(dataset, '__iter__'):
+        raise TypeError('BrainModel.evaluate must be called with tf.data.Dataset object.')
+      return _evaluate_minibatches(
+          dataset, h, lambda feats: self._predict_lagged_device(feats['input_1'], h), truth_from_y=True)
     dataset = dataset.resolved()     # mixup_batch: evaluate against the shuffled output
     pred = self.predict_device(dataset, handle=h)
     _, _, y, offs = dataset.device_arrays(h)
@@ -329,3 +334,39 @@ class BrainModelLinearRegression(object):
     sq = s[:, :, 2] - 2 * s[:, :, 4] + s[:, :, 3]     # sum (y - p)^2 per batch and column
     loss = float(np.mean(np.sum(sq, axis=1) / (bsz * s.shape[1])))
     return {'loss': loss, 'pearson_correlation_first': float(np.mean(r[:, 0]))}
+
+  def _predict_lagged_device(self, lagged, h):
+    w, b = self._device_weights(h)
+    x = _as_2d_device(h, lagged)
+    return device.predict_fir(x, [0, int(x.shape[0])], w, b, 0, 0, handle=h)
+
+
+def _evaluate_minibatches(batches, h, predict, truth_from_y, metric_name='pearson_correlation_first'):
+  """Keras-style evaluation of an iterable of (dict, y) minibatches (reference
+  brain_model.py:206-253): per minibatch the mean squared error and the first column's Pearson
+  correlation (with the reference's zero rule, :72-79) of truth against prediction, both from ONE
+  window-sums launch (the minibatch is the window); the unweighted mean over minibatches.
+  truth_from_y False: the prediction carries both halves (CCA: correlate them, cca.py:61-68) and
+  the loss is the metric itself (cca.py:196-199)."""
+  losses, metrics = [], []
+  for feats, y in batches:
+    pred = predict(feats)
+    rows = int(pred.shape[0])
+    if rows == 0:
+      continue
+    if truth_from_y:
+      a, b = _as_2d_device(h, y), pred
+    else:
+      dims = int(pred.shape[1]) // 2
+      a, b = pred[:, :dims].contiguous(), pred[:, dims:].contiguous()
+    sums = device.window_sums(a, b, [0, rows], rows, rows, handle=h)
+    r = device.window_scores(sums, rows, mode=1, handle=h).cpu().numpy()[0]
+    metrics.append(float(r[0]))
+    if truth_from_y:
+      s = sums.cpu().numpy()[0]
+      losses.append(float(np.sum(s[:, 2] - 2 * s[:, 4] + s[:, 3]) / (rows * s.shape[0])))
+    else:
+      losses.append(float(r[0]))
+  if not metrics:
+    return {'loss': float('nan'), metric_name: float('nan')}
+  return {'loss': float(np.mean(losses)), metric_name: float(np.mean(metrics))}

@@ -1,8 +1,8 @@
 """Linear canonical-correlation analysis on the HIP hot path.
 
-Mirrors reference cca.py for the linear path: `cca_pearson_correlation[_first/
-_second]` (cca.py:39-78), `calculate_cca_parameters_from_dataset` (:272-369),
-`BrainCcaLayer.call` (:150-161) and `BrainModelCCA` (:169-244).  The TF-graph
+Mirrors reference cca.py for the linear path: `rmss` (cca.py:31-36),
+`cca_pearson_correlation[_first/_second]` (:39-78), `BrainCcaLayer` (:84-166),
+`calculate_cca_parameters_from_dataset` (:272-369) and `BrainModelCCA` (:169-244).  The TF-graph
 deep-CCA loss (`cca_loss`, :372-443) is out of scope.
 
 Everything runs in HIP kernels behind the C-ABI: the accumulate over all frames
@@ -16,6 +16,18 @@ import numpy as np
 from telluride_decoding_amd import brain_data
 from telluride_decoding_amd import brain_model
 from telluride_decoding_amd import device
+
+
+def rmss(x):
+  """Root-mean-sign-squared of a vector of correlation dimensions (reference cca.py:31-36):
+  sqrt(|mean(sign(x) x^2)|) * sign(mean(sign(x) x^2)).  A handful of scalars (one per CCA
+  dimension): host float64, like the correlator's mean / power bookkeeping; the per-FRAME form of
+  the same reduction over a whole recording is the 'mean-squared' mode of td_frame_scores."""
+  x = np.asarray(x.numpy() if hasattr(x, 'numpy') and not hasattr(x, 'is_cuda') else
+                 (x.cpu().numpy() if hasattr(x, 'is_cuda') else x))
+  ss = np.sign(x) * np.square(x)
+  mss = np.mean(ss)
+  return np.sqrt(np.abs(mss)) * np.sign(mss)
 
 
 def cca_pearson_correlation(x, y):
@@ -83,6 +95,69 @@ def calculate_cca_parameters_from_dataset(dataset, dim, regularization=0.1,
   rot_x, rot_y, mean_x, mean_y, e, _ = st.cca_solve(num_mini_batches * n_row - 1, regularization,
                                                     dim_eff, eps_eig, handle=h)
   return tuple(t.cpu().numpy() for t in (rot_x, rot_y, mean_x, mean_y, e))
+
+
+class BrainCcaLayer(object):
+  """The rotation half of a CCA model as a layer (reference cca.BrainCcaLayer, cca.py:84-166):
+  holds mean1 [1, c1], mean2 [1, c2], rot1 [c1, dims], rot2 [c2, dims] and maps a pair of
+  minibatches to [(x1 - mean1) rot1 | (x2 - mean2) rot2] (:150-161) with the CCA projection kernel
+  (td_cca_transform).  The Keras plumbing of the reference (add_weight, initialisers) has no
+  counterpart: the weights are plain arrays, `build` only records the input widths."""
+
+  def __init__(self, requested_cca_dims, **kwargs):
+    del kwargs
+    self.output_dims = requested_cca_dims
+    self.input1_dim = self.input2_dim = None
+    self.mean1 = self.mean2 = self.rot1 = self.rot2 = None
+    self._dev = None
+
+  def build(self, input_shapes):
+    self.input1_dim = int(input_shapes[0][-1])
+    self.input2_dim = int(input_shapes[1][-1])
+
+  def set_initial_weights(self, mean1, mean2, rot1, rot2):
+    mean1, mean2, rot1, rot2 = (np.asarray(a) for a in (mean1, mean2, rot1, rot2))
+    if mean1.ndim != 2 or mean1.shape[0] != 1:
+      raise TypeError('mean1 matrix has the wrong size (%s)' % (mean1.shape,))
+    if mean2.ndim != 2 or mean2.shape[0] != 1:
+      raise TypeError('mean2 matrix has the wrong size (%s)' % (mean2.shape,))
+    real_dims = min(mean1.shape[1], mean2.shape[1], self.output_dims)
+    if rot1.ndim != 2 or rot1.shape != (mean1.shape[1], real_dims):
+      raise TypeError('rot1 matrix has the wrong size (%s not %s)' % (rot1.shape, self.output_dims))
+    if rot2.ndim != 2 or rot2.shape != (mean2.shape[1], real_dims):
+      raise TypeError('rot2 matrix has the wrong size (%s)' % (rot2.shape,))
+    self.set_weights([mean1, mean2, rot1, rot2])
+
+  def set_weights(self, weights):
+    self.mean1, self.mean2, self.rot1, self.rot2 = (np.asarray(a, np.float32) for a in weights)
+    self.build([(None, self.mean1.shape[1]), (None, self.mean2.shape[1])])
+    self._dev = None
+
+  def get_weights(self):
+    return [self.mean1, self.mean2, self.rot1, self.rot2]
+
+  def __call__(self, inputs):
+    return self.call(inputs)
+
+  def call(self, inputs):
+    if self.rot1 is None:
+      raise ValueError('BrainCcaLayer has no weights yet: call set_initial_weights first.')
+    h = device.default_handle()
+    x1 = brain_model._as_2d_device(h, inputs[0])
+    x2 = brain_model._as_2d_device(h, inputs[1])
+    if int(x1.shape[1]) != self.input1_dim or int(x2.shape[1]) != self.input2_dim:
+      # the reference reshapes to (-1, input_dim) (:154-155)
+      x1 = x1.reshape(-1, self.input1_dim).contiguous()
+      x2 = x2.reshape(-1, self.input2_dim).contiguous()
+    if self._dev is None:
+      self._dev = tuple(h.to_device(a) for a in (self.mean1, self.rot1, self.mean2, self.rot2))
+    m1, r1, m2, r2 = self._dev
+    out = device.cca_transform(x1, x2, [0, int(x1.shape[0])], m1, r1, m2, r2, 0, 0, 0, 0, handle=h)
+    return brain_data._t(out.cpu().numpy())
+
+  def get_config(self):
+    """The parameters needed to re-create this layer (cca.py:163-166)."""
+    return {'requested_cca_dims': self.output_dims}
 
 
 class BrainModelCCA(object):
@@ -156,10 +231,23 @@ class BrainModelCCA(object):
 
   def evaluate(self, dataset, **kwargs):
     """Loss and metric are both cca_pearson_correlation_first (cca.py:196-199),
-    averaged over minibatches as Keras does."""
+    averaged over minibatches as Keras does.  `dataset`: a brain_data.Dataset or any iterable of
+    (dict, y) minibatches with 'input_1' and 'input_2' already lagged."""
     del kwargs
     import torch
     h = device.default_handle()
+    if not isinstance(dataset, brain_data.Dataset):
+      if not hasattr(dataset, '__iter__'):
+        raise TypeError('BrainModel.evaluate must be called with tf.data.Dataset object.')
+      m1, r1, m2, r2 = self._device_params(h)
+
+      def predict(feats):
+        x = brain_model._as_2d_device(h, feats['input_1'])
+        x2 = brain_model._as_2d_device(h, feats['input_2'])
+        return device.cca_transform(x, x2, [0, int(x.shape[0])], m1, r1, m2, r2, 0, 0, 0, 0, handle=h)
+
+      return brain_model._evaluate_minibatches(dataset, h, predict, truth_from_y=False,
+                                               metric_name='cca_pearson_correlation_first')
     dataset = dataset.resolved()
     out = self.transform_device(dataset, handle=h)
     _, _, _, offs = dataset.device_arrays(h)

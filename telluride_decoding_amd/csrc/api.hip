@@ -348,6 +348,9 @@ int td_destroy(td_handle* h) {
   if (h->dev_flag) hipFree(h->dev_flag);
   if (h->chan_max) hipFree(h->chan_max);
   if (h->dev_flags) hipFree(h->dev_flags);
+  if (h->cg_packets) hipFree(h->cg_packets);
+  for (hipEvent_t e : h->async_events) if (e) hipEventDestroy(e);
+  if (h->cg_status) hipFree(h->cg_status);
   if (h->host_flags) hipHostFree(h->host_flags);
   if (h->ev_start) hipEventDestroy(h->ev_start);
   if (h->ev_stop) hipEventDestroy(h->ev_stop);

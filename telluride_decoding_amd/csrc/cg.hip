@@ -1,0 +1,464 @@
+// One ridge system in ONE launch: conjugate gradients with the matrix resident in LDS.
+//
+// brain_model.py:447-477 solves (X^T X / n + lambda I) w = X^T y / n with a dense LU.  The blocked
+// Cholesky of solve.hip does the same in float64 but is a chain of ~100 dependent launches for
+// one n = 2049 system (33 block steps x [diagonal factorisation 12 us + panel + update]): 1.06 ms
+// whatever the chip could do in parallel -- half of a C2 fit.  The chain cannot be shortened much:
+// column k of a factorisation needs column k - 1.
+//
+// A Krylov method has no such chain inside a step -- an iteration is one matrix-vector product and
+// a few dot products -- and the matrix of a ridge TRF fit is benign (lambda and the sensor noise
+// floor bound the smallest eigenvalue; the large ones are the few dozen directions the stimulus
+// drives): the C2 system converges to 1e-12 in 54-56 iterations.  What an iteration costs on a GPU
+// is not arithmetic (2 n^2 = 8.4 MFLOP) but the exchange between workgroups.  So:
+//   * ONE persistent launch of W <= (CUs) workgroups, workgroup w owning R = ceil(k / W) rows of the
+//     matrix, which it keeps in LDS for the whole solve (k = 2048, W = 256: 8 rows = 128 KB of the
+//     160 KB a CU has; the whole 33 MB matrix lives in the chip's 40 MB of LDS);
+//   * every workgroup keeps EVERY vector (x, r, p; thread t holds entries t + 256 j) and repeats the
+//     scalar recurrences -- identical arithmetic in identical order, so all workgroups take the same
+//     alpha, beta and the same decision to stop -- so that the matrix-vector product is the only
+//     thing exchanged: after it workgroup w publishes its R entries of q = A p and reads all k;
+//   * the exchange is the low-latency protocol of collective libraries: a double travels as two
+//     8-byte packets {32 data bits, 32-bit round number}, written with one 8-byte store each
+//     (single-copy atomic) at device scope, readers poll the packets themselves -- no counter, no
+//     fence, ONE trip through the memory fabric per iteration: 3.0 us measured for 32..256
+//     workgroups on the 8 XCDs (tools/micro/grid_exchange.hip; an atomic counter barrier + loads:
+//     3.7..9.5 us).  Two buffers in turn (a workgroup is at most one round ahead of a reader).
+//   * The bias unknown (the ones column, brain_model.py:434-436) is eliminated analytically, so
+//     that k = n - 1 = 2048 rows split evenly: with A = [[M, s], [s^T, c]] the system is
+//     (M - s s^T / c) w = b_w - s b_k / c, bias = (b_k - s^T w) / c; s^T p follows the recurrence of p.
+//   * Every spin loop watches a device-wide abort word and the clock: a workgroup that waits longer
+//     than the time limit (its partners are not resident: another persistent grid holds their CUs)
+//     raises the abort, every wave leaves, the status says so and the caller takes the Cholesky
+//     route.  The grid always drains.
+//   * The result is checked with its TRUE residual (one more product with x), not the recurrence's.
+// Not converged / not positive definite (p^T A p <= 0) / aborted -> status != 0 -> the caller falls
+// back to the blocked Cholesky (which also owns the "Singular matrix" report).
+#include "td_common.h"
+
+namespace {
+
+constexpr int kCgThreads = 256;
+constexpr int kCgMaxCols = 8;          // entries of a vector per thread: k <= 2048
+
+struct CgParams {
+  const double* xtx;      // dense moment sums [n][ld], unscaled (td_stats_moments_ld)
+  const double* xty;      // [n][d]
+  const double* lams;     // [n_lambda] device
+  unsigned long long* packets;   // [2][k][2]
+  unsigned* abort_word;
+  float* w;               // [n_lambda][k][d]
+  float* bias;            // [n_lambda][d]
+  int* status;            // [0] = 0 ok / 2 not converged or not positive definite / 3 aborted, [1] = iterations (max over systems)
+  double inv;             // 1 / frames
+  double tol2;            // (relative residual)^2
+  int n, ld, d, n_lambda, k, rows, max_iter;
+  unsigned epoch;         // round numbers of this launch start above it
+  long long limit_ticks;  // wall_clock64 ticks (100 MHz) a wait may last
+};
+
+// A packet pair is ONE 16-byte access: volatile vector accesses are device-coherent on gfx950 (sc0 sc1:
+// past the per-XCD L2) and stay one global_load / global_store_dwordx4; each 8-byte half carries its
+// own round number, so a reader never depends on the 16 bytes arriving together.  The 8 packets of a
+// workgroup (8 rows) are one 128-byte line stored by 8 lanes of ONE instruction: a full-line write.
+// (Written by four waves in 16-byte pieces the same line cost the exchange ~1 us: partial-sector
+// writes are read-modify-write at the memory side.)
+typedef unsigned cg_u32x4 __attribute__((ext_vector_type(4)));
+typedef double cg_f64x2 __attribute__((ext_vector_type(2)));
+
+// Thread t owns the vector entries 2 t, 2 t + 1 (+ 512 per further pair): its columns of a matrix row are
+// pairs of neighbours, one 16-byte LDS read each (one wave per SIMD reaches the LDS rate with
+// ds_read_b128, a fifth of it with 8-byte reads: MI355X_MICROARCH.md, LDS).
+__device__ __forceinline__ int cg_col(int t, int j) { return 2 * t + (j & 1) + 2 * kCgThreads * (j >> 1); }
+typedef __attribute__((address_space(1))) volatile cg_u32x4 cg_gvec;       // (global, not flat, addressing)
+
+__device__ __forceinline__ void ll_store(unsigned long long* p, double v, unsigned round) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  const cg_u32x4 d = {(unsigned)bits, round, (unsigned)(bits >> 32), round};
+  *(cg_gvec*)(unsigned long long)p = d;
+}
+
+__device__ __forceinline__ bool ll_try(const unsigned long long* p, unsigned round, double& v) {
+  const cg_u32x4 d = *(cg_gvec*)(unsigned long long)p;
+  v = __longlong_as_double((long long)((unsigned long long)d.x | ((unsigned long long)d.z << 32)));
+  return d.y == round && d.w == round;
+}
+
+// Sum over the 64 lanes of a wave, the same value in every lane: four DPP row rotations leave the
+// total of each row of 16 lanes in all its lanes, lanes 0 / 16 / 32 / 48 are read back as scalars.
+// (A butterfly of __shfl_xor is twelve ds_bpermute round trips per double: the three reductions of
+// an iteration were ~2 us of its ~8.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<0x128>(v);      // row_ror:8
+  v += dpp_f64<0x124>(v);      // row_ror:4
+  v += dpp_f64<0x122>(v);      // row_ror:2
+  v += dpp_f64<0x121>(v);      // row_ror:1
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double a = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double b = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double c = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double d = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (a + b) + (c + d);
+}
+
+// Chronopoulos-Gear form of conjugate gradients: the product is taken with the RESIDUAL, w = A r, and
+// the search direction and its image follow by recurrence (p = r + beta p, v = w + beta v), so the two
+// inner products of an iteration -- (r, r) and (w, r) -- need no second product and no second
+// exchange: beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old).  The bias
+// term's s^T r follows by recurrence as well (s^T v = s^T w + beta s^T v, s^T r -= alpha s^T v), so
+// an iteration has ONE reduction point, behind the exchange: {r^T r, w^T r, s^T w}.
+// Per iteration: [r -> LDS] barrier [my rows of A r: a wave owns whole rows over all columns, so
+// their sums are wave sums; 8 columns in flight per lane] publish, poll [three wave sums -> LDS]
+// barrier [scalars, four vector updates].  |r| is looked at when its product has come back, i.e.
+// convergence is noticed one product late; x is then checked with its TRUE residual (one more).
+template <int R>
+__global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
+  constexpr int RW = (R + 3) / 4;                  // rows per wave
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int k = P.k, t = threadIdx.x, lane = t & 63, w = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  double* rows = lds;                              // [R][k]
+  const int ks = (k + 1) & ~1;                     // row stride (16-byte aligned pairs)
+  double* red = rows + (size_t)R * ks;              // [4][8] row sums of the product per wave (256 reserved)
+  double* prow = red + kCgThreads;                 // [8] the multiplied vector's entries of my rows
+  double* part_a = prow + 8;                       // [4] wave sums in front of the product (check pass)
+  double* part_b = part_a + 4;                     // [4][4] wave sums behind the exchange
+  __shared__ int s_abort;
+  const int i0 = w * R;
+  const double inv = P.inv;
+  if (t == 0) s_abort = 0;
+  // -- the matrix rows and the bias column
+  for (int r = 0; r < R; ++r) {
+    const int i = i0 + r;
+    for (int c = t; c < ks; c += kCgThreads) rows[(size_t)r * ks + c] = (i < k && c < k) ? P.xtx[(size_t)i * P.ld + c] * inv : 0.0;
+  }
+  double s_reg[kCgMaxCols];
+#pragma unroll
+  for (int j = 0; j < kCgMaxCols; ++j) {
+    const int c = cg_col(t, j);
+    s_reg[j] = c < k ? P.xtx[(size_t)k * P.ld + c] * inv : 0.0;
+  }
+  const double srow_t = (t < R && i0 + t < k) ? P.xtx[(size_t)k * P.ld + i0 + t] * inv : 0.0;
+  const double a_kk = P.xtx[(size_t)k * P.ld + k] * inv;
+  __syncthreads();
+
+  const long long t_start = wall_clock64();
+  unsigned round = P.epoch;
+  int status = 0, iters_max = 0;
+  bool aborted = false;
+
+  for (int sys = 0; sys < P.n_lambda * P.d && !aborted && status == 0; ++sys) {
+    const int li = sys / P.d, qo = sys % P.d;
+    const double lam = P.lams[li];
+    const double ckk = a_kk + lam;
+    const double inv_ckk = 1.0 / ckk;
+    const double bk = P.xty[(size_t)k * P.d + qo] * inv;
+    double x[kCgMaxCols], r_[kCgMaxCols], p[kCgMaxCols], v[kCgMaxCols], b[kCgMaxCols], wq[kCgMaxCols];
+#pragma unroll
+    for (int j = 0; j < kCgMaxCols; ++j) {
+      const int c = cg_col(t, j);
+      b[j] = c < k ? P.xty[(size_t)c * P.d + qo] * inv - s_reg[j] * (bk * inv_ckk) : 0.0;
+      x[j] = 0.0; r_[j] = b[j]; p[j] = 0.0; v[j] = 0.0;
+    }
+    // s^T b and |b|^2 (the only reduction in front of the first product)
+    double sdot, bnorm2;
+    {
+      double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) { e0 += s_reg[j] * b[j]; e1 += b[j] * b[j]; }
+      e0 = wave_sum(e0);
+      e1 = wave_sum(e1);
+      if (lane == 0) { part_b[4 * wave] = e0; part_b[4 * wave + 1] = e1; }
+      __syncthreads();
+      sdot = (part_b[0] + part_b[4]) + (part_b[8] + part_b[12]);
+      bnorm2 = (part_b[1] + part_b[5]) + (part_b[9] + part_b[13]);
+      __syncthreads();
+    }
+    double gamma_old = 1.0, denom_old = 1.0, sv = 0.0;      // sv = s^T v, sdot = s^T r: recurrences
+    int it = 0;
+    bool check_pass = false;       // the product in flight is A x (true residual), not A r
+    const bool done = bnorm2 == 0.0;         // b = 0: x = 0
+#ifdef TD_CG_TIMING
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+#define TD_CG_T(i) do { const long long now_ = wall_clock64(); tph[i] += now_ - tlast; tlast = now_; } while (0)
+    long long tlast = wall_clock64();
+#else
+#define TD_CG_T(i)
+#endif
+    while (!done) {
+      // -- my rows of the product with r (or with x for the final check, whose s^T x is summed here):
+      // a thread multiplies the columns of the entries it owns, so the vector never leaves its registers
+      double acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = 0.0;
+      double sx = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < kCgMaxCols / 2; ++jj) {
+        // (no branch around the loads: a pair past k reads the last pair against zeros -- with a branch
+        // per group the groups of row reads wait for one another: 1.5 us instead of 0.4)
+        const int c = cg_col(t, 2 * jj);
+        const double v0 = c < k ? (check_pass ? x[2 * jj] : r_[2 * jj]) : 0.0;
+        const double v1 = c + 1 < k ? (check_pass ? x[2 * jj + 1] : r_[2 * jj + 1]) : 0.0;
+        const int cc = c < k ? c : ks - 2;
+        sx += s_reg[2 * jj] * x[2 * jj] + s_reg[2 * jj + 1] * x[2 * jj + 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const cg_f64x2 a = *reinterpret_cast<const cg_f64x2*>(rows + (size_t)r * ks + cc);
+          acc[r] += a.x * v0 + a.y * v1;
+        }
+      }
+      // (after the loads: an LDS store between them, possibly aliasing, would serialise the row reads)
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        const int c = cg_col(t, j);
+        if (c >= i0 && c < i0 + R && c < k) prow[c - i0] = check_pass ? x[j] : r_[j];
+      }
+      if (check_pass) {
+        sx = wave_sum(sx);
+        if (lane == 0) part_a[wave] = sx;
+      } else {
+        ++it;
+      }
+      TD_CG_T(0);
+      // 8 sums per lane -> 1: three exchange-and-halve steps (lane ^ 1, ^ 2, ^ 4) leave lane l with the
+      // sum over its group of 8 lanes of row ((l & 1) << 2) | (l & 2) | ((l >> 2) & 1)
+      double a4[4], a2[2], a1;
+      {
+        const bool up = lane & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          a4[i] = (up ? acc[i + 4] : acc[i]) + dpp_f64<0xB1>(up ? acc[i] : acc[i + 4]);     // quad_perm [1,0,3,2]
+        const bool up2 = lane & 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          a2[i] = (up2 ? a4[i + 2] : a4[i]) + dpp_f64<0x4E>(up2 ? a4[i] : a4[i + 2]);       // quad_perm [2,3,0,1]
+        const bool up4 = lane & 4;
+        a1 = (up4 ? a2[1] : a2[0]) + __shfl_xor(up4 ? a2[0] : a2[1], 4, 64);
+      }
+      // ... and over the 8 groups of the wave: the other half of the row of 16, then the other rows
+      a1 += dpp_f64<0x128>(a1);                    // row_ror:8
+      a1 += __shfl_xor(a1, 16, 64);
+      a1 += __shfl_xor(a1, 32, 64);
+      if (lane < 8) red[wave * 8 + lane] = a1;     // lane l < 8: row ((l & 1) << 2) | (l & 2) | ((l >> 2) & 1)
+      __syncthreads();
+      if (check_pass) sdot = (part_a[0] + part_a[1]) + (part_a[2] + part_a[3]);
+      TD_CG_T(1);
+      ++round;
+      unsigned long long* buf = P.packets + (size_t)(round & 1u) * 2 * k;
+      if (t < R && i0 + t < k) {
+        const int pi = ((t >> 2) & 1) | (t & 2) | ((t & 1) << 2);      // the lane that holds row t
+        const double tot = (red[pi] + red[8 + pi]) + (red[16 + pi] + red[24 + pi]);
+        ll_store(buf + 2 * (i0 + t), tot + lam * prow[t] - srow_t * (sdot * inv_ckk), round);
+      }
+      TD_CG_T(2);
+#ifdef TD_CG_TIMING
+      if (it == 20 && t == 0) reinterpret_cast<long long*>(P.abort_word + 64)[w] = wall_clock64();
+#endif
+      // -- every entry of the product.  256 workgroups x 2048 packets x 16 bytes are 8 MB per pass over the
+      // buffer, and a pass that finds nothing is traffic in front of the very stores it waits for: a
+      // thread first watches ONE packet (of a workgroup 32 j0 away from its first: the watched ones
+      // cover every publisher), after a pause of about the time the fabric needs, and reads the rest
+      // when that one has come.
+      int polls = 0;
+      bool gave_up = false;
+      __builtin_amdgcn_s_sleep(24);
+      {
+        int j0 = (t >> 5) & 7;
+        if (cg_col(t, j0) >= k) j0 = 0;
+        const unsigned long long* pp = buf + 2 * cg_col(t, j0);
+        if (cg_col(t, j0) < k) {
+          double dummy;
+          while (!ll_try(pp, round, dummy)) {
+            if ((++polls & 15) == 0 || P.limit_ticks < 16) {
+              if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.epoch + 1u) { gave_up = true; break; }
+              if (wall_clock64() - t_start > P.limit_ticks) {
+                __hip_atomic_store(P.abort_word, P.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+              }
+            }
+          }
+        }
+      }
+      // (every pass loads all eight packets, no branch between the loads: with one around each, a load
+      // waited for its predecessor -- eight round trips per pass instead of one)
+      while (!gave_up) {
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < kCgMaxCols; ++j) {
+          const int c = cg_col(t, j);
+          double val;
+          const bool got = ll_try(buf + 2 * (c < k ? c : k - 1), round, val);
+          wq[j] = c < k ? val : 0.0;
+          all = all && got;
+        }
+        if (all) break;
+        if ((++polls & 15) == 0 || P.limit_ticks < 16) {
+          if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.epoch + 1u) { gave_up = true; break; }
+          if (wall_clock64() - t_start > P.limit_ticks) {
+            __hip_atomic_store(P.abort_word, P.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
+            break;
+          }
+        }
+      }
+      if (gave_up) s_abort = 1;
+#ifdef TD_CG_TIMING
+      if (it == 20 && t == 0) reinterpret_cast<long long*>(P.abort_word + 64)[512 + w] = wall_clock64();
+#endif
+      TD_CG_T(3);
+      // -- ONE reduction: r^T r, w^T r, s^T w (in the check pass: |b - A x|^2)
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        const double dj = b[j] - wq[j];
+        e0 += check_pass ? dj * dj : r_[j] * r_[j];
+        e1 += wq[j] * r_[j];
+        e2 += s_reg[j] * wq[j];
+      }
+      e0 = wave_sum(e0);
+      e1 = wave_sum(e1);
+      e2 = wave_sum(e2);
+      if (lane == 0) { part_b[4 * wave] = e0; part_b[4 * wave + 1] = e1; part_b[4 * wave + 2] = e2; }
+      __syncthreads();
+      if (s_abort) { aborted = true; break; }
+      const double gamma = (part_b[0] + part_b[4]) + (part_b[8] + part_b[12]);
+      const double delta = (part_b[1] + part_b[5]) + (part_b[9] + part_b[13]);
+      const double sw = (part_b[2] + part_b[6]) + (part_b[10] + part_b[14]);
+      TD_CG_T(4);
+      if (check_pass) {
+        if (!(gamma <= 100.0 * P.tol2 * bnorm2)) status = 2;      // (also catches NaN)
+        break;
+      }
+      if (gamma <= P.tol2 * bnorm2) {       // r (whose product just came back) is small: x is the answer;
+        check_pass = true;                  // look at its TRUE residual with one more product
+        --it;                               // (the product with the converged r was not a step)
+        continue;
+      }
+      if (it >= P.max_iter) { status = 2; break; }
+      const double beta = it == 1 ? 0.0 : gamma / gamma_old;
+      const double denom = it == 1 ? delta : delta - beta * beta * denom_old;       // = p^T A p (recurrence: beta gamma / alpha_old = beta^2 denom_old)
+      if (!(denom > 0.0)) { status = 2; break; }                   // not positive definite (or NaN)
+      const double alpha = gamma / denom;
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        p[j] = r_[j] + beta * p[j];
+        v[j] = wq[j] + beta * v[j];
+        x[j] += alpha * p[j];
+        r_[j] -= alpha * v[j];
+      }
+      sv = sw + beta * sv;
+      sdot -= alpha * sv;
+      gamma_old = gamma;
+      denom_old = denom;
+      TD_CG_T(5);
+    }
+#ifdef TD_CG_TIMING
+    if (w == 0 && t == 0) for (int i = 0; i < 6; ++i) P.status[2 + i] = (int)tph[i];
+#endif
+    iters_max = it > iters_max ? it : iters_max;
+    if (aborted || status != 0) break;
+    // bias = (b_k - s^T x) / c, and the weights (workgroup 0 writes)
+    __syncthreads();
+    double e0 = 0.0;
+#pragma unroll
+    for (int j = 0; j < kCgMaxCols; ++j) e0 += s_reg[j] * x[j];
+    e0 = wave_sum(e0);
+    if (lane == 0) part_a[wave] = e0;
+    __syncthreads();
+    const double sx = (part_a[0] + part_a[1]) + (part_a[2] + part_a[3]);
+    if (w == 0) {
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        const int c = cg_col(t, j);
+        if (c < k) P.w[((size_t)li * k + c) * P.d + qo] = (float)x[j];
+      }
+      if (t == 0) P.bias[(size_t)li * P.d + qo] = (float)((bk - sx) * inv_ckk);
+    }
+    __syncthreads();
+  }
+  if (w == 0 && t == 0) {
+    P.status[0] = aborted ? 3 : status;
+    P.status[1] = iters_max;
+  }
+}
+
+template <int R>
+int launch_cg(td_handle* h, const CgParams& p, int wgs, size_t lds_bytes) {
+  static bool opted[64] = {};
+  if (lds_bytes > 65536 && !opted[h->device & 63]) {
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(cg_resident_kernel<R>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    opted[h->device & 63] = true;
+  }
+  hipLaunchKernelGGL(cg_resident_kernel<R>, dim3((unsigned)wgs), dim3(kCgThreads), lds_bytes, h->stream, p);
+  return TD_OK;
+}
+
+}  // namespace
+
+// Plan: rows per workgroup for k unknowns on `cus` compute units; 0 when the matrix does not fit
+// the LDS of that many workgroups (the caller then takes the Cholesky route).
+int td_cg_rows(int k, int cus) {
+  if (k < 1 || cus < 1 || k > kCgThreads * kCgMaxCols) return 0;
+  const int rows = (k + cus - 1) / cus;
+  if (rows > 8) return 0;
+  const size_t lds = sizeof(double) * ((size_t)rows * ((k + 1) & ~1) + kCgThreads + 48);
+  return lds <= 160 * 1024 - 64 ? rows : 0;
+}
+
+// Queues the solve of the n_lambda x d systems of one statistics object (dense sums xtx [n][ld],
+// xty [n][d] already on the device) on h->stream.  status_dev[0..1] receive status and iterations.
+int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const double* xty, int d, double inv,
+                      const double* lams_dev, int n_lambda, int cus, int max_iter, double tol, float* w_dev,
+                      float* b_dev, int* status_dev) {
+  const int k = n - 1;
+  const int rows = td_cg_rows(k, cus);
+  TD_REQUIRE(h, rows > 0, "td_cg_solve_dense: %d unknowns do not fit the LDS of %d workgroups", k, cus);
+  if (!h->cg_packets) {
+    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->cg_packets),
+                        sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192));
+    TD_HIP(h, hipMemsetAsync(h->cg_packets, 0, sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192,
+                             h->stream));
+    h->cg_epoch = 0;
+  }
+  const unsigned rounds = (unsigned)(n_lambda * d) * (unsigned)(max_iter + 4) + 8u;
+  if (h->cg_epoch > 0xffffffffu - rounds - 16u) {          // the 32-bit round numbers wrap: start over
+    TD_HIP(h, hipMemsetAsync(h->cg_packets, 0, sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192,
+                             h->stream));
+    h->cg_epoch = 0;
+  }
+  CgParams p;
+  p.xtx = xtx; p.xty = xty; p.lams = lams_dev;
+  p.packets = h->cg_packets;
+  p.abort_word = reinterpret_cast<unsigned*>(h->cg_packets + 2 * 2 * kCgThreads * kCgMaxCols);
+  p.w = w_dev; p.bias = b_dev; p.status = status_dev;
+  p.inv = inv; p.tol2 = tol * tol;
+  p.n = n; p.ld = ld; p.d = d; p.n_lambda = n_lambda; p.k = k; p.rows = rows; p.max_iter = max_iter;
+  p.epoch = h->cg_epoch;
+  p.limit_ticks = 100000LL * 20;          // 20 ms at 100 MHz
+  if (const char* e = getenv("TD_CG_LIMIT_TICKS")) p.limit_ticks = atoll(e);      // development: 0 = abort at the first empty poll
+  h->cg_epoch += rounds;
+  // (the abort word holds the launch number -- epoch + 1, never 0 -- of the last aborted launch: no reset)
+  const int wgs = (k + rows - 1) / rows;
+  const size_t lds = sizeof(double) * ((size_t)rows * ((k + 1) & ~1) + kCgThreads + 48);
+  switch (rows) {
+    case 1: TD_TRY(launch_cg<1>(h, p, wgs, lds)); break;
+    case 2: TD_TRY(launch_cg<2>(h, p, wgs, lds)); break;
+    case 3: TD_TRY(launch_cg<3>(h, p, wgs, lds)); break;
+    case 4: TD_TRY(launch_cg<4>(h, p, wgs, lds)); break;
+    case 5: TD_TRY(launch_cg<5>(h, p, wgs, lds)); break;
+    case 6: TD_TRY(launch_cg<6>(h, p, wgs, lds)); break;
+    case 7: TD_TRY(launch_cg<7>(h, p, wgs, lds)); break;
+    default: TD_TRY(launch_cg<8>(h, p, wgs, lds)); break;
+  }
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}

@@ -842,6 +842,42 @@ int spd_check_flag(td_handle* h) {
   return TD_OK;
 }
 
+// The ring of asynchronous result flags (td_ridge_solve_async / _multi): slot = the next of
+// kAsyncFlags pinned host ints + device ints.  A slot is handed out again only when the copy that
+// filled it last has COMPLETED (an event per slot): with more than kAsyncFlags solves outstanding the
+// new call would overwrite a flag the caller cannot have read yet -- TD_ERR_STATE instead of a
+// silently stale (or clobbered) flag.
+int async_slot_acquire(td_handle* h, int* slot_out) {
+  if (!h->dev_flags) {
+    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flags), sizeof(int) * td_handle::kAsyncFlags));
+    TD_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags), sizeof(int) * td_handle::kAsyncFlags,
+                            hipHostMallocDefault));
+  }
+  const int slot = h->async_next;
+  if (h->async_events[slot]) {
+    const hipError_t q = hipEventQuery(h->async_events[slot]);
+    if (q == hipErrorNotReady)
+      return td_fail(h, TD_ERR_STATE,
+                     "asynchronous solve: the ring of %d result flags is full (the solve that owns the oldest "
+                     "slot has not finished): wait for an earlier solve and read its flag first",
+                     td_handle::kAsyncFlags);
+    if (q != hipSuccess) return td_fail(h, TD_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+  }
+  h->async_next = (h->async_next + 1) % td_handle::kAsyncFlags;
+  *slot_out = slot;
+  return TD_OK;
+}
+
+// ... and the copy of slot's device flag to its host int, with the event that frees the slot
+int async_slot_publish(td_handle* h, int slot, bool copy_from_device) {
+  if (copy_from_device)
+    TD_HIP(h, hipMemcpyAsync(h->host_flags + slot, h->dev_flags + slot, sizeof(int), hipMemcpyDeviceToHost,
+                             h->stream));
+  if (!h->async_events[slot]) TD_HIP(h, hipEventCreateWithFlags(&h->async_events[slot], hipEventDisableTiming));
+  TD_HIP(h, hipEventRecord(h->async_events[slot], h->stream));
+  return TD_OK;
+}
+
 // ---- padding / unpadding --------------------------------------------------------------
 // dst [batch][np][np] = src [batch][n][n] * scale + lambda_b * I, identity beyond n -- the 64x64
 // tiles on and below the diagonal only: the factorisation never touches the others, and this
@@ -967,6 +1003,11 @@ __global__ void unpad_rows_kernel(const double* __restrict__ src, int nb, int n,
 // Vectors are ROWS of np doubles in the order [lambda][output q][fold]: the rows of a lambda are
 // contiguous (the triangular solves), the rows of a fold a constant stride apart (the products).
 constexpr int kLosoRows = 32;      // right-hand-side rows per workgroup
+// td_ridge_solve: when the one-launch conjugate-gradient solve (cg.hip) is tried first
+constexpr int kCgAutoSystems = 4;     // (lambda, output) systems; more: the batched factorisation shares its chain
+constexpr int kCgAutoMinN = 768;      // below ~12 block steps the factorisation's chain is as short
+constexpr int kCgMaxIter = 400;
+constexpr double kCgTol = 1e-12;      // relative residual, as td_ridge_solve_loso
 
 // C[32 x 64] (+)= As[32 x 64] . Bs^T (kNT) or As . Bs (!kNT); As rows r, Bs 64 x 64, both LDS with
 // stride LS.  4 waves: wave w owns output columns 16 w .. 16 w + 15, both 16-row tiles.
@@ -1614,6 +1655,49 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
   TD_TRY(td_stats_moments_ld(h, s, xtx, np, xty, nullptr, nullptr, nullptr));
   TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, w.lams));
   const double inv = 1.0 / (double)frames;
+  // A few large systems, synchronous caller, the whole matrix fits the LDS of the CUs this handle runs
+  // on: conjugate gradients in ONE launch (cg.hip) instead of the ~100 launches of the factorisation.
+  // Anything but "converged, true residual checked" falls through to the Cholesky below, which also
+  // owns the "Singular matrix" report.
+  h->last_solver = TD_SOLVER_CHOLESKY; h->last_iterations = 0; h->last_cg_status = 0;
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  const bool cg_auto = n_lambda * d <= kCgAutoSystems && n >= kCgAutoMinN;
+  // (lambda = 0 leaves a matrix that may be exactly singular -- a duplicated channel -- on which conjugate
+  // gradients happily converges to SOME solution of the consistent system where np.linalg.solve
+  // (brain_model.py:477) and the factorisation report "Singular matrix": only lambda > 0 goes this way)
+  bool all_positive = true;
+  for (int i = 0; i < n_lambda; ++i) all_positive = all_positive && lambdas_host[i] > 0.0;
+  if (!flag_dev && h->solver_mode != TD_SOLVER_CHOLESKY && (cg_auto || h->solver_mode == TD_SOLVER_CG) &&
+      all_positive && n >= 3 && td_cg_rows(n - 1, cus) > 0) {
+    if (!h->cg_status) TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->cg_status), sizeof(int) * 16));
+    TD_TRY(td_cg_solve_dense(h, xtx, n, np, xty, d, inv, w.lams, n_lambda, cus, kCgMaxIter, kCgTol, w_dev, b_dev,
+                             h->cg_status));
+    int st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    TD_HIP(h, hipMemcpyAsync(st, h->cg_status, sizeof(int) * 8, hipMemcpyDeviceToHost, h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+    if (getenv("TD_CG_TIMING"))      // development (a -DTD_CG_TIMING build fills them): 10 ns ticks per phase
+      fprintf(stderr, "cg phases (10 ns ticks over %d iterations): pre %d matvec %d publish %d poll %d post %d update %d\n",
+              st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+    if (getenv("TD_CG_TIMING") && h->cg_packets) {
+      static long long ts[1024];
+      hipMemcpy(ts, reinterpret_cast<char*>(h->cg_packets) + sizeof(unsigned long long) * 2 * 2 * 256 * 8 + 256, sizeof(ts),
+                hipMemcpyDeviceToHost);
+      long long p0 = ts[0], p1 = ts[0], d0 = ts[512], d1 = ts[512];
+      for (int i = 0; i < 256; ++i) {
+        if (ts[i] < p0) p0 = ts[i];
+        if (ts[i] > p1) p1 = ts[i];
+        if (ts[512 + i] < d0) d0 = ts[512 + i];
+        if (ts[512 + i] > d1) d1 = ts[512 + i];
+      }
+      fprintf(stderr, "iteration 20: publish spread %lld ticks, first done %lld after first publish, last done %lld; wg0 publish +%lld done +%lld\n",
+              p1 - p0, d0 - p0, d1 - p0, ts[0] - p0, ts[512] - p0);
+    }
+    h->last_iterations = st[1]; h->last_cg_status = st[0];
+    if (st[0] == 0) {
+      h->last_solver = TD_SOLVER_CG;
+      return TD_OK;
+    }
+  }
   // cov = M / n + lambda I for each lambda (same xtx for the whole batch: stride 0); rhs = xty / n
   hipLaunchKernelGGL(pad_matrix_kernel, dim3(lower_tiles(np), (unsigned)n_lambda), dim3(256), 0, h->stream, xtx,
                      0LL, np, n, np, inv, w.lams, w.a);
@@ -1629,6 +1713,22 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
 int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
                    float* w_dev, float* b_dev) {
   return ridge_solve_impl(h, s, lambdas_host, n_lambda, w_dev, b_dev, nullptr);
+}
+
+int td_set_solver(td_handle* h, int mode) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "td_set_solver: NULL handle");
+  TD_REQUIRE(h, mode == TD_SOLVER_AUTO || mode == TD_SOLVER_CHOLESKY || mode == TD_SOLVER_CG,
+             "td_set_solver: unknown mode %d", mode);
+  h->solver_mode = mode;
+  return TD_OK;
+}
+
+int td_last_solve_info(td_handle* h, int* solver, int* iterations, int* cg_status) {
+  if (!h) return td_fail(nullptr, TD_ERR_INVALID, "td_last_solve_info: NULL handle");
+  if (solver) *solver = h->last_solver;
+  if (iterations) *iterations = h->last_iterations;
+  if (cg_status) *cg_status = h->last_cg_status;
+  return TD_OK;
 }
 
 // Several statistics x several lambdas in ONE batched factorisation (the folds of a
@@ -1665,14 +1765,10 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
     if (!singular_flag_host)
       return singular ? td_fail(h, TD_ERR_SINGULAR, "Singular matrix: covariance is not positive definite")
                       : TD_OK;
-    if (!h->dev_flags) {
-      TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flags), sizeof(int) * td_handle::kAsyncFlags));
-      TD_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags),
-                              sizeof(int) * td_handle::kAsyncFlags, hipHostMallocDefault));
-    }
-    const int slot = h->async_next;
-    h->async_next = (h->async_next + 1) % td_handle::kAsyncFlags;
+    int slot = 0;
+    TD_TRY(async_slot_acquire(h, &slot));
     h->host_flags[slot] = singular;       // (everything above has finished: the solves are synchronous)
+    TD_TRY(async_slot_publish(h, slot, false));
     *singular_flag_host = h->host_flags + slot;
     return TD_OK;
   }
@@ -1697,24 +1793,18 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats, int n_stats,
                        0LL, n, d, np, inv, w.rt + (size_t)i * n_lambda * kMaxRhs * np);
   }
   int* flag_dev = nullptr;
+  int slot = 0;
   if (singular_flag_host) {
     *singular_flag_host = nullptr;
-    if (!h->dev_flags) {
-      TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flags), sizeof(int) * td_handle::kAsyncFlags));
-      TD_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags),
-                              sizeof(int) * td_handle::kAsyncFlags, hipHostMallocDefault));
-    }
-    flag_dev = h->dev_flags + h->async_next;
+    TD_TRY(async_slot_acquire(h, &slot));
+    flag_dev = h->dev_flags + slot;
   }
   TD_TRY(spd_solve_padded(h, w.a, w.rt, w.sol, w.linv, w.tol, np, n, d, batch, flag_dev));
   hipLaunchKernelGGL(ridge_emit_kernel, dim3(256), dim3(256), 0, h->stream, w.sol, k1, d, np, batch,
                      w_dev, b_dev);
   TD_HIP(h, hipGetLastError());
   if (!singular_flag_host) return spd_check_flag(h);
-  const int slot = h->async_next;
-  h->async_next = (h->async_next + 1) % td_handle::kAsyncFlags;
-  TD_HIP(h, hipMemcpyAsync(h->host_flags + slot, h->dev_flags + slot, sizeof(int),
-                           hipMemcpyDeviceToHost, h->stream));
+  TD_TRY(async_slot_publish(h, slot, true));
   *singular_flag_host = h->host_flags + slot;
   return TD_OK;
 }
@@ -1724,16 +1814,10 @@ int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, 
   if (!h || !singular_flag_host)
     return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_async: NULL argument");
   *singular_flag_host = nullptr;
-  if (!h->dev_flags) {
-    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->dev_flags), sizeof(int) * td_handle::kAsyncFlags));
-    TD_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags),
-                            sizeof(int) * td_handle::kAsyncFlags, hipHostMallocDefault));
-  }
-  const int slot = h->async_next;
-  h->async_next = (h->async_next + 1) % td_handle::kAsyncFlags;
+  int slot = 0;
+  TD_TRY(async_slot_acquire(h, &slot));
   TD_TRY(ridge_solve_impl(h, s, lambdas_host, n_lambda, w_dev, b_dev, h->dev_flags + slot));
-  TD_HIP(h, hipMemcpyAsync(h->host_flags + slot, h->dev_flags + slot, sizeof(int),
-                           hipMemcpyDeviceToHost, h->stream));
+  TD_TRY(async_slot_publish(h, slot, true));
   *singular_flag_host = h->host_flags + slot;
   return TD_OK;
 }

@@ -72,6 +72,16 @@ struct td_handle {
   int* dev_flags = nullptr;
   int* host_flags = nullptr;
   int async_next = 0;
+  hipEvent_t async_events[kAsyncFlags] = {};    // recorded behind the copy that fills a slot
+  // One-launch conjugate-gradient solve (cg.hip): exchange packets + abort word, the running round
+  // number (packets of earlier launches carry smaller ones: the buffer is never cleared), a device
+  // status block {status, iterations}, the solver selection (td_set_solver) and what the last
+  // td_ridge_solve on this handle did (td_last_solve_info).
+  unsigned long long* cg_packets = nullptr;
+  unsigned cg_epoch = 0;
+  int* cg_status = nullptr;
+  int solver_mode = 0;          // TD_SOLVER_AUTO
+  int last_solver = 0, last_iterations = 0, last_cg_status = 0;
   // Optional per-kernel hipEvent timing of the dominant kernel (td_profile_*):
   // event pairs recorded on h->stream around every lagcov MFMA launch.
   bool profile = false;
@@ -109,6 +119,12 @@ int td_fail(td_handle* h, int code, const char* fmt, ...);
 // Scratch: returns a device pointer valid until the next td_scratch call that
 // needs more room (stream-ordered reuse is safe: one stream per handle).
 int td_scratch(td_handle* h, size_t bytes, void** out);
+
+// cg.hip: rows per workgroup of the LDS-resident conjugate-gradient solve (0: does not fit), and the solve itself
+int td_cg_rows(int k, int cus);
+int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const double* xty, int d, double inv,
+                      const double* lams_dev, int n_lambda, int cus, int max_iter, double tol, float* w_dev,
+                      float* b_dev, int* status_dev);
 
 // Solver workspace: like td_scratch, a separate arena.
 int td_workspace(td_handle* h, size_t bytes, void** out);

@@ -67,6 +67,21 @@ class Handle(object):
     or 'f32' (the float32 matrix instruction): td_set_accumulate_mode."""
     self.check(self.lib.td_set_accumulate_mode(self.ptr, self.ACCUMULATE_MODES[mode]))
 
+  SOLVERS = {'auto': 0, 'cholesky': 1, 'cg': 2}
+
+  def set_solver(self, mode):
+    """'auto' (default: a few large systems on an unmasked handle try the one-launch conjugate
+    gradients first), 'cholesky' or 'cg': td_set_solver."""
+    self.check(self.lib.td_set_solver(self.ptr, self.SOLVERS[mode]))
+
+  def last_solve_info(self):
+    """What the last synchronous ridge solve on this handle did: {'solver': 'cholesky' | 'cg',
+    'iterations': n, 'cg_status': 0 converged / 2 not converged / 3 aborted} (td_last_solve_info)."""
+    s, it, st = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    self.check(self.lib.td_last_solve_info(self.ptr, ctypes.byref(s), ctypes.byref(it), ctypes.byref(st)))
+    return {'solver': {1: 'cholesky', 2: 'cg'}.get(s.value, 'none'), 'iterations': int(it.value),
+            'cg_status': int(st.value)}
+
   def timer_start(self):
     self.check(self.lib.td_timer_start(self.ptr))
 

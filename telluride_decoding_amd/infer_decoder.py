@@ -3,8 +3,8 @@
 Same public surface as reference infer_decoder.py: `Decoder` (:95-580) with its
 streaming correlator (`add_data_correlator` :288-310, `compute_correlation`
 :312-328), `train` (:330-400), `infer_one` (:416-455), `test_all` (:457-482),
-`test_by_window` (:484-504), LDA helpers (:506-550), JSON persistence
-(:75-92, 240-248); `LinearRegressionDecoder` (:583-604), `CCADecoder` (:607-632),
+`test_by_window` (:484-504), LDA helpers (:506-550), `check_model_and_data` (:552-580),
+JSON persistence (:75-92, 240-248); `LinearRegressionDecoder` (:583-604), `CCADecoder` (:607-632),
 `create_decoder` (:635-666), `calculate_dprime` (:717-745), `average_data`
 (:748-783).  SavedModel loading and TFRecord datasets (:250-286, :669-713) are TF
 file formats and out of scope.
@@ -72,6 +72,23 @@ class Decoder(object):
     self._reduction = reduction
     self._lda = None
     self.reset_correlation_statistics()
+    self._signature_from_model(decoding_model)
+
+  def _signature_from_model(self, model):
+    """model_inputs / model_output of one of this package's estimators.  The reference fills them
+    from the SavedModel's signature in load_decoding_model (:250-286, a TF file format: out of
+    scope); a decoder built around a live estimator gets the same shapes from it."""
+    if isinstance(model, brain_model.BrainModelLinearRegression):
+      self.set_model_signature({'input_1': (None, model._input_width)}, (None, model._output_width))
+    elif hasattr(model, '_input1_width') and hasattr(model, 'output_dims'):
+      self.set_model_signature({'input_1': (None, model._input1_width),
+                                'input_2': (None, model._input2_width)}, (None, 2 * model.output_dims))
+
+  def set_model_signature(self, model_inputs, model_output):
+    """Declares the shapes the decoding model expects: {input name: (None, width)} and the
+    output's (None, width) -- what check_model_and_data compares a dataset with."""
+    self._model_inputs = dict(model_inputs)
+    self._model_output = tuple(model_output)
 
   # -- bookkeeping properties (reference :148-238) ------------------------------
   @property
@@ -324,6 +341,36 @@ class Decoder(object):
     if not isinstance(d1, np.ndarray):
       raise TypeError('Input data must be an numpy array, not %s.' % type(d1))
     return self._lda.transform(d1)
+
+  def check_model_and_data(self, actual_dataset):
+    """Raises if `actual_dataset` does not fit the decoding model: a missing input, a wrong input
+    width or a wrong output width (reference :552-580)."""
+    if not self.model_inputs or not self.model_output:
+      raise ValueError('Model has not been initialized yet. Use load_model first')
+    if isinstance(actual_dataset, brain_data.Dataset):
+      spec_in, spec_out = actual_dataset.element_spec
+      actual_inputs = {k: v.shape for k, v in spec_in.items()}
+      actual_output = spec_out.shape
+    elif hasattr(actual_dataset, 'take') or hasattr(actual_dataset, '__iter__'):
+      first = None
+      for first in (actual_dataset.take(1) if hasattr(actual_dataset, 'take') else actual_dataset):
+        break
+      if first is None:
+        return
+      actual_inputs = {k: np.shape(_host(v)) for k, v in first[0].items()}
+      actual_output = np.shape(_host(first[1]))
+    else:
+      raise TypeError('Actual_dataset is not a dataset, but a %s.' % (type(actual_dataset)))
+    for expected_key, expected_input_spec in self.model_inputs.items():
+      if expected_key not in actual_inputs:
+        raise TypeError('Can\'t find needed key %s in input_data (%s)' %
+                        (expected_key, actual_inputs.keys()))
+      if actual_inputs[expected_key][1] != expected_input_spec[1]:
+        raise TypeError('Data for %s has the wrong shape, expected %s, got %s' %
+                        (expected_key, expected_input_spec, actual_inputs[expected_key]))
+    if actual_output[1] != self.model_output[1]:
+      raise TypeError('Output data has the wrong shape, expected %s, got %s' %
+                      (self.model_output, actual_output))
 
   # -- batched fast path ----------------------------------------------------------
   def decode_windows(self, truth, prediction, trial_offsets, window_size, window_step=None):

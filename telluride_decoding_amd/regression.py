@@ -76,7 +76,7 @@ def _pcg_chunk(n_folds, n_lambda, n, d):
 
 
 def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, world_size=1,
-                                   group=None, device=None):
+                                   group=None, device=None, folds=None):
   """dataset: brain_data.Dataset whose files are the jackknife units (subjects).
 
   Returns an OrderedDict {lambda: (mean, std)} of the held-out
@@ -97,6 +97,9 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
 
   device: the device layer (default: telluride_decoding_amd.device, the HIP path); the CPU
   tests of the multi-rank orchestration pass a NumPy stand-in with the same interface.
+
+  folds: the held-out files to run (default: every file; jackknife_one_model's max_test_count /
+  test_file); 'all_runs' and the statistics then cover those files only, in ascending order.
   """
   dev = device or _device
   lambdas = parse_regularization_values() if regularization_list is None else list(regularization_list)
@@ -157,7 +160,10 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     st.unpack(table[i].contiguous(), 1, zipped[i])
     stats.append(st)
   # 3-4. folds of this rank
-  my_folds = distributed.split_round_robin(list(range(n_files)), rank, world_size)
+  fold_list = list(range(n_files)) if folds is None else sorted(set(int(f) for f in folds))
+  if not fold_list or fold_list[0] < 0 or fold_list[-1] >= n_files:
+    raise ValueError('folds must name files of the dataset (0..%d), not %s' % (n_files - 1, folds))
+  my_folds = distributed.split_round_robin(fold_list, rank, world_size)
   n_lam, d = len(lambdas), dataset.d
   scores = []
   truncated = {}            # (file, frames dropped from its end) -> statistics
@@ -314,9 +320,52 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   import torch
   rows = (torch.stack(scores).cpu().numpy() if scores else np.zeros((0, n_lam)))   # one copy
   # 5. gather
-  all_folds = distributed.gather_rows(rows, n_files, my_folds, group)     # [F, Lambda]
+  all_folds = distributed.gather_rows(rows, n_files, my_folds, group)[fold_list]     # [F, Lambda]
   results = collections.OrderedDict()
   for li, lam in enumerate(lambdas):
     results[lam] = calculate_stats(all_folds[:, li])
   results['all_runs'] = all_folds.T
   return results
+
+
+def jackknife_one_model(dataset, regularization_lambda, max_test_count=-1, test_name='telluride4',
+                        trial_number=0, summary_file=None, test_file=None,
+                        test_metric='pearson_correlation_first', experiment_parameters='',
+                        rank=0, world_size=1, group=None, device=None):
+  """One regularisation value, every file held out in turn: the list of held-out test metrics,
+  one per test file in file order (reference regression.jackknife_one_model, regression.py:151-242).
+
+  The reference re-trains through decoding.train_and_test for every held-out file (:212-214); here
+  the folds share one accumulate pass and the sweep solver (jackknife_over_regularizations with a
+  one-entry lambda list).  `dataset`: a brain_data.Dataset whose files are the jackknife units --
+  where the reference takes a BrainData object, a model object, a model directory and its flags
+  (file patterns, SavedModel output: control plane).  max_test_count: only the first so many files
+  are held out (brain_data.all_files, -1 = all); test_file: hold out just this file (an index).
+  summary_file: a path (appended to) or an open file that receives the reference's log entry
+  (:224-241).  Only the linear model's 'pearson_correlation_first' is a sweep metric.
+  """
+  if test_metric != 'pearson_correlation_first':
+    raise ValueError('Could not find metric %s in results %s.' % (test_metric, ['loss', 'pearson_correlation_first']))
+  n_files = len(dataset.files)
+  if test_file is not None:
+    folds = [int(test_file)]
+  elif max_test_count is not None and max_test_count >= 0:
+    folds = list(range(min(int(max_test_count), n_files)))
+  else:
+    folds = list(range(n_files))
+  res = jackknife_over_regularizations(dataset, [regularization_lambda], rank=rank, world_size=world_size,
+                                       group=group, device=device, folds=folds)
+  all_cor = [float(v) for v in res['all_runs'][0]]
+  log_entry = ('Jackknife test result test={}, regularization lambda={}, '
+               'trial={}, mean correlation={}, std={}, '
+               'test count={}\n'.format(test_name, regularization_lambda, trial_number,
+                                        np.mean(all_cor), np.std(all_cor), len(all_cor)))
+  log_entry += 'Jackknife parameters:' + experiment_parameters
+  log_entry += '\n'
+  if summary_file:
+    if isinstance(summary_file, str):
+      with open(summary_file, 'a') as fp:
+        fp.write(log_entry)
+    else:
+      summary_file.write(log_entry)
+  return all_cor

@@ -483,7 +483,103 @@ def g10_decoder_train():
   save('g10_decoder_train', **out)
 
 
+# ----------------------------------------------------------------- G11 decode harness
+def g11_data():
+  """Two-speaker test stream with attention switching twice, in the style of
+  test/infer_decoder_test.py:86-148 (uniform intensities; eeg = the attended speaker's intensity,
+  here plus noise so that short windows make mistakes), 200-frame minibatches."""
+  rng = np.random.default_rng(11)
+  n, dims, batch = 4000, 3, 200
+  out = {}
+  for name, switches in (('train', ()), ('test', (1400, 2600))):
+    i1 = rng.random((n, dims)).astype(np.float32)
+    i2 = rng.random((n, dims)).astype(np.float32)
+    flag = np.zeros((n, 1), np.float32)
+    for k, s in enumerate(switches):
+      flag[s:] = (k + 1) % 2
+    eeg = (np.where(flag > 0.5, (i2 - 0.5) * 2.0, (i1 - 0.5) * 2.0) +
+           1.5 * rng.standard_normal((n, dims))).astype(np.float32)
+    out.update({name + '_eeg': eeg, name + '_i1': i1, name + '_i2': i2, name + '_flag': flag})
+  out['mix_perm_x2'] = np.stack([rng.permutation(batch) for _ in range(n // batch)])
+  out['mix_perm_y'] = np.stack([rng.permutation(batch) for _ in range(n // batch)])
+  out['cfg'] = np.array([n, dims, batch], np.int64)
+  return out
+
+
+def g11_datasets(d):
+  """(train, mixed-up train, test against speaker 1, test against speaker 2) minibatch lists."""
+  n, _, batch = (int(v) for v in d['cfg'])
+  def batches(eeg, audio, flag, perm_x2=None, perm_y=None):
+    items = []
+    for k, s in enumerate(range(0, n, batch)):
+      x2 = audio[s:s + batch]
+      y = audio[s:s + batch]
+      if perm_x2 is not None:
+        x2, y = x2[perm_x2[k]], y[perm_y[k]]
+      items.append(({'input_1': eeg[s:s + batch], 'input_2': x2,
+                     'attended_speaker': flag[s:s + batch]}, y))
+    return items
+  train = batches(d['train_eeg'], d['train_i1'], d['train_flag'])
+  mixed = batches(d['train_eeg'], d['train_i1'], d['train_flag'], d['mix_perm_x2'],
+                  d['mix_perm_y'])
+  test1 = batches(d['test_eeg'], d['test_i1'], d['test_flag'])
+  test2 = batches(d['test_eeg'], d['test_i2'], d['test_flag'])
+  return train, mixed, test1, test2
+
+
+def g11_decode_harness():
+  """The reference's own regress_and_correlate / find_first_segment (infer.py:247-266, 301-324) and
+  the body of its window loop (infer.py:376-407: create_attention_decoder, tune on the first
+  segment, attention per window, the accuracy rule) on a stream whose attention switches twice --
+  run_reduction_test itself takes a SavedModel directory and TFRecord patterns (TF file formats)."""
+  from telluride_decoding import infer as ref_infer
+  import io
+  import contextlib
+  out = g11_data()
+  train, mixed, test1, test2 = (tf.data.Dataset(b) for b in g11_datasets(out))
+  linear = lambda d: tf._t(np.asarray(d['input_1']) / 2.0 + 0.5)
+  out['windows'] = np.array([10, 100, 200, 400, 700, 1000], np.int64)       # infer.py:376
+  out['ffs_kat'] = np.array([ref_infer.find_first_segment([0, 0, 0, 0, 0, 1, 1, 1, 1]),
+                             ref_infer.find_first_segment(np.logical_not([0, 0, 0, 0, 0, 1, 1, 1, 1])),
+                             ref_infer.find_first_segment([0, 0, 0])])          # test/infer_test.py:55-59
+  for red in ('first', 'lda', 'mean-squared'):
+    dec = ref_id.LinearRegressionDecoder(linear, reduction=red)
+    with contextlib.redirect_stdout(io.StringIO()):
+      out[red.replace('-', '_') + '_dprime'] = np.array(dec.train(mixed, train))
+    for w in (int(v) for v in out['windows']):
+      d1, _ = ref_infer.regress_and_correlate(dec, test1, w)
+      d2, labels = ref_infer.regress_and_correlate(dec, test2, w)
+      k = '%s_w%d_' % (red.replace('-', '_'), w)
+      out[k + 'd1'] = np.asarray(d1)
+      out[k + 'd2'] = np.asarray(d2)
+      out[k + 'labels'] = np.asarray(labels)
+      end = ref_infer.find_first_segment(labels)
+      out[k + 'end'] = np.array(end)
+      for dtype in ('wta', 'stepped', 'ssd'):
+        if dtype == 'ssd' and red != 'first':
+          continue
+        with contextlib.redirect_stdout(io.StringIO()):
+          decoder = ref_ad.create_attention_decoder(dtype, window_step=w // 2, frame_rate=100.0)
+          if end:
+            decoder.tune(d1[:end], d2[:end])
+          attention = np.array([decoder.attention(c1, c2) for c1, c2 in zip(d1, d2)],
+                               dtype=np.float64)
+        lab = np.reshape(np.asarray(labels), (-1, 1))
+        correct = np.logical_xor(attention[:, 0:1] >= 0.5, lab)
+        out[k + dtype + '_attention'] = attention
+        out[k + dtype + '_frac'] = np.array(np.sum(correct) / float(len(correct)))
+  rng = np.random.default_rng(111)
+  for i, v in enumerate((rng.standard_normal(7), -np.abs(rng.standard_normal(5)), np.array([1., -2., 3.]))):
+    out['rmss_in%d' % i] = v                          # cca.py:31-36
+    out['rmss_out%d' % i] = np.asarray(ref_cca.rmss(v))
+  save('g11_decode_harness', **out)
+
+
 if __name__ == '__main__':
+  if len(sys.argv) > 1:           # python generate_golden.py g11_decode_harness ...
+    for name in sys.argv[1:]:
+      globals()[name]()
+    sys.exit(0)
   g1_lag()
   g2_ridge()
   g3_pearson()
@@ -494,3 +590,4 @@ if __name__ == '__main__':
   g8_lda()
   g9_end_to_end()
   g10_decoder_train()
+  g11_decode_harness()

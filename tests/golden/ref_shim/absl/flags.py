@@ -3,6 +3,8 @@ class _Flags(object):
     return None
   def __call__(self, *a, **k):
     return []
+  def __contains__(self, name):
+    return False
 FLAGS = _Flags()
 FlagValues = _Flags
 def _define(*a, **k):

@@ -1,0 +1,181 @@
+"""GPU tests of the one-launch conjugate-gradient ridge solve (csrc/cg.hip, td_set_solver) and of the
+asynchronous flag ring: the same weights as the blocked Cholesky and as the float64 oracle, every
+fallback route (not positive definite, no convergence, aborted launch) and the shapes around its
+limits (rows per workgroup, odd unknown counts, several lambdas and outputs)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import lag as o_lag
+from oracle import regression as o_reg
+from tests import parity_log
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def dev():
+  from telluride_decoding_amd import device
+  return device
+
+
+def _stats(dev, c, post, frames, files, d=1, seed=3, low_pass=True):
+  from telluride_decoding_amd import synth
+  h = dev.default_handle()
+  if low_pass:
+    trials = synth.make_trials(seed, files, frames, c)
+    eeg = np.concatenate([t[0] for t in trials])
+    env = np.concatenate([t[1][:, :d] if d <= 2 else np.tile(t[1], (1, d))[:, :d] for t in trials])
+  else:
+    rng = np.random.default_rng(seed)
+    eeg = rng.standard_normal((files * frames, c)).astype(np.float32)
+    env = (eeg[:, :d] * 0.5 + rng.standard_normal((files * frames, d))).astype(np.float32)
+  offs = np.arange(files + 1, dtype=np.int64) * frames
+  st = dev.LagStats(c, 0, post, d=d, handle=h)
+  st.accumulate(h.to_device(eeg), None, h.to_device(env), offs)
+  return h, st, eeg, env, offs
+
+
+def _oracle_weights(eeg, env, offs, post, lamb):
+  files = [(eeg[offs[i]:offs[i + 1]].astype(np.float64), env[offs[i]:offs[i + 1]].astype(np.float64),
+            env[offs[i]:offs[i + 1]].astype(np.float64), np.zeros((offs[i + 1] - offs[i], 1)))
+           for i in range(len(offs) - 1)]
+  w, b, _, _, _ = o_reg.linear_regressor_from_batches(
+      o_lag.minibatches(files, int(offs[1] - offs[0]), pre=0, post=post), lamb=lamb)
+  return w, b
+
+
+@pytest.mark.parametrize('c,post,frames,files,lams,d', [
+    (64, 31, 6000, 3, [0.1], 1),              # the C2 shape: 2048 unknowns, 8 rows per workgroup
+    (64, 31, 6000, 3, [0.01, 0.1, 3.0], 1),   # several lambdas share the resident rows
+    (64, 31, 5000, 2, [0.1], 2),              # two outputs
+    (40, 19, 4000, 2, [0.1], 1),              # 800 unknowns: 4 rows per workgroup, 200 workgroups
+    (33, 24, 4000, 2, [0.5], 1),              # 825 unknowns: odd count (padded row stride), ragged last workgroup
+    (16, 3, 3000, 2, [0.1], 1),               # 64 unknowns: one row per workgroup
+])
+def test_cg_solve_matches_cholesky_and_oracle(dev, c, post, frames, files, lams, d):
+  h, st, eeg, env, offs = _stats(dev, c, post, frames, files, d=d)
+  try:
+    h.set_solver('cholesky')
+    wc, bc = (t.cpu().numpy().astype(np.float64) for t in st.ridge_solve(lams))
+    assert h.last_solve_info()['solver'] == 'cholesky'
+    h.set_solver('cg')
+    wg, bg = (t.cpu().numpy().astype(np.float64) for t in st.ridge_solve(lams))
+    info = h.last_solve_info()
+    assert info['solver'] == 'cg' and info['cg_status'] == 0 and 0 < info['iterations'] <= 400, info
+  finally:
+    h.set_solver('auto')
+  scale = np.max(np.abs(wc))
+  # float32 outputs of two float64 solves of one system: a rounding flip apart at most
+  assert np.max(np.abs(wg - wc)) <= 2.5e-7 * scale
+  assert np.max(np.abs(bg - bc)) <= 2.5e-7 * max(np.max(np.abs(bc)), scale)
+  if d == 1:
+    for li, lam in enumerate(lams):
+      w64, b64 = _oracle_weights(eeg, env, offs, post, lam)
+      err = np.max(np.abs(wg[li] - w64)) / np.max(np.abs(w64))
+      parity_log.record('cg_solve c%d post%d lam%g' % (c, post, lam), gpu_vs_ref64=err,
+                        iterations=info['iterations'])
+      # a few thousand low-pass frames amplify the ACCUMULATE's ~1e-7 through the solve (both solvers
+      # agree to a float32 rounding, above; the strict 1e-5 cases of the fit are in test_gpu_fit.py)
+      assert err < (2e-5 if lam >= 0.1 else 1e-4), err
+
+
+def test_auto_picks_cg_for_one_large_system_and_cholesky_otherwise(dev):
+  h, st, _, _, _ = _stats(dev, 64, 31, 4000, 2)
+  st.ridge_solve([0.1])
+  assert h.last_solve_info()['solver'] == 'cg'
+  st.ridge_solve(list(np.logspace(-3, 1, 7)))           # 7 systems share one batched factorisation
+  assert h.last_solve_info()['solver'] == 'cholesky'
+  h2, st2, _, _, _ = _stats(dev, 16, 7, 3000, 2)         # 129 unknowns: the chain is short
+  st2.ridge_solve([0.1])
+  assert h2.last_solve_info()['solver'] == 'cholesky'
+
+
+def test_singular_system_is_reported_like_the_reference(dev):
+  """An exactly duplicated channel and lambda = 0: the matrix is singular.  Conjugate gradients
+  would converge to SOME solution of the consistent system; np.linalg.solve (brain_model.py:477) and
+  the factorisation raise -- so lambda = 0 never takes the conjugate-gradient route."""
+  from telluride_decoding_amd import synth
+  h = dev.default_handle()
+  t = synth.make_trials(5, 1, 5000, 24)[0]
+  eeg = np.concatenate((t[0], t[0][:, :8]), axis=1)      # 32 channels, 8 of them copies
+  st = dev.LagStats(32, 0, 24, d=1, handle=h)             # 800 unknowns
+  st.accumulate(h.to_device(eeg), None, h.to_device(t[1][:, 0:1]), [0, 5000])
+  h.set_solver('cg')
+  try:
+    with pytest.raises(np.linalg.LinAlgError):
+      st.ridge_solve([0.0])
+    info = h.last_solve_info()
+    assert info['solver'] == 'cholesky' and info['cg_status'] == 0 and info['iterations'] == 0, info
+    # with a ridge the same data is fine again
+    w, _ = st.ridge_solve([0.1])
+    assert np.all(np.isfinite(w.cpu().numpy()))
+    assert h.last_solve_info()['solver'] == 'cg'
+  finally:
+    h.set_solver('auto')
+
+
+def test_cg_ill_conditioned_system_takes_the_cholesky_route_and_is_right(dev):
+  """lambda = 1e-9 on low-pass data: thousands of iterations would be needed; the launch gives up at
+  its iteration limit (status 2) and the factorisation delivers the answer."""
+  h, st, eeg, env, offs = _stats(dev, 40, 19, 6000, 2, seed=9)
+  h.set_solver('cholesky')
+  wc = st.ridge_solve([1e-9])[0].cpu().numpy()
+  h.set_solver('cg')
+  try:
+    wg = st.ridge_solve([1e-9])[0].cpu().numpy()
+    info = h.last_solve_info()
+  finally:
+    h.set_solver('auto')
+  if info['solver'] == 'cg':            # (it may converge after all: then it must agree)
+    assert np.max(np.abs(wg - wc)) <= 1e-4 * np.max(np.abs(wc))
+  else:
+    assert info['cg_status'] == 2
+    assert np.array_equal(wg, wc)
+
+
+def test_cg_aborted_launch_drains_and_falls_back():
+  """TD_CG_LIMIT_TICKS=0: every workgroup gives up at its first empty poll (what happens when the
+  persistent grid cannot become resident), the launch drains with status 3 and td_ridge_solve takes
+  the Cholesky route.  In a child process: the switch is read from the environment."""
+  code = r'''
+import numpy as np
+from telluride_decoding_amd import device, synth
+h = device.default_handle()
+t = synth.make_trials(5, 1, 6000, 64)[0]
+st = device.LagStats(64, 0, 31, d=1, handle=h)
+st.accumulate(h.to_device(t[0]), None, h.to_device(t[1][:, 0:1]), [0, 6000])
+h.set_solver('cholesky'); wc = st.ridge_solve([0.1])[0].cpu().numpy()
+h.set_solver('cg'); wg = st.ridge_solve([0.1])[0].cpu().numpy()
+info = h.last_solve_info()
+assert info['solver'] == 'cholesky' and info['cg_status'] == 3, info
+assert np.array_equal(wc, wg)
+print('aborted-ok')
+'''
+  env = dict(os.environ, TD_CG_LIMIT_TICKS='0', PYTHONPATH=ROOT)
+  out = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300, text=True)
+  assert out.returncode == 0 and 'aborted-ok' in out.stdout, out.stdout[-2000:]
+
+
+def test_async_flag_ring_overrun_is_an_error(dev):
+  """More than 8 asynchronous solves outstanding: the 9th would reuse a flag slot whose solve has not
+  finished -- TD_ERR_STATE (HotPathError), not a silently overwritten flag."""
+  from telluride_decoding_amd import _lib
+  h, st, _, _, _ = _stats(dev, 64, 31, 3000, 2)
+  flags = []
+  with pytest.raises(_lib.HotPathError, match='ring of 8 result flags is full'):
+    for _ in range(40):                # (each solve is ~1 ms of queued device work; the host is far ahead)
+      flags.append(st.ridge_solve_async([0.1], handle=h))
+  assert 8 <= len(flags) < 40
+  h.synchronize()
+  assert all(f[2]() == 0 for f in flags[-8:])
+  # after the wait the ring is free again
+  w, b, flag = st.ridge_solve_async([0.1], handle=h)
+  h.synchronize()
+  assert flag() == 0 and np.all(np.isfinite(w.cpu().numpy()))
