@@ -131,12 +131,35 @@ def cpu_baseline(eeg, env):
   }
 
 
+def _decode_cpu_rate(trials, wn, bn, corr, dtype):
+  """The reference's decode on the host (oracle/: materialised lag matrix -> dense forward ->
+  per-frame global-statistics correlation -> Python window loop -> strict > ; brain_model.py:335-341,
+  infer_decoder.py:312-328, infer.py:247-266, attention_decoder.py:128-134) in `dtype`: windows/s."""
+  from oracle import attention as o_att
+  from oracle import correlator as o_cor
+  from oracle import lag as o_lag
+  from oracle import regression as o_reg
+  t0 = time.perf_counter()
+  n_win = 0
+  for t in trials:
+    p = o_reg.dense_forward(o_lag.lag_matrix(t[0].astype(dtype), PRE, POST), wn.astype(dtype), bn.astype(dtype))
+    sc = []
+    for spk in (0, 1):
+      cor = o_cor.Correlator()
+      cor.mean_x, cor.mean_y, cor.power = corr[3 * spk], corr[3 * spk + 1], corr[3 * spk + 2]
+      sc.append(o_cor.windowed_means(cor.correlate(t[1][:, spk:spk + 1].astype(dtype), p), t[2], 1000, 100)[0])
+    n_win += len(o_att.wta_sequence(sc[0], sc[1]))
+  return n_win / (time.perf_counter() - t0)
+
+
 def decode_leg(h, device, iters=200):
-  """Config C4: 200 trials x 6000 frames x 64 ch, two envelopes, 10 s windows
-  (W = 1000) every 1 s (hop = 100): raw EEG -> decisions with td_decode_fused."""
+  """Config C4: 200 DISTINCT trials x 6000 frames x 64 ch, two envelopes, 10 s windows
+  (W = 1000) every 1 s (hop = 100): raw EEG -> decisions with td_decode_fused.  Timed twice: replaying
+  one 317 MB input back to back (which the 256 MiB Infinity Cache partly serves) and ROTATING over
+  three copies of the input at different addresses (951 MB: no call finds its input cached)."""
+  import threadpoolctl
   from telluride_decoding_amd import synth
-  base = synth.make_trials(4, 20, 6000, C, switch_half=True)
-  trials = base * 10                                     # 200 trials (20 distinct, tiled)
+  trials = synth.make_trials(4, 200, 6000, C, switch_half=True)
   eeg = np.concatenate([t[0] for t in trials])
   env = np.concatenate([t[1] for t in trials])
   att = np.concatenate([t[2] for t in trials])
@@ -153,18 +176,25 @@ def decode_leg(h, device, iters=200):
   for spk in (0, 1):
     s = device.window_sums(envd[:, spk:spk + 1], pred, [0, n], n, n, handle=h).cpu().numpy()[0, 0]
     corr += [s[0] / n, s[1] / n, np.sqrt((s[2] - s[0] ** 2 / n) * (s[3] - s[1] ** 2 / n)) / n]
+  del pred, st
+  inputs = [(xd, envd), (xd.clone(), envd.clone()), (xd.clone(), envd.clone())]
 
-  def timed(width, hop):
-    for _ in range(3):
-      out = device.decode_fused(xd, envd, offs, w, b, PRE, POST, width, hop, corr, handle=h)
+  def timed(width, hop, rotate):
+    sets = inputs if rotate else inputs[:1]
+    for i in range(3):
+      out = device.decode_fused(sets[i % len(sets)][0], sets[i % len(sets)][1], offs, w, b, PRE, POST,
+                                width, hop, corr, handle=h)
     gc.collect()           # (a collection inside the loop can free a device arena: a 40-70 ms stall)
     h.synchronize()
     h.timer_start()                                      # hipEvents on the launching stream
-    for _ in range(iters):
-      out = device.decode_fused(xd, envd, offs, w, b, PRE, POST, width, hop, corr, handle=h)
+    for i in range(iters):
+      xs, es = sets[i % len(sets)]
+      out = device.decode_fused(xs, es, offs, w, b, PRE, POST, width, hop, corr, handle=h)
     return h.timer_stop() / iters, out
 
-  ms, (scores, dec) = timed(1000, 100)
+  ms, (scores, dec) = timed(1000, 100, False)
+  ms_rot, (scores_r, dec_r) = timed(1000, 100, True)
+  assert bool((dec == dec_r).all())
   n_win = int(dec.shape[0])
   labels = device.window_means(h.to_device(att.astype(np.float64), np.float64).reshape(-1), offs,
                                1000, 100, handle=h).cpu().numpy()
@@ -172,17 +202,16 @@ def decode_leg(h, device, iters=200):
   scores = scores.cpu().numpy()
   clear = (labels < 0.05) | (labels > 0.95)
   acc = float(np.mean((dec[clear] == 1) == (labels[clear] < 0.5)))
-  # CPU: the reference's per-frame correlation + Python window loop + WTA on the 20 DISTINCT
-  # trials (the other 180 are copies): decision flips of the device against the oracle
+  # CPU: the reference's per-frame correlation + Python window loop + WTA on ALL 200 trials in
+  # float64: decision flips of the device against the oracle over all 10 200 decisions
   from oracle import attention as o_att
   from oracle import correlator as o_cor
   from oracle import lag as o_lag
   from oracle import regression as o_reg
   wn, bn = w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
-  t0 = time.perf_counter()
   flips = cpu_win = 0
   margins, acc_o = [], []
-  for ti, t in enumerate(base):
+  for ti, t in enumerate(trials):
     p = o_reg.dense_forward(o_lag.lag_matrix(t[0].astype(np.float64), PRE, POST), wn, bn)
     sc = []
     for spk in (0, 1):
@@ -198,22 +227,36 @@ def decode_leg(h, device, iters=200):
     lab = labels[ti * len(truth):(ti + 1) * len(truth)]
     ok = (lab < 0.05) | (lab > 0.95)
     acc_o.append(np.mean((truth[ok] == 1) == (lab[ok] < 0.5)))
-  cpu_dt = time.perf_counter() - t0
+  # the timed CPU baseline: the same chain in float32 (the reference's dtype for TFRecord data) on
+  # 20 trials, the library default and a thread sweep (as the fit leg)
+  cores = os.cpu_count()
+  sample = trials[:20]
+  _decode_cpu_rate(sample[:2], wn, bn, corr, np.float32)
+  cpu_sweep = {'default': _decode_cpu_rate(sample, wn, bn, corr, np.float32)}
+  for threads in sorted(set([1, 4, 16, 64]) & set(range(1, cores + 1))):
+    with threadpoolctl.threadpool_limits(limits=threads, user_api='blas'):
+      cpu_sweep[str(threads)] = _decode_cpu_rate(sample, wn, bn, corr, np.float32)
+  cpu_best = max(cpu_sweep, key=cpu_sweep.get)
   # the reference harness: W in {10, 100, 200, 400, 700, 1000} with hop = W // 2
   # (infer.py:376-378; W = 10 shares no block of >= 32 frames: thread-per-window sums)
   native = {}
   for width in (10, 100, 200, 400, 700, 1000):
-    ms_w, (_, d_w) = timed(width, width // 2)
+    ms_w, (_, d_w) = timed(width, width // 2, True)
     native['W%d' % width] = {'hop': width // 2, 'windows': int(d_w.shape[0]), 'ms': ms_w,
                              'windows_per_s': int(d_w.shape[0]) / ms_w * 1e3,
                              'hbm_frac': n * 4 * (C + 2) / (ms_w * 1e-3) / 1e9 / PEAK_HBM_GBPS}
   gbps = n * 4 * (C + 2) / (ms * 1e-3) / 1e9
+  gbps_rot = n * 4 * (C + 2) / (ms_rot * 1e-3) / 1e9
   return {
-      'workload': 'C4: 200 trials x 60 s x 64 ch, two envelopes, W=1000/hop=100 (10 s / 1 s)',
-      'windows': n_win, 'ms': ms, 'windows_per_s': n_win / ms * 1e3,
-      'timing': 'hipEvents around %d back-to-back td_decode_fused calls' % iters,
-      'algorithmic_bytes': int(n) * 4 * (C + 2), 'hbm_gbps_algorithmic': gbps,
-      'roofline': {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+      'workload': 'C4: 200 distinct trials x 60 s x 64 ch, two envelopes, W=1000/hop=100 (10 s / 1 s)',
+      'windows': n_win, 'ms': ms_rot, 'windows_per_s': n_win / ms_rot * 1e3,
+      'timing': ('hipEvents around %d back-to-back td_decode_fused calls ROTATING over three copies of the '
+                 'input at different addresses (951 MB > the 256 MiB Infinity Cache); `replayed` = the '
+                 'same call on one copy back to back' % iters),
+      'algorithmic_bytes': int(n) * 4 * (C + 2), 'hbm_gbps_algorithmic': gbps_rot,
+      'roofline': {'bound': 'hbm', 'achieved': gbps_rot, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                   'frac': gbps_rot / PEAK_HBM_GBPS, 'inputs': 'rotated'},
+      'replayed': {'ms': ms, 'windows_per_s': n_win / ms * 1e3, 'hbm_gbps_algorithmic': gbps,
                    'frac': gbps / PEAK_HBM_GBPS},
       'wta_accuracy_clear_windows': acc,
       'oracle_accuracy_clear_windows': float(np.mean(acc_o)),
@@ -221,9 +264,10 @@ def decode_leg(h, device, iters=200):
       'min_margin_checked': float(np.min(margins)),
       'accuracy_delta_vs_oracle': float(flips) / max(cpu_win, 1),
       'reference_harness_hop_half_window': native,
-      'cpu_baseline_windows_per_s': cpu_win / cpu_dt,
-      'cpu_sample': 'oracle on the 20 distinct trials (%d windows), NumPy default threads on %d cores'
-                    % (cpu_win, os.cpu_count()),
+      'cpu_baseline_windows_per_s': cpu_sweep[cpu_best],
+      'cpu_baseline': {'dtype': 'float32', 'threads': cpu_best, 'thread_sweep': cpu_sweep,
+                       'host_cores': cores},
+      'cpu_sample': 'oracle in float32 on 20 of the 200 trials (1020 windows); best of the thread sweep',
   }
 
 
@@ -255,11 +299,31 @@ def cca_leg(h, device, eeg):
     st.reset()
     st.accumulate(x, x2, None, offs)
 
-  t_acc = timed(acc)
+  # three copies of the two views at different addresses (864 MB): rotating over them no call finds
+  # its input in the 256 MiB Infinity Cache; `replayed` = one copy back to back
+  copies = [(x, x2), (x.clone(), x2.clone()), (x.clone(), x2.clone())]
+  turn = [0]
+
+  def acc_rot():
+    a, a2 = copies[turn[0] % 3]
+    turn[0] += 1
+    st.reset()
+    st.accumulate(a, a2, None, offs)
+
+  t_acc_replayed = timed(acc)
+  t_acc = timed(acc_rot, 99)
   t_solve = timed(lambda: st.cca_solve(n - 1, 0.1, 5), 20)
   rot_x, rot_y, mean_x, mean_y, e, _ = st.cca_solve(n - 1, 0.1, 5)
-  t_tr = timed(lambda: device.cca_transform(x, x2, offs, mean_x, rot_x, mean_y, rot_y, 0, 0, 0, 0,
-                                            handle=h))
+  t_tr_replayed = timed(lambda: device.cca_transform(x, x2, offs, mean_x, rot_x, mean_y, rot_y, 0, 0, 0, 0,
+                                                     handle=h))
+
+  def tr_rot():
+    a, a2 = copies[turn[0] % 3]
+    turn[0] += 1
+    device.cca_transform(a, a2, offs, mean_x, rot_x, mean_y, rot_y, 0, 0, 0, 0, handle=h)
+
+  t_tr = timed(tr_rot, 99)
+  del copies
   # codelab shape on 200k samples
   m = 200000
   # (69 channels: the 64 + five mixtures with their own noise -- exact copies would make the
@@ -306,7 +370,11 @@ def cca_leg(h, device, eeg):
       'workload': 'C3: CCA, 64-ch EEG vs 8-band envelope, 1e6 samples, no context, 5 components',
       'fit_ms': (t_acc + t_solve) * 1e3, 'accumulate_ms': t_acc * 1e3,
       'solve_ms': t_solve * 1e3, 'transform_ms': t_tr * 1e3,
-      'timing': 'hipEvents on the launching stream around 100 back-to-back calls (20 for the solve)',
+      'timing': ('hipEvents on the launching stream around 99 back-to-back calls (20 for the solve) ROTATING '
+                 'over three copies of the inputs at different addresses; `replayed` = one copy'),
+      'replayed': {'accumulate_ms': t_acc_replayed * 1e3, 'transform_ms': t_tr_replayed * 1e3,
+                   'accumulate_hbm_frac': n * 4 * 72 / t_acc_replayed / 1e9 / PEAK_HBM_GBPS,
+                   'transform_hbm_frac': n * 4 * (72 + 10) / t_tr_replayed / 1e9 / PEAK_HBM_GBPS},
       'accumulate_hbm_gbps_algorithmic': n * 4 * 72 / t_acc / 1e9,
       'transform_hbm_gbps_algorithmic': n * 4 * (72 + 10) / t_tr / 1e9,
       'accumulate_roofline': {'kernel': 'gram_bf16x3_kernel + stats_finalize_kernel', 'bound': 'hbm',
@@ -707,7 +775,8 @@ def main():
         'config': {
             'workload': ('C2: 64-ch x 1e6-sample ridge TRF fit%s (10 recordings x 100k frames), '
                          '32 lags (K = 2048 + bias), lambda = 0.1, D = 1: lagged-covariance MFMA '
-                         'accumulate + float64 Cholesky solve'
+                         'accumulate + float64 solve (blocked Cholesky on the solve streams of the pipeline; '
+                         'one-launch conjugate gradients where a fit runs alone: serial_ms_per_step, single_fit)'
                          % (' per GPU' if args.scaling == 'weak' else ', ONE job shared by all GPUs')),
             'samples_per_step': samples_per_step, 'channels': C, 'lags': POST + 1,
             'parallelism': ('single GPU' if world == 1 else
@@ -759,6 +828,7 @@ def main():
       k = C * (PRE + 1 + POST)
       a1 = 2.0 * C * k * (smp1 / max(l1, 1)) / (ms1 / max(l1, 1) / 1e3) / 1e12
       line['serial_ms_per_step'] = e_s / 10 * 1e3
+      line['serial_solver'] = h.last_solve_info()
       # what a bare loop of the kernel's MFMA sustains on this chip (power / clock ceiling)
       sustained = h.probe_bf16_mfma(True)
       line['roofline']['pipe_sustained'] = {
@@ -788,6 +858,47 @@ def main():
   acc_ms = accumulate_only(shard)
   if rank == 0:
     line['accumulate_only_ms_per_step'] = acc_ms
+
+  if world == 1 and args.scaling == 'weak':
+    # ONE fit with nothing else in flight: accumulate -> solve -> weights on the host's side of a
+    # synchronise (what a caller of BrainModelLinearRegression.fit waits for, minus the Python class
+    # layer).  The pipelined `value` needs >= 3 independent fits in flight; this is the other end.
+    x_, y_, offs_, kw_ = shard
+    st1 = device.LagStats(C, PRE, POST, d=D, handle=h)
+    lat = {}
+    for solver in ('auto', 'cholesky'):
+      h.set_solver(solver)
+      ts = []
+      for _ in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st1.reset()
+        st1.accumulate(x_, None, y_, offs_, **kw_)
+        st1.ridge_solve(lam)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+      lat[solver] = (float(np.median(ts[2:])) * 1e3, h.last_solve_info())
+    h.set_solver('auto')
+    line['single_fit_latency_ms'] = lat['auto'][0]
+    line['single_fit'] = {
+        'latency_ms': lat['auto'][0], 'solver': lat['auto'][1],
+        'latency_ms_cholesky_solver': lat['cholesky'][0],
+        'what': 'median wall time of one synchronous C2 fit (accumulate + solve) alone on the chip; the '
+                'solve of ONE large system is a one-launch conjugate-gradient kernel (cg.hip), the '
+                'blocked Cholesky when that does not converge'}
+    # the headline with the exact float32 matrix instruction in the accumulate (TD_ACC_F32), same pipeline
+    run_f, hp_f, pipe_f = make_runner(shard, reduce_fn, solves, False)
+    hp_f.set_accumulate_mode('f32')
+    e_f, _ = time_region(run_f, 20, 3)
+    hp_f.set_accumulate_mode('f16x2')
+    del pipe_f, run_f
+    torch.cuda.synchronize()
+    line['f32_mode'] = {'samples_per_s': samples_per_step * 20 / e_f, 'ms_per_step': e_f / 20 * 1e3,
+                        'what': 'the same pipelined fit with td_set_accumulate_mode(TD_ACC_F32): every product '
+                                'on v_mfma_f32_32x32x2_f32 (20 steps)'}
+  if rank == 0:
+    line['collective'] = (dict(distributed.LAST_COLLECTIVE) if distributed.LAST_COLLECTIVE else
+                          {'route': 'none (one rank, no exchange)', 'ranks': 1})
   if world > 1 and args.scaling == 'weak':
     # informational strong-scaling leg: the ONE-GPU job cut into N time ranges
     _, shard2, reduce2, solves2, _ = strong_setup()

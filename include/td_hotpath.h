@@ -213,6 +213,9 @@ int td_allreduce_f64(td_handle* h, double* buf_dev, int64_t count, void* rccl_co
 /* Communicator plumbing for callers that have no ncclComm_t of their own: rank 0 makes a
  * 128-byte id (ncclGetUniqueId), hands it to the other ranks by any means, then every rank
  * creates its communicator on the handle's device (ncclCommInitRank; collective). */
+/* TD_OK when librccl can be bound in this process (dlopen + the six symbols; no RCCL call is made --
+ * ncclGetUniqueId would start a bootstrap thread and socket), TD_ERR_STATE with the reason otherwise. */
+int td_rccl_available(td_handle* h);
 int td_rccl_unique_id(td_handle* h, void* id_out_128);
 int td_rccl_comm_create(td_handle* h, int num_ranks, int rank, const void* id_128, void** comm_out);
 int td_rccl_comm_count(td_handle* h, void* comm, int* num_ranks);

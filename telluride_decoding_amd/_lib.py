@@ -78,6 +78,7 @@ SIGNATURES = {
     'td_stats_unpack_known': [_vp, _vp, _vp, _i64, _i64],
     'td_stats_allreduce': [_vp, _vp, _vp, _i64, _i64, _i64],
     'td_allreduce_f64': [_vp, _vp, _i64, _vp],
+    'td_rccl_available': [_vp],
     'td_rccl_unique_id': [_vp, _vp],
     'td_rccl_comm_create': [_vp, _i, _i, _vp, _c.POINTER(_vp)],
     'td_rccl_comm_count': [_vp, _vp, _c.POINTER(_i)],

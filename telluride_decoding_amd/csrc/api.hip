@@ -51,7 +51,7 @@ struct PoolBlock {
 };
 std::mutex g_pool_mu;
 std::vector<PoolBlock> g_pool;                       // free blocks, most recently freed last
-std::vector<hipEvent_t> g_pool_events;               // spare event objects
+std::unordered_map<int, std::vector<hipEvent_t>> g_pool_events;   // spare event objects, per device
 std::unordered_map<void*, size_t> g_pool_sizes;      // live blocks handed out by td_alloc_async
 size_t g_pool_bytes = 0;
 constexpr size_t kPoolMaxBytes = (size_t)4 << 30;
@@ -59,13 +59,15 @@ constexpr size_t kPoolMaxBlocks = 4096;
 
 void pool_drain_locked() {
   for (PoolBlock& b : g_pool) {
+    (void)hipSetDevice(b.device);
     hipEventSynchronize(b.ev);
     hipFree(b.p);
     hipEventDestroy(b.ev);
   }
   g_pool.clear();
   g_pool_bytes = 0;
-  for (hipEvent_t e : g_pool_events) hipEventDestroy(e);
+  for (auto& kv : g_pool_events)
+    for (hipEvent_t e : kv.second) hipEventDestroy(e);
   g_pool_events.clear();
 }
 }  // namespace
@@ -73,18 +75,25 @@ void pool_drain_locked() {
 int td_alloc_async(td_handle* h, size_t bytes, void** out) {
   *out = nullptr;
   bytes = (size_t)td_round_up((int64_t)(bytes ? bytes : 1), 256);
+  // (a process may hold handles on several devices: the allocation, and the events of this device's
+  // blocks, belong to h->device, not to whatever device happens to be current)
+  TD_HIP(h, hipSetDevice(h->device));
   {
     std::unique_lock<std::mutex> lock(g_pool_mu);
     for (size_t i = g_pool.size(); i-- > 0;) {
       if (g_pool[i].device != h->device || g_pool[i].bytes != bytes) continue;
       const PoolBlock b = g_pool[i];
+      // the block is free from the point its last owner recorded; this stream starts after it
+      // (the event object may be recorded again later: a wait refers to the record it saw)
+      const hipError_t e = hipStreamWaitEvent(h->stream, b.ev, 0);
+      if (e != hipSuccess) {               // the block stays pooled
+        (void)hipGetLastError();
+        return td_fail(h, TD_ERR_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+      }
       g_pool.erase(g_pool.begin() + (long)i);
       g_pool_bytes -= bytes;
       g_pool_sizes[b.p] = bytes;
-      g_pool_events.push_back(b.ev);
-      // the block is free from the point its last owner recorded; this stream starts after it
-      // (the event object may be recorded again later: a wait refers to the record it saw)
-      TD_HIP(h, hipStreamWaitEvent(h->stream, b.ev, 0));
+      g_pool_events[b.device].push_back(b.ev);
       *out = b.p;
       return TD_OK;
     }
@@ -96,6 +105,7 @@ int td_alloc_async(td_handle* h, size_t bytes, void** out) {
     pool_drain_locked();
     lock.unlock();
     (void)hipGetLastError();
+    TD_HIP(h, hipSetDevice(h->device));
     e = hipMalloc(out, bytes);
   }
   if (e != hipSuccess) {
@@ -109,6 +119,7 @@ int td_alloc_async(td_handle* h, size_t bytes, void** out) {
 
 int td_free_async(td_handle* h, void* p, bool own_stream_only) {
   if (!p) return TD_OK;
+  TD_HIP(h, hipSetDevice(h->device));
   if (!own_stream_only) TD_TRY(td_order_after_others(h));
   std::unique_lock<std::mutex> lock(g_pool_mu);
   const auto it = g_pool_sizes.find(p);
@@ -121,13 +132,27 @@ int td_free_async(td_handle* h, void* p, bool own_stream_only) {
   PoolBlock b;
   b.p = p; b.bytes = it->second; b.device = h->device; b.ev = nullptr;
   g_pool_sizes.erase(it);
-  if (!g_pool_events.empty()) {
-    b.ev = g_pool_events.back();
-    g_pool_events.pop_back();
+  // From here on the block is neither pooled nor owned by the caller: whatever fails below, it goes
+  // back to the driver the slow way (wait for the stream, hipFree) and is never lost.
+  std::vector<hipEvent_t>& spare = g_pool_events[h->device];       // events are per device
+  hipError_t e = hipSuccess;
+  if (!spare.empty()) {
+    b.ev = spare.back();
+    spare.pop_back();
   } else {
-    TD_HIP(h, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+    e = hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
+    if (e != hipSuccess) b.ev = nullptr;
   }
-  TD_HIP(h, hipEventRecord(b.ev, h->stream));
+  if (e == hipSuccess) e = hipEventRecord(b.ev, h->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (b.ev) spare.push_back(b.ev);
+    lock.unlock();
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(p);
+    return td_fail(h, TD_ERR_HIP, "td_free_async: event record failed (%s); the block was freed synchronously",
+                   hipGetErrorString(e));
+  }
   g_pool.push_back(b);
   g_pool_bytes += b.bytes;
   // over the limits: the oldest blocks go back to the driver (this waits for them)
@@ -137,7 +162,7 @@ int td_free_async(td_handle* h, void* p, bool own_stream_only) {
     g_pool_bytes -= old.bytes;
     hipEventSynchronize(old.ev);
     hipFree(old.p);
-    g_pool_events.push_back(old.ev);
+    g_pool_events[old.device].push_back(old.ev);
   }
   return TD_OK;
 }

@@ -96,6 +96,11 @@ int need_rccl(td_handle* h, Rccl** out) {
 
 extern "C" {
 
+int td_rccl_available(td_handle* h) {
+  Rccl* r = nullptr;
+  return need_rccl(h, &r);       // dlopen + dlsym only: no RCCL call, no bootstrap thread
+}
+
 int td_rccl_unique_id(td_handle* h, void* id_out_128) {
   if (!id_out_128) return td_fail(h, TD_ERR_INVALID, "td_rccl_unique_id: NULL");
   Rccl* r = nullptr;

@@ -37,6 +37,7 @@ class Handle(object):
     self.ptr = ptr
     self.device_id = int(device_id)
     self.device = torch.device('cuda', self.device_id)
+    self.accumulate_mode = 'f16x2'
     self.use_torch_stream()
 
   def use_torch_stream(self):
@@ -66,6 +67,7 @@ class Handle(object):
     """'f16x2' (default: two float16 pieces, 3 products), 'bf16x3' (6 products, exact to 2^-27)
     or 'f32' (the float32 matrix instruction): td_set_accumulate_mode."""
     self.check(self.lib.td_set_accumulate_mode(self.ptr, self.ACCUMULATE_MODES[mode]))
+    self.accumulate_mode = mode
 
   SOLVERS = {'auto': 0, 'cholesky': 1, 'cg': 2}
 

@@ -184,7 +184,28 @@ class RcclComm(object):
       pass
 
 
-_comms = {}
+_comms = {}                 # (id(group), ranks of the group, device) -> (communicator or None, group)
+LAST_COLLECTIVE = {}        # what the last all-reduce of this process went through (bench.py reports it)
+
+
+def _comm_key(dist, handle, group):
+  """The cache key of a process group: its identity AND its membership.  id() alone can be reused by
+  a new group once the old object is collected (the new group would inherit a communicator with the
+  wrong ranks and hang); the entry also keeps the group object alive, so the id cannot come back
+  while the communicator is cached."""
+  ranks = tuple(dist.get_process_group_ranks(group)) if group is not None else \
+      tuple(range(dist.get_world_size()))
+  return (id(group) if group is not None else 0, ranks, handle.device_id)
+
+
+def init_native_comm(handle, group=None):
+  """Creates the C-ABI communicator of `group` NOW.  Creation is itself collective (two agreement
+  all-reduces, a broadcast of the id, ncclCommInitRank): every rank of the group must call this at
+  the same point of the program -- right after init_process_group / new_group is the place.
+  (allreduce_stats / allreduce_packed create it lazily at their first use, which is only safe when
+  every rank reaches that first use together.)  Returns the communicator, or None when the exchange
+  goes through torch.distributed (no process group, gloo, TD_ALLREDUCE_TORCH, librccl missing)."""
+  return native_comm(handle, group)
 
 
 def native_comm(handle, group=None):
@@ -200,9 +221,8 @@ def native_comm(handle, group=None):
   world = dist.get_world_size(group)
   if world == 1 and not os.environ.get('TD_ALLREDUCE_ALWAYS'):
     return None
-  key = (id(group) if group is not None else 0, handle.device_id)
+  key = _comm_key(dist, handle, group)
   if key not in _comms:
-    import ctypes
     import sys
     import torch
 
@@ -217,9 +237,8 @@ def native_comm(handle, group=None):
       dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
       return bytes(t.cpu().tolist())
 
-    # (1) can every rank bind librccl at all?  (a throw-away id: no collective inside)
-    probe = (ctypes.c_char * 128)()
-    usable = handle.lib.td_rccl_unique_id(handle.ptr, probe) == _lib_ok()
+    # (1) can every rank bind librccl at all?  (dlopen + dlsym: no RCCL call, no bootstrap thread)
+    usable = handle.lib.td_rccl_available(handle.ptr) == _lib_ok()
     comm = None
     if agree(usable):
       # (2) the communicator itself (ncclCommInitRank: a collective of its own), then agree again
@@ -238,8 +257,8 @@ def native_comm(handle, group=None):
     else:
       sys.stderr.write('telluride_decoding_amd: librccl could not be bound on every rank; the '
                        'statistics all-reduce goes through torch.distributed\n')
-    _comms[key] = comm
-  return _comms[key]
+    _comms[key] = (comm, group)
+  return _comms[key][0]
 
 
 def _lib_ok():
@@ -249,7 +268,7 @@ def _lib_ok():
 
 def close_native_comms():
   """Destroys the C-ABI communicators (before torch.distributed.destroy_process_group)."""
-  for c in _comms.values():
+  for c, _ in _comms.values():
     if c is not None:
       c.close()
   _comms.clear()
@@ -269,8 +288,10 @@ def allreduce_packed(buf, group=None, handle=None):
         raise TypeError('the packed buffer must be a contiguous float64 tensor')
       handle.check(handle.lib.td_allreduce_f64(handle.ptr, ctypes.c_void_p(buf.data_ptr()),
                                                buf.numel(), comm.ptr))
+      LAST_COLLECTIVE.update(route='td_allreduce_f64', ranks=comm.world_size)
     else:
       dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+      LAST_COLLECTIVE.update(route='torch.distributed', ranks=dist.get_world_size(group))
   return buf
 
 
@@ -290,6 +311,7 @@ def allreduce_stats(stats, plan, rank, group=None, total_frames=None, handle=Non
     h.check(h.lib.td_stats_allreduce(
         h.ptr, stats.ptr, comm.ptr, int(plan.total_files), int(plan.slot_of(rank)),
         -1 if total_frames is None else int(total_frames)))
+    LAST_COLLECTIVE.update(route='td_stats_allreduce', ranks=comm.world_size)
     return stats
   buf = stats.pack(plan.total_files, plan.slot_of(rank), handle=handle)
   allreduce_packed(buf, group)

@@ -47,11 +47,20 @@ def _class_moments_device(x, y):
   dims = int(x.shape[1])
   h = device.default_handle()
   moments = []
-  for label in labels:
-    rows = x[torch.from_numpy(y == label).to(x.device)].contiguous()       # device gather: plumbing
-    st = device.LagStats(dims, handle=h)
-    st.accumulate(rows, None, None, [0, int(rows.shape[0])])
-    moments.append(st.moments(want_xty=False)['xtx'].cpu().numpy())
+  # The class scatter is X^T X - n m m^T, a difference: the moments are taken with the float32 matrix
+  # instruction (every product exact to 2^-24, float64 slab sums), whatever accumulate mode the fits of
+  # this handle use -- the float16 two-piece form scales a column by its largest magnitude, and
+  # per-frame correlation products are heavy-tailed.
+  mode = h.accumulate_mode
+  h.set_accumulate_mode('f32')
+  try:
+    for label in labels:
+      rows = x[torch.from_numpy(y == label).to(x.device)].contiguous()       # device gather: plumbing
+      st = device.LagStats(dims, handle=h)
+      st.accumulate(rows, None, None, [0, int(rows.shape[0])])
+      moments.append(st.moments(want_xty=False)['xtx'].cpu().numpy())
+  finally:
+    h.set_accumulate_mode(mode)
   total = sum(m[dims, dims] for m in moments)
   grand_mean = sum(m[dims, :dims] for m in moments) / total
   within = np.zeros((dims, dims))

@@ -575,6 +575,21 @@ def g11_decode_harness():
   save('g11_decode_harness', **out)
 
 
+# ----------------------------------------------------------------- G12 BASELINE config C1 exactly
+def g12_c1_10k():
+  """BASELINE.json configs[0] as stated: ONE 16-channel x 10 000-sample recording -> 1-channel
+  envelope, batch 100, lambda = 0.1 (regression_test.py-sized), without lags and with 4 lags."""
+  t = synth.make_trials(12, 1, 10000, 16)[0]
+  out = dict(eeg=t[0], env=t[1])
+  files = [(t[0], t[1][:, 1:2], t[1][:, 0:1], t[2])]
+  for name, post in (('nolag', 0), ('post3', 3)):
+    ds = dataset_from_files(files, 100, pre=0, post=post)
+    w, b, cx, cxy, _ = ref_bm.calculate_linear_regressor_parameters_from_dataset(ds, lamb=0.1)
+    out.update({name + '_w': w, name + '_b': b, name + '_cov_x': cx, name + '_cov_xy': cxy,
+                name + '_cfg': np.array([0, post, 100], np.int64)})
+  save('g12_c1_10k', **out)
+
+
 if __name__ == '__main__':
   if len(sys.argv) > 1:           # python generate_golden.py g11_decode_harness ...
     for name in sys.argv[1:]:
@@ -591,3 +606,4 @@ if __name__ == '__main__':
   g9_end_to_end()
   g10_decoder_train()
   g11_decode_harness()
+  g12_c1_10k()

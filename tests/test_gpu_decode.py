@@ -716,3 +716,66 @@ def test_long_window_sums_match_float64(dev, rows, width, hop):
     want = np.stack([a64[s].sum(0), b64[s].sum(0), (a64[s] ** 2).sum(0), (b64[s] ** 2).sum(0),
                      (a64[s] * b64[s]).sum(0)], axis=1)
     np.testing.assert_allclose(got[w], want, rtol=1e-12, atol=1e-9)
+
+
+def test_decode_fused_at_full_c4_size(dev):
+  """BASELINE config C4 at its full size -- 200 DISTINCT trials x 6000 frames x 64 channels, W = 1000,
+  hop = 100 -- through td_decode_fused: every one of the 10 200 scores and decisions bit-identical to
+  the unfused kernel chain (FIR prediction -> window sums -> scores -> winner-take-all), and a seeded
+  subset of 16 trials against the float64 oracle chain with 0 decision flips (the full
+  size was only checked inside bench.py, on 20 distinct trials)."""
+  from telluride_decoding_amd import synth
+  h = dev.default_handle()
+  n_trials, frames, c, pre, post, width, hop = 200, 6000, 64, 0, 31, 1000, 100
+  trials = synth.make_trials(44, n_trials, frames, c, switch_half=True)
+  eeg = np.concatenate([t[0] for t in trials])
+  env = np.concatenate([t[1] for t in trials])
+  att = np.concatenate([t[2] for t in trials])
+  offs = np.arange(n_trials + 1, dtype=np.int64) * frames
+  attended = np.where(att > 0.5, env[:, 1:2], env[:, 0:1]).astype(np.float32)
+  xd, envd = h.to_device(eeg), h.to_device(env)
+  st = dev.LagStats(c, pre, post, d=1)
+  st.accumulate(xd, None, h.to_device(attended), offs)
+  w, b = st.ridge_solve([0.1])
+  w, b = w[0].contiguous(), b[0].contiguous()
+  pred = dev.predict_fir(xd, offs, w, b, pre, post, handle=h)
+  n = eeg.shape[0]
+  corr = []
+  for spk in (0, 1):
+    s = dev.window_sums(envd[:, spk:spk + 1], pred, [0, n], n, n, handle=h).cpu().numpy()[0, 0]
+    corr += [s[0] / n, s[1] / n, np.sqrt((s[2] - s[0] ** 2 / n) * (s[3] - s[1] ** 2 / n)) / n]
+  scores, decisions = dev.decode_fused(xd, envd, offs, w, b, pre, post, width, hop, corr, handle=h)
+  scores, decisions = scores.cpu().numpy(), decisions.cpu().numpy()
+  per_trial = (frames - width) // hop + 1
+  assert scores.shape == (n_trials * per_trial, 2) == (10200, 2)
+  # (1) all trials: fused == unfused, bit for bit
+  for spk in (0, 1):
+    sums = dev.window_sums(envd[:, spk:spk + 1], pred, offs, width, hop, handle=h)
+    want = dev.window_scores(sums, width, 0, 'first', corr[3 * spk], corr[3 * spk + 1],
+                             corr[3 * spk + 2], handle=h).cpu().numpy()
+    np.testing.assert_array_equal(scores[:, spk], want)
+  np.testing.assert_array_equal(decisions, scores[:, 0] > scores[:, 1])
+  # (2) a seeded subset against the oracle chain in float64
+  wn, bn = w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+  subset = sorted(np.random.default_rng(4).choice(n_trials, 16, replace=False).tolist())
+  flips = checked = 0
+  worst = 0.0
+  for ti in subset:
+    t = trials[ti]
+    p = o_reg.dense_forward(o_lag.lag_matrix(t[0].astype(np.float64), pre, post), wn, bn)
+    sc = []
+    for spk in (0, 1):
+      cor = o_cor.Correlator()
+      cor.mean_x, cor.mean_y, cor.power = corr[3 * spk], corr[3 * spk + 1], corr[3 * spk + 2]
+      sc.append(o_cor.windowed_means(cor.correlate(t[1][:, spk:spk + 1].astype(np.float64), p),
+                                     t[2], width, hop)[0])
+    truth = o_att.wta_sequence(sc[0], sc[1])
+    got = decisions[ti * per_trial:(ti + 1) * per_trial]
+    flips += int(np.sum(got != truth))
+    checked += len(truth)
+    for spk in (0, 1):
+      worst = max(worst, float(np.max(np.abs(scores[ti * per_trial:(ti + 1) * per_trial, spk] - sc[spk]))))
+  parity_log.record('decode_fused_full_c4', windows=10200, checked_vs_oracle=checked, flips=flips,
+                    max_score_err=worst)
+  assert checked == 16 * per_trial and flips == 0
+  assert worst <= 1e-5 * np.max(np.abs(scores))

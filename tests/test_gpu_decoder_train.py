@@ -280,3 +280,32 @@ def test_lda_scatter_on_the_device():
   np.testing.assert_allclose(devm.transform(x)[:, 0], host.transform(x)[:, 0], rtol=1e-4, atol=1e-5)
   for a, b in zip(devm.mean_vectors, host.mean_vectors):
     np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_device_lda_dprime_on_heavy_tailed_correlations_matches_host():
+  """Decoder.train with window_size <= 1 takes its LDA class moments on the device and d'
+  from those moments; compute_lda_model (host float64, projected samples) is the reference
+  formulation (infer_decoder.py:506-536).  On per-frame correlation products with a heavy tail
+  (one frame in a thousand 300x the rest) the two agree to 1e-5 -- the device moments use the
+  float32 matrix instruction whatever accumulate mode the handle's fits use, and restore it."""
+  from telluride_decoding_amd import device as dev, infer_decoder
+  rng = np.random.default_rng(33)
+  n, dims = 60000, 5
+  def corr(shift):
+    a = rng.standard_normal((n, dims)) * rng.standard_normal((n, dims)) + shift
+    spikes = rng.random((n, dims)) < 1e-3
+    a[spikes] *= 300.0
+    return a.astype(np.float32)
+  c0, c1 = corr(0.0), corr(np.linspace(0.05, 0.4, dims))
+  h = dev.default_handle()
+  host = infer_decoder.Decoder(lambda v: v, reduction='lda')
+  d_host = host.compute_lda_model(c0.astype(np.float64), c1.astype(np.float64))
+  devd = infer_decoder.Decoder(lambda v: v, reduction='lda')
+  assert h.accumulate_mode == 'f16x2'
+  d_dev = devd._compute_lda_model_device([h.to_device(c0), h.to_device(c1)])
+  assert h.accumulate_mode == 'f16x2'
+  assert abs(abs(d_dev) - abs(d_host)) <= 1e-5 * abs(d_host), (d_dev, d_host)
+  # the SCALED axis (slope * w) maps the class means to fixed targets: no sign ambiguity
+  v_h = np.real(np.asarray(host.lda_params.w_real))[:, 0] * host.lda_params.slope
+  v_d = np.real(np.asarray(devd.lda_params.w_real))[:, 0] * devd.lda_params.slope
+  np.testing.assert_allclose(v_d, v_h, rtol=2e-5, atol=1e-6 * np.max(np.abs(v_h)))

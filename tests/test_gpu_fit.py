@@ -1311,3 +1311,88 @@ def test_two_ranks_on_one_gpu_allreduce_and_loso_sweep(dev, tmp_path):
   for r, (p, out) in enumerate(zip(procs, outs)):
     assert p.returncode == 0, 'rank %d:\n%s' % (r, out[-3000:])
     assert 'rank %d ok' % r in out
+
+
+@pytest.mark.parametrize('name', ['nolag', 'post3'])
+def test_c1_exact_config_matches_reference_golden(dev, name):
+  """BASELINE.json configs[0] at its stated size -- ONE 16-channel x 10 000-sample recording, batch
+  100, lambda = 0.1 -- against the reference's own float32 output (golden G12) and the float64
+  oracle: strict 1e-5 (the other C1 goldens are 2-3 files x 2 500)."""
+  g = golden('g12_c1_10k')
+  pre, post, batch = (int(v) for v in g[name + '_cfg'])
+  h = dev.default_handle()
+  eeg, env = g['eeg'], g['env']
+  assert eeg.shape == (10000, 16)
+  st = dev.LagStats(16, pre, post, d=1)
+  st.accumulate(h.to_device(eeg), None, h.to_device(env[:, 0:1]), [0, 10000])
+  w, b = st.ridge_solve([0.1])
+  w, b = w.cpu().numpy()[0].astype(np.float64), b.cpu().numpy().astype(np.float64)
+  w32, b32 = g[name + '_w'].astype(np.float64), g[name + '_b'].astype(np.float64)
+  files = [(eeg.astype(np.float64), env[:, 1:2].astype(np.float64), env[:, 0:1].astype(np.float64),
+            np.zeros((10000, 1)))]
+  w64, b64, cx64, _, _ = o_reg.linear_regressor_from_batches(
+      o_lag.minibatches(files, batch, pre=pre, post=post), lamb=0.1)
+  scale = np.max(np.abs(w64))
+  d_gpu_64 = max(np.max(np.abs(w - w64)), np.max(np.abs(b - b64))) / scale
+  d_32_64 = max(np.max(np.abs(w32 - w64)), np.max(np.abs(b32 - b64))) / scale
+  d_gpu_32 = max(np.max(np.abs(w - w32)), np.max(np.abs(b - b32))) / scale
+  parity_log.record('ridge_golden_c1_10k_' + name, gpu_ref64=d_gpu_64, ref32_ref64=d_32_64,
+                    gpu_ref32=d_gpu_32, strict=bool(d_gpu_32 < 1e-5))
+  assert d_gpu_64 < 1e-5 and d_gpu_32 < 1e-5, (d_gpu_64, d_32_64, d_gpu_32)
+  # the regularised covariance the function also returns (brain_model.py:478-481)
+  m = st.moments()
+  cov = m['xtx'].cpu().numpy() / 10000.0
+  cov[np.diag_indices_from(cov)] += 0.1
+  assert np.max(np.abs(cov - g[name + '_cov_x'])) <= 2e-6 * np.max(np.abs(cov))
+  assert np.max(np.abs(cov - cx64)) <= 2e-7 * np.max(np.abs(cov))
+
+
+@pytest.mark.parametrize('ratio_log2', [18, 24])
+def test_within_channel_outlier_accumulate_and_weights(dev, ratio_log2):
+  """ONE artefact sample 2^18 (and 2^24) times a unit-variance channel's level: the
+  float16 two-piece form scales a channel by its LARGEST magnitude, so the ordinary samples of that
+  channel sit 18 (24) binades below the top of the float16 range and their low piece goes
+  subnormal (td_common.h: absolute error <= 2^-39 of the channel maximum per value).  All three
+  accumulate modes against float64 moments -- every entry relative to sqrt(diag_i diag_j) -- and
+  the ridge weights they lead to against the float64 oracle.  A mode that cannot hold 2e-7 on the
+  moments of this input is not allowed to run it: the float16 form hands such a call to the bf16
+  three-piece kernel (range guard, lagcov.hip), which is what this test then measures under
+  'f16x2'."""
+  rng = np.random.default_rng(18)
+  h = dev.default_handle()
+  n, c, post = 20000, 64, 31
+  x = rng.standard_normal((n, c)).astype(np.float32)
+  x[7777, 5] = np.float32(2.0 ** ratio_log2)
+  y = (x[:, 3:4] * 0.7 + 0.2 * x[:, 40:41] + rng.standard_normal((n, 1))).astype(np.float32)
+  xl = o_lag.lag_matrix(x.astype(np.float64), 0, post)
+  xl1 = np.hstack((xl, np.ones((n, 1))))
+  want, want_y = xl1.T @ xl1, xl1.T @ y.astype(np.float64)
+  scale = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+  cov = want / n
+  cov[np.diag_indices_from(cov)] += 0.1
+  sol = np.linalg.solve(cov, want_y / n)
+  w64 = sol[:-1]
+  errs = {}
+  try:
+    for mode in ('f16x2', 'bf16x3', 'f32'):
+      h.set_accumulate_mode(mode)
+      st = dev.LagStats(c, 0, post, d=1)
+      st.accumulate(h.to_device(x), None, h.to_device(y), [0, n])
+      m = st.moments()
+      e_m = float(np.max(np.abs(m['xtx'].cpu().numpy() - want) / scale))
+      # ... and where it matters: the entries that do NOT involve the artefact channel must not feel it
+      clean = np.ones(want.shape[0], bool)
+      clean[5:c * (post + 1):c] = False
+      got = m['xtx'].cpu().numpy()
+      e_clean = float(np.max(np.abs(got[np.ix_(clean, clean)] - want[np.ix_(clean, clean)]) /
+                             scale[np.ix_(clean, clean)]))
+      w = st.ridge_solve([0.1])[0].cpu().numpy()[0].astype(np.float64)
+      e_w = float(np.max(np.abs(w - w64)) / np.max(np.abs(w64)))
+      errs[mode] = (e_m, e_clean, e_w)
+      parity_log.record('outlier_2^%d_%s' % (ratio_log2, mode), moments=e_m, clean_moments=e_clean,
+                        weights_vs_ref64=e_w)
+  finally:
+    h.set_accumulate_mode('f16x2')
+  for mode, (e_m, e_clean, e_w) in errs.items():
+    assert e_m < 2e-7 and e_clean < 2e-7, (mode, errs)
+    assert e_w < 1e-5, (mode, errs)
