@@ -563,6 +563,9 @@ def main():
                        'after seconds of host-side set-up the first ~25 launches run in a power / '
                        'clock transient (tools/clock_transient.py); 0 = none')
   ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+  ap.add_argument('--strong-samples', type=int, default=FILES_PER_GPU * FRAMES_PER_FILE,
+                  help='samples of the ONE job a strong-scaling run shares (default 1e6 = C2; SURVEY 8e: "state '
+                       'N" -- at 8e6 a rank\'s 1/8 share is a whole C2 job and the fixed costs amortise)')
   ap.add_argument('--no-decode', action='store_true', help='skip the informational decode leg')
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
   ap.add_argument('--no-extra', action='store_true', help='skip the C3 / C5 legs')
@@ -675,11 +678,18 @@ def main():
         s, plan, rank, total_frames=sum(plan.file_lengths), handle=hs)) if dist_on else None
     return (eeg, env), (x, y, offs, kw), reduce_fn, None, full * world
 
-  def strong_setup():
+  def strong_setup(total_samples=None, n_ranks=None, as_rank=None):
+    total_samples = int(total_samples or args.strong_samples)
+    n_ranks = world if n_ranks is None else n_ranks
+    as_rank = rank if as_rank is None else as_rank
+    reps = max(1, int(round(total_samples / float(full))))
     eeg, env, offs = make_workload(0)                    # the SAME job on every rank
+    if reps > 1:                                         # (a longer job: the recordings repeated)
+      eeg, env = np.tile(eeg, (reps, 1)), np.tile(env, (reps, 1))
+      offs = np.arange(FILES_PER_GPU * reps + 1, dtype=np.int64) * FRAMES_PER_FILE
     hw = PRE + POST + 1
-    plan = distributed.TimeShardPlan([FRAMES_PER_FILE] * FILES_PER_GPU, world, halo=hw)
-    pieces = plan.pieces_of(rank)
+    plan = distributed.TimeShardPlan([FRAMES_PER_FILE] * (FILES_PER_GPU * reps), n_ranks, halo=hw)
+    pieces = plan.pieces_of(as_rank)
     xs = np.concatenate([eeg[offs[f] + a:offs[f] + b] for f, a, b, *_ in pieces])
     ys = np.concatenate([env[offs[f] + a:offs[f] + b] for f, a, b, *_ in pieces])
     loc = np.concatenate(([0], np.cumsum([b - a for _, a, b, *_ in pieces]))).astype(np.int64)
@@ -689,7 +699,7 @@ def main():
     reduce_fn = (lambda s, hs: distributed.allreduce_stats(
         s, plan, rank, total_frames=plan.total_frames, handle=hs)) if dist_on else None
     solves = (lambda i: i % world == rank) if world > 1 else None
-    return (eeg, env), (x, y, loc, kw), reduce_fn, solves, full
+    return (eeg, env), (x, y, loc, kw), reduce_fn, solves, full * reps
 
   def make_runner(shard, reduce_fn, solves, serial):
     x, y, offs, kw = shard
@@ -899,6 +909,24 @@ def main():
   if rank == 0:
     line['collective'] = (dict(distributed.LAST_COLLECTIVE) if distributed.LAST_COLLECTIVE else
                           {'route': 'none (one rank, no exchange)', 'ranks': 1})
+  if world == 1 and args.scaling == 'weak' and not args.no_extra:
+    # What ONE GPU can say about strong scaling (no multi-GPU node was ever available to this
+    # build): the accumulate call of rank 0's 1/8 share of the job against the whole job -- the
+    # bound on the 8-GPU speed-up of the accumulate before the collective -- at 1e6 samples (C2) and
+    # at 8e6 (a strong-scaling run must state N; at 8e6 a rank's share is a whole C2 job).
+    bound = {}
+    for total in (full, 8 * full):
+      t = {}
+      for nr in (1, 8):
+        _, sh, _, _, _ = strong_setup(total, n_ranks=nr, as_rank=0)
+        t[nr] = accumulate_only(sh, steps=20 if total == full else 8)
+        del sh
+        gc.collect()
+      bound['%.0e_samples' % total] = {'whole_job_ms': t[1], 'one_eighth_share_ms': t[8],
+                                       'speedup_bound_of_8': t[1] / t[8]}
+    bound['what'] = ('accumulate call (targets + lag kernel + finalize) of rank 0 of a distributed.TimeShardPlan '
+                     'over 8 ranks vs over 1, same GPU, serial; the all-reduce (0.5 MB) comes on top')
+    line['strong_share_bound_one_gpu'] = bound
   if world > 1 and args.scaling == 'weak':
     # informational strong-scaling leg: the ONE-GPU job cut into N time ranges
     _, shard2, reduce2, solves2, _ = strong_setup()
@@ -909,11 +937,26 @@ def main():
     acc2 = accumulate_only(shard2)
     if rank == 0:
       line['strong'] = {
-          'workload': 'the single-GPU job (1e6 samples) cut into %d time ranges + halo' % world,
-          'fit_ms_per_step': e2 / 50 * 1e3, 'samples_per_s': full * 50 / e2,
+          'workload': 'the single-GPU job (%d samples) cut into %d time ranges + halo' % (args.strong_samples, world),
+          'fit_ms_per_step': e2 / 50 * 1e3, 'samples_per_s': args.strong_samples * 50 / e2,
           'accumulate_only_ms_per_step': acc2,
           'note': 'divide the N = 1 run\'s accumulate_only_ms_per_step / ms_per_step by these for '
                   'the strong-scaling speed-up',
+      }
+    # ... and the same at 8e6 samples (a rank's share of 8 is then a whole C2 job): N stated, SURVEY 8e
+    del shard2
+    _, shard3, reduce3, solves3, n3 = strong_setup(8 * full)
+    run3, _, pipe3 = make_runner(shard3, reduce3, solves3, False)
+    e3, _ = time_region(run3, 20, 3)
+    del pipe3, run3
+    torch.cuda.synchronize()
+    acc3 = accumulate_only(shard3, steps=10)
+    if rank == 0:
+      line['strong_8e6'] = {
+          'workload': 'ONE job of %d samples cut into %d time ranges + halo' % (n3, world),
+          'fit_ms_per_step': e3 / 20 * 1e3, 'samples_per_s': n3 * 20 / e3,
+          'accumulate_only_ms_per_step': acc3,
+          'one_gpu_reference': 'strong_share_bound_one_gpu["8e+06_samples"].whole_job_ms of the N = 1 line',
       }
 
   if rank == 0:

@@ -48,7 +48,7 @@ class FitPipeline(object):
   """
 
   def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=64, targets_on_solve=False,
-               buffers=None, solves=None, solve_streams=2):
+               buffers=None, solves=None, solve_streams=2, latency_flush=True):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -120,6 +120,10 @@ class FitPipeline(object):
     self._results = []           # queued solves: (w, b, flag reader, event)
     self.count = 0
     self.allreduce = allreduce   # optional callable(stats, handle), run on the SOLVE stream
+    # flush(): the last fit of a burst is solved by the one-launch conjugate-gradient kernel on the
+    # whole chip (single-GPU pipelines without an exchange; False = the solve streams' Cholesky)
+    self.latency_flush = latency_flush
+    self.h_full = self.s_full = None
     self.targets_on_solve = targets_on_solve
 
   def _solve(self, buf, lambdas, args, kw, index=0):
@@ -178,11 +182,35 @@ class FitPipeline(object):
     self.pending = (buf, np.atleast_1d(lambdas), (x, None, y, file_offsets), kw, self.count - 1)
     return self._pop() if len(self._results) > len(self.s_solves) else None
 
+  def _solve_last(self, buf, lambdas, args, kw, index=0):
+    """The solve of the LAST fit of a burst, which no accumulate runs beside: the latency solver --
+    one conjugate-gradient launch with the matrix resident in the LDS of the whole chip (cg.hip:
+    0.36 ms where the chain of the blocked Cholesky takes 1.1) -- on an unmasked stream of its own,
+    synchronously (the caller is about to wait for it anyway).  td_ridge_solve falls back to the
+    Cholesky by itself when the conjugate gradients do not converge."""
+    torch = self.torch
+    if self.h_full is None:
+      self.s_full = torch.cuda.Stream()
+      with torch.cuda.stream(self.s_full):
+        self.h_full = device.Handle()
+    with torch.cuda.stream(self.s_full):
+      self.s_full.wait_event(self.ev_acc[buf])
+      w, b = self.stats[buf].ridge_solve(lambdas, handle=self.h_full)     # (synchronises s_full)
+      ev = torch.cuda.Event()
+      ev.record(self.s_full)
+      self.ev_solved[buf] = ev
+    self._results.append((w, b, (lambda: 0), ev))
+
   def flush(self):
     """Solves the last submitted fit and returns every solution not yet handed out (a list,
     oldest first), all waited for."""
     if self.pending is not None:
-      self._solve(*self.pending)
+      plain = (self.allreduce is None and self.solves is None and not self.targets_on_solve and
+               self.latency_flush)
+      if plain:
+        self._solve_last(*self.pending)
+      else:
+        self._solve(*self.pending)
       self.pending = None
     out = []
     while self._results:

@@ -27,4 +27,6 @@ def test_bench_two_ranks_share_the_gpu():
   assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launcher'] == 'self'
   assert line['steps'] == 3 and line['value'] > 0 and line['scaling'] == 'weak'
   assert line['strong']['fit_ms_per_step'] > 0
+  assert line['strong_8e6']['fit_ms_per_step'] > 0 and line['strong_8e6']['samples_per_s'] > 0
+  assert line['collective']['ranks'] == 2
   assert line['roofline']['launches'] == 3

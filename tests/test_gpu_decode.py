@@ -720,8 +720,8 @@ def test_long_window_sums_match_float64(dev, rows, width, hop):
 
 def test_decode_fused_at_full_c4_size(dev):
   """BASELINE config C4 at its full size -- 200 DISTINCT trials x 6000 frames x 64 channels, W = 1000,
-  hop = 100 -- through td_decode_fused: every one of the 10 200 scores and decisions bit-identical to
-  the unfused kernel chain (FIR prediction -> window sums -> scores -> winner-take-all), and a seeded
+  hop = 100 -- through td_decode_fused: every one of the 10 200 decisions identical to (and every score
+  within 4e-15 of) the unfused kernel chain (FIR prediction -> window sums -> scores -> winner-take-all), and a seeded
   subset of 16 trials against the float64 oracle chain with 0 decision flips (the full
   size was only checked inside bench.py, on 20 distinct trials)."""
   from telluride_decoding_amd import synth
@@ -748,13 +748,18 @@ def test_decode_fused_at_full_c4_size(dev):
   scores, decisions = scores.cpu().numpy(), decisions.cpu().numpy()
   per_trial = (frames - width) // hop + 1
   assert scores.shape == (n_trials * per_trial, 2) == (10200, 2)
-  # (1) all trials: fused == unfused, bit for bit
+  # (1) all trials: fused == unfused -- the same float64 block sums; the score formula is contracted
+  # into fused multiply-adds differently in the two kernels, so a score may differ in its last bits
+  # (1 of 10 200 did, by 2.7e-16 relative); the decisions must be identical
+  unfused = []
   for spk in (0, 1):
     sums = dev.window_sums(envd[:, spk:spk + 1], pred, offs, width, hop, handle=h)
     want = dev.window_scores(sums, width, 0, 'first', corr[3 * spk], corr[3 * spk + 1],
                              corr[3 * spk + 2], handle=h).cpu().numpy()
-    np.testing.assert_array_equal(scores[:, spk], want)
+    unfused.append(want)
+    np.testing.assert_allclose(scores[:, spk], want, rtol=4e-15, atol=1e-19)
   np.testing.assert_array_equal(decisions, scores[:, 0] > scores[:, 1])
+  np.testing.assert_array_equal(decisions, unfused[0] > unfused[1])
   # (2) a seeded subset against the oracle chain in float64
   wn, bn = w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
   subset = sorted(np.random.default_rng(4).choice(n_trials, 16, replace=False).tolist())
