@@ -147,9 +147,16 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
  * TD_ACC_TARGETS = [y | 1]^T x~ (Xty, the bias moments, sum y) and the lagged column sums of
  * input_2.  Both parts of a call take identical arguments; TARGETS must be ordered after
  * MAIN of the same files (it reads their boundary windows).  parts = 3 is
- * td_stats_accumulate. */
+ * td_stats_accumulate.
+ * TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST (regression statistics): the targets part AHEAD of the MAIN
+ * call of the same files, possibly on another handle / stream -- it streams every row the matrix
+ * kernel will read (HBM-bound, ~65 us at C2) and also measures the channel maxima the float16
+ * accumulate scales by, leaving them in the statistics object; the MAIN call that follows (ordered
+ * after it by the caller: an event) then starts its matrix kernel at once.  A pipeline runs
+ * targets(i + 1) beside the matrix kernel of fit i this way (pipeline.FitPipeline). */
 #define TD_ACC_MAIN 1
 #define TD_ACC_TARGETS 2
+#define TD_ACC_TARGETS_FIRST 4
 int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
                               const float* x2_dev, int64_t ldx2, const float* y_dev,
                               int64_t ldy, const int64_t* file_offsets_host, int num_files,

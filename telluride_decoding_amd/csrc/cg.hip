@@ -202,23 +202,28 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
 #pragma unroll
       for (int jj = 0; jj < kCgMaxCols / 2; ++jj) {
         // (no branch around the loads: a pair past k reads the last pair against zeros -- with a branch
-        // per group the groups of row reads wait for one another: 1.5 us instead of 0.4)
+        // per group the groups of row reads wait for one another: 1.5 us instead of 0.4.  In the check
+        // pass r_ HOLDS x: the residual is not needed any more, and a select per entry is not free)
         const int c = cg_col(t, 2 * jj);
-        const double v0 = c < k ? (check_pass ? x[2 * jj] : r_[2 * jj]) : 0.0;
-        const double v1 = c + 1 < k ? (check_pass ? x[2 * jj + 1] : r_[2 * jj + 1]) : 0.0;
+        const double v0 = c < k ? r_[2 * jj] : 0.0;
+        const double v1 = c + 1 < k ? r_[2 * jj + 1] : 0.0;
         const int cc = c < k ? c : ks - 2;
-        sx += s_reg[2 * jj] * x[2 * jj] + s_reg[2 * jj + 1] * x[2 * jj + 1];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const cg_f64x2 a = *reinterpret_cast<const cg_f64x2*>(rows + (size_t)r * ks + cc);
-          acc[r] += a.x * v0 + a.y * v1;
+          acc[r] = fma(a.x, v0, acc[r]);
+          acc[r] = fma(a.y, v1, acc[r]);
         }
       }
       // (after the loads: an LDS store between them, possibly aliasing, would serialise the row reads)
 #pragma unroll
       for (int j = 0; j < kCgMaxCols; ++j) {
         const int c = cg_col(t, j);
-        if (c >= i0 && c < i0 + R && c < k) prow[c - i0] = check_pass ? x[j] : r_[j];
+        if (c >= i0 && c < i0 + R && c < k) prow[c - i0] = r_[j];
+      }
+      if (check_pass) {
+#pragma unroll
+        for (int j = 0; j < kCgMaxCols; ++j) sx = fma(s_reg[j], x[j], sx);
       }
       if (check_pass) {
         sx = wave_sum(sx);
@@ -340,6 +345,8 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
       if (gamma <= P.tol2 * bnorm2) {       // r (whose product just came back) is small: x is the answer;
         check_pass = true;                  // look at its TRUE residual with one more product
         --it;                               // (the product with the converged r was not a step)
+#pragma unroll
+        for (int j = 0; j < kCgMaxCols; ++j) r_[j] = x[j];       // (the product is taken with r_)
         continue;
       }
       if (it >= P.max_iter) { status = 2; break; }

@@ -44,6 +44,11 @@ struct td_stats {
   // `fresh_main` covers fxx and n, `fresh_tgt` gxo and sy -- and no memset is queued.  Every
   // other reader of `g` calls stats_materialize first.
   bool fresh_main = false, fresh_tgt = false;
+  // Channel maxima measured by a TARGETS call that runs AHEAD of the MAIN call of the same files
+  // (TD_ACC_TARGETS_FIRST: pipelined fits take the HBM-bound targets pass off the stream the matrix
+  // kernel runs on): the float16 lag kernel of that MAIN call scales by them, from whichever handle.
+  unsigned* chan_tab = nullptr;
+  bool tab_ready = false;
 };
 
 namespace {
@@ -781,11 +786,13 @@ int td_stats_destroy(td_handle* h, td_stats* s) {
     td_free_async(h, s->g);
     td_free_async(h, s->win1);
     td_free_async(h, s->win2);
+    td_free_async(h, s->chan_tab);
   } else {
     hipDeviceSynchronize();
     if (s->g) hipFree(s->g);
     if (s->win1) hipFree(s->win1);
     if (s->win2) hipFree(s->win2);
+    if (s->chan_tab) hipFree(s->chan_tab);
   }
   delete s;
   return TD_OK;
@@ -801,6 +808,7 @@ int td_stats_reset(td_handle* h, td_stats* s) {
   }
   s->n_files = 0;
   s->frames = 0;
+  s->tab_ready = false;
   return TD_OK;
 }
 
@@ -973,7 +981,7 @@ namespace {
 int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx, const float* y_dev,
                      int64_t ldy, const std::vector<LagSeg>& sxx, const std::vector<LagSeg>& syx,
                      const std::vector<WinJob>& j1, int num_files, int64_t new_frames,
-                     int64_t first_slot, bool do_main, bool do_targets) {
+                     int64_t first_slot, bool do_main, bool do_targets, bool tgt_first) {
   LagcovPlan mp;
   TargetsPlan tp;
   PrepassPlan pp;
@@ -1046,16 +1054,31 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     if (do_main && mp.f16 && s->pre1 == 0) {
       TD_TRY(td_chan_tab(h, &to.maxtab));
       mp.tab = to.maxtab;
+    } else if (!do_main && tgt_first && s->pre1 == 0 && h->acc_mode == TD_ACC_F16X2) {
+      // ahead of the MAIN call (which may run on another handle): the maxima go into the statistics'
+      // own table, zeroed here in stream order
+      if (!s->chan_tab) {
+        void* p = nullptr;
+        TD_TRY(td_alloc_async(h, sizeof(unsigned) * kChanTab, &p));
+        s->chan_tab = reinterpret_cast<unsigned*>(p);
+      }
+      TD_HIP(h, hipMemsetAsync(s->chan_tab, 0, sizeof(unsigned) * kChanTab, h->stream));
+      to.maxtab = s->chan_tab;
+      s->tab_ready = true;
     }
     TD_TRY(td_lagcov_targets_launch(h, &tp, base + main_bytes, s->g + s->off_gxo, !s->fresh_tgt, &to));
   }
   if (do_main) {
     LagReduceJob job, tjob;
+    // (the maxima a TARGETS_FIRST call of these files left in the statistics: no pre-pass here)
+    const bool ahead = !do_targets && s->tab_ready && mp.f16 && s->pre1 == 0;
+    if (ahead) mp.tab = s->chan_tab;
+    s->tab_ready = false;
     TD_TRY(td_lagcov_launch(h, &mp, base, s->g + s->off_fxx, !s->fresh_main, 0, 0, &job,
                             s->g + s->off_gxo, !s->fresh_tgt, s->d + 1, folded ? &tjob : nullptr));
     add_reduce(job);
     if (folded) add_reduce(tjob);
-    if (mp.f16) {                // this call used table chan_phase & 1: clear the other for the next
+    if (mp.f16 && !ahead) {      // this call used table chan_phase & 1: clear the other for the next
       ++h->chan_phase;
       fp.zero_tab = h->chan_max + kChanTab * (h->chan_phase & 1);
     }
@@ -1107,8 +1130,12 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
              "td_stats_accumulate_ranges: give both range arrays or neither");
   TD_REQUIRE(h, !range_begin_host || input_offset == 0,
              "td_stats_accumulate_ranges: time ranges need input_offset = 0");
-  TD_REQUIRE(h, parts >= 1 && parts <= 3, "td_stats_accumulate_parts: parts must be 1, 2 or 3");
+  TD_REQUIRE(h, (parts >= 1 && parts <= 3) || parts == (TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST),
+             "td_stats_accumulate_parts: parts must be 1, 2, 3 or TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST");
   const bool do_main = (parts & TD_ACC_MAIN) != 0, do_targets = (parts & TD_ACC_TARGETS) != 0;
+  const bool tgt_first = (parts & TD_ACC_TARGETS_FIRST) != 0;
+  TD_REQUIRE(h, !tgt_first || stats_fusable(s),
+             "td_stats_accumulate_parts: TARGETS_FIRST is for regression statistics (targets, no second input)");
   TD_REQUIRE(h, x_dev && file_offsets_host && num_files >= 0, "td_stats_accumulate: NULL input");
   TD_REQUIRE(h, ldx >= s->c1, "ldx (%lld) < channels (%d)", (long long)ldx, s->c1);
   TD_REQUIRE(h, !s->c2 || (x2_dev && ldx2 >= s->c2), "input_2 missing or ldx2 too small");
@@ -1171,8 +1198,8 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
 
   // window slot of the first new file: MAIN appends the files, a TARGETS-only call comes
   // after the MAIN call of the same files
-  const int64_t first_slot = do_main ? s->n_files : s->n_files - num_files;
-  TD_REQUIRE(h, first_slot >= 0, "td_stats_accumulate_parts: TARGETS before MAIN");
+  const int64_t first_slot = (do_main || tgt_first) ? s->n_files : s->n_files - num_files;
+  TD_REQUIRE(h, first_slot >= 0, "td_stats_accumulate_parts: TARGETS before MAIN (say TD_ACC_TARGETS_FIRST)");
   // CCA without context on either input: every moment is one Gram matrix of [x | x2 | 1]
   // (td_gram), done by MAIN; TARGETS then has nothing left to add.
   const bool one_pass = stats_one_pass(s);
@@ -1180,7 +1207,8 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
   static const bool no_fuse = getenv("TD_ACC_UNFUSED") != nullptr;     // development: A/B runs
   if (stats_fusable(s) && new_frames > 0 && !no_fuse)
     return accumulate_fused(h, s, x_dev, ldx, y_dev, ldy, sxx, syx, j1, num_files, new_frames,
-                            first_slot, do_main, do_targets);
+                            first_slot, do_main, do_targets, tgt_first);
+  TD_REQUIRE(h, !tgt_first, "td_stats_accumulate_parts: TARGETS_FIRST needs the fused accumulate path");
   // (the one-pass Gram reduction overwrites fresh statistics itself)
   const bool gram_fresh = one_pass && do_main && s->fresh_main && s->fresh_tgt && new_frames > 0;
   if (!gram_fresh) TD_TRY(stats_materialize(h, s));

@@ -194,7 +194,9 @@ class LagStats(object):
     """x [rows, c1], x2 [rows, c2] / y [rows, d]: device float32 tensors holding
     the files concatenated along time; file_offsets has F+1 row offsets.
     parts: 1 = covariances + windows + counters, 2 = targets / bias moments (after part 1 of
-    the same files, possibly on another handle's stream), 3 = both.
+    the same files, possibly on another handle's stream), 3 = both; 2 | 4 = the targets part
+    AHEAD of part 1 of the same files (TD_ACC_TARGETS_FIRST: it also leaves the channel maxima
+    the float16 matrix kernel of part 1 scales by in the statistics).
     ranges: per file (begin, end) rows of the file that this call sums, for ranks that share a
     long recording by time range (each holds its range plus a halo of pre + post rows);
     edges: per file bit 0 / bit 1 = the piece holds the recording's first / last row

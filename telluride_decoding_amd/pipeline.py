@@ -48,7 +48,7 @@ class FitPipeline(object):
   """
 
   def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=64, targets_on_solve=False,
-               buffers=None, solves=None, solve_streams=2, latency_flush=True):
+               buffers=None, solves=None, solve_streams=2, latency_flush=True, targets_ahead=False):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -80,23 +80,43 @@ class FitPipeline(object):
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     self.s_acc = None
     self.s_solves = []
+    self.s_tgt = self.h_tgt = None
+    # targets_ahead: the y^T x~ / bias / channel-maximum pass of fit i + 1 (HBM-bound, ~65 us at C2) runs
+    # on a stream of its own on the solve partition while the matrix kernel of fit i fills the
+    # accumulate partition, and leaves the maxima in the statistics (TD_ACC_TARGETS_FIRST): the
+    # accumulate stream then carries the matrix kernel and its finalize launch only.
+    # OFF by default -- measured at C2 (round 4): on the 64 CUs of the solve partition the HBM-bound
+    # targets kernel takes 230-300 us (68 us on the whole chip) and stalls the two Cholesky chains it
+    # shares them with (1.06 -> 1.37 ms per solve); the solve partition becomes the slower stage and
+    # the pipelined fit goes 0.92 -> 1.14 ms.  The matrix kernel's workgroups own every register and
+    # most of the LDS of their CUs, so a streaming kernel cannot hide beside it on the accumulate
+    # partition either.
+    self.targets_ahead = bool(targets_ahead) and not targets_on_solve
+    n_extra = 1 if self.targets_ahead else 0
     if solve_cus and 0 < solve_cus < n_cu:
       ptrs = []
-      for first, count in [(solve_cus, n_cu - solve_cus)] + [(0, solve_cus)] * solve_streams:
+      for first, count in [(solve_cus, n_cu - solve_cus)] + [(0, solve_cus)] * (solve_streams + n_extra):
         p = ctypes.c_void_p()
         if lib.td_stream_create_masked(dev, first, count, ctypes.byref(p)) != _lib.TD_OK:
           break
         ptrs.append(p)
-      if len(ptrs) == 1 + solve_streams:
+      if len(ptrs) == 1 + solve_streams + n_extra:
         self._masked = ptrs
         self.s_acc = torch.cuda.ExternalStream(ptrs[0].value)
-        self.s_solves = [torch.cuda.ExternalStream(p.value) for p in ptrs[1:]]
+        self.s_solves = [torch.cuda.ExternalStream(p.value) for p in ptrs[1:1 + solve_streams]]
+        if n_extra:
+          self.s_tgt = torch.cuda.ExternalStream(ptrs[-1].value)
       else:
         for p in ptrs:
           lib.td_stream_destroy(p)
     if self.s_acc is None:
       self.s_acc = torch.cuda.Stream()
       self.s_solves = [torch.cuda.Stream() for _ in range(solve_streams)]
+      if n_extra:
+        self.s_tgt = torch.cuda.Stream()
+    if self.s_tgt is not None:
+      with torch.cuda.stream(self.s_tgt):
+        self.h_tgt = device.Handle()
     with torch.cuda.stream(self.s_acc):
       self.h_acc = device.Handle()
     self.h_solves = []
@@ -107,14 +127,15 @@ class FitPipeline(object):
     if self._masked:
       # the accumulate plans its work items for the CUs it really has
       self.h_acc.check(lib.td_set_cu_count(self.h_acc.ptr, n_cu - solve_cus))
-      for hs in self.h_solves:
+      for hs in self.h_solves + ([self.h_tgt] if self.h_tgt is not None else []):
         hs.check(lib.td_set_cu_count(hs.ptr, solve_cus))
     owner = _MaskedStreams(self._masked)
     self.h_acc.keepalive = owner
-    for hs in self.h_solves:
+    for hs in self.h_solves + ([self.h_tgt] if self.h_tgt is not None else []):
       hs.keepalive = owner
     self.stats = [device.LagStats(c, pre, post, d=d, handle=self.h_acc) for _ in range(buffers)]
     self.ev_acc = [torch.cuda.Event() for _ in range(buffers)]
+    self.ev_tgt = [torch.cuda.Event() for _ in range(buffers)]
     self.ev_solved = [None] * buffers
     self.pending = None          # (buffer index, lambdas) of the fit whose solve is not queued yet
     self._results = []           # queued solves: (w, b, flag reader, event)
@@ -170,12 +191,23 @@ class FitPipeline(object):
     torch = self.torch
     buf = self.count % len(self.stats)
     self.count += 1
+    st = self.stats[buf]
+    if self.targets_ahead:
+      with torch.cuda.stream(self.s_tgt):
+        if self.ev_solved[buf] is not None:
+          self.s_tgt.wait_event(self.ev_solved[buf])
+        st.reset()
+        st.accumulate(x, None, y, file_offsets, parts=2 | 4, handle=self.h_tgt, **kw)
+        self.ev_tgt[buf].record(self.s_tgt)
     with torch.cuda.stream(self.s_acc):
-      if self.ev_solved[buf] is not None:
-        self.s_acc.wait_event(self.ev_solved[buf])
-      st = self.stats[buf]
-      st.reset()
-      st.accumulate(x, None, y, file_offsets, parts=1 if self.targets_on_solve else 3, **kw)
+      if self.targets_ahead:
+        self.s_acc.wait_event(self.ev_tgt[buf])
+        st.accumulate(x, None, y, file_offsets, parts=1, **kw)
+      else:
+        if self.ev_solved[buf] is not None:
+          self.s_acc.wait_event(self.ev_solved[buf])
+        st.reset()
+        st.accumulate(x, None, y, file_offsets, parts=1 if self.targets_on_solve else 3, **kw)
       self.ev_acc[buf].record(self.s_acc)
     if self.pending is not None:
       self._solve(*self.pending)

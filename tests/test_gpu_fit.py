@@ -1395,3 +1395,55 @@ def test_within_channel_outlier_accumulate_and_weights(dev, ratio_log2):
   for mode, (e_m, e_clean, e_w) in errs.items():
     assert e_m < 2e-7 and e_clean < 2e-7, (mode, errs)
     assert e_w < 1e-5, (mode, errs)
+
+
+@pytest.mark.parametrize('c,post,lens,off,drop', [
+    (64, 31, (9000, 4000, 6001), 0, 0),       # the float16 matrix kernel: maxima travel in the statistics
+    (64, 15, (5000, 5000), 0, 37),            # a dropped remainder
+    (40, 7, (3000, 2500), 0, 0),              # float32 matrix kernel (<= 32... no: 40 channels, 8 lags)
+    (16, 3, (2000, 1500), 2, 13),             # narrow: no maxima at all; input_offset
+])
+def test_targets_first_equals_the_fused_call(dev, c, post, lens, off, drop):
+  """TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST on ANOTHER handle and stream, then TD_ACC_MAIN (what
+  pipeline.FitPipeline queues: targets(i + 1) beside the matrix kernel of fit i): the statistics --
+  and the weights -- are bit-identical to the one fused call (same kernels, same maxima, same
+  reduction order)."""
+  import torch
+  rng = np.random.default_rng(c + post)
+  h = dev.default_handle()
+  n = sum(lens)
+  x = (rng.standard_normal((n, c)) * np.logspace(-1, 1, c)).astype(np.float32)
+  y = (x[:, :1] * 0.3 + rng.standard_normal((n, 1))).astype(np.float32)
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  zipped = [m - abs(off) for m in lens]
+  used = list(zipped)
+  used[-1] -= drop
+  xd, yd = h.to_device(x), h.to_device(y)
+  ref = dev.LagStats(c, 0, post, d=1, handle=h)
+  ref.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used)
+  m_ref = ref.moments()
+  w_ref = ref.ridge_solve([0.1])[0].cpu().numpy()
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):
+    h2 = dev.Handle()
+  st = dev.LagStats(c, 0, post, d=1, handle=h)
+  for rep in range(2):                       # (twice: the statistics' own table is reused)
+    st.reset()
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(side):
+      st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=2 | 4, handle=h2)
+      ev.record(side)
+    torch.cuda.current_stream().wait_event(ev)
+    st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=1)
+    m = st.moments()
+    assert st.counts() == ref.counts()
+    assert torch.equal(m['xtx'], m_ref['xtx']) and torch.equal(m['xty'], m_ref['xty'])
+    assert np.array_equal(st.ridge_solve([0.1])[0].cpu().numpy(), w_ref)
+  # the old order still works, and a TARGETS call without MAIN before it still says so
+  st.reset()
+  with pytest.raises(ValueError, match='TARGETS before MAIN'):
+    st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=2)
+  st.reset()
+  st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=1)
+  st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=2)
+  assert torch.equal(st.moments()['xty'], m_ref['xty'])
