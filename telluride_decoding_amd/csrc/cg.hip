@@ -38,8 +38,9 @@
 
 namespace {
 
-constexpr int kCgThreads = 256;
-constexpr int kCgMaxCols = 8;          // entries of a vector per thread: k <= 2048
+constexpr int kCgThreads = 512;        // 8 waves: two per SIMD (a thread owns 4 entries of every vector)
+constexpr int kCgWaves = kCgThreads / 64;
+constexpr int kCgMaxCols = 4;          // entries of a vector per thread: k <= 2048
 
 struct CgParams {
   const double* xtx;      // dense moment sums [n][ld], unscaled (td_stats_moments_ld)
@@ -108,6 +109,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (a + b) + (c + d);
 }
 
+// sum of the waves' partial values part[wave * stride + col], fixed order
+__device__ __forceinline__ double wave_parts(const double* part, int stride, int col) {
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int wv = 0; wv < kCgWaves; wv += 2) { a += part[wv * stride + col]; b += part[(wv + 1) * stride + col]; }
+  return a + b;
+}
+
 // Chronopoulos-Gear form of conjugate gradients: the product is taken with the RESIDUAL, w = A r, and
 // the search direction and its image follow by recurrence (p = r + beta p, v = w + beta v), so the two
 // inner products of an iteration -- (r, r) and (w, r) -- need no second product and no second
@@ -126,10 +135,10 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   double* rows = lds;                              // [R][k]
   const int ks = (k + 1) & ~1;                     // row stride (16-byte aligned pairs)
-  double* red = rows + (size_t)R * ks;              // [4][8] row sums of the product per wave (256 reserved)
-  double* prow = red + kCgThreads;                 // [8] the multiplied vector's entries of my rows
-  double* part_a = prow + 8;                       // [4] wave sums in front of the product (check pass)
-  double* part_b = part_a + 4;                     // [4][4] wave sums behind the exchange
+  double* red = rows + (size_t)R * ks;              // [waves][8] row sums of the product per wave
+  double* prow = red + 8 * kCgWaves;               // [8] the multiplied vector's entries of my rows
+  double* part_a = prow + 8;                       // [waves] wave sums in front of the product (check pass)
+  double* part_b = part_a + kCgWaves;              // [waves][4] wave sums behind the exchange
   __shared__ int s_abort;
   const int i0 = w * R;
   const double inv = P.inv;
@@ -177,8 +186,8 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
       e1 = wave_sum(e1);
       if (lane == 0) { part_b[4 * wave] = e0; part_b[4 * wave + 1] = e1; }
       __syncthreads();
-      sdot = (part_b[0] + part_b[4]) + (part_b[8] + part_b[12]);
-      bnorm2 = (part_b[1] + part_b[5]) + (part_b[9] + part_b[13]);
+      sdot = wave_parts(part_b, 4, 0);
+      bnorm2 = wave_parts(part_b, 4, 1);
       __syncthreads();
     }
     double gamma_old = 1.0, denom_old = 1.0, sv = 0.0;      // sv = s^T v, sdot = s^T r: recurrences
@@ -253,13 +262,13 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
       a1 += __shfl_xor(a1, 32, 64);
       if (lane < 8) red[wave * 8 + lane] = a1;     // lane l < 8: row ((l & 1) << 2) | (l & 2) | ((l >> 2) & 1)
       __syncthreads();
-      if (check_pass) sdot = (part_a[0] + part_a[1]) + (part_a[2] + part_a[3]);
+      if (check_pass) sdot = wave_parts(part_a, 1, 0);
       TD_CG_T(1);
       ++round;
       unsigned long long* buf = P.packets + (size_t)(round & 1u) * 2 * k;
       if (t < R && i0 + t < k) {
         const int pi = ((t >> 2) & 1) | (t & 2) | ((t & 1) << 2);      // the lane that holds row t
-        const double tot = (red[pi] + red[8 + pi]) + (red[16 + pi] + red[24 + pi]);
+        const double tot = wave_parts(red, 8, pi);
         ll_store(buf + 2 * (i0 + t), tot + lam * prow[t] - srow_t * (sdot * inv_ckk), round);
       }
       TD_CG_T(2);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
       bool gave_up = false;
       __builtin_amdgcn_s_sleep(24);
       {
-        int j0 = (t >> 5) & 7;
+        int j0 = (t >> 5) & (kCgMaxCols - 1);
         if (cg_col(t, j0) >= k) j0 = 0;
         const unsigned long long* pp = buf + 2 * cg_col(t, j0);
         if (cg_col(t, j0) < k) {
@@ -334,9 +343,9 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
       if (lane == 0) { part_b[4 * wave] = e0; part_b[4 * wave + 1] = e1; part_b[4 * wave + 2] = e2; }
       __syncthreads();
       if (s_abort) { aborted = true; break; }
-      const double gamma = (part_b[0] + part_b[4]) + (part_b[8] + part_b[12]);
-      const double delta = (part_b[1] + part_b[5]) + (part_b[9] + part_b[13]);
-      const double sw = (part_b[2] + part_b[6]) + (part_b[10] + part_b[14]);
+      const double gamma = wave_parts(part_b, 4, 0);
+      const double delta = wave_parts(part_b, 4, 1);
+      const double sw = wave_parts(part_b, 4, 2);
       TD_CG_T(4);
       if (check_pass) {
         if (!(gamma <= 100.0 * P.tol2 * bnorm2)) status = 2;      // (also catches NaN)
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
     e0 = wave_sum(e0);
     if (lane == 0) part_a[wave] = e0;
     __syncthreads();
-    const double sx = (part_a[0] + part_a[1]) + (part_a[2] + part_a[3]);
+    const double sx = wave_parts(part_a, 1, 0);
     if (w == 0) {
 #pragma unroll
       for (int j = 0; j < kCgMaxCols; ++j) {
@@ -417,7 +426,7 @@ int td_cg_rows(int k, int cus) {
   if (k < 1 || cus < 1 || k > kCgThreads * kCgMaxCols) return 0;
   const int rows = (k + cus - 1) / cus;
   if (rows > 8) return 0;
-  const size_t lds = sizeof(double) * ((size_t)rows * ((k + 1) & ~1) + kCgThreads + 48);
+  const size_t lds = sizeof(double) * ((size_t)rows * ((k + 1) & ~1) + 14 * kCgWaves + 16);
   return lds <= 160 * 1024 - 64 ? rows : 0;
 }
 
@@ -455,7 +464,7 @@ int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const doub
   h->cg_epoch += rounds;
   // (the abort word holds the launch number -- epoch + 1, never 0 -- of the last aborted launch: no reset)
   const int wgs = (k + rows - 1) / rows;
-  const size_t lds = sizeof(double) * ((size_t)rows * ((k + 1) & ~1) + kCgThreads + 48);
+  const size_t lds = sizeof(double) * ((size_t)rows * ((k + 1) & ~1) + 14 * kCgWaves + 16);
   switch (rows) {
     case 1: TD_TRY(launch_cg<1>(h, p, wgs, lds)); break;
     case 2: TD_TRY(launch_cg<2>(h, p, wgs, lds)); break;
