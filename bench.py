@@ -763,7 +763,7 @@ def main():
     avg_s = kernel_ms / max(launches, 1) / 1e3
     achieved = flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
     traffic, traffic_source = None, None
-    for name in ('r03_lagcov_pmc.json',):
+    for name in ('r04_lagcov_pmc.json', 'r03_lagcov_pmc.json'):
       pmc = os.path.join(ROOT, 'profiles', name)
       if os.path.exists(pmc) and args.scaling == 'weak':
         with open(pmc) as f:

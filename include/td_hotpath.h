@@ -295,8 +295,9 @@ int td_ridge_solve_multi(td_handle* h, td_stats* const* stats_host, int n_stats,
  * MFMA and two blocked triangular substitutions per iteration.  total = statistics of all
  * recordings, folds[f] = training statistics of fold f.  Synchronous.  *status_host = 0: every
  * system converged to the relative residual `tol` (outputs as td_ridge_solve_multi);
- * 1: the preconditioner is not positive definite or max_iter was not enough -- use
- * td_ridge_solve_multi.  iterations_host (may be NULL) receives the iteration count. */
+ * 1: max_iter iterations were not enough; 2: the preconditioner (total covariance + lambda I) is not
+ * positive definite -- in both cases use td_ridge_solve_multi.  iterations_host (may be NULL)
+ * receives the iteration count. */
 int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, int n_folds,
                         const double* lambdas_host, int n_lambda, int max_iter, double tol,
                         float* w_dev, float* b_dev, int* status_host, int* iterations_host);

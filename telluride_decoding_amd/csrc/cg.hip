@@ -9,24 +9,27 @@
 // A Krylov method has no such chain inside a step -- an iteration is one matrix-vector product and
 // a few dot products -- and the matrix of a ridge TRF fit is benign (lambda and the sensor noise
 // floor bound the smallest eigenvalue; the large ones are the few dozen directions the stimulus
-// drives): the C2 system converges to 1e-12 in 54-56 iterations.  What an iteration costs on a GPU
-// is not arithmetic (2 n^2 = 8.4 MFLOP) but the exchange between workgroups.  So:
+// drives): the C2 system converges to 1e-12 in 54-56 iterations (block-circulant, Kronecker and
+// coarse-space preconditioners make it WORSE or cost more exchanges than they save: DESIGN.md 8).
+// What an iteration costs on a GPU is not arithmetic (2 n^2 = 8.4 MFLOP) but the exchange between
+// workgroups.  So:
 //   * ONE persistent launch of W <= (CUs) workgroups, workgroup w owning R = ceil(k / W) rows of the
 //     matrix, which it keeps in LDS for the whole solve (k = 2048, W = 256: 8 rows = 128 KB of the
 //     160 KB a CU has; the whole 33 MB matrix lives in the chip's 40 MB of LDS);
-//   * every workgroup keeps EVERY vector (x, r, p; thread t holds entries t + 256 j) and repeats the
-//     scalar recurrences -- identical arithmetic in identical order, so all workgroups take the same
-//     alpha, beta and the same decision to stop -- so that the matrix-vector product is the only
-//     thing exchanged: after it workgroup w publishes its R entries of q = A p and reads all k;
+//   * every workgroup keeps EVERY vector (x, r, p, v; thread t of 512 holds entries 2t, 2t + 1 and the
+//     pair 1024 further) and repeats the scalar recurrences -- identical arithmetic in identical order,
+//     so all workgroups take the same alpha, beta and the same decision to stop -- so that the
+//     matrix-vector product is the only thing exchanged: after it workgroup w publishes its R entries of
+//     A r and reads all k;
 //   * the exchange is the low-latency protocol of collective libraries: a double travels as two
-//     8-byte packets {32 data bits, 32-bit round number}, written with one 8-byte store each
-//     (single-copy atomic) at device scope, readers poll the packets themselves -- no counter, no
-//     fence, ONE trip through the memory fabric per iteration: 3.0 us measured for 32..256
-//     workgroups on the 8 XCDs (tools/micro/grid_exchange.hip; an atomic counter barrier + loads:
-//     3.7..9.5 us).  Two buffers in turn (a workgroup is at most one round ahead of a reader).
+//     8-byte halves {32 data bits, 32-bit round number} = one 16-byte packet, readers poll the packets
+//     themselves -- no counter, no fence, ONE trip through the memory fabric per iteration: 3.0 us
+//     measured for 32..256 workgroups on the 8 XCDs in a bare loop (tools/micro/grid_exchange.hip; an
+//     atomic counter barrier + loads: 3.7..9.5 us), 1.9 us in this kernel (16-byte accesses, 512 pollers
+//     per CU).  Two buffers in turn (a workgroup is at most one round ahead of a reader).
 //   * The bias unknown (the ones column, brain_model.py:434-436) is eliminated analytically, so
 //     that k = n - 1 = 2048 rows split evenly: with A = [[M, s], [s^T, c]] the system is
-//     (M - s s^T / c) w = b_w - s b_k / c, bias = (b_k - s^T w) / c; s^T p follows the recurrence of p.
+//     (M - s s^T / c) w = b_w - s b_k / c, bias = (b_k - s^T w) / c; s^T r follows the recurrence of r.
 //   * Every spin loop watches a device-wide abort word and the clock: a workgroup that waits longer
 //     than the time limit (its partners are not resident: another persistent grid holds their CUs)
 //     raises the abort, every wave leaves, the status says so and the caller takes the Cholesky

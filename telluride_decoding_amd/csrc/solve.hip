@@ -767,10 +767,12 @@ int chol_factor_forward(td_handle* h, double* a_dev, double* rt_dev, double* sol
   // (n = 2049: 1.10 ms with 1 column per outer block, 1.28 ms with 4; 160 systems: 21.6 -> 16.8 ms).
   int ow = batch <= 2 ? 1 : kOuterCols;
   const int panel_tiles = batch <= 2 ? 1 : kPanelTiles;
-  if (const char* e = getenv("TD_OUTER_COLS")) {            // development: ablation of the blocking
+#ifdef TD_DEV_SWITCHES                                       // development builds only: ablation of the blocking
+  if (const char* e = getenv("TD_OUTER_COLS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4) ow = v;
   }
+#endif
   auto launch_update = [&](int kf, int kw, int jlo, int col_mode) {
     const int rem = nblk - jlo;                  // block rows jlo .. nblk-1
     const int tri = col_mode ? rem : rem * (rem + 1) / 2;
@@ -1887,7 +1889,11 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
                      0LL, np, n, np, 1.0 / (double)frames_total, lams, pa);
   TD_HIP(h, hipMemsetAsync(rt, 0, sizeof(double) * (size_t)n_lambda * kMaxRhs * np, h->stream));
   TD_TRY(chol_factor_forward(h, pa, rt, sol, linv, tolv, np, 1, n_lambda, nullptr, kMaxRhs, n));
-  static const bool trsm64 = getenv("TD_LOSO_TRSM64") != nullptr;        // development: A/B runs
+#ifdef TD_DEV_SWITCHES
+  static const bool trsm64 = getenv("TD_LOSO_TRSM64") != nullptr;        // development builds only: A/B runs
+#else
+  constexpr bool trsm64 = false;
+#endif
   if (!trsm64)
     hipLaunchKernelGGL(loso_binv_kernel, dim3((unsigned)nbig, (unsigned)n_lambda, kBig), dim3(256), 0, h->stream,
                        pa, linv, xinv, np, nblk, nbig);
@@ -1970,7 +1976,7 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
     int pd_flag = 0;
     TD_HIP(h, hipMemcpyAsync(&pd_flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     TD_HIP(h, hipStreamSynchronize(h->stream));
-    if (pd_flag) { flag = 1; break; }
+    if (pd_flag) { flag = 2; break; }          // 2: the preconditioner's factorisation failed
     vec_stage(4);
     TD_HIP(h, hipMemcpyAsync(&flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     TD_HIP(h, hipStreamSynchronize(h->stream));
@@ -1980,7 +1986,7 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
   hipLaunchKernelGGL(loso_emit_kernel, dim3(1024), dim3(256), 0, h->stream, X, k1, d, np, n_folds, n_lambda,
                      w_dev, b_dev);
   TD_HIP(h, hipGetLastError());
-  *status_host = flag ? 1 : 0;
+  *status_host = flag == 2 ? 2 : flag ? 1 : 0;      // 0 converged, 1 not converged in max_iter, 2 not positive definite
   if (iterations_host) *iterations_host = it;
   return TD_OK;
 }

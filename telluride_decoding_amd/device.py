@@ -159,6 +159,7 @@ def _ptr(t):
 
 class LagStats(object):
   """Device-resident sufficient statistics of lagged inputs (C-ABI td_stats).
+  `LagStats.last_loso_status`: what the last ridge_solve_loso call of this process reported.
 
   Replaces the accumulate loops of
   brain_model.calculate_linear_regressor_parameters_from_dataset
@@ -349,6 +350,8 @@ class LagStats(object):
     h.check(h.lib.td_ridge_solve_loso(h.ptr, total.ptr, arr, len(folds), lam_p, len(lam), int(max_iter),
                                       float(tol), _ptr(w), _ptr(b), ctypes.byref(status),
                                       ctypes.byref(iters)))
+    LagStats.last_loso_status = {0: 'converged', 1: 'not converged', 2: 'preconditioner not positive definite'}.get(
+        status.value, 'status %d' % status.value)
     if status.value:
       return None
     return w, b, int(iters.value)

@@ -278,6 +278,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
       except MemoryError:
         out = None
       if out is None:
+        LAST_SWEEP['pcg_fallback_reason'] = getattr(dev.LagStats, 'last_loso_status', 'unknown')
         break
       w_all_folds, b_all_folds, iters = out
       iters_max = max(iters_max, int(iters))

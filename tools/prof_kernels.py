@@ -1,12 +1,12 @@
 """Runs only the hot kernels a few times (for rocprofv3 kernel-trace / PMC passes):
-   python tools/prof_kernels.py [fit] [cca] [ccasolve] [decode]"""
+   python tools/prof_kernels.py [fit] [cg] [cca] [ccasolve] [decode]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from telluride_decoding_amd import device
 
-what = sys.argv[1:] or ['fit', 'cca', 'ccasolve', 'decode']
+what = sys.argv[1:] or ['fit', 'cg', 'cca', 'ccasolve', 'decode']
 h = device.default_handle()
 torch.manual_seed(0)
 if 'fit' in what:
@@ -17,6 +17,19 @@ if 'fit' in what:
   for rep in range(3):
     st.reset(); st.accumulate(x, None, y, offs)
   w, b = st.ridge_solve([0.1])
+  torch.cuda.synchronize()
+if 'cg' in what:
+  # the one-launch conjugate-gradient solve (cg.hip) and the blocked Cholesky on the bench's C2 data
+  from telluride_decoding_amd import synth
+  trials = synth.make_trials(2, 10, 20000, 64)
+  eeg = np.concatenate([t[0] for t in trials]); env = np.concatenate([t[1][:, 0:1] for t in trials])
+  st = device.LagStats(64, 0, 31, d=1)
+  st.accumulate(h.to_device(eeg), None, h.to_device(env), np.arange(11, dtype=np.int64) * 20000)
+  for mode in ('cg', 'cholesky'):
+    h.set_solver(mode)
+    for rep in range(3):
+      st.ridge_solve([0.1])
+  h.set_solver('auto')
   torch.cuda.synchronize()
 if 'cca' in what:
   # C3: 64-ch EEG vs 8-band envelope, 1e6 samples, no context: one-pass Gram + transform
