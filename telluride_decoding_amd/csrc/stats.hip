@@ -394,13 +394,29 @@ __global__ __launch_bounds__(kFinThreads) void stats_finalize_kernel(FinalizePar
       }
       for (; w < p.cs_n_work; w += 16) a[0] += p.csum[(size_t)w * p.cs_pad + j];
       s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-      for (int f = q; f < p.n_files; f += 16) {
-        const WinJob jw = p.jobs[f];
-        double v = 0.0;
-        for (int m = 0; m < e; ++m)
-          v += fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j) - fin_edge(p, jw, m, jw.head != 0, j);
-        for (int m = e; m < 0; ++m) v -= fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j);
-        s += v;
+      if (p.n_files >= 32) {
+        // many recordings: a phase per recording, the (<= 2 x 31) edge rows of one in sequence
+        for (int f = q; f < p.n_files; f += 16) {
+          const WinJob jw = p.jobs[f];
+          double v = 0.0;
+          for (int m = 0; m < e; ++m)
+            v += fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j) - fin_edge(p, jw, m, jw.head != 0, j);
+          for (int m = e; m < 0; ++m) v -= fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j);
+          s += v;
+        }
+      } else {
+        // few recordings (a C2 call has 10, a rank's share of a strong-scaled job 2): the phases split
+        // the edge ROWS -- with a phase per recording one thread walked 62 dependent loads while 14 of
+        // the 16 phases idled, and this job (~20 us) was the long pole of the finalize launch of a
+        // short call (22 us at a 1/8 share, whose slab reduction needs 8)
+        for (int f = 0; f < p.n_files; ++f) {
+          const WinJob jw = p.jobs[f];
+          double v = 0.0;
+          for (int m = q; m < e; m += 16)
+            v += fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j) - fin_edge(p, jw, m, jw.head != 0, j);
+          for (int m = e + q; m < 0; m += 16) v -= fin_edge(p, jw, jw.nprime + m, jw.tail != 0, j);
+          s += v;
+        }
       }
     }
     part[q * 64 + j] = s;
