@@ -457,3 +457,88 @@ def test_time_shard_halo_must_cover_the_context():
   st = host_device.LagStats(4, 2, 3, d=1)
   with pytest.raises(ValueError, match='halo'):
     distributed.accumulate_time_shard(st, plan, 0, lambda f, a, b: (None, None, None))
+
+
+def test_jackknife_one_model_against_refits_from_scratch():
+  """regression.py:151-242: ONE lambda, every file held out in turn -> the per-file metrics in file
+  order (here the host orchestration with the NumPy stand-in as device layer, against from-scratch
+  oracle refits), the summary line of :224-241, max_test_count and test_file."""
+  import io
+  from telluride_decoding_amd import brain_data, regression
+  from tests import host_device
+  files = _loso_case()
+  batch, pre, post, lam = 100, 1, 2, 0.1
+  ds = brain_data.Dataset(files, batch, pre, post)
+  want = _loso_refits(files, batch, pre, post, 0, [lam])[0]
+  buf = io.StringIO()
+  cors = regression.jackknife_one_model(ds, lam, test_name='t4', trial_number=7, summary_file=buf,
+                                        experiment_parameters='a=1', device=host_device)
+  np.testing.assert_allclose(cors, want, rtol=0, atol=2e-6)
+  text = buf.getvalue()
+  assert text == ('Jackknife test result test=t4, regularization lambda=0.1, trial=7, mean correlation=%s, '
+                  'std=%s, test count=%d\nJackknife parameters:a=1\n' % (np.mean(cors), np.std(cors), len(cors)))
+  first2 = regression.jackknife_one_model(ds, lam, max_test_count=2, device=host_device)
+  np.testing.assert_allclose(first2, want[:2], rtol=0, atol=2e-6)
+  only = regression.jackknife_one_model(ds, lam, test_file=len(files) - 1, device=host_device)
+  np.testing.assert_allclose(only, want[-1:], rtol=0, atol=2e-6)
+  with pytest.raises(ValueError, match='Could not find metric'):
+    regression.jackknife_one_model(ds, lam, test_metric='loss2', device=host_device)
+  with pytest.raises(ValueError, match='folds must name files'):
+    regression.jackknife_over_regularizations(ds, [lam], device=host_device, folds=[99])
+
+
+def test_infer_host_rules_and_rmss_match_the_reference():
+  """infer.find_first_segment (infer.py:301-324; test/infer_test.py:55-66), the accuracy rule of
+  run_reduction_test (:395-402) and cca.rmss (cca.py:31-36) are host arithmetic: checked against the
+  reference's own outputs (golden G11) without a GPU."""
+  from telluride_decoding_amd import cca, infer
+  g = golden('g11_decode_harness')
+  pattern = [0, 0, 0, 0, 0, 1, 1, 1, 1]
+  assert [infer.find_first_segment(pattern), infer.find_first_segment(np.logical_not(pattern)),
+          infer.find_first_segment(pattern[:3])] == [int(v) for v in g['ffs_kat']] == [5, 5, 0]
+  with pytest.raises(TypeError, match='Labels input must be an ndarray'):
+    infer.find_first_segment(True)
+  with pytest.raises(TypeError, match='Labels input must be one-dimensional'):
+    infer.find_first_segment(np.array(((1, 2), (3, 4))))
+  for red in ('first', 'lda', 'mean_squared'):
+    for w in (int(v) for v in g['windows']):
+      k = '%s_w%d_' % (red, w)
+      assert infer.find_first_segment(g[k + 'labels']) == int(g[k + 'end'])
+      for dtype in ('wta', 'stepped', 'ssd'):
+        if k + dtype + '_frac' in g.files:
+          frac = infer.fraction_correct(g[k + dtype + '_attention'], g[k + 'labels'])
+          assert frac == float(g[k + dtype + '_frac'])
+  for i in range(3):
+    assert float(cca.rmss(g['rmss_in%d' % i])) == pytest.approx(float(g['rmss_out%d' % i]), rel=1e-14)
+  assert tuple(int(v) for v in g['windows']) == infer.WINDOW_LIST
+
+
+def test_decoder_signature_check_and_cca_layer_without_a_gpu():
+  """Decoder.check_model_and_data (infer_decoder.py:552-580) and BrainCcaLayer's weight plumbing
+  (cca.py:84-148) are host logic; only BrainCcaLayer.call touches the device."""
+  from telluride_decoding_amd import cca, infer_decoder
+  dec = infer_decoder.LinearRegressionDecoder(lambda d: d['input_1'])
+  with pytest.raises(ValueError, match='Model has not been initialized yet'):
+    dec.check_model_and_data([])
+  dec.set_model_signature({'input_1': (None, 6)}, (None, 2))
+  ok = [({'input_1': np.ones((5, 6)), 'input_2': np.ones((5, 1))}, np.ones((5, 2)))]
+  dec.check_model_and_data(ok)
+  with pytest.raises(TypeError, match='Actual_dataset is not a dataset'):
+    dec.check_model_and_data(3.0)
+  with pytest.raises(TypeError, match="Can't find needed key input_1"):
+    dec.check_model_and_data([({'input_2': np.ones((5, 1))}, np.ones((5, 2)))])
+  with pytest.raises(TypeError, match='Data for input_1 has the wrong shape'):
+    dec.check_model_and_data([({'input_1': np.ones((5, 7))}, np.ones((5, 2)))])
+  with pytest.raises(TypeError, match='Output data has the wrong shape'):
+    dec.check_model_and_data([({'input_1': np.ones((5, 6))}, np.ones((5, 3)))])
+  layer = cca.BrainCcaLayer(3)
+  assert layer.get_config() == {'requested_cca_dims': 3}
+  m1, m2 = np.zeros((1, 5), np.float32), np.zeros((1, 4), np.float32)
+  r1, r2 = np.ones((5, 3), np.float32), np.ones((4, 3), np.float32)
+  layer.set_initial_weights(m1, m2, r1, r2)
+  assert (layer.input1_dim, layer.input2_dim) == (5, 4)
+  assert all(np.array_equal(a, b) for a, b in zip(layer.get_weights(), (m1, m2, r1, r2)))
+  with pytest.raises(TypeError, match='mean2 matrix has the wrong size'):
+    layer.set_initial_weights(m1, m2.reshape(2, 2), r1, r2)
+  with pytest.raises(TypeError, match='rot2 matrix has the wrong size'):
+    layer.set_initial_weights(m1, m2, r1, r2[:, :2])
