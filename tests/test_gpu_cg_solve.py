@@ -57,6 +57,8 @@ def _oracle_weights(eeg, env, offs, post, lamb):
     (40, 19, 4000, 2, [0.1], 1),              # 800 unknowns: 4 rows per workgroup, 200 workgroups
     (33, 24, 4000, 2, [0.5], 1),              # 825 unknowns: odd count (padded row stride), ragged last workgroup
     (16, 3, 3000, 2, [0.1], 1),               # 64 unknowns: one row per workgroup
+    (16, 0, 3000, 2, [0.1, 1.0], 1),          # 16 unknowns, no lags: 16 workgroups of one row
+    (64, 15, 4000, 2, [0.05, 0.2, 1.0, 5.0], 2),   # 8 systems one after the other in the same launch
 ])
 def test_cg_solve_matches_cholesky_and_oracle(dev, c, post, frames, files, lams, d):
   h, st, eeg, env, offs = _stats(dev, c, post, frames, files, d=d)
