@@ -5,9 +5,9 @@ Same call surface as the arithmetic half of reference infer.py: `regress_and_cor
 (:326-466: window sizes [10, 100, 200, 400, 700, 1000], step = size // 2, tune the decoder on the
 first same-label stretch, accuracy = mean(xor(attention >= 0.5, label)), :376-407).  The TFRecord
 directory / SavedModel / flag / plot plumbing around it (`load_model`, `get_data_for_model`,
-`run_comparison_test`, `main`: TF file formats, control plane) is out of scope: where the
-reference takes a model directory and file patterns, `run_reduction_test` takes the decoder object
-and the two speakers' datasets.
+`main`: TF file formats, control plane) is out of scope: where the reference takes a model
+directory and file patterns, `run_reduction_test` takes the decoder object and the two speakers'
+datasets, and `run_comparison_test` (:466-502) a factory of decoders.
 
 Everything per frame and per window runs in HIP kernels: the model's forward pass and the
 per-frame correlation scores through `Decoder.test_all` (one launch set for the whole dataset), the
@@ -16,12 +16,15 @@ in one launch -- the reference walks a Python generator that copies each window,
 result_store.py:253-271), the decisions through the decoders' batched entry points
 (`td_decide_wta` / `td_decide_step` / `td_decode_ssd`).
 """
+import collections
+
 import numpy as np
 
 from telluride_decoding_amd import attention_decoder
 from telluride_decoding_amd import device
 
 WINDOW_LIST = (10, 100, 200, 400, 700, 1000)       # infer.py:376
+ALLOWABLE_DECODER_TYPES = ('wta', 'stepped', 'ssd')  # infer.py:99
 
 
 def _window_means_host(values, window_size, window_step):
@@ -135,3 +138,20 @@ def run_reduction_test(model_object, bd1_test, bd2_test, decoder_type='wta', bd1
                                   labels=np.asarray(labels), attention=attention,
                                   end_first_section=int(end_first_section))
   return dict(zip(window_list, window_results))
+
+
+def run_comparison_test(make_decoder, bd1_test, bd2_test, reduction_list, decoder_list=None,
+                        bd1_train=None, bd2_train=None, **kwargs):
+  """run_reduction_test for every (reduction, decoder type) pair (reference
+  infer.run_comparison_test, infer.py:466-502): an OrderedDict keyed by (reduction, decoder) of
+  {window size: fraction correct}.  `make_decoder(reduction)` returns the infer_decoder.Decoder for
+  one reduction -- the reference loads the saved model anew per pair (`load_model`, infer.py:268-298);
+  the comparison plot it then draws is reporting and left to the caller."""
+  all_results = collections.OrderedDict()
+  for reduction in reduction_list:
+    for decoder in decoder_list or ALLOWABLE_DECODER_TYPES:
+      model_object = make_decoder(reduction)
+      all_results[(reduction, decoder)] = run_reduction_test(
+          model_object, bd1_test, bd2_test, decoder_type=decoder, bd1_train=bd1_train,
+          bd2_train=bd2_train, **kwargs)
+  return all_results

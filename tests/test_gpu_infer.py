@@ -221,3 +221,21 @@ def test_evaluate_on_a_plain_iterable_of_minibatches():
   cg = cmodel.evaluate(list(ds))
   assert cg['cca_pearson_correlation_first'] == pytest.approx(cw['cca_pearson_correlation_first'], abs=2e-6)
   assert cg['loss'] == cg['cca_pearson_correlation_first']
+
+
+def test_run_comparison_test_loops_reductions_and_decoders():
+  """infer.py:466-502: every (reduction, decoder) pair; the values are run_reduction_test's (golden G11)."""
+  from telluride_decoding_amd import infer, infer_decoder
+  g = golden('g11_decode_harness')
+  train, mixed, test1, test2 = _g11_datasets(g)
+
+  def make(reduction):
+    dec = infer_decoder.LinearRegressionDecoder(_linear, reduction=reduction)
+    dec.train(mixed, train)
+    return dec
+  res = infer.run_comparison_test(make, test1, test2, ['first', 'lda'], decoder_list=['wta', 'stepped'],
+                                  window_list=[100, 400])
+  assert list(res.keys()) == [('first', 'wta'), ('first', 'stepped'), ('lda', 'wta'), ('lda', 'stepped')]
+  for (red, dtype), by_window in res.items():
+    for w, frac in by_window.items():
+      assert frac == pytest.approx(float(g['%s_w%d_%s_frac' % (red, w, dtype)]), abs=1e-12)
