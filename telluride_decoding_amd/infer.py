@@ -60,7 +60,13 @@ def regress_and_correlate(model_object, test_data, window_size):
     # TwoResultStore with a step of 0 never advances (result_store.py:262-271 yields the first
     # window for ever); the reference's harness never asks for it
     raise ValueError('Window size %d gives a window step of 0.' % window_size)
-  scores, labels = model_object.test_all(test_data)
+  return _window_results(model_object.test_all(test_data), window_size)
+
+
+def _window_results(decoded, window_size):
+  """(window scores, window label means) of one decoded dataset = test_all's (scores, labels)."""
+  scores, labels = decoded
+  step = window_size // 2
   if scores is None:
     return [], []
   if labels is None:
@@ -121,10 +127,17 @@ def run_reduction_test(model_object, bd1_test, bd2_test, decoder_type='wta', bd1
     model_object.train(bd1_train, bd2_train)
   window_list = list(WINDOW_LIST if window_list is None else window_list)
   window_results = []
+  # The reference decodes both datasets again for every window size (regress_and_correlate inside
+  # the loop, infer.py:380-386); the per-frame scores do not depend on the window, so each dataset is
+  # decoded ONCE here and only the window means are taken per size.
+  decoded1 = model_object.test_all(bd1_test)
+  decoded2 = model_object.test_all(bd2_test)
   for window_size in window_list:
     window_step = window_size // 2
-    d1_results, _ = regress_and_correlate(model_object, bd1_test, window_size)
-    d2_results, labels = regress_and_correlate(model_object, bd2_test, window_size)
+    if window_step < 1:
+      raise ValueError('Window size %d gives a window step of 0.' % window_size)
+    d1_results, _ = _window_results(decoded1, window_size)
+    d2_results, labels = _window_results(decoded2, window_size)
     decoder = attention_decoder.create_attention_decoder(
         decoder_type, window_step=window_step, frame_rate=frame_rate, ssd_offset=ssd_offset)
     end_first_section = find_first_segment(labels)
