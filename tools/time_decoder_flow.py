@@ -41,6 +41,16 @@ def main():
   tm('Decoder.test_all (60k frames)', lambda: dec.test_all(test))
   tm('model.evaluate(test)', lambda: model.evaluate(test))
   tm('model.predict(test)', lambda: model.predict(test))
+  # the decode harness (infer.py:359-407): two speakers, six window sizes, all three decoders
+  from telluride_decoding_amd import infer
+  sw = synth.make_trials(9, 10, 6000, 64, switch_half=True)
+  def spk(tr, k):
+    files = [(t[0], t[1][:, 1 - k:2 - k], t[1][:, k:k + 1], t[2]) for t in tr]
+    return brain_data.Dataset(files, 1000, 0, 31)
+  bd1, bd2 = spk(sw, 0), spk(sw, 1)
+  for dtype in ('wta', 'stepped', 'ssd'):
+    tm('infer.run_reduction_test, %s' % dtype, lambda: infer.run_reduction_test(dec, bd1, bd2, decoder_type=dtype))
+  print('  accuracy by window size (wta):', infer.run_reduction_test(dec, bd1, bd2, decoder_type='wta'))
 
 
 if __name__ == '__main__':
