@@ -251,7 +251,8 @@ int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_
                    float* w_dev, float* b_dev);
 /* How td_ridge_solve solves (brain_model.py:477 is one dense np.linalg.solve):
  *   TD_SOLVER_AUTO (default) a synchronous call with at most 4 (lambda, output) systems, every lambda > 0, of
- *                  at least 768 unknowns whose matrix fits the LDS of the CUs the handle runs on (td_set_cu_count;
+ *                  n >= 128 / 192 / 512 (one / two / three or four systems: where one launch measures faster than the
+ *                  factorisation's chain) whose matrix fits the LDS of the CUs the handle runs on (td_set_cu_count;
  *                  n = 2049 on the 256 CUs of an MI355X does) runs conjugate gradients in ONE persistent
  *                  launch -- the matrix resident in LDS, one packet exchange per iteration -- and takes the
  *                  blocked Cholesky only when that does not converge to a relative residual of 1e-12

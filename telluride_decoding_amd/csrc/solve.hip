@@ -1006,8 +1006,14 @@ __global__ void unpad_rows_kernel(const double* __restrict__ src, int nb, int n,
 // contiguous (the triangular solves), the rows of a fold a constant stride apart (the products).
 constexpr int kLosoRows = 32;      // right-hand-side rows per workgroup
 // td_ridge_solve: when the one-launch conjugate-gradient solve (cg.hip) is tried first
-constexpr int kCgAutoSystems = 4;     // (lambda, output) systems; more: the batched factorisation shares its chain
-constexpr int kCgAutoMinN = 768;      // below ~12 block steps the factorisation's chain is as short
+// (measured, tools/time_cg.py at 64 channels x 2..32 lags: one system 0.12 / 0.16 / 0.19 / 0.35 ms at
+// n = 129 / 513 / 769 / 2049 against 0.20 / 0.39 / 0.51 / 1.15 for the factorisation; the systems run one
+// after another, the batched factorisation shares its chain: two systems win from n = 129 by little and
+// from 257 clearly, four only from n = 513 -- 0.40 against 0.47)
+constexpr int kCgAutoSystems = 4;     // (lambda, output) systems at most
+constexpr int kCgAutoMinN1 = 128;     // smallest n for one system,
+constexpr int kCgAutoMinN2 = 192;     // two,
+constexpr int kCgAutoMinN4 = 512;     // three or four
 constexpr int kCgMaxIter = 400;
 constexpr double kCgTol = 1e-12;      // relative residual, as td_ridge_solve_loso
 
@@ -1663,7 +1669,9 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
   // owns the "Singular matrix" report.
   h->last_solver = TD_SOLVER_CHOLESKY; h->last_iterations = 0; h->last_cg_status = 0;
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
-  const bool cg_auto = n_lambda * d <= kCgAutoSystems && n >= kCgAutoMinN;
+  const int systems = n_lambda * d;
+  const bool cg_auto = systems <= kCgAutoSystems &&
+                       n >= (systems == 1 ? kCgAutoMinN1 : systems == 2 ? kCgAutoMinN2 : kCgAutoMinN4);
   // (lambda = 0 leaves a matrix that may be exactly singular -- a duplicated channel -- on which conjugate
   // gradients happily converges to SOME solution of the consistent system where np.linalg.solve
   // (brain_model.py:477) and the factorisation report "Singular matrix": only lambda > 0 goes this way)

@@ -93,9 +93,17 @@ def test_auto_picks_cg_for_one_large_system_and_cholesky_otherwise(dev):
   assert h.last_solve_info()['solver'] == 'cg'
   st.ridge_solve(list(np.logspace(-3, 1, 7)))           # 7 systems share one batched factorisation
   assert h.last_solve_info()['solver'] == 'cholesky'
-  h2, st2, _, _, _ = _stats(dev, 16, 7, 3000, 2)         # 129 unknowns: the chain is short
-  st2.ridge_solve([0.1])
-  assert h2.last_solve_info()['solver'] == 'cholesky'
+  # the size from which one launch beats the factorisation's chain depends on the system count
+  # (solve.hip kCgAutoMinN*: 128 / 192 / 512 unknowns + bias for 1 / 2 / 3-4 systems)
+  for c, post, lams, want in ((16, 7, [0.1], 'cg'),              # n = 129, one system
+                              (16, 6, [0.1], 'cholesky'),        # n = 113
+                              (16, 7, [0.1, 1.0], 'cholesky'),   # n = 129, two systems
+                              (16, 15, [0.1, 1.0], 'cg'),        # n = 257, two
+                              (16, 15, [0.1, 1.0, 3.0], 'cholesky'),   # n = 257, three
+                              (32, 15, [0.1, 1.0, 3.0, 9.0], 'cg')):   # n = 513, four
+    h2, st2, _, _, _ = _stats(dev, c, post, 3000, 2)
+    st2.ridge_solve(lams)
+    assert h2.last_solve_info()['solver'] == want, (c, post, lams, h2.last_solve_info())
 
 
 def test_singular_system_is_reported_like_the_reference(dev):

@@ -1,6 +1,6 @@
 """The one-launch conjugate-gradient ridge solve (cg.hip) against the blocked Cholesky at the C2 shape:
 weights, iterations and device time of td_ridge_solve (expansion included) per solver.
-   python tools/time_cg.py [frames_per_file] [n_lambda]"""
+   python tools/time_cg.py [frames_per_file] [n_lambda] [channels] [lags]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +8,8 @@ from telluride_decoding_amd import device, synth
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 n_lambda = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-C, POST = 64, 31
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+POST = (int(sys.argv[4]) if len(sys.argv) > 4 else 32) - 1
 trials = synth.make_trials(2, 10, frames, C)
 eeg = np.concatenate([t[0] for t in trials]); env = np.concatenate([t[1][:, 0:1] for t in trials])
 offs = np.arange(11, dtype=np.int64) * frames
