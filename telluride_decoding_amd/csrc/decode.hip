@@ -766,11 +766,24 @@ __global__ __launch_bounds__(kTrialThreads) void decode_trial_kernel(
     const bool live = blk < n_blocks;               // dead groups stay for the shuffles
     const long long r0 = tr.row0 + (long long)(live ? blk : n_blocks - 1) * g;
     double sa0 = 0, sa1 = 0, sb = 0, p0 = 0, p1 = 0;
-    for (int r = sub; r < g; r += kBlockLanes) {
-      const double a0 = (double)a[(r0 + r) * lda], a1 = (double)a[(r0 + r) * lda + 1];
-      const double bv = (double)b[r0 + r];
-      sa0 += a0; sa1 += a1; sb += bv;
-      p0 += a0 * bv; p1 += a1 * bv;
+    // eight rows per lane at a time, every load issued before the first sum (a rolled loop waits out one
+    // memory latency per row: 7 in a row at g = 100, most of this kernel's 9 us); same order of sums
+    for (int rb = sub; rb < g; rb += 8 * kBlockLanes) {
+      float va0[8], va1[8], vb[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = rb + i * kBlockLanes;
+        const long long rr = r0 + (r < g ? r : sub);
+        va0[i] = a[rr * lda]; va1[i] = a[rr * lda + 1]; vb[i] = b[rr];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (rb + i * kBlockLanes < g) {
+          const double a0 = (double)va0[i], a1 = (double)va1[i], bv = (double)vb[i];
+          sa0 += a0; sa1 += a1; sb += bv;
+          p0 += a0 * bv; p1 += a1 * bv;
+        }
+      }
     }
     sa0 = group16_sum(sa0); sa1 = group16_sum(sa1); sb = group16_sum(sb);
     p0 = group16_sum(p0); p1 = group16_sum(p1);
@@ -1664,6 +1677,297 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
   emit(u_first + 16LL * (n_tiles + 1));
 }
 
+// ---- one-output FIR prediction, streamed through LDS by DMA (round 4) ---------------------------
+//   out[t] = b + sum_l sum_c x~[t + l - pre][c] W[l][c]                       (brain_model.py:335-341)
+// The same product as above with the operands SWAPPED: P[l][u] = sum_c W[l][c] x[u][c], M = lag,
+// N = time, K = channel, so a lane of the 32 x 32 result holds ONE time column and its registers run
+// over the lags -- the diagonal sum out[u] = sum_l P[l][u + l] becomes a Horner chain of lane shifts,
+//   low <- shl1(low) + P[l]   (l = 31 .. 0;  v_add_f32_dpp wave_shl:1),
+// one vector instruction per lag, no P tile in LDS, no barrier.  What the previous forms spend around
+// their matrix instructions (transposition through registers, split, P tile, diagonal walk: ~270
+// instructions per 32 rows) is ~55 here:
+//   * rows reach LDS by DMA (`buffer_load_dwordx4 ... lds`: no registers, no ds_write): lane l of
+//     instruction m fetches row 4m + (l >> 4), granule (l & 15) ^ (row & 15) -- whole 256-byte rows per
+//     16 lanes -- and the lane-linear LDS image is that XOR-swizzled [32][64] tile, read back in operand
+//     order (lane (n, g): row n, granules 8g .. 8g+7 = channels 32g .. 32g+31) by conflict-free
+//     ds_read_b128.  Rows outside the recording are outside the buffer descriptor and read as zeros.
+//     Two 8 KB slots per wave; a slot is refilled as soon as its rows are in registers, so two tiles
+//     (16 KB per wave, 32 MB on the chip) are in flight under every chain of matrix instructions;
+//   * v_mfma_f32_32x32x2_f32 on the values as they are (exact float32 products, no split): the
+//     weights are the A operand, 32 registers per lane for the whole strip; instruction i multiplies
+//     channels i (lane half 0) and 32 + i (half 1);
+//   * matrix row m holds lag 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3), so that result register r of
+//     lane half g is lag 16 g + r; v_permlane32_swap of the registers of two consecutive tiles makes
+//     32 vectors of 64 consecutive time columns, one per lag.  The chain above leaves the outputs of
+//     lanes 0..32 complete; what lanes 33..63 lack comes from the first 31 columns of the NEXT pair:
+//     a second chain with right shifts (high <- shr1(high) + P[l], l = 1 .. 31), moved up 33 lanes.
+// A wave owns a strip of outputs of one recording.  No workgroup barrier anywhere.
+typedef int fs_i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kFsSlotFloats = 32 * 64;     // one tile: 32 rows x 64 channels
+#ifndef TD_FS_SLOTS
+#define TD_FS_SLOTS 2
+#endif
+#ifndef TD_FS_OCC
+#define TD_FS_OCC 2
+#endif
+constexpr int kFsSlots = TD_FS_SLOTS;      // tiles of LDS per wave (1 or 2)
+constexpr int kFsOcc = TD_FS_OCC;          // workgroups (of four waves) per CU
+#ifndef TD_FS_ABL
+#define TD_FS_ABL 0     // development: 1 no matrix instructions, 2 no DMA after the first two tiles, 3 no chains, 4 DMA only,
+                        // 5 setup only, 6 = 2 + no products / chains, 7 = 2 + no chains
+#endif
+
+struct FirStreamParams {
+  const float* x;
+  long long ldx;
+  const FileDesc* files;
+  int n_files;
+  long long n_strips;
+  int strip, pre, post;
+  const float* w;        // [nl * 64][d]
+  const float* bias;     // [d] or null
+  int d, q0;
+  float* out;
+  long long ldout;
+  const int* strip_file; // [n_strips]: the recording of every strip (a binary search over `files` is 8
+                         // dependent loads = ~5 us before a wave's first row is asked for)
+};
+
+// the 8 DMA instructions of one tile: LDS slot at byte address lds (wave-uniform), lane offsets v[m]
+__device__ __forceinline__ void fs_issue_tile(fs_i32x4 rs, unsigned lds, const unsigned (&v)[8]) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v0], %[rs], 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v1], %[rs], 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v2], %[rs], 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v3], %[rs], 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v4], %[rs], 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v5], %[rs], 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v6], %[rs], 0 offen lds\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+      "buffer_load_dwordx4 %[v7], %[rs], 0 offen lds\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [lds] "s"(lds), [rs] "s"(rs), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
+        [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
+      : "memory", "scc");
+}
+
+// (x0, x1) times the power-of-two scale s -> packed float16 pairs of the two pieces (x s = h + l; the
+// residual x s - h is exact in float32).  Compiles to 2 v_mul + v_cvt_pk_f16_f32 + 2 v_fma_mix_f32 +
+// v_cvt_pk_f16_f32; the fused v_fma_mixlo/hi_f16 forms (4 instructions) measure SLOWER: 4.6 ns each per
+// SIMD against 1.4-2.8 for these (tools/micro/valu_rate.hip).
+__device__ __forceinline__ void fs_split2(float x0, float x1, float s, unsigned& h, unsigned& l) {
+  h = td_pack_f16(x0 * s, x1 * s);
+  const td_f16x2 hv = __builtin_bit_cast(td_f16x2, h);
+  l = td_pack_f16(__builtin_fmaf(x0, s, -(float)hv[0]), __builtin_fmaf(x1, s, -(float)hv[1]));
+}
+
+__device__ __forceinline__ float fs_shl1(float v) {      // lane i <- lane i + 1, lane 63 <- 0
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float fs_shr1(float v) {      // lane i <- lane i - 1, lane 0 <- 0
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x138, 0xf, 0xf, true));
+}
+
+template <bool kF16, int kSlots, int kOcc>   // LDS slots (tiles) per wave; workgroups per CU
+__global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamParams p) {
+  extern __shared__ __attribute__((aligned(16))) float fs_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long sidx = blockIdx.x * (long long)(kThreads / 64) + wave;
+  if (sidx >= p.n_strips) return;
+  const FileDesc st = p.files[__builtin_amdgcn_readfirstlane(p.strip_file[sidx])];
+  const long long ts = (sidx - st.first) * p.strip;             // first output of the strip
+  const int st_len = (int)(st.nrows - ts < p.strip ? st.nrows - ts : p.strip);
+  if (st_len <= 0) return;
+  const int nl = p.pre + 1 + p.post;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ldb = (int)p.ldx * 4;                               // row pitch in bytes
+
+  float wreg[32];
+  td_u32x4 wh[4], wl[4];
+  float w_unscale = 1.f;
+  const float bias = p.bias ? p.bias[p.q0] : 0.f;
+
+  // buffer descriptor of the recording: rows outside [0, nrows) read as zeros
+  const unsigned long long base = reinterpret_cast<unsigned long long>(p.x + st.row0 * p.ldx);
+  fs_i32x4 rs;
+  rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+  rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
+  rs.z = __builtin_amdgcn_readfirstlane((int)(unsigned)(st.nrows * ldb));
+  rs.w = 0x00020000;
+  // lane part of the source offsets: row 4m + (lane >> 4), swizzled granule
+  unsigned lpart[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int r = 4 * m + (lane >> 4);
+    lpart[m] = (unsigned)(r * ldb + 16 * ((lane & 15) ^ (r & 15)));
+  }
+  float* slots = fs_lds + wave * kSlots * kFsSlotFloats;
+  const unsigned slot_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)slots);
+  const int row_b = (int)(ts - p.pre);                          // first input row of the strip
+  const int n_tiles = 2 * ((st_len + nl - 1 + 63) / 64);        // whole pairs
+  auto issue = [&](int t) {
+    const unsigned tb = (unsigned)((row_b + 32 * t) * ldb);     // (negative rows wrap: out of range)
+    unsigned v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = lpart[m] + tb;
+    fs_issue_tile(rs, slot_addr + (unsigned)(t & (kSlots - 1)) * (kFsSlotFloats * 4), v);
+  };
+  // the rows of tile t: wait for them, read them in operand order, refill the slot
+  auto fetch = [&](int t, float4 (&xb)[8]) {
+    if (TD_FS_ABL == 2 || TD_FS_ABL >= 6 || kSlots == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* xt = slots + (t & (kSlots - 1)) * kFsSlotFloats + li * 64;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      xb[k] = *reinterpret_cast<const float4*>(xt + 4 * ((8 * lh + k) ^ (li & 15)));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (TD_FS_ABL != 2 && TD_FS_ABL < 6 && t + kSlots < n_tiles) issue(t + kSlots);
+  };
+  // kF16: the power-of-two scale of a row (its 64 samples' largest magnitude into [2^13, 2^14)) and
+  // the factor that takes a result back
+  auto row_scale = [&](const float4 (&xb)[8], float& xs, float& un) {
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      mx = fmaxf(fmaxf(fabsf(xb[k].x), fabsf(xb[k].y)), mx);       // (v_max3_f32 with |.| modifiers)
+      mx = fmaxf(fmaxf(fabsf(xb[k].z), fabsf(xb[k].w)), mx);
+    }
+    const auto ex = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mx = fmaxf(__uint_as_float(ex[0]), __uint_as_float(ex[1]));
+    unsigned e = __float_as_uint(mx) >> 23;
+    e = e < 20u ? 20u : e;
+    xs = __uint_as_float((267u - e) << 23);
+    un = __uint_as_float((e - 13u) << 23) * w_unscale;
+  };
+  auto split_step = [&](const float4 (&xb)[8], int j, float xs, td_u32x4& xh, td_u32x4& xl) {
+    const float4 v0 = xb[2 * j], v1 = xb[2 * j + 1];
+    unsigned hh, ll;
+    fs_split2(v0.x, v0.y, xs, hh, ll); xh[0] = hh; xl[0] = ll;
+    fs_split2(v0.z, v0.w, xs, hh, ll); xh[1] = hh; xl[1] = ll;
+    fs_split2(v1.x, v1.y, xs, hh, ll); xh[2] = hh; xl[2] = ll;
+    fs_split2(v1.z, v1.w, xs, hh, ll); xh[3] = hh; xl[3] = ll;
+  };
+  // one tile's products P[lag][time] (32 x 32 in 16 registers)
+  auto products = [&](const float4 (&xa)[8], f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+    if (TD_FS_ABL == 1 || TD_FS_ABL == 4 || TD_FS_ABL == 6) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = xa[k].x + xa[k].y + xa[k].z + xa[k].w;
+      return;
+    }
+    if (kF16) {
+      // every row as two float16 pieces (td_common.h): three products per k-step of 16 channels
+      // instead of 8 float32 ones
+      float sa, ua;
+      row_scale(xa, sa, ua);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        td_u32x4 ah, al;
+        split_step(xa, j, sa, ah, al);
+        a = td_mfma_f16(wl[j], ah, a);
+        a = td_mfma_f16(wh[j], al, a);
+        a = td_mfma_f16(wh[j], ah, a);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] *= ua;
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      a = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[i], reinterpret_cast<const float*>(&xa[i >> 2])[i & 3], a, 0, 0, 0);
+  };
+  float* orow = p.out + (st.out0 + ts) * p.ldout + p.q0;
+  auto emit = [&](int pair, float v) {
+    const int o = 64 * pair + lane;
+    if (o < st_len) orow[(long long)o * p.ldout] = v + bias;
+  };
+
+  issue(0);
+  if (kSlots == 2) issue(1);
+  // (the first rows are on their way while the weights are fetched and split)
+  // A operand: lane (m = li, g = lh) holds W[lag(m)][32 g + i] for instruction i
+  {
+    const int lag = 16 * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3);
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      wreg[i] = lag < nl ? p.w[((size_t)lag * 64 + 32 * lh + i) * p.d + p.q0] : 0.f;
+  }
+  // kF16: the weights as two float16 pieces under ONE power-of-two scale (largest magnitude in
+  // [2^13, 2^14)): k-step j multiplies channels 32 g + 8 j .. + 7
+  if (kF16) {
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mx = fmaxf(mx, fabsf(wreg[i]));
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft, 64));
+    unsigned e = __float_as_uint(mx) >> 23;
+    e = e < 20u ? 20u : e;
+    const float ws = __uint_as_float((267u - e) << 23);         // 2^(140 - e)
+    w_unscale = __uint_as_float((e - 13u) << 23);               // 2^(e - 140)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned hh, ll;
+        td_split2_f16(wreg[8 * j + 2 * q] * ws, wreg[8 * j + 2 * q + 1] * ws, hh, ll);
+        wh[j][q] = hh;
+        wl[j][q] = ll;
+      }
+  }
+  float low_prev = 0.f;
+  if (TD_FS_ABL == 5) { emit(0, wreg[0] + __uint_as_float(wh[0][0])); return; }
+  for (int pr = 0; 2 * pr < n_tiles; ++pr) {
+    f32x16 a, b;
+    {
+      float4 xa[8];
+      fetch(2 * pr, xa);
+      products(xa, a);
+      fetch(2 * pr + 1, xa);
+      products(xa, b);
+    }
+    if (TD_FS_ABL >= 3) {
+      float sa = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa += a[r] + b[r];
+      if (pr > 0) emit(pr - 1, low_prev + sa);
+      low_prev = sa;
+      continue;
+    }
+    // V[l]: lag l over the pair's 64 time columns
+    float V[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+      V[r] = __uint_as_float(sw[0]);
+      V[16 + r] = __uint_as_float(sw[1]);
+    }
+    float low = V[31], high = V[1];
+#pragma unroll
+    for (int l = 30; l >= 0; --l) low = fs_shl1(low) + V[l];
+#pragma unroll
+    for (int l = 2; l < 32; ++l) high = fs_shr1(high) + V[l];
+    // lanes 0..30 of `high` belong to lanes 33..63 of the previous pair
+    const auto up = __builtin_amdgcn_permlane32_swap(0u, __float_as_uint(high), false, false);
+    const float h = fs_shr1(__uint_as_float(up[0]));
+    if (pr > 0) emit(pr - 1, low_prev + h);
+    low_prev = low;
+  }
+  emit(n_tiles / 2 - 1, low_prev);
+}
+
 // The per-file descriptor table goes through the handle's content-cached table slots
 // (td_table_upload): no td_scratch use, and no upload at all when the layout repeats.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
@@ -1730,6 +2034,64 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
 #undef TD_PROJ
     TD_HIP(h, hipGetLastError());
     return TD_OK;
+  }
+  {
+    // one output, 64 channels, <= 32 lags, every recording below 2 GB: the DMA-streamed kernel
+    bool stream_ok = !w_file_stride && d == 1 && nl <= 32 && c == 64 && vec4 && ldx < (1 << 20);
+    for (int f = 0; f < num_files && stream_ok; ++f)
+      stream_ok = (offs[f + 1] - offs[f]) * ldx * 4 < (int64_t)0x7fc00000;
+#ifdef TD_DEV_SWITCHES
+    if (getenv("TD_FIR_STREAM_OFF")) stream_ok = false;
+#endif
+    if (stream_ok) {
+      const int cus = h->cu_count > 0 ? h->cu_count : 256;
+      // one strip per resident wave (kFsOcc workgroups of four waves per CU), a multiple of 32 outputs
+      int64_t strip = td_round_up(td_ceil_div(total, (int64_t)cus * kFsOcc * (kThreads / 64)), 32);
+      if (strip < 256) strip = 256;
+      // one table: the recordings' descriptors, then the recording of every strip
+      std::vector<FileDesc> files(num_files);
+      std::vector<int> strip_file;
+      long long n_strips = 0;
+      for (int f = 0; f < num_files; ++f) {
+        const int64_t n = offs[f + 1] - offs[f] - shift;
+        files[f].row0 = offs[f] + shift;
+        files[f].nrows = n > 0 ? n : 0;
+        files[f].out0 = offs[f];
+        files[f].first = n_strips;
+        if (n > 0) {
+          n_strips += td_ceil_div(n, strip);
+          strip_file.resize((size_t)n_strips, f);
+        }
+      }
+      std::vector<char> table(files.size() * sizeof(FileDesc) + strip_file.size() * sizeof(int));
+      memcpy(table.data(), files.data(), files.size() * sizeof(FileDesc));
+      memcpy(table.data() + files.size() * sizeof(FileDesc), strip_file.data(), strip_file.size() * sizeof(int));
+      TD_TRY(td_table_upload(h, table.data(), table.size(), &table_dev));
+      FirStreamParams fp;
+      fp.x = x; fp.ldx = ldx; fp.files = reinterpret_cast<const FileDesc*>(table_dev);
+      fp.strip_file = reinterpret_cast<const int*>(reinterpret_cast<const char*>(table_dev) +
+                                                   files.size() * sizeof(FileDesc));
+      fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = (int)strip;
+      fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
+      fp.out = out; fp.ldout = ldout;
+      constexpr size_t kLds = sizeof(float) * (kThreads / 64) * kFsSlots * kFsSlotFloats;
+      if (!h->lds_opt_fir_stream) {
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_stream_kernel<true, kFsSlots, kFsOcc>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_stream_kernel<false, kFsSlots, kFsOcc>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        h->lds_opt_fir_stream = true;
+      }
+      const dim3 grid((unsigned)td_ceil_div(n_strips, kThreads / 64)), block(kThreads);
+      // (TD_ACC_F32: exact float32 products on the float32 matrix instruction; otherwise each as three
+      // float16 products -- the rule of the accumulate)
+      if (h->acc_mode == TD_ACC_F32)
+        hipLaunchKernelGGL((fir_stream_kernel<false, kFsSlots, kFsOcc>), grid, block, kLds, h->stream, fp);
+      else
+        hipLaunchKernelGGL((fir_stream_kernel<true, kFsSlots, kFsOcc>), grid, block, kLds, h->stream, fp);
+      TD_HIP(h, hipGetLastError());
+      return TD_OK;
+    }
   }
   // (Measured at C4, decode step: 90.1 us with fir_tile16_kernel against 86.3 us with
   // predict_fir_mfma_kernel -- its split + MFMA cost 26 us and its loads 19 us that overlap only

@@ -25,3 +25,10 @@ e1.record()
 torch.cuda.synchronize()
 us = 1e3 * e0.elapsed_time(e1) / reps
 print('%s: FIR %.1f us per call = %.2f TB/s of x' % (os.environ.get('TD_HOTPATH_LIB', 'default'), us, x.numel() * 4 / us / 1e6))
+# correctness of the same call against float64 on the first and last recording
+for tr in (0, n_trials - 1):
+  xs = x[tr * t_len:(tr + 1) * t_len].double()
+  xp = torch.cat([xs, torch.zeros(31, c, dtype=torch.float64, device='cuda')])
+  ref = sum(xp[l:l + t_len] @ w.double()[l * c:(l + 1) * c] for l in range(32))
+  got = out[tr * t_len:(tr + 1) * t_len].double()
+  print('  recording %d: max |out - float64| = %.3g (scale %.3g)' % (tr, (got - ref).abs().max().item(), ref.abs().max().item()))
