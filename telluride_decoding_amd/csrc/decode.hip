@@ -1710,6 +1710,7 @@ constexpr int kFsSlotFloats = 32 * 64;     // one tile: 32 rows x 64 channels
 #ifndef TD_FS_OCC
 #define TD_FS_OCC 2
 #endif
+#define FS_NODMA (TD_FS_ABL == 2 || (TD_FS_ABL >= 6 && TD_FS_ABL <= 9))   // (18 / 19: 8 / 9 with the DMA)
 constexpr int kFsSlots = TD_FS_SLOTS;      // tiles of LDS per wave (1 or 2)
 constexpr int kFsOcc = TD_FS_OCC;          // workgroups (of four waves) per CU
 #ifndef TD_FS_ABL
@@ -1825,7 +1826,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
   };
   // the rows of tile t: wait for them, read them in operand order, refill the slot
   auto fetch = [&](int t, float4 (&xb)[8]) {
-    if (TD_FS_ABL == 2 || TD_FS_ABL >= 6 || kSlots == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FS_NODMA || kSlots == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const float* xt = slots + (t & (kSlots - 1)) * kFsSlotFloats + li * 64;
@@ -1833,7 +1834,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
     for (int k = 0; k < 8; ++k)
       xb[k] = *reinterpret_cast<const float4*>(xt + 4 * ((8 * lh + k) ^ (li & 15)));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (TD_FS_ABL != 2 && TD_FS_ABL < 6 && t + kSlots < n_tiles) issue(t + kSlots);
+    if (!FS_NODMA && t + kSlots < n_tiles) issue(t + kSlots);
   };
   // kF16: the power-of-two scale of a row (its 64 samples' largest magnitude into [2^13, 2^14)) and
   // the factor that takes a result back
@@ -1876,7 +1877,16 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         td_u32x4 ah, al;
-        split_step(xa, j, sa, ah, al);
+        if (TD_FS_ABL % 10 == 9) {        // no split: the rows' bits as they are
+          ah = __builtin_bit_cast(td_u32x4, xa[2 * j]); al = __builtin_bit_cast(td_u32x4, xa[2 * j + 1]);
+        } else {
+          split_step(xa, j, sa, ah, al);
+        }
+        if (TD_FS_ABL % 10 == 8) {        // no matrix instructions
+          a[4 * j] += __uint_as_float(ah[0] ^ al[1]); a[4 * j + 1] += __uint_as_float(ah[2] ^ al[3]);
+          a[4 * j + 2] += __uint_as_float(ah[1] ^ al[0]); a[4 * j + 3] += __uint_as_float(ah[3] ^ al[2]);
+          continue;
+        }
         a = td_mfma_f16(wl[j], ah, a);
         a = td_mfma_f16(wh[j], al, a);
         a = td_mfma_f16(wh[j], ah, a);

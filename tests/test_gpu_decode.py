@@ -62,6 +62,82 @@ def test_predict_fir_matches_dense_forward(dev, c, pre, post, d, lens, off):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('pre,post,lens,off,mode', [
+    (0, 31, (6000, 6000, 6000), 0, 'f16x2'),     # the C4 shape: strips of several tile pairs
+    (5, 20, (700, 64, 1, 31, 33, 1300), 0, 'f16x2'),   # context before the frame, recordings of 1 / 31 / 33 rows
+    (31, 0, (900, 257), 0, 'f16x2'),             # only past context
+    (0, 0, (640, 100), 0, 'f16x2'),              # one lag
+    (3, 7, (500, 300), 2, 'f16x2'),              # input_offset drops leading rows of every recording
+    (0, 31, (1000, 300, 257), 0, 'f32'),         # the float32 matrix instruction (td_set_accumulate_mode F32)
+    (2, 9, (77, 2049), 1, 'f32'),
+])
+def test_predict_fir_streamed_kernel_edges(dev, pre, post, lens, off, mode):
+  """One output, 64 channels, <= 32 lags: fir_stream_kernel (decode.hip).  Rows before / after a
+  recording come from the buffer descriptor's range check as zeros, a wave's strip ends anywhere in a
+  pair of tiles, the diagonal sums are DPP lane shifts across two tiles: every one of those against
+  the float64 lag matrix of the oracle (brain_model.py:335-341), in both arithmetic modes, with rows
+  of very different magnitudes (the float16 pieces are scaled per row)."""
+  rng = np.random.default_rng(pre * 37 + post)
+  h = dev.default_handle()
+  c, nl = 64, pre + 1 + post
+  w = (rng.standard_normal((c * nl, 1)) / np.sqrt(c * nl)).astype(np.float32)
+  b = rng.standard_normal(1).astype(np.float32)
+  xs = [rng.standard_normal((n, c)).astype(np.float32) for n in lens]
+  # rows 2^-20 ... 2^20 apart in scale, one all-zero row, one row with a single huge sample
+  for x in xs:
+    n = x.shape[0]
+    x *= np.exp2(rng.integers(-20, 21, size=(n, 1))).astype(np.float32)
+    if n > 40:
+      x[7] = 0.0
+      x[20, 3] = 3.0e30
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  saved = h.accumulate_mode
+  try:
+    h.set_accumulate_mode(mode)
+    out = dev.predict_fir(h.to_device(np.concatenate(xs)), offs, h.to_device(w),
+                          h.to_device(b.reshape(1, -1)).reshape(-1), pre, post, handle=h,
+                          input_offset=off).cpu().numpy()
+  finally:
+    h.set_accumulate_mode(saved)
+  worst = 0.0
+  for i, x in enumerate(xs):
+    if x.shape[0] <= off:
+      continue
+    xl = o_lag.lag_matrix(x[off:].astype(np.float64), pre, post)
+    want = xl @ w.astype(np.float64) + b
+    got = out[offs[i]:offs[i] + want.shape[0]].astype(np.float64)
+    # error relative to the size of the terms of each output's sum (a float32 rounding of every term)
+    size = np.abs(xl) @ np.abs(w.astype(np.float64)) + np.abs(b)
+    err = np.max(np.abs(got - want) / size)
+    worst = max(worst, err)
+    assert err < 4e-7, (i, err)
+  parity_log.record('fir_stream pre%d post%d %s' % (pre, post, mode), gpu_vs_ref64=worst)
+
+
+def test_predict_fir_streamed_kernel_strided_rows_and_nonfinite(dev):
+  """Rows wider than the 64 channels used (a column slice of a wider array), and what a NaN / Inf
+  sample does: exactly the outputs whose lag window holds it become non-finite (numpy's answer)."""
+  import torch
+  rng = np.random.default_rng(11)
+  h = dev.default_handle()
+  n, pre, post = 1500, 0, 31
+  wide = rng.standard_normal((n, 80)).astype(np.float32)
+  w = (rng.standard_normal((64 * 32, 1)) / 45.0).astype(np.float32)
+  xd = h.to_device(wide)[:, 8:72]                      # ldx = 80, base 32-byte aligned
+  out = dev.predict_fir(xd, [0, n], h.to_device(w), None, pre, post, handle=h).cpu().numpy()
+  want = o_lag.lag_matrix(wide[:, 8:72].astype(np.float64), pre, post) @ w.astype(np.float64)
+  np.testing.assert_allclose(out, want, rtol=2e-5, atol=2e-5)
+  x = np.ascontiguousarray(wide[:, :64])
+  x[700, 5] = np.nan
+  x[900, 60] = np.inf
+  out = dev.predict_fir(h.to_device(x), [0, n], h.to_device(w), None, pre, post, handle=h).cpu().numpy()
+  bad = ~np.isfinite(out[:, 0])
+  expect = np.zeros(n, bool)
+  expect[700 - 31:701] = True
+  expect[900 - 31:901] = True
+  assert np.array_equal(bad, expect)
+
+
 def test_window_pearson_zero_rule_is_per_model(dev):
   """td_window_pearson: the columns are several models of `group` outputs each (the lambdas of a
   jackknife fold); a constant column zeroes the Pearson result of ITS model only -- the
