@@ -756,9 +756,19 @@ constexpr int kTrialBlocksMax = 1536;    // 5 float64 per block in LDS: 60 KB
 __global__ __launch_bounds__(kTrialThreads) void decode_trial_kernel(
     const float* __restrict__ a, long long lda, const float* __restrict__ b,
     const FileDesc* __restrict__ trials, int g, int blocks_per_win, int blocks_per_hop, int width,
-    FusedCorr fc, double* __restrict__ scores, unsigned char* __restrict__ decisions) {
+    FusedCorr fc, double* __restrict__ scores, unsigned char* __restrict__ decisions,
+    long long u_stride, FileDesc u0) {
   extern __shared__ double tb_sums[];     // [block][5]: sum a0, sum a1, sum b, sum a0 b, sum a1 b
-  const FileDesc tr = trials[blockIdx.x];
+  // (u_stride > 0: trials of one length, one after the other -- trial t's descriptor follows from
+  // trial 0's, a kernel argument: no table read per workgroup in front of everything else)
+  FileDesc tr;
+  if (u_stride > 0) {
+    tr = u0;
+    tr.row0 += blockIdx.x * u_stride;
+    tr.first = blockIdx.x * tr.out0;
+  } else {
+    tr = trials[blockIdx.x];
+  }
   const int n_blocks = (int)tr.nrows, n_win = (int)tr.out0;
   const int sub = threadIdx.x & (kBlockLanes - 1), grp = threadIdx.x / kBlockLanes;
   for (int base = 0; base < n_blocks; base += kTrialThreads / kBlockLanes) {
@@ -1732,6 +1742,10 @@ struct FirStreamParams {
   long long ldout;
   const int* strip_file; // [n_strips]: the recording of every strip (a binary search over `files` is 8
                          // dependent loads = ~5 us before a wave's first row is asked for)
+  // recordings of ONE length, one after the other (strips_per_file > 0): every descriptor follows from
+  // the strip index alone -- no table read in front of a wave's first row (two dependent loads, ~2 us)
+  int strips_per_file;
+  long long u_row0, u_stride, u_nrows, u_out0;
 };
 
 // the 8 DMA instructions of one tile: LDS slot at byte address lds (wave-uniform), lane offsets v[m]
@@ -1786,7 +1800,16 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long sidx = blockIdx.x * (long long)(kThreads / 64) + wave;
   if (sidx >= p.n_strips) return;
-  const FileDesc st = p.files[__builtin_amdgcn_readfirstlane(p.strip_file[sidx])];
+  FileDesc st;
+  if (p.strips_per_file > 0) {
+    const long long f = sidx / p.strips_per_file;
+    st.row0 = p.u_row0 + f * p.u_stride;
+    st.nrows = p.u_nrows;
+    st.out0 = p.u_out0 + f * p.u_stride;
+    st.first = f * p.strips_per_file;
+  } else {
+    st = p.files[__builtin_amdgcn_readfirstlane(p.strip_file[sidx])];
+  }
   const long long ts = (sidx - st.first) * p.strip;             // first output of the strip
   const int st_len = (int)(st.nrows - ts < p.strip ? st.nrows - ts : p.strip);
   if (st_len <= 0) return;
@@ -1826,9 +1849,12 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
   };
   // the rows of tile t: wait for them, read them in operand order, refill the slot
   auto fetch = [&](int t, float4 (&xb)[8]) {
-    if (FS_NODMA || kSlots == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (tiles t+1 .. t+kSlots-1 may still be on their way: 8 DMA instructions each)
+    const int ahead = n_tiles - 1 - t < kSlots - 1 ? n_tiles - 1 - t : kSlots - 1;
+    if (FS_NODMA || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     const float* xt = slots + (t & (kSlots - 1)) * kFsSlotFloats + li * 64;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -1905,8 +1931,9 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
     if (o < st_len) orow[(long long)o * p.ldout] = v + bias;
   };
 
-  issue(0);
-  if (kSlots == 2) issue(1);
+#pragma unroll
+  for (int t = 0; t < kSlots; ++t)
+    if (t < n_tiles) issue(t);
   // (the first rows are on their way while the weights are fetched and split)
   // A operand: lane (m = li, g = lh) holds W[lag(m)][32 g + i] for instruction i
   {
@@ -2081,6 +2108,12 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       fp.x = x; fp.ldx = ldx; fp.files = reinterpret_cast<const FileDesc*>(table_dev);
       fp.strip_file = reinterpret_cast<const int*>(reinterpret_cast<const char*>(table_dev) +
                                                    files.size() * sizeof(FileDesc));
+      bool uniform = files[0].nrows > 0;
+      for (int f = 1; f < num_files && uniform; ++f)
+        uniform = files[f].nrows == files[0].nrows && files[f].row0 - files[f - 1].row0 == files[1].row0 - files[0].row0;
+      fp.strips_per_file = uniform ? (int)td_ceil_div(files[0].nrows, strip) : 0;
+      fp.u_row0 = files[0].row0; fp.u_nrows = files[0].nrows; fp.u_out0 = files[0].out0;
+      fp.u_stride = num_files > 1 ? files[1].row0 - files[0].row0 : 0;
       fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = (int)strip;
       fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
       fp.out = out; fp.ldout = ldout;
@@ -2678,6 +2711,11 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
       tt[t].out0 = (t + 1 < num_trials ? win_tab[t + 1].first : nwin) - win_tab[t].first;
       tt[t].first = win_tab[t].first;
     }
+    int64_t tt_stride = num_trials > 1 ? tt[1].row0 - tt[0].row0 : 0;
+    for (int t = 1; t < num_trials && tt_stride > 0; ++t)
+      if (tt[t].row0 - tt[t - 1].row0 != tt_stride || tt[t].nrows != tt[0].nrows || tt[t].out0 != tt[0].out0 ||
+          tt[t].first != t * tt[0].out0)
+        tt_stride = 0;
     const size_t s_pred1 = td_round_up(sizeof(float) * rows, 256);
     void* scratch1 = nullptr;
     TD_TRY(td_scratch(h, s_pred1, &scratch1));
@@ -2689,7 +2727,7 @@ int td_decode_fused(td_handle* h, const float* eeg_dev, int64_t ldx, int c, int 
     hipLaunchKernelGGL(decode_trial_kernel, dim3((unsigned)num_trials), dim3(kTrialThreads),
                        sizeof(double) * 5 * (size_t)max_tb, h->stream, env_dev, (long long)ldenv,
                        pred1, reinterpret_cast<const FileDesc*>(tt_dev), g, width / g, hop / g, width,
-                       fc, scores_dev, decisions_dev);
+                       fc, scores_dev, decisions_dev, (long long)tt_stride, tt[0]);
     TD_HIP(h, hipGetLastError());
     return TD_OK;
   }
