@@ -1746,6 +1746,7 @@ struct FirStreamParams {
   // the strip index alone -- no table read in front of a wave's first row (two dependent loads, ~2 us)
   int strips_per_file;
   long long u_row0, u_stride, u_nrows, u_out0;
+  long long* dbg;        // development (-DTD_FS_TIMING): [strip][2] start / end of every wave, 10 ns ticks
 };
 
 // the 8 DMA instructions of one tile: LDS slot at byte address lds (wave-uniform), lane offsets v[m]
@@ -1800,6 +1801,9 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long sidx = blockIdx.x * (long long)(kThreads / 64) + wave;
   if (sidx >= p.n_strips) return;
+#ifdef TD_FS_TIMING
+  const long long t_begin = wall_clock64();
+#endif
   FileDesc st;
   if (p.strips_per_file > 0) {
     const long long f = sidx / p.strips_per_file;
@@ -1860,6 +1864,8 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
     for (int k = 0; k < 8; ++k)
       xb[k] = *reinterpret_cast<const float4*>(xt + 4 * ((8 * lh + k) ^ (li & 15)));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto refill = [&](int t) {
     if (!FS_NODMA && t + kSlots < n_tiles) issue(t + kSlots);
   };
   // kF16: the power-of-two scale of a row (its 64 samples' largest magnitude into [2^13, 2^14)) and
@@ -1890,9 +1896,11 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
   auto products = [&](const float4 (&xa)[8], f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
-    if (TD_FS_ABL == 1 || TD_FS_ABL == 4 || TD_FS_ABL == 6) {
+    if (TD_FS_ABL == 1 || TD_FS_ABL == 4 || TD_FS_ABL == 6 || TD_FS_ABL == 10 || TD_FS_ABL == 11) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) a[k] = xa[k].x + xa[k].y + xa[k].z + xa[k].w;
+      if (TD_FS_ABL == 10) __builtin_amdgcn_s_sleep(20);     // ~0.55 us of nothing per tile
+      if (TD_FS_ABL == 11) __builtin_amdgcn_s_sleep(40);     // ~1.1 us
       return;
     }
     if (kF16) {
@@ -1966,20 +1974,29 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
   }
   float low_prev = 0.f;
   if (TD_FS_ABL == 5) { emit(0, wreg[0] + __uint_as_float(wh[0][0])); return; }
+  // The 64 outputs of a pair leave one iteration late, BETWEEN the wait for a tile and the DMA that
+  // refills its slot: vmcnt counts stores too and they retire out of order with the loads, so a wait
+  // can only count the loads issued after the tile it needs -- a store issued just in front of such a
+  // wait would have to be acknowledged (~1 us) before the wave goes on; here it has a tile's products
+  // to retire in.
+  float pend = 0.f;
   for (int pr = 0; 2 * pr < n_tiles; ++pr) {
     f32x16 a, b;
     {
       float4 xa[8];
       fetch(2 * pr, xa);
+      if (pr > 1) emit(pr - 2, pend);
+      refill(2 * pr);
       products(xa, a);
       fetch(2 * pr + 1, xa);
+      refill(2 * pr + 1);
       products(xa, b);
     }
     if (TD_FS_ABL >= 3) {
       float sa = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sa += a[r] + b[r];
-      if (pr > 0) emit(pr - 1, low_prev + sa);
+      pend = low_prev + sa;
       low_prev = sa;
       continue;
     }
@@ -1999,10 +2016,14 @@ __global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamPar
     // lanes 0..30 of `high` belong to lanes 33..63 of the previous pair
     const auto up = __builtin_amdgcn_permlane32_swap(0u, __float_as_uint(high), false, false);
     const float h = fs_shr1(__uint_as_float(up[0]));
-    if (pr > 0) emit(pr - 1, low_prev + h);
+    pend = low_prev + h;            // pair pr - 1, complete
     low_prev = low;
   }
+  if (n_tiles >= 4) emit(n_tiles / 2 - 2, pend);
   emit(n_tiles / 2 - 1, low_prev);
+#ifdef TD_FS_TIMING
+  if (p.dbg && lane == 0) { p.dbg[2 * sidx] = t_begin; p.dbg[2 * sidx + 1] = wall_clock64(); }
+#endif
 }
 
 // The per-file descriptor table goes through the handle's content-cached table slots
@@ -2117,6 +2138,42 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = (int)strip;
       fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
       fp.out = out; fp.ldout = ldout;
+      fp.dbg = nullptr;
+#ifdef TD_FS_TIMING
+      static long long* dbg_dev = nullptr;
+      static int dbg_calls = 0;
+      if (!dbg_dev) hipMalloc(reinterpret_cast<void**>(&dbg_dev), sizeof(long long) * 2 * 8192);
+      fp.dbg = n_strips <= 8192 ? dbg_dev : nullptr;
+      if (fp.dbg && ++dbg_calls == 50) {       // the 49th call's clocks: finish-time histogram
+        hipStreamSynchronize(h->stream);
+        std::vector<long long> hb(2 * n_strips);
+        hipMemcpy(hb.data(), dbg_dev, sizeof(long long) * 2 * n_strips, hipMemcpyDeviceToHost);
+        long long t0 = hb[0];
+        for (long long i = 0; i < n_strips; ++i) t0 = hb[2 * i] < t0 ? hb[2 * i] : t0;
+        int hs[16] = {0}, he[16] = {0};
+        for (long long i = 0; i < n_strips; ++i) {
+          int bs = (int)((hb[2 * i] - t0) / 500), be = (int)((hb[2 * i + 1] - t0) / 500);
+          hs[bs > 15 ? 15 : bs]++; he[be > 15 ? 15 : be]++;
+        }
+        fprintf(stderr, "fir_stream waves by 5 us bins since the first start:\n  start:");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %d", hs[i]);
+        fprintf(stderr, "\n  end:  ");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %d", he[i]);
+        fprintf(stderr, "\n  by position in the recording (mean end, us):");
+        for (int k = 0; k < fp.strips_per_file; ++k) {
+          double m = 0; int cnt = 0;
+          for (long long i = k; i < n_strips; i += fp.strips_per_file) { m += (hb[2 * i + 1] - t0) * 0.01; ++cnt; }
+          fprintf(stderr, " %.1f", m / cnt);
+        }
+        fprintf(stderr, "\n  by block of 250 strips (mean start / end, us):");
+        for (long long k = 0; k < n_strips; k += 250) {
+          double ms = 0, me = 0; int cnt = 0;
+          for (long long i = k; i < k + 250 && i < n_strips; ++i) { ms += (hb[2 * i] - t0) * 0.01; me += (hb[2 * i + 1] - t0) * 0.01; ++cnt; }
+          fprintf(stderr, " %.1f/%.1f", ms / cnt, me / cnt);
+        }
+        fprintf(stderr, "\n");
+      }
+#endif
       constexpr size_t kLds = sizeof(float) * (kThreads / 64) * kFsSlots * kFsSlotFloats;
       if (!h->lds_opt_fir_stream) {
         TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_stream_kernel<true, kFsSlots, kFsOcc>),
