@@ -1721,12 +1721,21 @@ constexpr int kFsSlotFloats = 32 * 64;     // one tile: 32 rows x 64 channels
 #define TD_FS_OCC 2
 #endif
 #define FS_NODMA (TD_FS_ABL == 2 || (TD_FS_ABL >= 6 && TD_FS_ABL <= 9))   // (18 / 19: 8 / 9 with the DMA)
+#ifndef TD_FS_THREADS
+#define TD_FS_THREADS 256
+#endif
+constexpr int kFsThreads = TD_FS_THREADS;  // waves x 64 per workgroup
 constexpr int kFsSlots = TD_FS_SLOTS;      // tiles of LDS per wave (1 or 2)
 constexpr int kFsOcc = TD_FS_OCC;          // workgroups (of four waves) per CU
 #ifndef TD_FS_ABL
 #define TD_FS_ABL 0     // development: 1 no matrix instructions, 2 no DMA after the first two tiles, 3 no chains, 4 DMA only,
                         // 5 setup only, 6 = 2 + no products / chains, 7 = 2 + no chains
 #endif
+
+// A wave's strip: recording, first output, outputs.
+struct FsStrip {
+  int file, first, len, pad;
+};
 
 struct FirStreamParams {
   const float* x;
@@ -1740,12 +1749,7 @@ struct FirStreamParams {
   int d, q0;
   float* out;
   long long ldout;
-  const int* strip_file; // [n_strips]: the recording of every strip (a binary search over `files` is 8
-                         // dependent loads = ~5 us before a wave's first row is asked for)
-  // recordings of ONE length, one after the other (strips_per_file > 0): every descriptor follows from
-  // the strip index alone -- no table read in front of a wave's first row (two dependent loads, ~2 us)
-  int strips_per_file;
-  long long u_row0, u_stride, u_nrows, u_out0;
+  const FsStrip* strips; // [n_strips]: recording, first output and length of every strip
   long long* dbg;        // development (-DTD_FS_TIMING): [strip][2] start / end of every wave, 10 ns ticks
 };
 
@@ -1795,27 +1799,19 @@ __device__ __forceinline__ float fs_shr1(float v) {      // lane i <- lane i - 1
 }
 
 template <bool kF16, int kSlots, int kOcc>   // LDS slots (tiles) per wave; workgroups per CU
-__global__ __launch_bounds__(kThreads, kOcc) void fir_stream_kernel(FirStreamParams p) {
+__global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamParams p) {
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long sidx = blockIdx.x * (long long)(kThreads / 64) + wave;
+  const long long sidx = blockIdx.x * (long long)(kFsThreads / 64) + wave;
   if (sidx >= p.n_strips) return;
 #ifdef TD_FS_TIMING
   const long long t_begin = wall_clock64();
 #endif
-  FileDesc st;
-  if (p.strips_per_file > 0) {
-    const long long f = sidx / p.strips_per_file;
-    st.row0 = p.u_row0 + f * p.u_stride;
-    st.nrows = p.u_nrows;
-    st.out0 = p.u_out0 + f * p.u_stride;
-    st.first = f * p.strips_per_file;
-  } else {
-    st = p.files[__builtin_amdgcn_readfirstlane(p.strip_file[sidx])];
-  }
-  const long long ts = (sidx - st.first) * p.strip;             // first output of the strip
-  const int st_len = (int)(st.nrows - ts < p.strip ? st.nrows - ts : p.strip);
+  const FsStrip sd = p.strips[sidx];
+  const FileDesc st = p.files[__builtin_amdgcn_readfirstlane(sd.file)];
+  const long long ts = __builtin_amdgcn_readfirstlane(sd.first);     // first output of the strip
+  const int st_len = __builtin_amdgcn_readfirstlane(sd.len);
   if (st_len <= 0) return;
   const int nl = p.pre + 1 + p.post;
   const int li = lane & 31, lh = lane >> 5;
@@ -2103,39 +2099,43 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
 #endif
     if (stream_ok) {
       const int cus = h->cu_count > 0 ? h->cu_count : 256;
-      // one strip per resident wave (kFsOcc workgroups of four waves per CU), a multiple of 32 outputs
-      int64_t strip = td_round_up(td_ceil_div(total, (int64_t)cus * kFsOcc * (kThreads / 64)), 32);
-      if (strip < 256) strip = 256;
-      // one table: the recordings' descriptors, then the recording of every strip
+      // One strip per resident wave (kFsOcc workgroups of kFsThreads / 64 waves per CU): every recording
+      // is cut into round(rows / mean strip) strips of one length, a multiple of 32 outputs.  (Unequal
+      // strips were tried: the scheduler serves the older wave of a SIMD first, the first four waves of
+      // an 8-wave workgroup are done at 40 us and the other four at 51 -- but 25 % longer strips for the
+      // first moved their end to 43 and left the others at 51: what ends the launch is the rate of the
+      // whole chip, not the share of a wave.)
+      constexpr int wpg = kFsThreads / 64;
+      double mean_strip = (double)total / ((double)cus * kFsOcc * wpg);
+      if (mean_strip < 256.0) mean_strip = 256.0;
       std::vector<FileDesc> files(num_files);
-      std::vector<int> strip_file;
-      long long n_strips = 0;
+      std::vector<FsStrip> strips;
       for (int f = 0; f < num_files; ++f) {
         const int64_t n = offs[f + 1] - offs[f] - shift;
         files[f].row0 = offs[f] + shift;
         files[f].nrows = n > 0 ? n : 0;
         files[f].out0 = offs[f];
-        files[f].first = n_strips;
-        if (n > 0) {
-          n_strips += td_ceil_div(n, strip);
-          strip_file.resize((size_t)n_strips, f);
+        files[f].first = (long long)strips.size();
+        if (n <= 0) continue;
+        int64_t k = (int64_t)((double)n / mean_strip + 0.5);
+        k = k < 1 ? 1 : k;
+        const int64_t len = td_round_up(td_ceil_div(n, k), 32);
+        for (int64_t at = 0; at < n; at += len) {
+          FsStrip sd;
+          sd.file = f; sd.first = (int)at; sd.len = (int)(n - at < len ? n - at : len); sd.pad = 0;
+          strips.push_back(sd);
         }
       }
-      std::vector<char> table(files.size() * sizeof(FileDesc) + strip_file.size() * sizeof(int));
+      const long long n_strips = (long long)strips.size();
+      std::vector<char> table(files.size() * sizeof(FileDesc) + strips.size() * sizeof(FsStrip));
       memcpy(table.data(), files.data(), files.size() * sizeof(FileDesc));
-      memcpy(table.data() + files.size() * sizeof(FileDesc), strip_file.data(), strip_file.size() * sizeof(int));
+      memcpy(table.data() + files.size() * sizeof(FileDesc), strips.data(), strips.size() * sizeof(FsStrip));
       TD_TRY(td_table_upload(h, table.data(), table.size(), &table_dev));
       FirStreamParams fp;
       fp.x = x; fp.ldx = ldx; fp.files = reinterpret_cast<const FileDesc*>(table_dev);
-      fp.strip_file = reinterpret_cast<const int*>(reinterpret_cast<const char*>(table_dev) +
+      fp.strips = reinterpret_cast<const FsStrip*>(reinterpret_cast<const char*>(table_dev) +
                                                    files.size() * sizeof(FileDesc));
-      bool uniform = files[0].nrows > 0;
-      for (int f = 1; f < num_files && uniform; ++f)
-        uniform = files[f].nrows == files[0].nrows && files[f].row0 - files[f - 1].row0 == files[1].row0 - files[0].row0;
-      fp.strips_per_file = uniform ? (int)td_ceil_div(files[0].nrows, strip) : 0;
-      fp.u_row0 = files[0].row0; fp.u_nrows = files[0].nrows; fp.u_out0 = files[0].out0;
-      fp.u_stride = num_files > 1 ? files[1].row0 - files[0].row0 : 0;
-      fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = (int)strip;
+      fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = 0;
       fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
       fp.out = out; fp.ldout = ldout;
       fp.dbg = nullptr;
@@ -2159,10 +2159,10 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d", hs[i]);
         fprintf(stderr, "\n  end:  ");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d", he[i]);
-        fprintf(stderr, "\n  by position in the recording (mean end, us):");
-        for (int k = 0; k < fp.strips_per_file; ++k) {
+        fprintf(stderr, "\n  by wave of the workgroup (mean end, us):");
+        for (int k = 0; k < kFsThreads / 64; ++k) {
           double m = 0; int cnt = 0;
-          for (long long i = k; i < n_strips; i += fp.strips_per_file) { m += (hb[2 * i + 1] - t0) * 0.01; ++cnt; }
+          for (long long i = k; i < n_strips; i += kFsThreads / 64) { m += (hb[2 * i + 1] - t0) * 0.01; ++cnt; }
           fprintf(stderr, " %.1f", m / cnt);
         }
         fprintf(stderr, "\n  by block of 250 strips (mean start / end, us):");
@@ -2174,7 +2174,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
         fprintf(stderr, "\n");
       }
 #endif
-      constexpr size_t kLds = sizeof(float) * (kThreads / 64) * kFsSlots * kFsSlotFloats;
+      constexpr size_t kLds = sizeof(float) * (kFsThreads / 64) * kFsSlots * kFsSlotFloats;
       if (!h->lds_opt_fir_stream) {
         TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_stream_kernel<true, kFsSlots, kFsOcc>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
@@ -2182,7 +2182,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
         h->lds_opt_fir_stream = true;
       }
-      const dim3 grid((unsigned)td_ceil_div(n_strips, kThreads / 64)), block(kThreads);
+      const dim3 grid((unsigned)td_ceil_div(n_strips, kFsThreads / 64)), block(kFsThreads);
       // (TD_ACC_F32: exact float32 products on the float32 matrix instruction; otherwise each as three
       // float16 products -- the rule of the accumulate)
       if (h->acc_mode == TD_ACC_F32)
