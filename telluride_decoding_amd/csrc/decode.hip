@@ -599,9 +599,23 @@ __global__ void window_sums_short_kernel(const float* __restrict__ a, long long 
 // trees for 2 rounds of loads (22 us at C4; 16 lanes per block: 8 us).
 constexpr int kBlockLanes = 16;
 
+// The tree v += v[lane ^ 8], ^ 4, ^ 2, ^ 1 within each group of 16 lanes, every lane ending with the
+// total -- as DPP row rotations instead of ds_bpermute shuffles: after the ^ 8 step the values repeat
+// every 8 lanes, so lane (i + 4) mod 16 holds what lane i ^ 4 holds, and so on down: the same operand
+// pairs, the same bits, no LDS crossbar (40 ds_bpermute per pass of blocks made the per-trial kernel
+// LDS-bound at short blocks: 50 us at W = 10 / hop 5).
+template <int kCtrl>
+__device__ __forceinline__ double dpp_row_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double group16_sum(double v) {
-#pragma unroll
-  for (int off = kBlockLanes / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  static_assert(kBlockLanes == 16, "a DPP row is 16 lanes");
+  v += dpp_row_f64<0x128>(v);     // row_ror:8
+  v += dpp_row_f64<0x124>(v);     // row_ror:4
+  v += dpp_row_f64<0x122>(v);     // row_ror:2
+  v += dpp_row_f64<0x121>(v);     // row_ror:1
   return v;
 }
 
@@ -771,7 +785,40 @@ __global__ __launch_bounds__(kTrialThreads) void decode_trial_kernel(
   }
   const int n_blocks = (int)tr.nrows, n_win = (int)tr.out0;
   const int sub = threadIdx.x & (kBlockLanes - 1), grp = threadIdx.x / kBlockLanes;
-  for (int base = 0; base < n_blocks; base += kTrialThreads / kBlockLanes) {
+  constexpr int kGroups = kTrialThreads / kBlockLanes;
+  // Short blocks (a row per lane at most: windows of a few frames, e.g. W = 10 / hop 5 -> 1200 blocks
+  // of 5 frames per minute): eight passes of blocks at a time, their loads issued together -- one
+  // memory latency per eight passes instead of one per pass.  The same sums in the same order.
+  int base0 = 0;
+  if (g <= kBlockLanes) {
+    for (; base0 + 8 * kGroups <= n_blocks + 7 * kGroups && base0 < n_blocks; base0 += 8 * kGroups) {
+      float va0[8], va1[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int blk = base0 + u * kGroups + grp;
+        const long long rr = tr.row0 + (long long)(blk < n_blocks ? blk : n_blocks - 1) * g + (sub < g ? sub : 0);
+        va0[u] = a[rr * lda]; va1[u] = a[rr * lda + 1]; vb[u] = b[rr];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int blk = base0 + u * kGroups + grp;
+        const bool live = blk < n_blocks;
+        double sa0 = 0, sa1 = 0, sb = 0, p0 = 0, p1 = 0;
+        if (sub < g) {
+          const double a0 = (double)va0[u], a1 = (double)va1[u], bv = (double)vb[u];
+          sa0 += a0; sa1 += a1; sb += bv;
+          p0 += a0 * bv; p1 += a1 * bv;
+        }
+        sa0 = group16_sum(sa0); sa1 = group16_sum(sa1); sb = group16_sum(sb);
+        p0 = group16_sum(p0); p1 = group16_sum(p1);
+        if (sub == 0 && live) {
+          double* o = tb_sums + blk * 5;
+          o[0] = sa0; o[1] = sa1; o[2] = sb; o[3] = p0; o[4] = p1;
+        }
+      }
+    }
+  }
+  for (int base = base0; base < n_blocks; base += kGroups) {
     const int blk = base + grp;
     const bool live = blk < n_blocks;               // dead groups stay for the shuffles
     const long long r0 = tr.row0 + (long long)(live ? blk : n_blocks - 1) * g;
