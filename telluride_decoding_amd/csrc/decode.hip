@@ -1790,8 +1790,8 @@ struct FirStreamParams {
   const FileDesc* files;
   int n_files;
   long long n_strips;
-  int strip, pre, post;
-  const float* w;        // [nl * 64][d]
+  int strip, c, pre, post;
+  const float* w;        // [nl * c][d]
   const float* bias;     // [d] or null
   int d, q0;
   float* out;
@@ -1881,7 +1881,10 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const int r = 4 * m + (lane >> 4);
-    lpart[m] = (unsigned)(r * ldb + 16 * ((lane & 15) ^ (r & 15)));
+    const int gran = (lane & 15) ^ (r & 15);
+    // (fewer than 64 channels: the granules past a row's end are asked for far outside the descriptor's
+    // range -- 2^31 and up, whatever the tile's base adds -- and arrive as zeros)
+    lpart[m] = 4 * gran < p.c ? (unsigned)(r * ldb + 16 * gran) : 0x80000000u;
   }
   float* slots = fs_lds + wave * kSlots * kFsSlotFloats;
   const unsigned slot_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)slots);
@@ -1991,7 +1994,7 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
     const int lag = 16 * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3);
 #pragma unroll
     for (int i = 0; i < 32; ++i)
-      wreg[i] = lag < nl ? p.w[((size_t)lag * 64 + 32 * lh + i) * p.d + p.q0] : 0.f;
+      wreg[i] = lag < nl && 32 * lh + i < p.c ? p.w[((size_t)lag * p.c + 32 * lh + i) * p.d + p.q0] : 0.f;
   }
   // kF16: the weights as two float16 pieces under ONE power-of-two scale (largest magnitude in
   // [2^13, 2^14)): k-step j multiplies channels 32 g + 8 j .. + 7
@@ -2137,8 +2140,9 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     return TD_OK;
   }
   {
-    // one output, 64 channels, <= 32 lags, every recording below 2 GB: the DMA-streamed kernel
-    bool stream_ok = !w_file_stride && d == 1 && nl <= 32 && c == 64 && vec4 && ldx < (1 << 20);
+    // one output, 4..64 channels in whole 16-byte granules, <= 32 lags, every recording below 2 GB: the
+    // DMA-streamed kernel
+    bool stream_ok = !w_file_stride && d == 1 && nl <= 32 && c >= 4 && c <= 64 && vec4 && ldx < (1 << 20);
     for (int f = 0; f < num_files && stream_ok; ++f)
       stream_ok = (offs[f + 1] - offs[f]) * ldx * 4 < (int64_t)0x7fc00000;
 #ifdef TD_DEV_SWITCHES
@@ -2183,7 +2187,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       fp.strips = reinterpret_cast<const FsStrip*>(reinterpret_cast<const char*>(table_dev) +
                                                    files.size() * sizeof(FileDesc));
       fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = 0;
-      fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
+      fp.c = c; fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
       fp.out = out; fp.ldout = ldout;
       fp.dbg = nullptr;
 #ifdef TD_FS_TIMING

@@ -62,6 +62,7 @@ def test_predict_fir_matches_dense_forward(dev, c, pre, post, d, lens, off):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize('c', [64, 32, 48, 4, 60])
 @pytest.mark.parametrize('pre,post,lens,off,mode', [
     (0, 31, (6000, 6000, 6000), 0, 'f16x2'),     # the C4 shape: strips of several tile pairs
     (5, 20, (700, 64, 1, 31, 33, 1300), 0, 'f16x2'),   # context before the frame, recordings of 1 / 31 / 33 rows
@@ -71,15 +72,16 @@ def test_predict_fir_matches_dense_forward(dev, c, pre, post, d, lens, off):
     (0, 31, (1000, 300, 257), 0, 'f32'),         # the float32 matrix instruction (td_set_accumulate_mode F32)
     (2, 9, (77, 2049), 1, 'f32'),
 ])
-def test_predict_fir_streamed_kernel_edges(dev, pre, post, lens, off, mode):
-  """One output, 64 channels, <= 32 lags: fir_stream_kernel (decode.hip).  Rows before / after a
+def test_predict_fir_streamed_kernel_edges(dev, c, pre, post, lens, off, mode):
+  """One output, 4..64 channels (whole 16-byte granules; the granules past a row's end are read as
+  zeros), <= 32 lags: fir_stream_kernel (decode.hip).  Rows before / after a
   recording come from the buffer descriptor's range check as zeros, a wave's strip ends anywhere in a
   pair of tiles, the diagonal sums are DPP lane shifts across two tiles: every one of those against
   the float64 lag matrix of the oracle (brain_model.py:335-341), in both arithmetic modes, with rows
   of very different magnitudes (the float16 pieces are scaled per row)."""
-  rng = np.random.default_rng(pre * 37 + post)
+  rng = np.random.default_rng(pre * 37 + post + c)
   h = dev.default_handle()
-  c, nl = 64, pre + 1 + post
+  nl = pre + 1 + post
   w = (rng.standard_normal((c * nl, 1)) / np.sqrt(c * nl)).astype(np.float32)
   b = rng.standard_normal(1).astype(np.float32)
   xs = [rng.standard_normal((n, c)).astype(np.float32) for n in lens]
@@ -111,7 +113,7 @@ def test_predict_fir_streamed_kernel_edges(dev, pre, post, lens, off, mode):
     err = np.max(np.abs(got - want) / size)
     worst = max(worst, err)
     assert err < 4e-7, (i, err)
-  parity_log.record('fir_stream pre%d post%d %s' % (pre, post, mode), gpu_vs_ref64=worst)
+  parity_log.record('fir_stream c%d pre%d post%d %s' % (c, pre, post, mode), gpu_vs_ref64=worst)
 
 
 def test_predict_fir_streamed_kernel_strided_rows_and_nonfinite(dev):
