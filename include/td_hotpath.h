@@ -334,7 +334,13 @@ int td_predict_fir(td_handle* h, const float* x_dev, int64_t ldx,
                    int d, float* out_dev, int64_t ldout);
 /* input_offset > 0 drops that many leading rows of every file of x BEFORE the
  * context is added (brain_data.py:466-475).  Output row file_offsets[f] + t is
- * frame t of the zipped streams of file f. */
+ * frame t of the zipped streams of file f.
+ * Arithmetic: float32 products accumulated in float32.  With td_set_accumulate_mode(TD_ACC_F32) the
+ * products are exact float32 ones (v_mfma_f32_32x32x2_f32); otherwise every sample and weight enters as
+ * two float16 pieces under a power-of-two scale of its row (22 significant bits; one output, <= 64
+ * channels, <= 32 lags: fir_stream_kernel) or three bf16 pieces (the other shapes): within 4e-7 of the
+ * sum of the terms' magnitudes against float64 either way (tests/test_gpu_decode.py).  A non-finite
+ * sample makes exactly the outputs whose lag window holds it non-finite. */
 
 /* The same forward with EVERY FILE UNDER ITS OWN MODEL: w_dev [num_files, K, d], b_dev
  * [num_files, d] (may be NULL).  This is the evaluation half of the leave-one-out sweep
