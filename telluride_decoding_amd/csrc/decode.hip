@@ -2054,6 +2054,12 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
       V[r] = __uint_as_float(sw[0]);
       V[16 + r] = __uint_as_float(sw[1]);
     }
+    if (nl < 32) {
+      // (lags past the filter carry zero weights, but 0 x NaN is NaN: they stay out of the sums, so a
+      // non-finite sample spoils exactly the outputs whose lag window holds it)
+#pragma unroll
+      for (int l = 0; l < 32; ++l) V[l] = l < nl ? V[l] : 0.f;
+    }
     float low = V[31], high = V[1];
 #pragma unroll
     for (int l = 30; l >= 0; --l) low = fs_shl1(low) + V[l];

@@ -132,12 +132,14 @@ def test_predict_fir_streamed_kernel_strided_rows_and_nonfinite(dev):
   x = np.ascontiguousarray(wide[:, :64])
   x[700, 5] = np.nan
   x[900, 60] = np.inf
-  out = dev.predict_fir(h.to_device(x), [0, n], h.to_device(w), None, pre, post, handle=h).cpu().numpy()
-  bad = ~np.isfinite(out[:, 0])
-  expect = np.zeros(n, bool)
-  expect[700 - 31:701] = True
-  expect[900 - 31:901] = True
-  assert np.array_equal(bad, expect)
+  for pre2, post2 in ((0, 31), (2, 9)):        # (a filter shorter than the 32-lag tile too)
+    w2 = (rng.standard_normal((64 * (pre2 + 1 + post2), 1)) / 45.0).astype(np.float32)
+    out = dev.predict_fir(h.to_device(x), [0, n], h.to_device(w2), None, pre2, post2, handle=h).cpu().numpy()
+    bad = ~np.isfinite(out[:, 0])
+    expect = np.zeros(n, bool)
+    expect[700 - post2:700 + pre2 + 1] = True
+    expect[900 - post2:900 + pre2 + 1] = True
+    assert np.array_equal(bad, expect), (pre2, post2, np.flatnonzero(bad != expect))
 
 
 def test_window_pearson_zero_rule_is_per_model(dev):
