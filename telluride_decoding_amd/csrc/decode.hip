@@ -2078,6 +2078,234 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
 #endif
 }
 
+// ---- CCA transform without context, streamed (round 4) -------------------------------------------
+//   out[t] = [ (x[t] - m1) R1 | (x2[t] - m2) R2 ]                         (cca.py:157-161)
+// cca_project_kernel above with the structure of fir_stream_kernel: the rows of both views reach LDS by
+// DMA (8 instructions for the <= 64 channels of x, XOR-swizzled as there, one for the <= 8 of x2; rows
+// past a view's end read as zeros through the descriptors' range checks), are read back in operand
+// order and enter v_mfma_f32_32x32x16_f16 as the B operand (N = time) in two float16 pieces under a
+// per-row power-of-two scale -- one scale per view: the views may be decades apart -- against
+// W = diag(R1, R2) as the A operand (M = output, <= 16 of the 32 rows), 15 matrix instructions per 32
+// rows instead of 36 and 3 vector instructions per sample instead of 5.5.  A lane of the result is one
+// ROW with its outputs in registers: scaled back per lane, biased, through a [32][17] LDS tile, and out
+// as whole lines -- one tile late, in front of the DMA that refills the slot (vmcnt counts stores too:
+// fir_stream_kernel).  No barrier.
+struct ProjStreamParams {
+  const float* x; const float* x2;
+  long long ldx, ldx2, ldout;
+  int c1, c2, dims;
+  const float* mean1; const float* rot1; const float* mean2; const float* rot2;
+  const ProjFile* files;
+  const FsStrip* strips;
+  long long n_strips;
+  float* out;
+};
+constexpr int kPsWaveFloats = kFsSlotFloats + 32 * 8 + 32 * 17 + 16;   // x tile, x2 tile, result tile, bias
+#ifndef TD_PS_OCC
+#define TD_PS_OCC 3
+#endif
+constexpr int kPsOcc = TD_PS_OCC;          // workgroups (of four waves) per CU
+
+template <int kOcc>
+__global__ __launch_bounds__(kThreads, kOcc) void cca_project_stream_kernel(ProjStreamParams p) {
+  extern __shared__ __attribute__((aligned(16))) float ps_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long sidx = blockIdx.x * (long long)(kThreads / 64) + wave;
+  if (sidx >= p.n_strips) return;
+  const FsStrip sd = p.strips[sidx];
+  const ProjFile fd = p.files[__builtin_amdgcn_readfirstlane(sd.file)];
+  const long long t0 = __builtin_amdgcn_readfirstlane(sd.first);
+  const int rows = __builtin_amdgcn_readfirstlane(sd.len);
+  if (rows <= 0) return;
+  const int li = lane & 31, lh = lane >> 5, d2 = 2 * p.dims;
+  const int ldb1 = (int)p.ldx * 4, ldb2 = (int)p.ldx2 * 4;
+  float* xt = ps_lds + wave * kPsWaveFloats;
+  float* yt = xt + kFsSlotFloats;
+  float* ot = yt + 32 * 8;
+  float* bias = ot + 32 * 17;
+  const unsigned slot_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)xt);
+
+  // descriptors: rows outside [0, nx) / [0, ny) of the recording's views read as zeros
+  auto make_rs = [](const float* base_ptr, long long bytes) {
+    const unsigned long long base = reinterpret_cast<unsigned long long>(base_ptr);
+    fs_i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+    rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
+    rs.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+    rs.w = 0x00020000;
+    return rs;
+  };
+  const fs_i32x4 rs1 = make_rs(p.x + fd.xrow0 * p.ldx, fd.nx * ldb1);
+  const fs_i32x4 rs2 = make_rs(p.x2 + fd.yrow0 * p.ldx2, fd.ny * ldb2);
+  unsigned lpart[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int r = 4 * m + (lane >> 4);
+    const int gran = (lane & 15) ^ (r & 15);
+    lpart[m] = 4 * gran < p.c1 ? (unsigned)(r * ldb1 + 16 * gran) : 0x80000000u;
+  }
+  // x2: lane l fetches row l >> 1, granule l & 1 -- the linear image is [32][8]
+  const unsigned lpart2 = 4 * (lane & 1) < p.c2 ? (unsigned)((lane >> 1) * ldb2 + 16 * (lane & 1)) : 0x80000000u;
+  const int n_tiles = (rows + 31) / 32;
+  auto issue = [&](int t) {
+    const int row = (int)t0 + 32 * t;
+    unsigned v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = lpart[m] + (unsigned)(row * ldb1);
+    fs_issue_tile(rs1, slot_addr, v);
+    const unsigned v2 = lpart2 + (unsigned)(row * ldb2);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v], %[rs], 0 offen lds\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [lds] "s"(slot_addr + (unsigned)(kFsSlotFloats * 4)), [rs] "s"(rs2), [v] "v"(v2)
+        : "memory");
+  };
+  issue(0);
+
+  // bias[q] = -(mean . rot[:, q]) of the view that owns output q: lane (q = lane & 15, part = lane >> 4)
+  {
+    const int q = lane & 15, part = lane >> 4;
+    double sacc = 0.0;
+    if (q < p.dims) {
+      for (int f = part; f < p.c1; f += 4) sacc += (double)p.mean1[f] * (double)p.rot1[f * p.dims + q];
+    } else if (q < d2) {
+      for (int f = part; f < p.c2; f += 4) sacc += (double)p.mean2[f] * (double)p.rot2[f * p.dims + q - p.dims];
+    }
+    sacc += __shfl_xor(sacc, 16, 64);
+    sacc += __shfl_xor(sacc, 32, 64);
+    if (lane < 16) bias[lane] = (float)(-sacc);
+  }
+  // W = diag(R1, R2) as the A operand: lane (m = li output, g = lh): k-step j < 4 channels 32 g + 8 j + kk of x,
+  // k-step 4 channels kk of x2 (g = 0); two float16 pieces under one scale per view
+  td_u32x4 wh[5], wl[5];
+  float un1w, un2w;
+  {
+    float wv[5][8];
+    float mx1 = 0.f, mx2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int ch = 32 * lh + 8 * j + kk;
+        wv[j][kk] = (li < p.dims && ch < p.c1) ? p.rot1[ch * p.dims + li] : 0.f;
+        mx1 = fmaxf(mx1, fabsf(wv[j][kk]));
+      }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      wv[4][kk] = (lh == 0 && li >= p.dims && li < d2 && kk < p.c2) ? p.rot2[kk * p.dims + li - p.dims] : 0.f;
+      mx2 = fmaxf(mx2, fabsf(wv[4][kk]));
+    }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      mx1 = fmaxf(mx1, __shfl_xor(mx1, sft, 64));
+      mx2 = fmaxf(mx2, __shfl_xor(mx2, sft, 64));
+    }
+    unsigned e1 = __float_as_uint(mx1) >> 23, e2 = __float_as_uint(mx2) >> 23;
+    e1 = e1 < 20u ? 20u : e1;
+    e2 = e2 < 20u ? 20u : e2;
+    const float ws1 = __uint_as_float((267u - e1) << 23), ws2 = __uint_as_float((267u - e2) << 23);
+    un1w = __uint_as_float((e1 - 13u) << 23);
+    un2w = __uint_as_float((e2 - 13u) << 23);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned hh, ll;
+        const float sc = j < 4 ? ws1 : ws2;
+        td_split2_f16(wv[j][2 * q] * sc, wv[j][2 * q + 1] * sc, hh, ll);
+        wh[j][q] = hh;
+        wl[j][q] = ll;
+      }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // the 8 outputs a lane's registers hold: m = (r & 3) + 8 (r >> 2) + 4 lh, r < 8
+  float bm[8];
+  bool own1[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    bm[r] = bias[m];
+    own1[r] = m < p.dims;
+  }
+
+  float* const obase = p.out + (fd.out0 + t0) * p.ldout;
+  auto store_tile = [&](int t) {       // the result tile of tile t -> out, whole lines
+    float* op = obase + (long long)(32 * t) * p.ldout;
+    for (int idx = lane; idx < 32 * d2; idx += 64) {
+      const int r = idx / d2, q = idx - r * d2;
+      const long long tt = t0 + 32 * t + r;
+      const bool ok = 32 * t + r < rows && (q < p.dims ? tt < fd.nx : tt < fd.ny);
+      if (ok) op[(long long)r * p.ldout + q] = ot[r * 17 + q];
+    }
+  };
+
+  for (int t = 0; t < n_tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float4 xb[8], yb[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      xb[k] = *reinterpret_cast<const float4*>(xt + li * 64 + 4 * ((8 * lh + k) ^ (li & 15)));
+    yb[0] = *reinterpret_cast<const float4*>(yt + li * 8);
+    yb[1] = *reinterpret_cast<const float4*>(yt + li * 8 + 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t > 0) store_tile(t - 1);
+    if (t + 1 < n_tiles) issue(t + 1);
+    if (lh) { yb[0] = float4{0.f, 0.f, 0.f, 0.f}; yb[1] = yb[0]; }
+    // per-row scales of the two views
+    float mx1 = 0.f, mx2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      mx1 = fmaxf(fmaxf(fabsf(xb[k].x), fabsf(xb[k].y)), mx1);
+      mx1 = fmaxf(fmaxf(fabsf(xb[k].z), fabsf(xb[k].w)), mx1);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      mx2 = fmaxf(fmaxf(fabsf(yb[k].x), fabsf(yb[k].y)), mx2);
+      mx2 = fmaxf(fmaxf(fabsf(yb[k].z), fabsf(yb[k].w)), mx2);
+    }
+    // (both halves of a row: v_permlane32_swap of a register with itself lays the two halves side by side)
+    const auto e1x = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx1), __float_as_uint(mx1), false, false);
+    const auto e2x = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx2), __float_as_uint(mx2), false, false);
+    mx1 = fmaxf(__uint_as_float(e1x[0]), __uint_as_float(e1x[1]));
+    mx2 = fmaxf(__uint_as_float(e2x[0]), __uint_as_float(e2x[1]));
+    unsigned e1 = __float_as_uint(mx1) >> 23, e2 = __float_as_uint(mx2) >> 23;
+    e1 = e1 < 20u ? 20u : e1;
+    e2 = e2 < 20u ? 20u : e2;
+    const float s1 = __uint_as_float((267u - e1) << 23), s2 = __uint_as_float((267u - e2) << 23);
+    const float un1 = __uint_as_float((e1 - 13u) << 23) * un1w, un2 = __uint_as_float((e2 - 13u) << 23) * un2w;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float4 v0 = j < 4 ? xb[2 * j] : yb[0], v1 = j < 4 ? xb[2 * j + 1] : yb[1];
+      const float sc = j < 4 ? s1 : s2;
+      td_u32x4 ah, al;
+      unsigned hh, ll;
+      fs_split2(v0.x, v0.y, sc, hh, ll); ah[0] = hh; al[0] = ll;
+      fs_split2(v0.z, v0.w, sc, hh, ll); ah[1] = hh; al[1] = ll;
+      fs_split2(v1.x, v1.y, sc, hh, ll); ah[2] = hh; al[2] = ll;
+      fs_split2(v1.z, v1.w, sc, hh, ll); ah[3] = hh; al[3] = ll;
+      acc = td_mfma_f16(wl[j], ah, acc);
+      acc = td_mfma_f16(wh[j], al, acc);
+      acc = td_mfma_f16(wh[j], ah, acc);
+    }
+    // lane (row li, half lh): registers r < 8 are outputs m = (r & 3) + 8 (r >> 2) + 4 lh
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      ot[li * 17 + m] = acc[r] * (own1[r] ? un1 : un2) + bm[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  store_tile(n_tiles - 1);
+}
+
 // The per-file descriptor table goes through the handle's content-cached table slots
 // (td_table_upload): no td_scratch use, and no upload at all when the layout repeats.
 int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, int num_files,
@@ -2443,7 +2671,11 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
   TD_REQUIRE(h, ldout >= 2 * dims, "td_cca_transform: ldout too small");
   const int k1 = c1 * (pre1 + 1 + post1), k2 = c2 * (pre2 + 1 + post2);
   // no context on either view, aligned rows, at most 16 outputs: one fused pass (cca_project_kernel)
+#ifdef TD_DEV_SWITCHES
   static const bool old_proj = getenv("TD_PROJECT_F32") != nullptr;        // development: A/B runs
+#else
+  constexpr bool old_proj = false;
+#endif
   const bool aligned = (ldx % 4 == 0) && (c1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0) &&
                        (ldx2 % 4 == 0) && (c2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x2_dev) & 15) == 0);
   if (k1 == c1 && k2 == c2 && c1 <= 64 && c2 <= 32 && 2 * dims <= 16 && aligned && !old_proj &&
@@ -2453,6 +2685,66 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
     for (int f = 0; f < num_files; ++f) total += file_offsets_host[f + 1] - file_offsets_host[f];
     if (total == 0) return TD_OK;
     const int cus = h->cu_count > 0 ? h->cu_count : 256;
+    // <= 8 channels in the second view, every view of every recording below 2 GB: the DMA-streamed kernel
+    bool stream_ok = c2 <= 8 && ldx < (1 << 20) && ldx2 < (1 << 20);
+    for (int f = 0; f < num_files && stream_ok; ++f) {
+      const int64_t n = file_offsets_host[f + 1] - file_offsets_host[f];
+      stream_ok = n * ldx * 4 < (int64_t)0x7fc00000 && n * ldx2 * 4 < (int64_t)0x7fc00000;
+    }
+#ifdef TD_DEV_SWITCHES
+    if (getenv("TD_PROJECT_STREAM_OFF")) stream_ok = false;
+#endif
+    if (stream_ok) {
+      // one strip per resident wave (kPsOcc workgroups of four waves per CU), a multiple of 32 rows
+      constexpr int wpg = kThreads / 64;
+      double mean_strip = (double)total / ((double)cus * kPsOcc * wpg);
+      if (mean_strip < 128.0) mean_strip = 128.0;
+      std::vector<ProjFile> files(num_files);
+      std::vector<FsStrip> strips;
+      for (int f = 0; f < num_files; ++f) {
+        const int64_t n = file_offsets_host[f + 1] - file_offsets_host[f];
+        ProjFile& pf = files[f];
+        pf.xrow0 = file_offsets_host[f] + dx; pf.yrow0 = file_offsets_host[f] + dy;
+        pf.out0 = file_offsets_host[f];
+        pf.nx = n - dx > 0 ? n - dx : 0; pf.ny = n - dy > 0 ? n - dy : 0;
+        pf.first = (long long)strips.size();
+        const int64_t nmax = pf.nx > pf.ny ? pf.nx : pf.ny;
+        if (nmax <= 0) continue;
+        int64_t k = (int64_t)((double)nmax / mean_strip + 0.5);
+        k = k < 1 ? 1 : k;
+        const int64_t len = td_round_up(td_ceil_div(nmax, k), 32);
+        for (int64_t at = 0; at < nmax; at += len) {
+          FsStrip sd;
+          sd.file = f; sd.first = (int)at; sd.len = (int)(nmax - at < len ? nmax - at : len); sd.pad = 0;
+          strips.push_back(sd);
+        }
+      }
+      if (strips.empty()) return TD_OK;
+      std::vector<char> table(files.size() * sizeof(ProjFile) + strips.size() * sizeof(FsStrip));
+      memcpy(table.data(), files.data(), files.size() * sizeof(ProjFile));
+      memcpy(table.data() + files.size() * sizeof(ProjFile), strips.data(), strips.size() * sizeof(FsStrip));
+      const void* table_dev = nullptr;
+      TD_TRY(td_table_upload(h, table.data(), table.size(), &table_dev));
+      ProjStreamParams sp;
+      sp.x = x_dev; sp.x2 = x2_dev; sp.ldx = ldx; sp.ldx2 = ldx2; sp.ldout = ldout;
+      sp.c1 = c1; sp.c2 = c2; sp.dims = dims;
+      sp.mean1 = mean1_dev; sp.rot1 = rot1_dev; sp.mean2 = mean2_dev; sp.rot2 = rot2_dev;
+      sp.files = reinterpret_cast<const ProjFile*>(table_dev);
+      sp.strips = reinterpret_cast<const FsStrip*>(reinterpret_cast<const char*>(table_dev) +
+                                                   files.size() * sizeof(ProjFile));
+      sp.n_strips = (long long)strips.size();
+      sp.out = out_dev;
+      constexpr size_t kLds = sizeof(float) * wpg * kPsWaveFloats;
+      if (!h->lds_opt_proj_stream) {
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&cca_project_stream_kernel<kPsOcc>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        h->lds_opt_proj_stream = true;
+      }
+      hipLaunchKernelGGL((cca_project_stream_kernel<kPsOcc>), dim3((unsigned)td_ceil_div(sp.n_strips, wpg)),
+                         dim3(kThreads), kLds, h->stream, sp);
+      TD_HIP(h, hipGetLastError());
+      return TD_OK;
+    }
     int64_t strip = td_round_up(td_ceil_div(total, 3 * cus), 32 * kProjWaves);    // three workgroups per CU
     if (strip < 32 * kProjWaves) strip = 32 * kProjWaves;
     std::vector<ProjFile> files(num_files);

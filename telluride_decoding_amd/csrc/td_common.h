@@ -21,7 +21,7 @@ struct td_handle {
   int acc_mode = 0;   // td_set_accumulate_mode: how the lag kernel multiplies float32 numbers
   int cu_count = 0;   // CUs the handle's stream runs on (the device's, or a CU mask's: td_set_cu_count)
   // kernels that opted in to more than 64 KB of dynamic LDS on this handle's device
-  bool lds_opt_lagcov = false, lds_opt_fir = false, lds_opt_fir_stream = false;
+  bool lds_opt_lagcov = false, lds_opt_fir = false, lds_opt_fir_stream = false, lds_opt_proj_stream = false;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // the one work is queued on (own or adopted)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;

@@ -635,6 +635,49 @@ def test_cca_lagged_fit_transform_and_model(dev):
     cca.BrainModelCCA(bd1.create_dataset('train'))
 
 
+@pytest.mark.parametrize('c1,c2,dims,lens,off', [
+    (64, 8, 5, (100000,), 0),            # the C3 shape (a tenth of its rows): strips of many tiles
+    (64, 8, 8, (700, 31, 1, 33, 1300), 0),   # 16 outputs; recordings of 1 / 31 / 33 rows
+    (32, 4, 2, (900, 257), 0),           # narrower views: granules past a row's end read as zeros
+    (4, 8, 1, (640, 100), 0),
+    (60, 8, 3, (500, 300), 2),           # input_offset > 0: x starts later, its last rows do not exist
+    (64, 4, 4, (500, 300), -3),          # input_offset < 0: the same for the second view
+])
+def test_cca_transform_streamed_kernel_edges(dev, c1, c2, dims, lens, off):
+  """The transform without context (cca.py:157-161) on cca_project_stream_kernel: both views by DMA,
+  float16 x 2 under a per-row, per-view scale -- the views decades apart in magnitude (EEG in volts,
+  envelopes in thousands), rows 2^30 apart in scale inside a view -- against float64."""
+  rng = np.random.default_rng(c1 + 7 * c2 + dims)
+  h = dev.default_handle()
+  n = int(np.sum(lens))
+  x = (rng.standard_normal((n, c1)) * 2e-5).astype(np.float32)
+  x2 = (rng.standard_normal((n, c2)) * 3e3 + 1e3).astype(np.float32)
+  x *= np.exp2(rng.integers(-15, 16, size=(n, 1))).astype(np.float32)
+  mean1 = x.mean(0).astype(np.float32)
+  mean2 = x2.mean(0).astype(np.float32)
+  rot1 = (rng.standard_normal((c1, dims)) * 1e4).astype(np.float32)
+  rot2 = (rng.standard_normal((c2, dims)) * 1e-3).astype(np.float32)
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  out = dev.cca_transform(h.to_device(x), h.to_device(x2), offs, h.to_device(mean1), h.to_device(rot1),
+                          h.to_device(mean2), h.to_device(rot2), 0, 0, 0, 0, handle=h,
+                          input_offset=off).cpu().numpy().astype(np.float64)
+  dx, dy = max(off, 0), max(-off, 0)
+  worst = 0.0
+  for f in range(len(lens)):
+    a, b = int(offs[f]), int(offs[f + 1])
+    nx, ny = max(b - a - dx, 0), max(b - a - dy, 0)
+    x64, y64 = x[a + dx:b].astype(np.float64), x2[a + dy:b].astype(np.float64)
+    for (v, m, r, cnt, col0) in ((x64, mean1, rot1, nx, 0), (y64, mean2, rot2, ny, dims)):
+      if cnt == 0:
+        continue
+      want = (v - m.astype(np.float64)) @ r.astype(np.float64)
+      size = np.abs(v) @ np.abs(r.astype(np.float64)) + np.abs(m.astype(np.float64)) @ np.abs(r.astype(np.float64))
+      err = np.max(np.abs(out[a:a + cnt, col0:col0 + dims] - want) / size)
+      worst = max(worst, err)
+      assert err < 6e-7, (f, col0, err)
+  parity_log.record('cca_transform_stream c%d+%d dims%d' % (c1, c2, dims), gpu_vs_ref64=worst)
+
+
 def test_linear_regression_model_api(dev):
   """BrainModelLinearRegression: the W/b known answer, predict, evaluate."""
   from telluride_decoding_amd import brain_data, brain_model

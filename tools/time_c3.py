@@ -28,3 +28,8 @@ for _ in range(iters): tr()
 ms = h.timer_stop() / iters
 print('transform  %.1f us = %.2f TB/s algorithmic (328 B/sample)' % (ms * 1e3, n * 328 / ms / 1e9))
 print('canonical correlations', [round(float(v), 6) for v in e.cpu().numpy()])
+# the transform against float64 on the first and last 4096 rows
+out = tr().double()
+for sl in (slice(0, 4096), slice(n - 4096, n)):
+  want = torch.cat([(x[sl].double() - mean_x.double()) @ rot_x.double(), (x2[sl].double() - mean_y.double()) @ rot_y.double()], dim=1)
+  print('  rows %d..: max |out - float64| = %.3g (scale %.3g)' % (sl.start, (out[sl] - want).abs().max().item(), want.abs().max().item()))
