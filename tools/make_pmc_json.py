@@ -27,7 +27,7 @@ for key, kernel, algo, note in (
      'the second read of x (+ y): y^T x~, column sums and the channel maxima of the float16 kernel'),
     ('gram', 'gram_bf16x3_kernel<5>', 288000000,
      'C3 one-pass CCA moments: every input byte read once; 512 partial slabs of 15 KB'),
-    ('project', 'cca_project_kernel<76>', 328000000,
+    ('project', 'cca_project_stream_kernel<3>', 328000000,
      'C3 transform: x and x2 read once, 40 MB of outputs written')):
   name, fetch = counter(os.path.join(root, tag + '_hotkernels_pmc1.txt'), kernel, 'FETCH_SIZE')
   _, write = counter(os.path.join(root, tag + '_hotkernels_pmc2.txt'), kernel, 'WRITE_SIZE')
@@ -44,6 +44,6 @@ doc['correction'] = ('gfx950: FETCH_SIZE counts 128-B read requests at 64 B -> x
                      '(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16-B-per-lane streaming stores')
 doc['lagcov_targets_mfma_kernel'] = out['targets']
 doc['gram_bf16x3_kernel'] = out['gram']
-doc['cca_project_kernel'] = out['project']
+doc['cca_project_stream_kernel'] = out['project']
 json.dump(doc, open(os.path.join(root, tag + '_lagcov_pmc.json'), 'w'), indent=1)
 print(json.dumps(doc, indent=1))
