@@ -1774,6 +1774,9 @@ constexpr int kFsSlotFloats = 32 * 64;     // one tile: 32 rows x 64 channels
 constexpr int kFsThreads = TD_FS_THREADS;  // waves x 64 per workgroup
 constexpr int kFsSlots = TD_FS_SLOTS;      // tiles of LDS per wave (1 or 2)
 constexpr int kFsOcc = TD_FS_OCC;          // workgroups (of four waves) per CU
+// (the DMA's LDS address goes through M0; every configuration measured and shipped keeps a workgroup's
+// tiles inside its first 64 KB -- larger offsets through M0 are not something this code has verified)
+static_assert(sizeof(float) * (kFsThreads / 64) * kFsSlots * kFsSlotFloats <= 65536, "fir_stream_kernel: LDS tiles past 64 KB");
 #ifndef TD_FS_ABL
 #define TD_FS_ABL 0     // development: 1 no matrix instructions, 2 no DMA after the first two tiles, 3 no chains, 4 DMA only,
                         // 5 setup only, 6 = 2 + no products / chains, 7 = 2 + no chains
@@ -2105,6 +2108,7 @@ constexpr int kPsWaveFloats = kFsSlotFloats + 32 * 8 + 32 * 17 + 16;   // x tile
 #define TD_PS_OCC 3
 #endif
 constexpr int kPsOcc = TD_PS_OCC;          // workgroups (of four waves) per CU
+static_assert(sizeof(float) * (kThreads / 64) * kPsWaveFloats <= 65536, "cca_project_stream_kernel: LDS tiles past 64 KB");
 
 template <int kOcc>
 __global__ __launch_bounds__(kThreads, kOcc) void cca_project_stream_kernel(ProjStreamParams p) {
