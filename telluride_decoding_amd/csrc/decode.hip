@@ -1804,26 +1804,30 @@ struct FirStreamParams {
 };
 
 // the 8 DMA instructions of one tile: LDS slot at byte address lds (wave-uniform), lane offsets v[m]
+#ifndef TD_FS_AUX
+#define TD_FS_AUX " nt"  // cache policy of the DMA: the rows are read once -- non-temporal (C4 decode on inputs that
+                         // no cache holds: 72.5 -> 67.7 us; replayed from the Infinity Cache: 66.2 -> 66.9; " sc1": 73.4)
+#endif
 __device__ __forceinline__ void fs_issue_tile(fs_i32x4 rs, unsigned lds, const unsigned (&v)[8]) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %[keep], m0\n\t"
       "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v0], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v0], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v1], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v1], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v2], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v2], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v3], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v3], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v4], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v4], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v5], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v5], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v6], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v6], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-      "buffer_load_dwordx4 %[v7], %[rs], 0 offen lds\n\t"
+      "buffer_load_dwordx4 %[v7], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
       "s_mov_b32 m0, %[keep]"
       : [keep] "=&s"(keep)
       : [lds] "s"(lds), [rs] "s"(rs), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
@@ -2163,7 +2167,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void cca_project_stream_kernel(Proj
     asm volatile(
         "s_mov_b32 %[keep], m0\n\t"
         "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %[v], %[rs], 0 offen lds\n\t"
+        "buffer_load_dwordx4 %[v], %[rs], 0 offen" TD_FS_AUX " lds\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep)
         : [lds] "s"(slot_addr + (unsigned)(kFsSlotFloats * 4)), [rs] "s"(rs2), [v] "v"(v2)
