@@ -116,6 +116,42 @@ def test_predict_fir_streamed_kernel_edges(dev, c, pre, post, lens, off, mode):
   parity_log.record('fir_stream c%d pre%d post%d %s' % (c, pre, post, mode), gpu_vs_ref64=worst)
 
 
+def test_predict_fir_streamed_kernel_random_shapes(dev):
+  """Forty random shapes of the streamed kernel's domain (channels in granules of four up to 64, up to
+  32 lags split any way between past and future, recordings of 1 .. 5000 rows, leading rows dropped,
+  rows wider than the channels used, with and without a bias) against the float64 lag matrix."""
+  import torch
+  rng = np.random.default_rng(2024)
+  h = dev.default_handle()
+  for case in range(40):
+    c = 4 * int(rng.integers(1, 17))
+    nl = int(rng.integers(1, 33))
+    pre = int(rng.integers(0, nl))
+    post = nl - 1 - pre
+    lens = [int(v) for v in rng.integers(1, 5001, size=int(rng.integers(1, 6)))]
+    off = int(rng.integers(0, 4)) if min(lens) > 8 else 0
+    pad = 4 * int(rng.integers(0, 4))
+    n = int(np.sum(lens))
+    wide = rng.standard_normal((n, c + pad)).astype(np.float32)
+    x = wide[:, :c]
+    w = (rng.standard_normal((c * nl, 1)) / np.sqrt(c * nl)).astype(np.float32)
+    b = rng.standard_normal(1).astype(np.float32) if case % 2 else None
+    offs = np.concatenate(([0], np.cumsum(lens)))
+    xd = h.to_device(wide)[:, :c]
+    bd = h.to_device(b.reshape(1, -1)).reshape(-1) if b is not None else None
+    out = dev.predict_fir(xd, offs, h.to_device(w), bd, pre, post, handle=h, input_offset=off).cpu().numpy()
+    for i in range(len(lens)):
+      xi = x[offs[i] + off:offs[i + 1]]
+      if xi.shape[0] == 0:
+        continue
+      xl = o_lag.lag_matrix(xi.astype(np.float64), pre, post)
+      want = xl @ w.astype(np.float64) + (b if b is not None else 0.0)
+      got = out[offs[i]:offs[i] + want.shape[0]].astype(np.float64)
+      size = np.abs(xl) @ np.abs(w.astype(np.float64)) + (np.abs(b) if b is not None else 0.0) + 1e-30
+      err = np.max(np.abs(got - want) / size)
+      assert err < 4e-7, (case, c, pre, post, lens, off, pad, i, err)
+
+
 def test_predict_fir_streamed_kernel_strided_rows_and_nonfinite(dev):
   """Rows wider than the 64 channels used (a column slice of a wider array), and what a NaN / Inf
   sample does: exactly the outputs whose lag window holds it become non-finite (numpy's answer)."""
