@@ -199,6 +199,39 @@ def decode_leg(h, device, iters=200):
   ms, (scores, dec) = timed(1000, 100, False)
   ms_rot, (scores_r, dec_r) = timed(1000, 100, True)
   assert bool((dec == dec_r).all())
+
+  def two_streams():
+    """Consecutive decodes on two handles / streams in turn (a caller that decodes batch after batch):
+    the per-trial tail of call i and the launch boundaries run beside the FIR pass of call i + 1.
+    Host clock around the loop, devices synchronised at both ends; rotated inputs."""
+    import torch
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    handles = []
+    for st_ in streams:
+      with torch.cuda.stream(st_):
+        handles.append(device.Handle())
+    outs = [None, None]
+    def call(i):
+      xs, es = inputs[i % 3]
+      with torch.cuda.stream(streams[i & 1]):
+        outs[i & 1] = device.decode_fused(xs, es, offs, w, b, PRE, POST, 1000, 100, corr, handle=handles[i & 1])
+    for i in range(6):
+      call(i)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+      t0 = time.perf_counter()
+      for i in range(iters):
+        call(i)
+      torch.cuda.synchronize()
+      t = (time.perf_counter() - t0) / iters * 1e3
+    finally:
+      gc.enable()
+    same = bool((outs[0][1] == dec_r).all()) or bool((outs[1][1] == dec_r).all())
+    return t, same
+
+  ms_two, two_same = two_streams()
   n_win = int(dec.shape[0])
   labels = device.window_means(h.to_device(att.astype(np.float64), np.float64).reshape(-1), offs,
                                1000, 100, handle=h).cpu().numpy()
@@ -262,6 +295,11 @@ def decode_leg(h, device, iters=200):
                    'frac': gbps_rot / PEAK_HBM_GBPS, 'inputs': 'rotated'},
       'replayed': {'ms': ms, 'windows_per_s': n_win / ms * 1e3, 'hbm_gbps_algorithmic': gbps,
                    'frac': gbps / PEAK_HBM_GBPS},
+      'two_streams': {'ms': ms_two, 'windows_per_s': n_win / ms_two * 1e3,
+                      'frac': n * 4 * (C + 2) / (ms_two * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                      'decisions_identical': two_same,
+                      'what': 'the same calls on two handles / streams in turn (host clock, rotated inputs): '
+                              'the per-trial tail of call i runs beside the FIR pass of call i + 1'},
       'wta_accuracy_clear_windows': acc,
       'oracle_accuracy_clear_windows': float(np.mean(acc_o)),
       'decision_flips_vs_oracle': flips, 'decisions_checked': cpu_win,
