@@ -152,6 +152,16 @@ def _decode_cpu_rate(trials, wn, bn, corr, dtype):
   return n_win / (time.perf_counter() - t0)
 
 
+def _pmc_bytes(kernel_key):
+  """HBM bytes per launch of one kernel from this round's PMC pass (profiles/), or None."""
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_lagcov_pmc.json')
+  try:
+    with open(path) as f:
+      return json.load(f).get(kernel_key, {}).get('hbm_bytes_per_launch')
+  except (OSError, ValueError):
+    return None
+
+
 def decode_leg(h, device, iters=200):
   """Config C4: 200 DISTINCT trials x 6000 frames x 64 ch, two envelopes, 10 s windows
   (W = 1000) every 1 s (hop = 100): raw EEG -> decisions with td_decode_fused.  Timed twice: replaying
@@ -292,7 +302,10 @@ def decode_leg(h, device, iters=200):
                  'same call on one copy back to back' % iters),
       'algorithmic_bytes': int(n) * 4 * (C + 2), 'hbm_gbps_algorithmic': gbps_rot,
       'roofline': {'bound': 'hbm', 'achieved': gbps_rot, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                   'frac': gbps_rot / PEAK_HBM_GBPS, 'inputs': 'rotated'},
+                   'frac': gbps_rot / PEAK_HBM_GBPS, 'inputs': 'rotated',
+                   'traffic_fir_kernel': _pmc_bytes('fir_stream_kernel'),
+                   'traffic_source': 'profiles/r04_lagcov_pmc.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE '
+                                     'of fir_stream_kernel, a separate run; the per-trial tail reads 14 MB more)'},
       'replayed': {'ms': ms, 'windows_per_s': n_win / ms * 1e3, 'hbm_gbps_algorithmic': gbps,
                    'frac': gbps / PEAK_HBM_GBPS},
       'two_streams': {'ms': ms_two, 'windows_per_s': n_win / ms_two * 1e3,

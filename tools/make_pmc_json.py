@@ -28,7 +28,10 @@ for key, kernel, algo, note in (
     ('gram', 'gram_bf16x3_kernel<5>', 288000000,
      'C3 one-pass CCA moments: every input byte read once; 512 partial slabs of 15 KB'),
     ('project', 'cca_project_stream_kernel<3>', 328000000,
-     'C3 transform: x and x2 read once, 40 MB of outputs written')):
+     'C3 transform: x and x2 read once, 40 MB of outputs written'),
+    ('fir', 'fir_stream_kernel<true, 2, 2>', 312000000,
+     'C4 decode, the FIR prediction: 307.2 MB of EEG read once (+ the 31 halo rows of every strip, '
+     'mostly L2 hits) and 4.8 MB of predictions written')):
   name, fetch = counter(os.path.join(root, tag + '_hotkernels_pmc1.txt'), kernel, 'FETCH_SIZE')
   _, write = counter(os.path.join(root, tag + '_hotkernels_pmc2.txt'), kernel, 'WRITE_SIZE')
   out[key] = {
@@ -45,5 +48,6 @@ doc['correction'] = ('gfx950: FETCH_SIZE counts 128-B read requests at 64 B -> x
 doc['lagcov_targets_mfma_kernel'] = out['targets']
 doc['gram_bf16x3_kernel'] = out['gram']
 doc['cca_project_stream_kernel'] = out['project']
+doc['fir_stream_kernel'] = out['fir']
 json.dump(doc, open(os.path.join(root, tag + '_lagcov_pmc.json'), 'w'), indent=1)
 print(json.dumps(doc, indent=1))
