@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void edge_outer_kernel(ExpandParams p) {
 }
 
 constexpr int kExpandSeg = 8;
+constexpr int kExpandFusedFiles = 2;   // up to this many files: no edge_outer_kernel pass
 
 __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
   __shared__ double tr[32][33];
@@ -580,11 +581,41 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandParams p) {
       }
     }
   };
-  auto add_step = [&](int s) {
-    const double* d = p.dstep + ((long long)s * p.e_count + blockIdx.x) * tile;
+  // D[s][e] of step s for this thread's four elements, formed on the spot when phase 1 was skipped
+  // (few files: its 32 MB of step tiles cost more to write and read back than these 2 |files| products
+  // per element and step) -- the same terms in the same order as edge_outer_kernel, so the same bits.
+  const long long wa = (long long)2 * p.hw * p.ca, wb = (long long)2 * p.hw * p.cb;
+  auto outer4 = [&](int which, int ra, int rb, double sign, double (&d)[4]) {
+    if (ra < 0 || ra >= 2 * p.hw || rb < 0 || rb >= 2 * p.hw) return;
+    const float* pa = p.wina + (long long)which * wa + (long long)ra * p.ca;
+    const float* pb = p.winb + (long long)which * wb + (long long)rb * p.cb;
+    for (long long f = 0; f < p.n_files; ++f) {
+      const double av = row_ok ? (double)pa[f * 2 * wa + i] : 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (row_ok && j0 + q < p.cb) v[q] += d[(long long)i * p.cb + j0 + q];
+      for (int q = 0; q < 4; ++q) {
+        const double bv = j0 + q < p.cb ? (double)pb[f * 2 * wb + j0 + q] : 0.0;
+        d[q] += sign * av * bv;
+      }
+    }
+  };
+  auto add_step = [&](int s) {
+    if (p.dstep) {
+      const double* d = p.dstep + ((long long)s * p.e_count + blockIdx.x) * tile;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (row_ok && j0 + q < p.cb) v[q] += d[(long long)i * p.cb + j0 + q];
+      return;
+    }
+    double d[4] = {0.0, 0.0, 0.0, 0.0};
+    if (s < p.posta) {
+      outer4(0, s + p.hw, s + e + p.hw, -1.0, d);
+      outer4(1, s + p.hw, s + e + p.hw, +1.0, d);
+    } else {
+      const int aa = -(s - p.posta + 1);
+      outer4(1, aa + p.hw, aa + e + p.hw, -1.0, d);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += d[q];
   };
 
   // The lag diagonal is walked in segments of kExpandSeg steps, one workgroup (blockIdx.z) each:
@@ -721,7 +752,9 @@ int expand_block(td_handle* h, const double* g, int e_min, int e_count, int ca, 
   p.m = m; p.ldm = ldm; p.symmetric = symmetric ? 1 : 0;
   const int n_steps = prea + posta;
   p.dstep = nullptr;
-  if (n_steps > 0) {
+  // (one or two files -- the per-recording statistics of a leave-one-out sweep, a single-recording fit:
+  // the expansion forms its edge terms itself, see expand_kernel)
+  if (n_steps > 0 && n_files > kExpandFusedFiles) {
     void* scratch = nullptr;
     TD_TRY(td_scratch(h, sizeof(double) * (size_t)n_steps * e_count * ca * cb, &scratch));
     p.dstep = reinterpret_cast<double*>(scratch);
