@@ -1741,8 +1741,8 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
 // over the lags -- the diagonal sum out[u] = sum_l P[l][u + l] becomes a Horner chain of lane shifts,
 //   low <- shl1(low) + P[l]   (l = 31 .. 0;  v_add_f32_dpp wave_shl:1),
 // one vector instruction per lag, no P tile in LDS, no barrier.  What the previous forms spend around
-// their matrix instructions (transposition through registers, split, P tile, diagonal walk: ~270
-// instructions per 32 rows) is ~55 here:
+// their matrix instructions (transposition through registers, three-way split, P tile, diagonal walk:
+// ~270 instructions per 32 rows) is ~200 here in the float16 form and ~60 in the float32 form:
 //   * rows reach LDS by DMA (`buffer_load_dwordx4 ... lds`: no registers, no ds_write): lane l of
 //     instruction m fetches row 4m + (l >> 4), granule (l & 15) ^ (row & 15) -- whole 256-byte rows per
 //     16 lanes -- and the lane-linear LDS image is that XOR-swizzled [32][64] tile, read back in operand
@@ -1750,9 +1750,13 @@ __global__ __launch_bounds__(kThreads, 3) void fir_tile16_kernel(Fir16Params p) 
 //     ds_read_b128.  Rows outside the recording are outside the buffer descriptor and read as zeros.
 //     Two 8 KB slots per wave; a slot is refilled as soon as its rows are in registers, so two tiles
 //     (16 KB per wave, 32 MB on the chip) are in flight under every chain of matrix instructions;
-//   * v_mfma_f32_32x32x2_f32 on the values as they are (exact float32 products, no split): the
-//     weights are the A operand, 32 registers per lane for the whole strip; instruction i multiplies
-//     channels i (lane half 0) and 32 + i (half 1);
+//   * the weights are the A operand, in registers for the whole strip.  kF16 (the default): every row as
+//     two float16 pieces under a power-of-two scale of ITS OWN (the largest magnitude of its 64 samples
+//     into [2^13, 2^14), measured in registers: artefact rows do not cost their neighbours precision),
+//     the weights under one scale, three v_mfma_f32_32x32x16_f16 per 16 channels, the 16 result
+//     registers scaled back per lane (a lane is one row).  !kF16 (TD_ACC_F32): v_mfma_f32_32x32x2_f32 on
+//     the values as they are -- exact float32 products, 32 instructions of twice the length per tile,
+//     instruction i multiplies channels i (lane half 0) and 32 + i (half 1): 72 us at C4 against 58;
 //   * matrix row m holds lag 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3), so that result register r of
 //     lane half g is lag 16 g + r; v_permlane32_swap of the registers of two consecutive tiles makes
 //     32 vectors of 64 consecutive time columns, one per lag.  The chain above leaves the outputs of
