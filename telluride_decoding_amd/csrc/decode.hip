@@ -2809,12 +2809,16 @@ int td_window_count(const int64_t* trial_offsets_host, int num_trials, int width
                     int64_t* window_offsets_host, int64_t* total_windows) {
   if (!trial_offsets_host || num_trials < 0 || width <= 0 || hop <= 0)
     return td_fail(nullptr, TD_ERR_INVALID, "td_window_count: bad argument");
-  std::vector<long long> row0;
-  std::vector<int64_t> off;
-  build_windows(trial_offsets_host, num_trials, width, hop, &row0, &off);
-  if (window_offsets_host)
-    for (int t = 0; t <= num_trials; ++t) window_offsets_host[t] = off[t];
-  if (total_windows) *total_windows = (int64_t)row0.size();
+  // (closed form: the windows themselves are not listed here -- a quarter of a million of them at
+  // W = 10 / hop 5 made this call 140 us of host time in front of every decode)
+  int64_t count = 0;
+  for (int t = 0; t < num_trials; ++t) {
+    const int64_t n = trial_offsets_host[t + 1] - trial_offsets_host[t];
+    if (window_offsets_host) window_offsets_host[t] = count;
+    if (n >= width) count += (n - width) / hop + 1;
+  }
+  if (window_offsets_host) window_offsets_host[num_trials] = count;
+  if (total_windows) *total_windows = count;
   return TD_OK;
 }
 

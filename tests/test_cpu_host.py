@@ -542,3 +542,20 @@ def test_decoder_signature_check_and_cca_layer_without_a_gpu():
     layer.set_initial_weights(m1, m2.reshape(2, 2), r1, r2)
   with pytest.raises(TypeError, match='rot2 matrix has the wrong size'):
     layer.set_initial_weights(m1, m2, r1, r2[:, :2])
+
+
+def test_window_count_is_the_reference_generator_count():
+  """td_window_count (host only): full windows [k * hop, k * hop + W) per trial, as the reference's
+  window generator yields them (result_store.py:253-271), for ragged trials including empty ones."""
+  import numpy as np
+  from telluride_decoding_amd import device
+  rng = np.random.default_rng(5)
+  for _ in range(200):
+    lens = rng.integers(0, 300, size=int(rng.integers(1, 8)))
+    offs = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    w, hop = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+    wo, total = device.window_layout(offs, w, hop)
+    want = [0]
+    for n in lens:
+      want.append(want[-1] + len(range(0, int(n) - w + 1, hop)) if n >= w else want[-1])
+    assert list(wo) == want and total == want[-1]
