@@ -197,17 +197,25 @@ def decode_leg(h, device, iters=200):
     gc.collect()           # (a collection inside the loop can free a device arena: a 40-70 ms stall;
     gc.disable()           #  the host runs only ~20 us per call ahead of the device: none in the loop)
     try:
-      h.synchronize()
-      h.timer_start()                                      # hipEvents on the launching stream
-      for i in range(iters):
-        xs, es = sets[i % len(sets)]
-        out = device.decode_fused(xs, es, offs, w, b, PRE, POST, width, hop, corr, handle=h)
-      return h.timer_stop() / iters, out
+      best = None
+      loops = []
+      for _ in range(3):   # (best of three loops: one preemption of the host thread stalls a whole loop)
+        h.synchronize()
+        h.timer_start()                                    # hipEvents on the launching stream
+        for i in range(iters):
+          xs, es = sets[i % len(sets)]
+          out = device.decode_fused(xs, es, offs, w, b, PRE, POST, width, hop, corr, handle=h)
+        t = h.timer_stop() / iters
+        loops.append(t)
+        best = t if best is None or t < best else best
+      timed.loops = loops
+      return best, out
     finally:
       gc.enable()
 
   ms, (scores, dec) = timed(1000, 100, False)
   ms_rot, (scores_r, dec_r) = timed(1000, 100, True)
+  loops_rot = list(timed.loops)
   assert bool((dec == dec_r).all())
 
   def two_streams():
@@ -231,11 +239,14 @@ def decode_leg(h, device, iters=200):
     gc.collect()
     gc.disable()
     try:
-      t0 = time.perf_counter()
-      for i in range(iters):
-        call(i)
-      torch.cuda.synchronize()
-      t = (time.perf_counter() - t0) / iters * 1e3
+      t = None
+      for _ in range(3):
+        t0 = time.perf_counter()
+        for i in range(iters):
+          call(i)
+        torch.cuda.synchronize()
+        ti = (time.perf_counter() - t0) / iters * 1e3
+        t = ti if t is None or ti < t else t
     finally:
       gc.enable()
     same = bool((outs[0][1] == dec_r).all()) or bool((outs[1][1] == dec_r).all())
@@ -296,8 +307,8 @@ def decode_leg(h, device, iters=200):
   gbps_rot = n * 4 * (C + 2) / (ms_rot * 1e-3) / 1e9
   return {
       'workload': 'C4: 200 distinct trials x 60 s x 64 ch, two envelopes, W=1000/hop=100 (10 s / 1 s)',
-      'windows': n_win, 'ms': ms_rot, 'windows_per_s': n_win / ms_rot * 1e3,
-      'timing': ('hipEvents around %d back-to-back td_decode_fused calls ROTATING over three copies of the '
+      'windows': n_win, 'ms': ms_rot, 'windows_per_s': n_win / ms_rot * 1e3, 'loops_ms': loops_rot,
+      'timing': ('hipEvents around %d back-to-back td_decode_fused calls (best of three such loops) ROTATING over three copies of the '
                  'input at different addresses (951 MB > the 256 MiB Infinity Cache); `replayed` = the '
                  'same call on one copy back to back' % iters),
       'algorithmic_bytes': int(n) * 4 * (C + 2), 'hbm_gbps_algorithmic': gbps_rot,
@@ -347,10 +358,15 @@ def cca_leg(h, device, eeg):
     gc.collect()
     gc.disable()           # (no collection inside the loop: the host is barely ahead of these 60 us calls)
     try:
-      h.timer_start()
-      for _ in range(reps):
-        fn()
-      return h.timer_stop() / reps / 1e3
+      best = None
+      for _ in range(3):   # (best of three loops, as the decode leg)
+        h.synchronize()
+        h.timer_start()
+        for _ in range(reps):
+          fn()
+        t = h.timer_stop() / reps / 1e3
+        best = t if best is None or t < best else best
+      return best
     finally:
       gc.enable()
 
