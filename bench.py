@@ -445,7 +445,8 @@ def cca_leg(h, device, eeg):
       'workload': 'C3: CCA, 64-ch EEG vs 8-band envelope, 1e6 samples, no context, 5 components',
       'fit_ms': (t_acc + t_solve) * 1e3, 'accumulate_ms': t_acc * 1e3,
       'solve_ms': t_solve * 1e3, 'transform_ms': t_tr * 1e3,
-      'timing': ('hipEvents on the launching stream around 99 back-to-back calls (20 for the solve) ROTATING '
+      'timing': ('hipEvents on the launching stream around 99 back-to-back calls (20 for the solve), the best of '
+                 'three such loops, ROTATING '
                  'over three copies of the inputs at different addresses; `replayed` = one copy'),
       'replayed': {'accumulate_ms': t_acc_replayed * 1e3, 'transform_ms': t_tr_replayed * 1e3,
                    'accumulate_hbm_frac': n * 4 * 72 / t_acc_replayed / 1e9 / PEAK_HBM_GBPS,
