@@ -607,9 +607,15 @@ __device__ __forceinline__ void tgt_tile(const unsigned* __restrict__ ap, const 
 
 // kTgt (float16 form only): one target column rides along (tgt_tile).  A variant of its own: the
 // extra code costs the plain kernel 20 registers and ~6 % of its time even when it is switched off.
-template <bool kVec4, int kBfRowDw, bool kF16, bool kTgt>
+//
+// kVirt (float16 form): the workgroup stages a VIRTUAL image (td_common.h: VirtImage -- every staged
+// channel is a source channel of x read `shift` rows later) and its waves run the tasks of its
+// group's table instead of the fixed (tile pair, lag quad) of their wave number; the sums leave as
+// blocks of four lags [4][32][32] where the task says.  <= 32 channels and 65..128 channels.
+template <bool kVec4, int kBfRowDw, bool kF16, bool kTgt, bool kVirt = false>
 __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   static_assert(kF16 || !kTgt, "targets ride along in the float16 form only");
+  static_assert(!kVirt || (kF16 && !kTgt), "virtual images: the plain float16 form");
 #ifndef TD_F16_CHAIN
 #define TD_F16_CHAIN 8
 #endif
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int quad = wave & 1, mt = (wave >> 1) & 1, nt = wave >> 2;
+  int quad = wave & 1, mt = (wave >> 1) & 1, nt = wave >> 2;
 
   // One workgroup = one lag group of the work items part, part + n_part, ... (n_part = n_work:
   // one item each; n_part = workgroups / n_groups: a workgroup per CU that walks its share of
@@ -635,6 +641,19 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   const int part = id;
   LagWork w = p.works[id];
   const int e0 = group * kLagsPerWg;                   // e_min == 0
+  // the wave's first lag, where its four lags go in the slab, and (virtual images) its task
+  int lag_off = e0 + 4 * quad, out_lag = lag_off;
+  bool active = true, a_ext = false;
+  const VirtImage* img = nullptr;
+  VirtSeg vs = {0, 0, 0};
+  if constexpr (kVirt) {
+    const VirtGroup* vg = p.vgroups + group;
+    const VirtTask tk = vg->task[wave];
+    img = p.vimgs + vg->image;
+    mt = tk.mt; nt = tk.nt; lag_off = tk.lag0; out_lag = tk.out_lag;
+    active = out_lag >= 0; a_ext = tk.a_ext != 0;
+    vs = p.vsegs[id];
+  }
 
   f32x16 total[4];                                     // [lag], the slab's sums
 #pragma unroll
@@ -652,10 +671,23 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
                                                        // the two waves of a SIMD at different points
   // float16 form: the power-of-two scales of this thread's four channels
   float sc[4] = {1.f, 1.f, 1.f, 1.f};
+  // virtual images: this thread's four staged channels -- source channel (-1: none), row shift, role
+  // (one word each, unpacked where it is used: the kernel has no registers to spare --
+  //  bits 0..7 source + 1 (0: none), bit 8 role, bits 16..31 shift)
+  int vdesc[4] = {0, 0, 0, 0};
+  if constexpr (kVirt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      vdesc[q] = (img->src[c4 + q] + 1) | (img->role[c4 + q] ? 0x100 : 0) | ((int)img->shift[c4 + q] << 16);
+  }
+  auto v_src = [&](int q) { return (vdesc[q] & 0xff) - 1; };
+  auto v_sh = [&](int q) { return vdesc[q] >> 16; };
+  auto v_role = [&](int q) { return (vdesc[q] & 0x100) != 0; };
   if (kF16) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int k = td_f16_scale_exp(td_chan_max_of(p.chan_max, min(c4 + q, 63)));
+      const int ch = kVirt ? v_src(q) : min(c4 + q, 63);
+      const int k = ch >= 0 ? td_f16_scale_exp(td_chan_max_of(p.chan_max, ch)) : 0;
       sc[q] = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
     }
     // one workgroup leaves the combined maxima in the table's last row (the finalize launch
@@ -702,10 +734,67 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   auto interior = [&](long long ut) -> bool {
     return kVec4 && p.ca == 64 && ut >= 0 && ut + kBfRows <= w.a_valid;
   };
+  // virtual images: per staged channel the rows that exist, relative to a tile that starts at row
+  // ut: [lo, hi) = the recording's rows (role 0) or the rows this call sums (role 1), moved by the
+  // channel's shift; an absent channel has none.  (32-bit: a tile never starts more than a context
+  // away from its segment, row_window.)
+  auto vrange = [&](long long ut, int q, int& lo, int& hi) {
+    // (wave-uniform bounds of the two roles, then the lane's shift)
+    const long long lim = 1 << 20;
+    const long long a0 = -ut, b0 = w.a_valid - ut;
+    const long long a1 = vs.seg_begin - ut, b1 = (vs.seg_end < w.a_valid ? vs.seg_end : w.a_valid) - ut;
+    const int a0i = (int)(a0 < -lim ? -lim : (a0 > lim ? lim : a0)), b0i = (int)(b0 < -lim ? -lim : (b0 > lim ? lim : b0));
+    const int a1i = (int)(a1 < -lim ? -lim : (a1 > lim ? lim : a1)), b1i = (int)(b1 < -lim ? -lim : (b1 > lim ? lim : b1));
+    lo = (v_role(q) ? a1i : a0i) - v_sh(q);
+    hi = (v_role(q) ? b1i : b0i) - v_sh(q);
+    if (v_src(q) < 0) { lo = 0; hi = 0; }
+  };
   auto prefetch = [&](long long ut) {
 #ifdef TD_ABL_NOSTAGE
     return;
 #endif
+    if constexpr (kVirt) {
+      // row r of the tile, staged channel q: x[(a_row0 + clamp(ut + r + shift))][src]
+      const float* base = p.a + (w.a_row0 + ut) * p.lda;
+      const int ld = (int)p.lda;
+      const long long l0 = -ut, h0 = w.a_valid - 1 - ut, lim = 1 << 20;
+      const int rlo = (int)(l0 < -lim ? -lim : (l0 > lim ? lim : l0));
+      const int rhi = (int)(h0 < -lim ? -lim : (h0 > lim ? lim : h0));
+      if (kVec4) {
+        // (the planner promises: the four channels are consecutive sources with one shift)
+        const int src = v_src(0) < 0 ? 0 : v_src(0), sh = v_sh(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int rc = max(rlo, min(4 * rg + s + sh, rhi));
+          pf[s] = *reinterpret_cast<const float4*>(base + rc * ld + src);
+        }
+        if (has_tail) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int rc = max(rlo, min(kBfTile + 2 * rg + s + sh, rhi));
+            pf[4 + s] = *reinterpret_cast<const float4*>(base + rc * ld + src);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int src = v_src(q) < 0 ? 0 : v_src(q), sh = v_sh(q);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int rc = max(rlo, min(4 * rg + s + sh, rhi));
+            reinterpret_cast<float*>(&pf[s])[q] = base[rc * ld + src];
+          }
+          if (has_tail) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const int rc = max(rlo, min(kBfTile + 2 * rg + s + sh, rhi));
+              reinterpret_cast<float*>(&pf[4 + s])[q] = base[rc * ld + src];
+            }
+          }
+        }
+      }
+      return;
+    }
     if (interior(ut)) {
       const float* base = p.a + (w.a_row0 + ut) * p.lda + c4;
       const int ld = (int)p.lda;
@@ -734,6 +823,26 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     float4 v[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) v[s] = pf[s];
+    if constexpr (kVirt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int lo, hi;
+        vrange(ut, kVec4 ? 0 : q, lo, hi);             // (kVec4: the four channels share a descriptor)
+        if (lo <= 0 && hi >= kBfRows) continue;        // every staged row of the channel exists
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = 4 * rg + s;
+          float& x = reinterpret_cast<float*>(&v[s])[q];
+          x = (r >= lo && r < hi) ? x : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int r = kBfTile + 2 * rg + s;
+          float& x = reinterpret_cast<float*>(&v[4 + s])[q];
+          x = (r >= lo && r < hi) ? x : 0.f;
+        }
+      }
+    } else
     if (!interior(ut)) {
       const RowWindow rw = row_window(p.a, p.lda, w.a_row0, ut, w.a_valid, 0, p.ca);
 #pragma unroll
@@ -789,7 +898,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
 
   const int lj = lane & 31, lg = lane >> 5;
   const int a_off = (mt * 32 + lj) * kBfRowDw + 4 * lg;
-  const int b_off = (nt * 32 + lj) * kBfRowDw + 4 * lg + (e0 >> 1) + 2 * quad;
+  const int b_off = (nt * 32 + lj) * kBfRowDw + 4 * lg + (lag_off >> 1);
 
   // Toeplitz operand of the targets: lane (lag m = lj, k half lg) reads y[v - m] for the 8 samples
   // v of its k half: staged index 16 s + 8 lg - m + 31 (the buffer starts at sample ut - 31)
@@ -809,6 +918,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   if (id != part) {
     __syncthreads();                                   // every wave is done with the last tile
     w = p.works[id];
+    if constexpr (kVirt) vs = p.vsegs[id];
   }
   prefetch(w.u_begin);
   prefetch_y(w.u_begin);
@@ -816,15 +926,24 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   store_y(ybuf);
   __syncthreads();
 
+  // (virtual images: the tile loop of a recording's last slab runs past its end, where only the
+  // shifted copies of the A-only channels are not zero; the other tasks stop at u_end)
+  const long long u_stop = kVirt ? vs.u_end_ext : w.u_end;
   int parity = 0;
-  for (long long ut = w.u_begin; ut < w.u_end; ut += kBfTile, parity ^= 1) {
+  for (long long ut = w.u_begin; ut < u_stop; ut += kBfTile, parity ^= 1) {
     const unsigned* cur = parity ? buf1 : buf0;
     unsigned* nxt = parity ? buf0 : buf1;
     unsigned* ynxt = ybuf + (parity ? 0 : 2 * kYDw);
     tl.y = ybuf + (parity ? 2 * kYDw : 0) + y_lane;
-    const bool more = ut + kBfTile < w.u_end;
+    const bool more = ut + kBfTile < u_stop;
     if (more) { prefetch(ut + kBfTile); prefetch_y(ut + kBfTile); }
-    const long long left = w.u_end - ut;
+    long long left = w.u_end - ut;
+    if constexpr (kVirt) {
+      if (a_ext) left = u_stop - ut;
+      if (!active) left = 0;
+      // a wave without a whole tile of its own stages first (the unrolled branch below interleaves)
+      if (left < kBfTile && more) store(ut + kBfTile, nxt);
+    }
     const unsigned* ap = cur + a_off;
     const unsigned* bp = cur + b_off;
     if (left >= kBfTile) {
@@ -864,6 +983,19 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   }   // work items of this workgroup
 
   // Epilogue: the wave's 32 x 32 block of its four lags in the workgroup's partial slab.
+  if constexpr (kVirt) {
+    if (active) {
+      float* slab = p.partial + (size_t)part * p.slab_elems;
+      const int lr = lane & 31, lk = lane >> 5;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* pe = slab + (size_t)(out_lag + r) * 1024;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pe[((k & 3) + 8 * (k >> 2) + 4 * lk) * 32 + lr] = total[r][k];
+      }
+    }
+    return;
+  }
   float* slab = p.partial + (size_t)part * p.e_pad * p.ca_pad * p.cb_pad;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -2302,6 +2434,54 @@ int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld) {
   return TD_OK;
 }
 
+// How many slabs each segment is cut into (see "Slab plan" in td_lagcov_plan): at most max_slab
+// samples per slab, the total rounded up to whole rounds of the workgroup slots the stream has.
+static void lag_slab_counts(const td_handle* h, const std::vector<LagSeg>& segs, long long total,
+                            long long per_item_wgs, bool split, std::vector<long long>* out) {
+  long long kMaxSlab = split ? 8192 : 2048;
+  if (const char* e = getenv("TD_MAX_SLAB")) kMaxSlab = atoll(e);   // development
+  std::vector<long long>& n_slabs = *out;
+  n_slabs.assign(segs.size(), 0);
+  long long min_items = 0, max_items = 0;
+  for (size_t f = 0; f < segs.size(); ++f) {
+    const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
+    n_slabs[f] = td_ceil_div(len, kMaxSlab);
+    min_items += n_slabs[f];
+    max_items += td_ceil_div(len, kTile);          // never cut below one tile per slab
+  }
+  // (one workgroup per CU for the bf16x3 kernel, two for the float32 one; the CUs of the
+  // stream's mask if the caller declared one: td_set_cu_count)
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  long long items_per_round = (split ? cus : 2 * cus) / per_item_wgs;
+  if (items_per_round < 1) items_per_round = 1;
+  long long target = td_ceil_div(min_items, items_per_round) * items_per_round;
+  if (target > max_items) target = max_items;
+  if (target > min_items) {
+    // proportional share first, then the remainder to the segments with the longest slabs
+    long long have = 0;
+    for (size_t f = 0; f < segs.size(); ++f) {
+      const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
+      long long share = (long long)((double)target * (double)len / (double)total);
+      const long long cap = td_ceil_div(len, kTile);
+      if (share > cap) share = cap;
+      if (share > n_slabs[f]) n_slabs[f] = share;
+      have += n_slabs[f];
+    }
+    for (long long extra = target - have; extra > 0; --extra) {
+      size_t best = segs.size();
+      double best_len = 0.0;
+      for (size_t f = 0; f < segs.size(); ++f) {
+        const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
+        if (n_slabs[f] == 0 || n_slabs[f] >= td_ceil_div(len, kTile)) continue;
+        const double sl = (double)len / (double)n_slabs[f];
+        if (sl > best_len) { best_len = sl; best = f; }
+      }
+      if (best == segs.size()) break;
+      ++n_slabs[best];
+    }
+  }
+}
+
 int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
                    int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
                    LagcovPlan* plan) {
@@ -2377,47 +2557,8 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   // float32 additions of at most 64 tile sums: slabs of up to 8192 samples -- a quarter of the
   // partial-slab traffic and of the per-slab prologues; C2: 1.48 -> 1.41 ms per pipelined fit,
   // diagonal of the Gram matrix 1.7e-8 (max) from the float64 sums instead of 0.9e-8.)
-  long long kMaxSlab = split ? 8192 : 2048;
-  if (const char* e = getenv("TD_MAX_SLAB")) kMaxSlab = atoll(e);   // development
-  std::vector<long long> n_slabs(segs.size(), 0);
-  long long min_items = 0, max_items = 0;
-  for (size_t f = 0; f < segs.size(); ++f) {
-    const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
-    n_slabs[f] = td_ceil_div(len, kMaxSlab);
-    min_items += n_slabs[f];
-    max_items += td_ceil_div(len, kTile);          // never cut below one tile per slab
-  }
-  // (one workgroup per CU for the bf16x3 kernel, two for the float32 one; the CUs of the
-  // stream's mask if the caller declared one: td_set_cu_count)
-  const int cus = h->cu_count > 0 ? h->cu_count : 256;
-  long long items_per_round = (split ? cus : 2 * cus) / per_item_wgs;
-  if (items_per_round < 1) items_per_round = 1;
-  long long target = td_ceil_div(min_items, items_per_round) * items_per_round;
-  if (target > max_items) target = max_items;
-  if (target > min_items) {
-    // proportional share first, then the remainder to the segments with the longest slabs
-    long long have = 0;
-    for (size_t f = 0; f < segs.size(); ++f) {
-      const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
-      long long share = (long long)((double)target * (double)len / (double)total);
-      const long long cap = td_ceil_div(len, kTile);
-      if (share > cap) share = cap;
-      if (share > n_slabs[f]) n_slabs[f] = share;
-      have += n_slabs[f];
-    }
-    for (long long extra = target - have; extra > 0; --extra) {
-      size_t best = segs.size();
-      double best_len = 0.0;
-      for (size_t f = 0; f < segs.size(); ++f) {
-        const long long len = segs[f].u_end > segs[f].u_begin ? segs[f].u_end - segs[f].u_begin : 0;
-        if (n_slabs[f] == 0 || n_slabs[f] >= td_ceil_div(len, kTile)) continue;
-        const double sl = (double)len / (double)n_slabs[f];
-        if (sl > best_len) { best_len = sl; best = f; }
-      }
-      if (best == segs.size()) break;
-      ++n_slabs[best];
-    }
-  }
+  std::vector<long long> n_slabs;
+  lag_slab_counts(h, segs, total, per_item_wgs, split, &n_slabs);
   std::vector<LagWork>& works = plan->works;
   plan->work_seg.clear();
   for (size_t f = 0; f < segs.size(); ++f) {
@@ -2673,6 +2814,403 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
     tjob->g = tg_dev; tjob->accumulate = t_accumulate ? 1 : 0; tjob->ca_dst = t_rows; tjob->ldg = cb;
     tjob->scale_a = p.ty_max + kChanShards * 128; tjob->scale_b = p.chan_max + kChanShards * 128;
   }
+  return TD_OK;
+}
+
+// ---- virtual images: <= 32 and 65..128 channels on the float16 split kernel -------------------------
+// (VirtImage, td_common.h.)  The plan cuts the channels into blocks of 32 and gives every ordered
+// pair of blocks (A block, B block) a run of slab entries and the tasks that fill it:
+//   * c <= 32: ONE image -- tile 0 holds nsa copies of the channels read 0, E, 2E, .. rows EARLIER
+//     (A operand), tile 1 nsb copies read 0, E nsa, 2 E nsa, .. rows LATER (B operand): the task
+//     (tile 0, tile 1, lags 4t .. 4t+3) covers the lags e1 + E sa + E nsa sb, so E = l / (nsa nsb)
+//     lags of matrix work cover all l (32 channels x 32 lags: 8 tasks = one workgroup per slab where
+//     the 64-channel shape has four; 16 channels: 2 tasks);
+//   * 65..128 channels: blocks 0 and 1 as the 64-channel shape (one image, the four pairs of a
+//     workgroup's eight waves); two more whole blocks (97..128) likewise, and every pair of a low
+//     and a high block as an image of its own whose tasks are the two cross pairs; ONE more block of
+//     w <= 32 channels (65..96): with w > 16 the same, with w <= 16 a tile W of B copies (read later)
+//     and A copies (read earlier) of it beside block 0 / block 1 -- (block, W), (W, block), (W, W)
+//     at l / copies lags each (69 channels x 37 lags: 5 + 3 workgroups per slab, was 3 passes of 5).
+// Exact for any summed range: A-only copies are zero outside the rows the call sums, everything else
+// outside its recording; a recording's last slab runs `ext` rows past its end for the tasks whose A
+// operand holds the earlier-read copies.
+namespace {
+VirtImage virt_blank() {
+  VirtImage im;
+  for (int k = 0; k < 64; ++k) { im.src[k] = -1; im.shift[k] = 0; im.role[k] = 0; }
+  return im;
+}
+void virt_put(VirtImage& im, int tile, int col0, int ch0, int w, int shift, int role) {
+  for (int k = 0; k < w; ++k) {
+    im.src[tile * 32 + col0 + k] = (short)(ch0 + k);
+    im.shift[tile * 32 + col0 + k] = (short)shift;
+    im.role[tile * 32 + col0 + k] = (signed char)role;
+  }
+}
+VirtTask virt_task(int mt, int nt, bool a_ext, int lag0, int out_lag) {
+  VirtTask t;
+  t.mt = (signed char)mt; t.nt = (signed char)nt; t.a_ext = a_ext ? 1 : 0; t.pad = 0;
+  t.lag0 = (short)lag0; t.pad2 = 0; t.out_lag = out_lag;
+  return t;
+}
+VirtPair virt_pair(int slot0, int E, int da, int db, int nsa, int nsb, int wa, int wb, int col_a, int col_b) {
+  VirtPair P;
+  P.slot0 = slot0; P.E = E; P.da = da; P.db = db;
+  P.nsa = (short)nsa; P.nsb = (short)nsb; P.wa = (short)wa; P.wb = (short)wb;
+  P.col_a = (short)col_a; P.col_b = (short)col_b;
+  return P;
+}
+int virt_up4(long long v) { return (int)(td_ceil_div(v, 4) * 4); }
+// tasks of one image -> workgroups of eight
+void virt_groups(std::vector<VirtGroup>* groups, int image, const std::vector<VirtTask>& tasks) {
+  for (size_t t0 = 0; t0 < tasks.size(); t0 += 8) {
+    VirtGroup g;
+    g.image = image; g.pad = 0;
+    for (int k = 0; k < 8; ++k)
+      g.task[k] = t0 + k < tasks.size() ? tasks[t0 + k] : virt_task(0, 0, false, 0, -1);
+    groups->push_back(g);
+  }
+}
+// both tiles whole blocks read as they are: the four pairs (blocks bm / bn) at E lags, a workgroup's
+// eight waves = the four pairs x two quads of eight consecutive lags -- the 64-channel shape
+void virt_full_image(VirtPlan* plan, int image, int bm, int bn, int E, int* next_slot) {
+  const int blk[2] = {bm, bn};
+  for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < 2; ++n) {
+      plan->map.pair[blk[m]][blk[n]] = virt_pair(*next_slot, E, 1 << 20, 1 << 20, 1, 1, 32, 32, 0, 0);
+      *next_slot += E;
+    }
+  for (int g = 0; 8 * g < E; ++g) {
+    VirtGroup vg;
+    vg.image = image; vg.pad = 0;
+    for (int wv = 0; wv < 8; ++wv) {
+      const int quad = wv & 1, mt = (wv >> 1) & 1, nt = wv >> 2, lag0 = 8 * g + 4 * quad;
+      vg.task[wv] = lag0 < E ? virt_task(mt, nt, false, lag0, plan->map.pair[blk[mt]][blk[nt]].slot0 + lag0)
+                             : virt_task(0, 0, false, 0, -1);
+    }
+    plan->groups.push_back(vg);
+  }
+}
+void virt_add(std::vector<VirtTask>* tasks, int mt, int nt, bool a_ext, int E, int slot0) {
+  for (int lag0 = 0; lag0 < E; lag0 += 4) tasks->push_back(virt_task(mt, nt, a_ext, lag0, slot0 + lag0));
+}
+}  // namespace
+
+int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
+                        int l, VirtPlan* plan) {
+  plan->ok = false;
+  plan->c = c; plan->l = l;
+  if (h->acc_mode != TD_ACC_F16X2 || l < 1 || l > 64) return TD_OK;
+  const bool narrow = c >= 9 && c <= 32 && l >= 5, wide = c > 64 && c <= 128;
+  if (!narrow && !wide) return TD_OK;
+  long long total = 0;
+  for (const LagSeg& sg : segs) {
+    if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) return TD_OK;
+    total += sg.u_end > sg.u_begin ? sg.u_end - sg.u_begin : 0;
+  }
+  plan->total = total;
+  if (total == 0) return TD_OK;
+  plan->images.clear(); plan->groups.clear();
+  memset(&plan->map, 0, sizeof(plan->map));
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) plan->map.pair[i][j] = virt_pair(0, 0, 1 << 20, 1 << 20, 1, 1, 32, 32, 0, 0);
+  int next_slot = 0, ext = 0;
+  if (narrow) {
+    const int w = c;
+    int nsa = 32 / w, nsb = 32 / w;
+    const int E = virt_up4(td_ceil_div(l, nsa * nsb));
+    while (nsb > 1 && E * nsa * (nsb - 1) >= l) --nsb;
+    while (nsa > 1 && E * (nsa - 1) * nsb >= l) --nsa;
+    VirtImage im = virt_blank();
+    for (int sa = 0; sa < nsa; ++sa) virt_put(im, 0, sa * w, 0, w, -E * sa, nsa > 1 ? 1 : 0);
+    for (int sb = 0; sb < nsb; ++sb) virt_put(im, 1, sb * w, 0, w, E * nsa * sb, 0);
+    plan->images.push_back(im);
+    plan->map.pair[0][0] = virt_pair(0, E, E, E * nsa, nsa, nsb, w, w, 0, 0);
+    std::vector<VirtTask> tasks;
+    virt_add(&tasks, 0, 1, nsa > 1, E, 0);
+    virt_groups(&plan->groups, 0, tasks);
+    next_slot = E;
+    ext = E * (nsa - 1);
+  } else {
+    const int E = virt_up4(l);
+    const int nb = (c + 31) / 32;
+    {
+      VirtImage im = virt_blank();
+      virt_put(im, 0, 0, 0, 32, 0, 0);
+      virt_put(im, 1, 0, 32, 32, 0, 0);
+      plan->images.push_back(im);
+      virt_full_image(plan, 0, 0, 1, E, &next_slot);
+    }
+    const int w2 = c - 64 < 32 ? c - 64 : 32;
+    const int n2 = 32 / w2;
+    if (nb == 4 || n2 < 2) {
+      // whole (or padded) high blocks: [2 | 3] as the 64-channel shape, every (low, high) pair of
+      // blocks as an image with the two cross pairs; a lone high block takes its own pair there
+      const int w3 = c - 96;
+      if (nb == 4) {
+        VirtImage im = virt_blank();
+        virt_put(im, 0, 0, 64, 32, 0, 0);
+        virt_put(im, 1, 0, 96, w3, 0, 0);
+        plan->images.push_back(im);
+        virt_full_image(plan, (int)plan->images.size() - 1, 2, 3, E, &next_slot);
+      }
+      for (int lo = 0; lo < 2; ++lo)
+        for (int hi = 2; hi < nb; ++hi) {
+          VirtImage im = virt_blank();
+          virt_put(im, 0, 0, 32 * lo, 32, 0, 0);
+          virt_put(im, 1, 0, 32 * hi, hi == 2 ? w2 : w3, 0, 0);
+          plan->images.push_back(im);
+          std::vector<VirtTask> tasks;
+          plan->map.pair[lo][hi] = virt_pair(next_slot, E, 1 << 20, 1 << 20, 1, 1, 32, 32, 0, 0);
+          virt_add(&tasks, 0, 1, false, E, next_slot); next_slot += E;
+          plan->map.pair[hi][lo] = virt_pair(next_slot, E, 1 << 20, 1 << 20, 1, 1, 32, 32, 0, 0);
+          virt_add(&tasks, 1, 0, false, E, next_slot); next_slot += E;
+          if (nb == 3 && lo == 1) {
+            plan->map.pair[2][2] = virt_pair(next_slot, E, 1 << 20, 1 << 20, 1, 1, 32, 32, 0, 0);
+            virt_add(&tasks, 1, 1, false, E, next_slot); next_slot += E;
+          }
+          virt_groups(&plan->groups, (int)plan->images.size() - 1, tasks);
+        }
+    } else {
+      // one narrow high block: W = [B copies (later rows) | A copies (earlier rows)]
+      int nB = (n2 + 1) / 2, nA = n2 - nB;
+      const int EB = virt_up4(td_ceil_div(l, nB)), EA = virt_up4(td_ceil_div(l, nA));
+      while (nB > 1 && EB * (nB - 1) >= l) --nB;
+      while (nA > 1 && EA * (nA - 1) >= l) --nA;
+      // (W, W): lag = e1 + EA sa + EB sb, decoded greedily (td_virt_offset): the e1 it leaves
+      VirtPair p22 = virt_pair(0, 0, EA, EB, nA, nB, w2, w2, nB * w2, 0);
+      int e22 = 0;
+      {
+        VirtMap probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.pair[0][0] = p22;
+        for (int e = 0; e < l; ++e) {
+          int e1 = 0;
+          td_virt_offset(&probe, e, 0, 0, &e1);
+          if (e1 + 1 > e22) e22 = e1 + 1;
+        }
+      }
+      const int E22 = virt_up4(e22);
+      for (int lo = 0; lo < 2; ++lo) {
+        VirtImage im = virt_blank();
+        virt_put(im, 0, 0, 32 * lo, 32, 0, 0);
+        for (int sb = 0; sb < nB; ++sb) virt_put(im, 1, sb * w2, 64, w2, EB * sb, 0);
+        for (int sa = 0; sa < nA; ++sa) virt_put(im, 1, (nB + sa) * w2, 64, w2, -EA * sa, 1);
+        plan->images.push_back(im);
+        std::vector<VirtTask> tasks;
+        plan->map.pair[lo][2] = virt_pair(next_slot, EB, 1 << 20, EB, 1, nB, 32, w2, 0, 0);
+        virt_add(&tasks, 0, 1, false, EB, next_slot); next_slot += EB;
+        plan->map.pair[2][lo] = virt_pair(next_slot, EA, EA, 1 << 20, nA, 1, w2, 32, nB * w2, 0);
+        virt_add(&tasks, 1, 0, true, EA, next_slot); next_slot += EA;
+        if (lo == 0) {
+          p22.slot0 = next_slot; p22.E = E22;
+          plan->map.pair[2][2] = p22;
+          virt_add(&tasks, 1, 1, true, E22, next_slot); next_slot += E22;
+        }
+        virt_groups(&plan->groups, (int)plan->images.size() - 1, tasks);
+      }
+      ext = EA * (nA - 1);
+    }
+  }
+  // every lag of every pair of blocks must decode into its run of slab entries
+  {
+    const int nb = (c + 31) / 32;
+    for (int bi = 0; bi < nb; ++bi)
+      for (int bj = 0; bj < nb; ++bj)
+        for (int e = 0; e < l; ++e) {
+          int e1 = 0;
+          td_virt_offset(&plan->map, e, 32 * bi, 32 * bj, &e1);
+          TD_REQUIRE(h, e1 >= 0 && e1 < plan->map.pair[bi][bj].E, "virtual images: lag %d of blocks (%d, %d) is not covered", e, bi, bj);
+        }
+  }
+  int max_lag0 = 0;
+  for (const VirtGroup& g : plan->groups)
+    for (int k = 0; k < 8; ++k)
+      if (g.task[k].out_lag >= 0 && g.task[k].lag0 > max_lag0) max_lag0 = g.task[k].lag0;
+  plan->rowdw = max_lag0 + 4 <= 32 ? 83 : 99;
+  plan->ext = ext;
+  plan->slab_elems = (long long)next_slot * 1024;
+  // four consecutive staged channels = four consecutive sources under one shift and role, 16-byte rows
+  bool vec4 = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  for (const VirtImage& im : plan->images)
+    for (int k = 0; k < 64 && vec4; k += 4) {
+      const bool none = im.src[k] < 0;
+      for (int q = 0; q < 4; ++q) {
+        if (none ? im.src[k + q] >= 0 : (im.src[k + q] != im.src[k] + q || im.shift[k + q] != im.shift[k] ||
+                                         im.role[k + q] != im.role[k]))
+          vec4 = false;
+      }
+      if (!none && (im.src[k] % 4 != 0)) vec4 = false;
+    }
+  plan->vec4 = vec4;
+  // slabs: as the 64-channel split kernel plans them (one workgroup per CU)
+  const int n_groups = (int)plan->groups.size();
+  std::vector<long long> n_slabs;
+  lag_slab_counts(h, segs, total, n_groups, true, &n_slabs);
+  plan->works.clear(); plan->vsegs.clear();
+  for (size_t f = 0; f < segs.size(); ++f) {
+    if (n_slabs[f] == 0) continue;
+    const long long len = segs[f].u_end - segs[f].u_begin;
+    std::vector<LagSeg> one(1, segs[f]);
+    std::vector<LagWork> ws = split_work(one, td_ceil_div(len, n_slabs[f]));
+    for (size_t k = 0; k < ws.size(); ++k) {
+      VirtSeg v;
+      v.seg_begin = segs[f].u_begin; v.seg_end = segs[f].u_end;
+      v.u_end_ext = ws[k].u_end + (k + 1 == ws.size() ? ext : 0);
+      plan->works.push_back(ws[k]);
+      plan->vsegs.push_back(v);
+    }
+  }
+  const long long n_work = (long long)plan->works.size();
+  const long long nwg = n_work * n_groups;
+  TD_REQUIRE(h, nwg < (1LL << 31), "lagcov: too many workgroups");
+  plan->grid = nwg; plan->n_part = (int)n_work;
+  {
+    const int cus = h->cu_count > 0 ? h->cu_count : 256;
+    const long long per_round = (long long)(cus / n_groups) * n_groups;
+    if (per_round > 0 && nwg > per_round) {
+      constexpr long long kMaxItemsPerChain = 4;       // (as td_lagcov_launch)
+      long long chains = per_round / n_groups;
+      const long long min_chains = td_ceil_div(n_work, kMaxItemsPerChain);
+      if (min_chains > chains) chains = min_chains;
+      if (chains < n_work) { plan->grid = chains * n_groups; plan->n_part = (int)chains; }
+    }
+  }
+  plan->scratch_bytes = td_round_up((size_t)plan->n_part * plan->slab_elems * sizeof(float), 256);
+  plan->ok = true;
+  return TD_OK;
+}
+
+int td_lagcov_virt_launch(td_handle* h, VirtPlan* plan, const float* x, int64_t ldx, void* scratch,
+                          const unsigned* tab, double* g_dev, bool accumulate, LagReduceJob* job) {
+  TD_REQUIRE(h, plan->ok && tab, "td_lagcov_virt_launch: no plan / no channel maxima");
+  // ONE table: work items | their recordings' rows | images | task tables | the reduction's map
+  const size_t b_works = plan->works.size() * sizeof(LagWork), b_segs = plan->vsegs.size() * sizeof(VirtSeg);
+  const size_t b_img = plan->images.size() * sizeof(VirtImage), b_grp = plan->groups.size() * sizeof(VirtGroup);
+  const size_t o_segs = td_round_up(b_works, 16), o_img = td_round_up(o_segs + b_segs, 16);
+  const size_t o_grp = td_round_up(o_img + b_img, 16), o_map = td_round_up(o_grp + b_grp, 16);
+  std::vector<char> blob(o_map + sizeof(VirtMap), 0);
+  memcpy(blob.data(), plan->works.data(), b_works);
+  memcpy(blob.data() + o_segs, plan->vsegs.data(), b_segs);
+  memcpy(blob.data() + o_img, plan->images.data(), b_img);
+  memcpy(blob.data() + o_grp, plan->groups.data(), b_grp);
+  memcpy(blob.data() + o_map, &plan->map, sizeof(VirtMap));
+  const void* dev = nullptr;
+  TD_TRY(td_table_upload(h, blob.data(), blob.size(), &dev));
+  const char* d = reinterpret_cast<const char*>(dev);
+  LagParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = x; p.b = x; p.lda = ldx; p.ldb = ldx; p.ca = plan->c; p.cb = plan->c;
+  p.works = reinterpret_cast<const LagWork*>(d);
+  p.vsegs = reinterpret_cast<const VirtSeg*>(d + o_segs);
+  p.vimgs = reinterpret_cast<const VirtImage*>(d + o_img);
+  p.vgroups = reinterpret_cast<const VirtGroup*>(d + o_grp);
+  p.n_work = (int)plan->works.size(); p.n_groups = (int)plan->groups.size(); p.n_part = plan->n_part;
+  p.n_cat = p.n_cbt = 1; p.e_count = plan->l;
+  p.partial = reinterpret_cast<float*>(scratch);
+  p.slab_elems = plan->slab_elems;
+  p.chan_max = tab;
+  if (!h->lds_opt_virt) {
+#define TD_VOPT(V, R)                                                                                   \
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_split_kernel<V, R, true, false, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)BfGeom<R, 2>::kLdsBytes))
+    TD_VOPT(true, 83); TD_VOPT(false, 83); TD_VOPT(true, 99); TD_VOPT(false, 99);
+#undef TD_VOPT
+    h->lds_opt_virt = true;
+  }
+  TD_TRY(td_profile_mark(h, true, (double)plan->total));
+#define TD_VLAUNCH(V, R)                                                                                \
+  hipLaunchKernelGGL((lagcov_split_kernel<V, R, true, false, true>), dim3((unsigned)plan->grid),        \
+                     dim3(kBfThreads), (BfGeom<R, 2>::kLdsBytes), h->stream, p)
+  if (plan->rowdw == 83) { if (plan->vec4) TD_VLAUNCH(true, 83); else TD_VLAUNCH(false, 83); }
+  else                   { if (plan->vec4) TD_VLAUNCH(true, 99); else TD_VLAUNCH(false, 99); }
+#undef TD_VLAUNCH
+  TD_TRY(td_profile_mark(h, false, 0.0));
+  TD_HIP(h, hipGetLastError());
+  *job = LagReduceJob{};
+  job->partial = p.partial; job->is_f64 = 0;
+  job->n_work = plan->n_part;
+  job->e_pad = 0; job->ca_pad = 32; job->cb_pad = 32;
+  job->e_count = plan->l; job->ca_eff = plan->c; job->cb = plan->c;
+  job->g = g_dev; job->accumulate = accumulate ? 1 : 0; job->ca_dst = plan->c; job->ldg = plan->c;
+  job->mirror = 1;
+  job->scale_a = job->scale_b = tab + kChanShards * 128;
+  job->vmap = reinterpret_cast<const VirtMap*>(d + o_map);
+  job->slab_elems = plan->slab_elems;
+  return TD_OK;
+}
+
+namespace {
+// the float64 reduction of virtual-image slabs as a launch of its own (td_lagcov_virt): 64 outputs x 4
+// slab phases per workgroup, fixed order
+__global__ __launch_bounds__(256) void virt_reduce_kernel(LagReduceJob jb) {
+  __shared__ double part[4][64];
+  const long long total = (long long)jb.e_count * jb.ca_eff * jb.cb;
+  const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long long o = blockIdx.x * 64LL + ol;
+  double s = 0.0;
+  int j = 0, i = 0, e = 0;
+  if (o < total) {
+    j = (int)(o % jb.cb);
+    i = (int)((o / jb.cb) % jb.ca_eff);
+    e = (int)(o / ((long long)jb.cb * jb.ca_eff));
+    const bool flip = jb.mirror && e == 0 && i > j;
+    const float* src = reinterpret_cast<const float*>(jb.partial) + td_virt_offset(jb.vmap, e, flip ? j : i, flip ? i : j);
+    double s0 = 0.0, s1 = 0.0;
+    int w = q;
+    for (; w + 4 < jb.n_work; w += 8) {
+      s0 += (double)src[(size_t)w * jb.slab_elems];
+      s1 += (double)src[(size_t)(w + 4) * jb.slab_elems];
+    }
+    if (w < jb.n_work) s0 += (double)src[(size_t)w * jb.slab_elems];
+    s = s0 + s1;
+  }
+  part[q][ol] = s;
+  __syncthreads();
+  if (q == 0 && o < total) {
+    double t = (part[0][ol] + part[1][ol]) + (part[2][ol] + part[3][ol]);
+    t = ldexp(t, -(td_f16_scale_exp(jb.scale_a[i]) + td_f16_scale_exp(jb.scale_b[j])));
+    if (td_chan_not_finite(jb.scale_a[i]) || td_chan_not_finite(jb.scale_b[j])) t = __builtin_nan("");
+    double* dst = jb.g + ((long long)e * jb.ca_dst + i) * jb.ldg + j;
+    *dst = jb.accumulate ? *dst + t : t;
+  }
+}
+}  // namespace
+
+int td_chan_max(td_handle* h, const float* x, int64_t ldx, int c, long long row0, long long row1, unsigned* tab) {
+  const long long blocks = td_ceil_div(row1 - row0, 16 * 8);       // >= 8 rows per thread
+  const bool al = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  for (int c0 = 0; c0 < c; c0 += 64)
+    hipLaunchKernelGGL(chan_max_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)),
+                       dim3(256), 0, h->stream, x + c0, (long long)ldx, c - c0 < 64 ? c - c0 : 64, row0, row1,
+                       tab + c0, al ? 1 : 0);
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_lagcov_virt(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
+                   int l, double* g_dev, bool accumulate, bool* handled) {
+  *handled = false;
+  VirtPlan plan;
+  TD_TRY(td_lagcov_virt_plan(h, x, ldx, c, segs, l, &plan));
+  if (!plan.ok) return TD_OK;
+  // channel maxima over the rows of the array that hold this call's recordings
+  unsigned* tab = nullptr;
+  TD_TRY(td_chan_tab_scratch(h, &tab));
+  long long lo = plan.works[0].a_row0, hi = lo;
+  for (const LagWork& wk : plan.works) {
+    lo = wk.a_row0 < lo ? wk.a_row0 : lo;
+    hi = wk.a_row0 + wk.a_valid > hi ? wk.a_row0 + wk.a_valid : hi;
+  }
+  TD_TRY(td_chan_max(h, x, ldx, c, lo, hi, tab));
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, plan.scratch_bytes, &scratch));
+  LagReduceJob job;
+  TD_TRY(td_lagcov_virt_launch(h, &plan, x, ldx, scratch, tab, g_dev, accumulate, &job));
+  const long long outs = (long long)l * c * c;
+  hipLaunchKernelGGL(virt_reduce_kernel, dim3((unsigned)td_ceil_div(outs, 64)), dim3(256), 0, h->stream, job);
+  TD_HIP(h, hipGetLastError());
+  *handled = true;
   return TD_OK;
 }
 

@@ -177,7 +177,8 @@ __device__ __forceinline__ void fin_reduce(const LagReduceJob& jb, int q_phases,
   const int outs_per = kFinThreads / q_phases;
   const int ol = threadIdx.x % outs_per, q = threadIdx.x / outs_per;
   const long long total = (long long)jb.e_count * jb.ca_eff * jb.cb;
-  const size_t slab = (size_t)jb.e_pad * jb.ca_pad * jb.cb_pad;
+  // (slabs of the virtual-image kernel: td_virt_offset says where an output's sums are)
+  const size_t slab = jb.vmap ? (size_t)jb.slab_elems : (size_t)jb.e_pad * jb.ca_pad * jb.cb_pad;
   const long long o = (long long)block * outs_per + ol;
   double s = 0.0;
   int j = 0, i = 0, e = 0;
@@ -188,7 +189,8 @@ __device__ __forceinline__ void fin_reduce(const LagReduceJob& jb, int q_phases,
     // a symmetric lag-0 block takes the sums of its upper triangle on both sides
     const bool flip = jb.mirror && e == 0 && i > j;
     const int is = flip ? j : i, js = flip ? i : j;
-    const size_t off = ((size_t)e * jb.ca_pad + is) * jb.cb_pad + js;
+    const size_t off = jb.vmap ? (size_t)td_virt_offset(jb.vmap, e, is, js)
+                               : ((size_t)e * jb.ca_pad + is) * jb.cb_pad + js;
     double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // eight loads in flight
     int w = q;
     if (jb.is_f64) {
@@ -969,6 +971,13 @@ int lagcov_auto_blocks(td_handle* h, const float* x, int64_t ldx, int c, const s
 
 int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
                 int l, double* g) {
+  {
+    // 9 .. 32 and 65 .. 128 channels, <= 64 lags: the float16 kernel on virtual images, no copies
+    // (lagcov.hip)
+    bool handled = false;
+    TD_TRY(td_lagcov_virt(h, x, ldx, c, segs, l, g, true, &handled));
+    if (handled) return TD_OK;
+  }
   if (c <= 64 || c > 128)
     return td_lagcov(h, x, ldx, c, false, x, ldx, c, segs, 0, l, g, true, 0, 0, false, true);
   static const bool blocks = getenv("TD_AUTO_BLOCKS") != nullptr;          // development: A/B runs
@@ -1034,11 +1043,14 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   LagcovPlan mp;
   TargetsPlan tp;
   PrepassPlan pp;
+  VirtPlan vp;                   // <= 32 channels: the float16 kernel on virtual images (lagcov.hip)
   if (do_main) {
     TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
+    TD_TRY(td_lagcov_virt_plan(h, x_dev, ldx, s->c1, sxx, s->l1, &vp));
     mp.allow_f16 = true;         // the finalize launch divides the channel scales out
-    TD_TRY(td_lagcov_plan(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1, &mp));
+    if (!vp.ok) TD_TRY(td_lagcov_plan(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1, &mp));
   }
+  const bool virt = do_main && vp.ok;
   // Two forms, 3 launches and two reads of x each:
   //   default: targets kernel (yT x~, column sums, channel maxima) -> lag kernel -> finalize;
   //   FOLDED (one target column, no pre-context, the float16 kernel): a streaming pre-pass
@@ -1049,7 +1061,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   // and measures the channel maxima on the way -- they cost 62 us in all.  So the folded form is
   // opt-in: TD_ACC_FOLDED.)
   static const bool want_fold = getenv("TD_ACC_FOLDED") != nullptr;      // development: A/B runs
-  const bool folded = do_main && do_targets && s->d == 1 && s->pre1 == 0 && want_fold &&
+  const bool folded = do_main && !virt && do_targets && s->d == 1 && s->pre1 == 0 && want_fold &&
                       td_lagcov_plan_targets(&mp);
   if (folded) {
     TD_TRY(td_chan_prepass_plan(h, syx, &pp));
@@ -1057,7 +1069,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     TD_TRY(td_lagcov_targets_plan(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1, &tp));
     TD_REQUIRE(h, tp.handled && tp.n_work > 0, "accumulate_fused: the targets kernel refused the shape");
   }
-  const size_t main_bytes = do_main ? mp.scratch_bytes + (folded ? mp.tpartial_bytes : 0) : 0;
+  const size_t main_bytes = virt ? vp.scratch_bytes : do_main ? mp.scratch_bytes + (folded ? mp.tpartial_bytes : 0) : 0;
   void* scratch = nullptr;
   TD_TRY(td_scratch(h, main_bytes + (folded ? pp.scratch_bytes : do_targets ? tp.scratch_bytes : 0),
                     &scratch));
@@ -1067,7 +1079,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   int blocks = 0;
   auto add_reduce = [&](const LagReduceJob& job) {
     const long long outs = (long long)job.e_count * job.ca_eff * job.cb;
-    const bool vec = !job.is_f64 && outs >= 32768 && job.cb % 4 == 0 && job.cb_pad % 4 == 0 &&
+    const bool vec = !job.is_f64 && !job.vmap && outs >= 32768 && job.cb % 4 == 0 && job.cb_pad % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(job.partial) & 15) == 0;
     const int q = vec ? 0 : outs < 32768 ? 16 : 4;
     fp.red[fp.n_red] = job;
@@ -1100,7 +1112,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   // measures for itself: chan_max_kernel).
   if (do_targets && !folded) {
     to.maxtab = nullptr;
-    if (do_main && mp.f16 && s->pre1 == 0) {
+    if (do_main && (mp.f16 || virt) && s->pre1 == 0) {
       TD_TRY(td_chan_tab(h, &to.maxtab));
       mp.tab = to.maxtab;
     } else if (!do_main && tgt_first && s->pre1 == 0 && h->acc_mode == TD_ACC_F16X2) {
@@ -1120,14 +1132,32 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   if (do_main) {
     LagReduceJob job, tjob;
     // (the maxima a TARGETS_FIRST call of these files left in the statistics: no pre-pass here)
-    const bool ahead = !do_targets && s->tab_ready && mp.f16 && s->pre1 == 0;
+    const bool ahead = !do_targets && s->tab_ready && (mp.f16 || virt) && s->pre1 == 0;
     if (ahead) mp.tab = s->chan_tab;
     s->tab_ready = false;
-    TD_TRY(td_lagcov_launch(h, &mp, base, s->g + s->off_fxx, !s->fresh_main, 0, 0, &job,
-                            s->g + s->off_gxo, !s->fresh_tgt, s->d + 1, folded ? &tjob : nullptr));
+    bool own_tab = false;
+    if (virt) {
+      unsigned* tab = mp.tab;
+      if (!tab) {
+        // nobody measured the channel maxima on the way (a pre-context, a MAIN-only call): a pass of
+        // its own over the rows of the array that hold this call's recordings
+        TD_TRY(td_chan_tab_scratch(h, &tab));
+        long long lo = vp.works[0].a_row0, hi = lo;
+        for (const LagWork& wk : vp.works) {
+          lo = wk.a_row0 < lo ? wk.a_row0 : lo;
+          hi = wk.a_row0 + wk.a_valid > hi ? wk.a_row0 + wk.a_valid : hi;
+        }
+        TD_TRY(td_chan_max(h, x_dev, ldx, s->c1, lo, hi, tab));
+        own_tab = true;
+      }
+      TD_TRY(td_lagcov_virt_launch(h, &vp, x_dev, ldx, base, tab, s->g + s->off_fxx, !s->fresh_main, &job));
+    } else {
+      TD_TRY(td_lagcov_launch(h, &mp, base, s->g + s->off_fxx, !s->fresh_main, 0, 0, &job,
+                              s->g + s->off_gxo, !s->fresh_tgt, s->d + 1, folded ? &tjob : nullptr));
+    }
     add_reduce(job);
     if (folded) add_reduce(tjob);
-    if (mp.f16 && !ahead) {      // this call used table chan_phase & 1: clear the other for the next
+    if ((mp.f16 || (virt && !own_tab)) && !ahead) {      // this call used table chan_phase & 1: clear the other for the next
       ++h->chan_phase;
       fp.zero_tab = h->chan_max + kChanTab * (h->chan_phase & 1);
     }

@@ -21,7 +21,7 @@ struct td_handle {
   int acc_mode = 0;   // td_set_accumulate_mode: how the lag kernel multiplies float32 numbers
   int cu_count = 0;   // CUs the handle's stream runs on (the device's, or a CU mask's: td_set_cu_count)
   // kernels that opted in to more than 64 KB of dynamic LDS on this handle's device
-  bool lds_opt_lagcov = false, lds_opt_fir = false, lds_opt_fir_stream = false, lds_opt_proj_stream = false;
+  bool lds_opt_lagcov = false, lds_opt_virt = false, lds_opt_fir = false, lds_opt_fir_stream = false, lds_opt_proj_stream = false;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // the one work is queued on (own or adopted)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -291,7 +291,73 @@ struct LagParams {
   const struct TgtWork* tworks;
   float* tpartial;
   const unsigned* ty_max;
+  // virtual images (kVirt): the images, the workgroups' task tables [n_groups], per work item the
+  // recording's summed rows; slab_elems floats per partial slab
+  const struct VirtImage* vimgs = nullptr;
+  const struct VirtGroup* vgroups = nullptr;
+  const struct VirtSeg* vsegs = nullptr;
+  long long slab_elems = 0;
 };
+
+// ---- virtual 64-channel images of the split kernel (lagcov.hip: lagcov_split_kernel<..., kVirt>) ----
+// Shapes the 64-channel tile does not fit (<= 32 channels, 65..128 channels) run on the same
+// float16 matrix kernel through VIRTUAL channels: a staged channel k of an image is source channel
+// src[k] of x read `shift[k]` rows later, Z[w][k] = x~[w + shift[k]][src[k]], so that the product of
+// two virtual channels at lag e is the lagged covariance of their sources at lag
+// e + shift[kb] - shift[ka]: a narrow block of channels fills a 32-channel tile with shifted copies of
+// itself and one 32 x 32 x 4-lag wave task covers copies_a x copies_b x 4 lags of it.  A workgroup
+// stages ONE image (two 32-channel tiles) and its eight waves run eight TASKS: (A tile, B tile,
+// first lag) -> a block of four lags [4][32][32] in the partial slab.
+//   role 0: the channel is read as the B operand (and as A when it is not shifted): zero outside
+//           the rows [0, valid) of its recording;
+//   role 1: a shifted copy read as the A operand only: zero outside the rows this call sums,
+//           [seg_begin, seg_end) (VirtSeg) -- the sums over w then run `ext` rows past a
+//           recording's last slab (tasks with a_ext), where only these channels are not zero.
+struct VirtImage {
+  short src[64];     // source channel, -1: a zero channel
+  short shift[64];   // rows (any sign)
+  signed char role[64];
+};
+struct VirtTask {
+  signed char mt, nt;    // A / B tile of the image (0 or 1)
+  signed char a_ext;     // the A tile holds role-1 copies: run over the extended range
+  signed char pad;
+  short lag0;            // first of the task's four lags (even)
+  short pad2;
+  int out_lag;           // slab entry of lag0 (units of 32 x 32 floats), -1: the wave idles
+};
+struct VirtGroup {
+  int image;
+  int pad;
+  VirtTask task[8];
+};
+struct VirtSeg {         // per work item
+  long long seg_begin, seg_end;   // the rows of the recording this call sums
+  long long u_end_ext;            // where the item's tile loop ends (u_end, or past it in a recording's last slab)
+};
+// where the reduction finds G[e][i][j] of an ordered pair of 32-channel blocks (bi = i >> 5, bj = j >> 5):
+//   sb = e / (E nsa), sa = (e % (E nsa)) / E, e1 = e % E
+//   slab[((slot0 + e1) * 32 + col_a + sa wa + (i & 31)) * 32 + col_b + sb wb + (j & 31)]
+//   (in general, with copy spacings da / db: sb = min(nsb - 1, e / db), rem = e - sb db,
+//    sa = min(nsa - 1, rem / da), e1 = rem - sa da < E)
+struct VirtPair {
+  int slot0, E, da, db;
+  short nsa, nsb, wa, wb, col_a, col_b;
+};
+struct VirtMap {
+  VirtPair pair[4][4];
+};
+__host__ __device__ __forceinline__ long long td_virt_offset(const VirtMap* vm, int e, int i, int j, int* e1_out = nullptr) {
+  const VirtPair& P = vm->pair[i >> 5][j >> 5];
+  int sb = e / P.db;
+  sb = sb < P.nsb - 1 ? sb : P.nsb - 1;
+  const int rem = e - sb * P.db;
+  int sa = rem / P.da;
+  sa = sa < P.nsa - 1 ? sa : P.nsa - 1;
+  const int e1 = rem - sa * P.da;
+  if (e1_out) *e1_out = e1;
+  return ((long long)(P.slot0 + e1) * 32 + P.col_a + sa * P.wa + (i & 31)) * 32 + P.col_b + sb * P.wb + (j & 31);
+}
 
 // Where work item i finds its targets: y[u] = ty[(y_row0 + u) * ldty], zero outside
 // [seg_begin, seg_end) (the rows of the recording this call sums) and outside [0, y_valid).
@@ -314,6 +380,10 @@ struct LagReduceJob {
   // k = td_f16_scale_exp(chan_max[.]), are divided out (exactly) as the sum is stored.  Null = none.
   const unsigned* scale_a;
   const unsigned* scale_b;
+  // slabs of the virtual-image kernel: where (e, i, j) is (VirtMap); null = the dense layout above.
+  // slab_elems then replaces e_pad * ca_pad * cb_pad as the size of one partial slab.
+  const struct VirtMap* vmap = nullptr;
+  long long slab_elems = 0;
 };
 
 // td_lagcov in two steps, for callers that run several kernels out of ONE scratch block and
@@ -349,6 +419,32 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
 int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_dev, bool accumulate,
                      int ldg, int rows_dst, LagReduceJob* job, double* tg_dev = nullptr,
                      bool t_accumulate = false, int t_rows = 0, LagReduceJob* tjob = nullptr);
+// The same for the shapes that run on virtual images (<= 32 or 65..128 channels of ONE stream, lags
+// 0 .. l - 1 <= 63, the float16 form): plan->ok says whether the shape is one of them.  The launch
+// queues the matrix kernel; `tab` holds the channel maxima of x (kChanTab layout, filled by the
+// caller's measuring pass); job describes the float64 reduction into g_dev [l][c][c].
+struct VirtPlan {
+  bool ok = false;
+  int c = 0, l = 0, rowdw = 83, n_part = 0, ext = 0;
+  bool vec4 = false;
+  std::vector<VirtImage> images;
+  std::vector<VirtGroup> groups;
+  VirtMap map;
+  std::vector<LagWork> works;
+  std::vector<VirtSeg> vsegs;
+  long long slab_elems = 0, total = 0, grid = 0;
+  size_t scratch_bytes = 0;
+};
+// largest magnitudes of the channels of x over the rows [row0, row1) into a zeroed table (<= 128 channels)
+int td_chan_max(td_handle* h, const float* x, int64_t ldx, int c, long long row0, long long row1, unsigned* tab);
+int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
+                        int l, VirtPlan* plan);
+int td_lagcov_virt_launch(td_handle* h, VirtPlan* plan, const float* x, int64_t ldx, void* scratch,
+                          const unsigned* tab, double* g_dev, bool accumulate, LagReduceJob* job);
+// plan + channel maxima + launch + reduction; *handled = false: not a virtual-image shape
+int td_lagcov_virt(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
+                   int l, double* g_dev, bool accumulate, bool* handled);
+
 // Asks the planned float16 launch to carry a target column: sizes its scratch.  False when the
 // plan cannot (not the float16 split kernel, or more than 32 lags).
 bool td_lagcov_plan_targets(LagcovPlan* plan);

@@ -118,6 +118,23 @@ def _rel(a, b):
     (64, 40, 20, 0, 0, 0, 1, 0, (3000, 260, 129), 0),
     (44, 0, 32, 0, 0, 0, 1, 3, (2500, 2049), 17),
     (64, 31, 32, 0, 0, 0, 1, 0, (191, 192, 193, 5000), 0),
+    # 9 .. 32 channels with at least 5 lags, 65 .. 128 channels: the float16 kernel on VIRTUAL images
+    # (shifted copies of a narrow block of channels fill a 32-channel tile): whole tiles, copies on
+    # both sides (<= 16 channels), dropped remainders (rows behind the summed range), offsets,
+    # recordings shorter than the copies' shifts, 33 .. 64 lags, a narrow third block (65 .. 80)
+    (32, 0, 31, 0, 0, 0, 1, 0, (5000, 4096, 300), 96),
+    (16, 0, 31, 0, 0, 0, 1, 0, (3000, 129, 2049), 57),
+    (16, 8, 8, 0, 0, 0, 2, -2, (700, 12, 1500), 0),
+    (10, 0, 15, 0, 0, 0, 1, 1, (7, 2600), 33),
+    (24, 4, 20, 0, 0, 0, 1, 0, (1300, 127, 128), 0),
+    (12, 0, 63, 0, 0, 0, 1, 0, (2100, 40), 0),
+    (28, 20, 20, 0, 0, 0, 1, 0, (1500, 400), 5),
+    (9, 2, 2, 0, 0, 0, 1, 0, (900, 3), 0),
+    (69, 0, 36, 0, 0, 0, 1, 1, (2500, 20, 700), 130),
+    (72, 0, 31, 0, 0, 0, 1, 0, (3000, 129), 0),
+    (80, 16, 15, 0, 0, 0, 1, 0, (2600,), 7),
+    (112, 0, 15, 0, 0, 0, 1, 0, (1400, 300), 0),
+    (20, 0, 11, 8, 3, 3, 0, 0, (1500, 5, 700), 11),
 ])
 def test_moments_match_dense_lag_matrix(dev, c1, pre, post, c2, pre2, post2, d, off, lens, drop):
   rng = np.random.default_rng(1234 + c1 + pre * 7 + post)
