@@ -677,9 +677,14 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   int vdesc[4] = {0, 0, 0, 0};
   if constexpr (kVirt) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      vdesc[q] = (img->src[c4 + q] + 1) | (img->role[c4 + q] ? 0x100 : 0) | ((int)img->shift[c4 + q] << 16);
+    for (int q = 0; q < 4; ++q) {
+      // (unaligned rows, !kVec4: a lane stages ONE channel -- its number -- whole rows per load)
+      const int k = kVec4 ? c4 + q : lane;
+      vdesc[q] = (img->src[k] + 1) | (img->role[k] ? 0x100 : 0) | ((int)img->shift[k] << 16);
+    }
   }
+  // !kVec4: wave w of the workgroup stages the row pairs w, w + 8, ... of the tile (rows 2 pi, 2 pi + 1)
+  constexpr int kVPairs = kBfRows / 16;
   auto v_src = [&](int q) { return (vdesc[q] & 0xff) - 1; };
   auto v_sh = [&](int q) { return vdesc[q] >> 16; };
   auto v_role = [&](int q) { return (vdesc[q] & 0x100) != 0; };
@@ -689,6 +694,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
       const int ch = kVirt ? v_src(q) : min(c4 + q, 63);
       const int k = ch >= 0 ? td_f16_scale_exp(td_chan_max_of(p.chan_max, ch)) : 0;
       sc[q] = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+      if (kVirt && ch < 0) sc[q] = 0.f;     // (an absent channel: whatever is staged for it becomes zero)
     }
     // one workgroup leaves the combined maxima in the table's last row (the finalize launch
     // divides the scales out and runs after this kernel)
@@ -749,11 +755,47 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     hi = (v_role(q) ? b1i : b0i) - v_sh(q);
     if (v_src(q) < 0) { lo = 0; hi = 0; }
   };
+  // virtual images, wave-uniform: every row any channel of the image stages for the tile at ut exists
+  // (no clamps, no masks -- all but the tiles at a recording's ends)
+  int v_min_shift = 0, v_max_shift = 0;
+  bool v_any_role1 = false;
+  if constexpr (kVirt) { v_min_shift = img->min_shift; v_max_shift = img->max_shift; v_any_role1 = img->any_role1 != 0; }
+  auto vinside = [&](long long ut) -> bool {
+    const long long lo = v_any_role1 && vs.seg_begin > 0 ? vs.seg_begin : 0;
+    const long long hi = v_any_role1 && vs.seg_end < w.a_valid ? vs.seg_end : w.a_valid;
+    return ut + v_min_shift >= lo && ut + kBfRows + v_max_shift <= hi;
+  };
   auto prefetch = [&](long long ut) {
 #ifdef TD_ABL_NOSTAGE
     return;
 #endif
     if constexpr (kVirt) {
+      if (vinside(ut)) {
+        // rows from wave-uniform bases (one per row slot), the lane's channel and shift in ONE offset
+        const int ld = (int)p.lda;
+        const float* base = p.a + (w.a_row0 + ut) * p.lda;
+        if (kVec4) {
+          const int off = (4 * rg + v_sh(0)) * ld + (v_src(0) < 0 ? 0 : v_src(0));
+#pragma unroll
+          for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const float4*>(base + s * ld + off);
+          if (has_tail) {
+            const float* tb = base + kBfTile * ld;
+            const int toff = off - 2 * rg * ld;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) pf[4 + s] = *reinterpret_cast<const float4*>(tb + s * ld + toff);
+          }
+        } else {
+          // lane = channel: a load instruction is (a contiguous run of) one row
+          const int off = (2 * wave + v_sh(0)) * ld + (v_src(0) < 0 ? 0 : v_src(0));
+          float* pv = reinterpret_cast<float*>(&pf[0]);
+#pragma unroll
+          for (int j = 0; j < kVPairs; ++j) {
+            pv[2 * j] = (base + 16 * j * ld)[off];
+            pv[2 * j + 1] = (base + (16 * j + 1) * ld)[off];
+          }
+        }
+        return;
+      }
       // row r of the tile, staged channel q: x[(a_row0 + clamp(ut + r + shift))][src]
       const float* base = p.a + (w.a_row0 + ut) * p.lda;
       const int ld = (int)p.lda;
@@ -776,21 +818,13 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
           }
         }
       } else {
+        const int src = v_src(0) < 0 ? 0 : v_src(0), sh = v_sh(0);
+        float* pv = reinterpret_cast<float*>(&pf[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int src = v_src(q) < 0 ? 0 : v_src(q), sh = v_sh(q);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int rc = max(rlo, min(4 * rg + s + sh, rhi));
-            reinterpret_cast<float*>(&pf[s])[q] = base[rc * ld + src];
-          }
-          if (has_tail) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const int rc = max(rlo, min(kBfTile + 2 * rg + s + sh, rhi));
-              reinterpret_cast<float*>(&pf[4 + s])[q] = base[rc * ld + src];
-            }
-          }
+        for (int j = 0; j < 2 * kVPairs; ++j) {
+          const int r = 16 * (j >> 1) + 2 * wave + (j & 1);
+          const int rc = max(rlo, min(r + sh, rhi));
+          pv[j] = base[rc * ld + src];
         }
       }
       return;
@@ -820,10 +854,39 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
 #ifdef TD_ABL_NOSTAGE    // timing ablation: no staging at all (with prefetch below)
     return;
 #endif
+    if constexpr (kVirt && !kVec4) {
+      // lane = channel: the pairs of rows this wave fetched, two samples a dword
+      const float* pv = reinterpret_cast<const float*>(&pf[0]);
+      unsigned* dst = buf + lane * kBfRowDw + wave;
+      if (vinside(ut)) {
+#pragma unroll
+        for (int j = 0; j < kVPairs; ++j) {
+          unsigned h, l;
+          td_split2_f16(pv[2 * j] * sc[0], pv[2 * j + 1] * sc[0], h, l);
+          dst[8 * j] = h;
+          dst[kBfPieceDw + 8 * j] = l;
+        }
+        return;
+      }
+      int lo, hi;
+      vrange(ut, 0, lo, hi);
+#pragma unroll
+      for (int j = 0; j < kVPairs; ++j) {
+        const int r = 16 * j + 2 * wave;
+        const float x0 = (r >= lo && r < hi) ? pv[2 * j] : 0.f;
+        const float x1 = (r + 1 >= lo && r + 1 < hi) ? pv[2 * j + 1] : 0.f;
+        unsigned h, l;
+        td_split2_f16(x0 * sc[0], x1 * sc[0], h, l);
+        dst[8 * j] = h;
+        dst[kBfPieceDw + 8 * j] = l;
+      }
+      return;
+    }
     float4 v[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) v[s] = pf[s];
     if constexpr (kVirt) {
+      if (!vinside(ut))
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int lo, hi;
@@ -1076,6 +1139,74 @@ __global__ __launch_bounds__(256) void chan_max_kernel(const float* __restrict__
     unsigned t = 0u;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t = max(t, red[k][tid]);
+    if (tid < c && t) atomicMax(tab + (blockIdx.x % kChanShards) * 128 + tid, t);
+  }
+}
+
+// The same for up to 128 channels in one pass (the virtual-image kernel's 65..128-channel inputs): 32
+// threads per row, 8 rows per step, four steps in flight.
+__global__ __launch_bounds__(256) void chan_max_wide_kernel(const float* __restrict__ x, long long ld, int c,
+                                                            long long row0, long long row1,
+                                                            unsigned* __restrict__ tab, int vec4) {
+  __shared__ unsigned red[8][128];
+  const int tid = threadIdx.x, c4 = (tid & 31) * 4, rl = tid >> 5;
+  unsigned m[4] = {0u, 0u, 0u, 0u};
+  const long long stride = (long long)gridDim.x * 8;
+  long long r = row0 + (long long)blockIdx.x * 8 + rl;
+  if (vec4) {
+    if (c4 < c) {
+      for (; r + 3 * stride < row1; r += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(x + (r + k * stride) * ld + c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m[0] = max(m[0], __float_as_uint(v[k].x) & 0x7fffffffu);
+          m[1] = max(m[1], __float_as_uint(v[k].y) & 0x7fffffffu);
+          m[2] = max(m[2], __float_as_uint(v[k].z) & 0x7fffffffu);
+          m[3] = max(m[3], __float_as_uint(v[k].w) & 0x7fffffffu);
+        }
+      }
+      for (; r < row1; r += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c4);
+        m[0] = max(m[0], __float_as_uint(v.x) & 0x7fffffffu);
+        m[1] = max(m[1], __float_as_uint(v.y) & 0x7fffffffu);
+        m[2] = max(m[2], __float_as_uint(v.z) & 0x7fffffffu);
+        m[3] = max(m[3], __float_as_uint(v.w) & 0x7fffffffu);
+      }
+    }
+  } else {
+    // unaligned rows: a thread is ONE channel (whole rows per load instruction), two rows per step of
+    // the workgroup, four steps in flight
+    const int ch = tid & 127, rh = tid >> 7;
+    unsigned mm = 0u;
+    const long long st2 = (long long)gridDim.x * 2;
+    long long rr = row0 + (long long)blockIdx.x * 2 + rh;
+    if (ch < c) {
+      for (; rr + 3 * st2 < row1; rr += 4 * st2) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = x[(rr + k * st2) * ld + ch];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mm = max(mm, __float_as_uint(v[k]) & 0x7fffffffu);
+      }
+      for (; rr < row1; rr += st2) mm = max(mm, __float_as_uint(x[rr * ld + ch]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][ch] = 0u;       // (both row halves write: combine below)
+    __syncthreads();
+    atomicMax(&red[0][ch], mm);
+    __syncthreads();
+    if (tid < 128 && tid < c && red[0][tid]) atomicMax(tab + (blockIdx.x % kChanShards) * 128 + tid, red[0][tid]);
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[rl][c4 + q] = m[q];
+  __syncthreads();
+  if (tid < 128) {
+    unsigned t = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t = max(t, red[k][tid]);
     if (tid < c && t) atomicMax(tab + (blockIdx.x % kChanShards) * 128 + tid, t);
   }
 }
@@ -2437,7 +2568,8 @@ int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld) {
 // How many slabs each segment is cut into (see "Slab plan" in td_lagcov_plan): at most max_slab
 // samples per slab, the total rounded up to whole rounds of the workgroup slots the stream has.
 static void lag_slab_counts(const td_handle* h, const std::vector<LagSeg>& segs, long long total,
-                            long long per_item_wgs, bool split, std::vector<long long>* out) {
+                            long long per_item_wgs, bool split, std::vector<long long>* out,
+                            long long want_items = 0) {
   long long kMaxSlab = split ? 8192 : 2048;
   if (const char* e = getenv("TD_MAX_SLAB")) kMaxSlab = atoll(e);   // development
   std::vector<long long>& n_slabs = *out;
@@ -2455,6 +2587,8 @@ static void lag_slab_counts(const td_handle* h, const std::vector<LagSeg>& segs,
   long long items_per_round = (split ? cus : 2 * cus) / per_item_wgs;
   if (items_per_round < 1) items_per_round = 1;
   long long target = td_ceil_div(min_items, items_per_round) * items_per_round;
+  // (want_items: the caller's own count, >= the least the slab length allows)
+  if (want_items > 0) target = want_items > min_items ? want_items : min_items;
   if (target > max_items) target = max_items;
   if (target > min_items) {
     // proportional share first, then the remainder to the segments with the longest slabs
@@ -2838,6 +2972,7 @@ namespace {
 VirtImage virt_blank() {
   VirtImage im;
   for (int k = 0; k < 64; ++k) { im.src[k] = -1; im.shift[k] = 0; im.role[k] = 0; }
+  im.min_shift = im.max_shift = im.any_role1 = im.pad = 0;
   return im;
 }
 void virt_put(VirtImage& im, int tile, int col0, int ch0, int w, int shift, int role) {
@@ -2901,8 +3036,12 @@ int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const 
   plan->ok = false;
   plan->c = c; plan->l = l;
   if (h->acc_mode != TD_ACC_F16X2 || l < 1 || l > 64) return TD_OK;
-  const bool narrow = c >= 9 && c <= 32 && l >= 5, wide = c > 64 && c <= 128;
-  if (!narrow && !wide) return TD_OK;
+  // (33 .. 64 channels: the plain kernel keeps whole aligned 64-channel rows -- its tile path has no
+  // masks for them; every other row shape stages faster here)
+  const bool aligned64 = c == 64 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  const bool narrow = c >= 9 && c <= 32 && l >= 5, mid = c > 32 && c <= 64 && l >= 5 && !aligned64;
+  const bool wide = c > 64 && c <= 128;
+  if (!narrow && !mid && !wide) return TD_OK;
   long long total = 0;
   for (const LagSeg& sg : segs) {
     if (sg.a_row0 != sg.b_row0 || sg.a_valid != sg.b_valid) return TD_OK;
@@ -2931,6 +3070,12 @@ int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const 
     virt_groups(&plan->groups, 0, tasks);
     next_slot = E;
     ext = E * (nsa - 1);
+  } else if (mid) {
+    VirtImage im = virt_blank();
+    virt_put(im, 0, 0, 0, 32, 0, 0);
+    virt_put(im, 1, 0, 32, c - 32, 0, 0);
+    plan->images.push_back(im);
+    virt_full_image(plan, 0, 0, 1, virt_up4(l), &next_slot);
   } else {
     const int E = virt_up4(l);
     const int nb = (c + 31) / 32;
@@ -3043,10 +3188,29 @@ int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const 
       if (!none && (im.src[k] % 4 != 0)) vec4 = false;
     }
   plan->vec4 = vec4;
+  for (VirtImage& im : plan->images) {
+    int lo = 0, hi = 0, r1 = 0;
+    for (int k = 0; k < 64; ++k) {
+      if (im.src[k] < 0) continue;
+      lo = im.shift[k] < lo ? im.shift[k] : lo;
+      hi = im.shift[k] > hi ? im.shift[k] : hi;
+      r1 |= im.role[k] != 0;
+    }
+    im.min_shift = (short)lo; im.max_shift = (short)hi; im.any_role1 = (short)r1; im.pad = 0;
+  }
   // slabs: as the 64-channel split kernel plans them (one workgroup per CU)
+  // A workgroup (one per CU) walks a CHAIN of at most four slabs and leaves one partial slab; R chains
+  // of each group fill the chip once.  The slab count is a whole number of rounds of R chains of k <= 4
+  // slabs -- (with 9 groups a count that only fills whole rounds of ITEMS left 35 chains for 28 slots:
+  // a second round a quarter full)
   const int n_groups = (int)plan->groups.size();
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  const long long R = cus / n_groups > 0 ? cus / n_groups : 1;
+  const long long least = td_ceil_div(total, 8192);
+  const long long rounds = td_ceil_div(least, 4 * R);
+  const long long per_chain = td_ceil_div(least, rounds * R);
   std::vector<long long> n_slabs;
-  lag_slab_counts(h, segs, total, n_groups, true, &n_slabs);
+  lag_slab_counts(h, segs, total, n_groups, true, &n_slabs, rounds * R * per_chain);
   plan->works.clear(); plan->vsegs.clear();
   for (size_t f = 0; f < segs.size(); ++f) {
     if (n_slabs[f] == 0) continue;
@@ -3066,15 +3230,10 @@ int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const 
   TD_REQUIRE(h, nwg < (1LL << 31), "lagcov: too many workgroups");
   plan->grid = nwg; plan->n_part = (int)n_work;
   {
-    const int cus = h->cu_count > 0 ? h->cu_count : 256;
-    const long long per_round = (long long)(cus / n_groups) * n_groups;
-    if (per_round > 0 && nwg > per_round) {
-      constexpr long long kMaxItemsPerChain = 4;       // (as td_lagcov_launch)
-      long long chains = per_round / n_groups;
-      const long long min_chains = td_ceil_div(n_work, kMaxItemsPerChain);
-      if (min_chains > chains) chains = min_chains;
-      if (chains < n_work) { plan->grid = chains * n_groups; plan->n_part = (int)chains; }
-    }
+    // chains: whole rounds of R, at most four slabs each (a chain of float32 slab sums stays short,
+    // td_lagcov_launch)
+    long long chains = R * td_ceil_div(td_ceil_div(n_work, 4), R);
+    if (chains < n_work) { plan->grid = chains * n_groups; plan->n_part = (int)chains; }
   }
   plan->scratch_bytes = td_round_up((size_t)plan->n_part * plan->slab_elems * sizeof(float), 256);
   plan->ok = true;
@@ -3178,12 +3337,17 @@ __global__ __launch_bounds__(256) void virt_reduce_kernel(LagReduceJob jb) {
 }  // namespace
 
 int td_chan_max(td_handle* h, const float* x, int64_t ldx, int c, long long row0, long long row1, unsigned* tab) {
-  const long long blocks = td_ceil_div(row1 - row0, 16 * 8);       // >= 8 rows per thread
+  TD_REQUIRE(h, c >= 1 && c <= 128, "td_chan_max: 1 .. 128 channels");
   const bool al = (ldx % 4 == 0) && (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  for (int c0 = 0; c0 < c; c0 += 64)
+  if (c <= 64) {
+    const long long blocks = td_ceil_div(row1 - row0, 16 * 8);       // >= 8 rows per thread
     hipLaunchKernelGGL(chan_max_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)),
-                       dim3(256), 0, h->stream, x + c0, (long long)ldx, c - c0 < 64 ? c - c0 : 64, row0, row1,
-                       tab + c0, al ? 1 : 0);
+                       dim3(256), 0, h->stream, x, (long long)ldx, c, row0, row1, tab, al ? 1 : 0);
+  } else {
+    const long long blocks = td_ceil_div(row1 - row0, (al ? 8 : 2) * 8);
+    hipLaunchKernelGGL(chan_max_wide_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)),
+                       dim3(256), 0, h->stream, x, (long long)ldx, c, row0, row1, tab, al ? 1 : 0);
+  }
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
@@ -3294,7 +3458,9 @@ int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, con
     if (d > 4 || e_min > 0 || e_min + e_count - 1 < 0) return TD_OK;
     // with targets at most 32 lags; without (column sums only: the lag count plays no part) the
     // wave kernel streams a strip from row u_begin + e_min on and covers it when e_min >= -31
-    if (d > 0 ? e_count > 32 : -e_min > 31) return TD_OK;
+    // (more lags with targets: windows of 32, the kernel's p.n_groups -- window 0, which holds lag 0
+    // and starts at most 31 lags back, leaves the column sums)
+    if (d > 0 ? (e_count > 32 * 8 || (e_count > 32 && e_min < -31)) : -e_min > 31) return TD_OK;
   }
   plan->handled = true;
   const int n_segs = (int)segs.size();
@@ -3435,7 +3601,9 @@ int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const fl
 }
 
 int td_lagcov_column(td_handle* h, const float* y, int64_t ldy, const float* b, int64_t ldb, int cb,
-                     const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev) {
+                     const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev, int rows_dst) {
+  // (rows_dst: rows of cb numbers per lag of g_dev when the column is one of several targets)
+  if (rows_dst <= 0) rows_dst = 1;
   if (segs.empty()) return TD_OK;
   for (int k0 = 0; k0 < e_count; k0 += 32 * 8) {       // (one launch covers 8 windows = 256 lags)
     const int cnt = e_count - k0 < 32 * 8 ? e_count - k0 : 32 * 8;
@@ -3447,11 +3615,11 @@ int td_lagcov_column(td_handle* h, const float* y, int64_t ldy, const float* b, 
     TD_TRY(td_scratch(h, plan.scratch_bytes, &scratch));
     TargetsOutputs out;
     out.maxtab = nullptr;
-    double* dst = g_dev + (size_t)k0 * cb;
+    double* dst = g_dev + (size_t)k0 * cb * rows_dst;
     TD_TRY(td_lagcov_targets_launch(h, &plan, scratch, dst, true, &out));
     const LagReduceJob& job = out.jobs[0];
     launch_lagcov_reduce<double>(h, reinterpret_cast<const double*>(job.partial), job.n_work, job.e_pad,
-                                 job.ca_pad, job.cb_pad, cnt, 1, cb, dst, true, 1);
+                                 job.ca_pad, job.cb_pad, cnt, 1, cb, dst, true, rows_dst);
   }
   TD_HIP(h, hipGetLastError());
   return TD_OK;

@@ -1507,7 +1507,30 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
         TD_TRY(td_colsum(h, y_dev, ldy, s->d, syx, s->g + s->off_sy, true));
       }
     }
-    if (!wide_done)
+    if (!wide_done && s->d >= 1 && s->d <= 4 && s->l1 > 32) {
+      // 33+ lags (the codelab's 37): the window of 32 lags around lag 0 on the matrix-core targets
+      // kernel (with the column sums the bias row needs), the lags outside it column by column in
+      // windows of 32 (td_lagcov_column).  (Before: the LDS-tiled VALU kernel on [y | 1], 0.6 ms of
+      // the codelab shape's 2.7.)
+      const int e_min = -s->pre1;
+      const int e_lo = e_min < -31 ? -31 : e_min;
+      const int here = e_min + s->l1 - e_lo < 256 ? e_min + s->l1 - e_lo : 256;   // windows of one launch
+      const size_t lag_stride = (size_t)(s->d + 1) * s->c1;
+      TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, e_lo, here,
+                               s->g + s->off_gxo + (size_t)(e_lo - e_min) * lag_stride, s->g + s->off_sy,
+                               colsum_seg, &handled));
+      TD_REQUIRE(h, handled, "accumulate: the targets kernel refused the windows from lag 0 on");
+      const int before = e_lo - e_min, after = e_min + s->l1 - (e_lo + here);
+      for (int i = 0; i < s->d; ++i) {
+        if (before > 0)
+          TD_TRY(td_lagcov_column(h, y_dev + i, ldy, x_dev, ldx, s->c1, syx, e_min, before,
+                                  s->g + s->off_gxo + (size_t)i * s->c1, s->d + 1));
+        if (after > 0)
+          TD_TRY(td_lagcov_column(h, y_dev + i, ldy, x_dev, ldx, s->c1, syx, e_lo + here, after,
+                                  s->g + s->off_gxo + (size_t)(before + here) * lag_stride + (size_t)i * s->c1,
+                                  s->d + 1));
+      }
+    } else if (!wide_done)
       TD_TRY(td_lagcov_targets(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1,
                                s->g + s->off_gxo, s->d ? s->g + s->off_sy : nullptr, colsum_seg,
                                &handled));

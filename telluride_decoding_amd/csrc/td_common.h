@@ -317,6 +317,8 @@ struct VirtImage {
   short src[64];     // source channel, -1: a zero channel
   short shift[64];   // rows (any sign)
   signed char role[64];
+  short min_shift, max_shift;   // over the channels that exist (set by the planner)
+  short any_role1, pad;
 };
 struct VirtTask {
   signed char mt, nt;    // A / B tile of the image (0 or 1)
@@ -510,7 +512,7 @@ int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld);
 // (zero outside the rows [u_begin, u_end) of a segment) against a view of any width, any lag
 // range: the matrix-core targets kernel in windows of 32 lags.
 int td_lagcov_column(td_handle* h, const float* y, int64_t ldy, const float* b, int64_t ldb, int cb,
-                     const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev);
+                     const std::vector<LagSeg>& segs, int e_min, int e_count, double* g_dev, int rows_dst = 1);
 int td_lagcov_targets(td_handle* h, const float* y, int64_t ldy, int d, const float* b, int64_t ldb,
                       int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,
                       double* g_dev, double* sy_dev, double* colsum_seg_dev, bool* handled, int rows_dst = 0);
