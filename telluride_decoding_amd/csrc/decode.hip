@@ -1805,6 +1805,10 @@ struct FirStreamParams {
   long long ldout;
   const FsStrip* strips; // [n_strips]: recording, first output and length of every strip
   long long* dbg;        // development (-DTD_FS_TIMING): [strip][2] start / end of every wave, 10 ns ticks
+  // a slice of a wider / longer filter: this launch multiplies the channels [ch0, ch0 + c) of rows of
+  // c_all channels by the lags [lag0, lag0 + nl) of a filter of c_all channels, and (accum) adds to out
+  int ch0, c_all, lag0, accum;
+  int cn;                // kNar: 1 .. 16 more channels [ch0 + 64, ch0 + 64 + cn) ride along (c = 64 then)
 };
 
 // the 8 DMA instructions of one tile: LDS slot at byte address lds (wave-uniform), lane offsets v[m]
@@ -1839,6 +1843,47 @@ __device__ __forceinline__ void fs_issue_tile(fs_i32x4 rs, unsigned lds, const u
       : "memory", "scc");
 }
 
+// The same tile by 4-byte DMA, one 256-byte row per instruction (32 of them): rows that are not whole
+// 16-byte granules (63 channels, a row pitch that is not a multiple of 4 floats) -- every lane is ONE
+// channel, so the channels past the row's end are exactly the lanes sent out of range.  v[k]: lane
+// offsets of the rows with r & 15 == k (the XOR swizzle has 16 patterns); rows r >= 16 add `half` bytes.
+// kNar: the <= 16 channels past the first 64 of a 65..80-channel row, 32 rows x 16 channels per tile in a
+// 2 KB slot of their own: eight 4-byte instructions, lane L of instruction m = row 4m + (L >> 4), LDS
+// dword 64m + L = position (L >> 2) & 3 of the row, which holds channel granule position ^ ((row >> 2) & 3)
+// (so that the operand reads of 16 consecutive rows hit 64 banks).
+__device__ __forceinline__ void fs_issue_narrow(fs_i32x4 rs, unsigned lds, const unsigned (&v)[8]) {
+  unsigned keep;
+#define TD_FS_DW(N) "buffer_load_dword %[v" #N "], %[rs], 0 offen" TD_FS_AUX " lds\n\ts_add_u32 m0, m0, 0x100\n\ts_nop 0\n\t"
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+      TD_FS_DW(0) TD_FS_DW(1) TD_FS_DW(2) TD_FS_DW(3) TD_FS_DW(4) TD_FS_DW(5) TD_FS_DW(6) TD_FS_DW(7)
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [lds] "s"(lds), [rs] "s"(rs), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
+        [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
+      : "memory", "scc");
+#undef TD_FS_DW
+}
+constexpr int kFsNarFloats = 32 * 16;
+
+__device__ __forceinline__ void fs_issue_half_dw(fs_i32x4 rs, unsigned lds, const unsigned (&v)[16]) {
+  unsigned keep;
+#define TD_FS_DW(N) "buffer_load_dword %[v" #N "], %[rs], 0 offen" TD_FS_AUX " lds\n\ts_add_u32 m0, m0, 0x100\n\ts_nop 0\n\t"
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+      TD_FS_DW(0) TD_FS_DW(1) TD_FS_DW(2) TD_FS_DW(3) TD_FS_DW(4) TD_FS_DW(5) TD_FS_DW(6) TD_FS_DW(7)
+      TD_FS_DW(8) TD_FS_DW(9) TD_FS_DW(10) TD_FS_DW(11) TD_FS_DW(12) TD_FS_DW(13) TD_FS_DW(14) TD_FS_DW(15)
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [lds] "s"(lds), [rs] "s"(rs), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]),
+        [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]), [v8] "v"(v[8]), [v9] "v"(v[9]),
+        [v10] "v"(v[10]), [v11] "v"(v[11]), [v12] "v"(v[12]), [v13] "v"(v[13]), [v14] "v"(v[14]), [v15] "v"(v[15])
+      : "memory", "scc");
+#undef TD_FS_DW
+}
+
 // (x0, x1) times the power-of-two scale s -> packed float16 pairs of the two pieces (x s = h + l; the
 // residual x s - h is exact in float32).  Compiles to 2 v_mul + v_cvt_pk_f16_f32 + 2 v_fma_mix_f32 +
 // v_cvt_pk_f16_f32; the fused v_fma_mixlo/hi_f16 forms (4 instructions) measure SLOWER: 4.6 ns each per
@@ -1856,8 +1901,13 @@ __device__ __forceinline__ float fs_shr1(float v) {      // lane i <- lane i - 1
   return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x138, 0xf, 0xf, true));
 }
 
-template <bool kF16, int kSlots, int kOcc>   // LDS slots (tiles) per wave; workgroups per CU
+// kDw: 4-byte DMA, one row per instruction (fs_issue_half_dw): any channel count <= 64, any row pitch.
+// kNar (with kF16): 65 .. 80 channels in ONE pass -- the channels past 64 as a fifth k-step from a
+// narrow tile of their own (fs_issue_narrow): a row's 276 bytes are fetched once, the diagonal sums and
+// the output pass are shared (69 channels: 98 us as two slices that each stream every row -> one pass).
+template <bool kF16, int kSlots, int kOcc, bool kDw = false, bool kNar = false>   // LDS slots (tiles) per wave; workgroups per CU
 __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamParams p) {
+  static_assert(!kNar || kF16, "the narrow fifth k-step exists in the float16 form only");
   extern __shared__ __attribute__((aligned(16))) float fs_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1877,42 +1927,91 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
 
   float wreg[32];
   td_u32x4 wh[4], wl[4];
+  td_u32x4 wnh = {0u, 0u, 0u, 0u}, wnl = {0u, 0u, 0u, 0u};       // kNar: the fifth k-step's weights
   float w_unscale = 1.f;
-  const float bias = p.bias ? p.bias[p.q0] : 0.f;
+  const float bias = p.bias && !p.accum ? p.bias[p.q0] : 0.f;
 
   // buffer descriptor of the recording: rows outside [0, nrows) read as zeros
-  const unsigned long long base = reinterpret_cast<unsigned long long>(p.x + st.row0 * p.ldx);
+  const unsigned long long base = reinterpret_cast<unsigned long long>(p.x + st.row0 * p.ldx + p.ch0);
   fs_i32x4 rs;
   rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
   rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
-  rs.z = __builtin_amdgcn_readfirstlane((int)(unsigned)(st.nrows * ldb));
+  // (a slice that starts at channel ch0: the descriptor ends with the last row's last channel)
+  rs.z = __builtin_amdgcn_readfirstlane((int)(unsigned)(st.nrows * ldb - 4 * p.ch0));
   rs.w = 0x00020000;
   // lane part of the source offsets: row 4m + (lane >> 4), swizzled granule
-  unsigned lpart[8];
+  unsigned lpart[kDw ? 16 : 8];
+  if (kDw) {
+    // lane L of row r's instruction: LDS dword L of the row = granule L >> 2 of the swizzled image =
+    // channel 4 ((L >> 2) ^ (r & 15)) + (L & 3) -- 16 patterns; channels past the slice out of range
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    const int r = 4 * m + (lane >> 4);
-    const int gran = (lane & 15) ^ (r & 15);
-    // (fewer than 64 channels: the granules past a row's end are asked for far outside the descriptor's
-    // range -- 2^31 and up, whatever the tile's base adds -- and arrive as zeros)
-    lpart[m] = 4 * gran < p.c ? (unsigned)(r * ldb + 16 * gran) : 0x80000000u;
+    for (int k = 0; k < 16; ++k) {
+      const int ch = 4 * ((lane >> 2) ^ k) + (lane & 3);
+      lpart[k] = ch < p.c ? (unsigned)(k * ldb + 4 * ch) : 0x80000000u;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int r = 4 * m + (lane >> 4);
+      const int gran = (lane & 15) ^ (r & 15);
+      // (fewer than 64 channels: the granules past a row's end are asked for far outside the descriptor's
+      // range -- 2^31 and up, whatever the tile's base adds -- and arrive as zeros)
+      lpart[m] = 4 * gran < p.c ? (unsigned)(r * ldb + 16 * gran) : 0x80000000u;
+    }
   }
   float* slots = fs_lds + wave * kSlots * kFsSlotFloats;
   const unsigned slot_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)slots);
+  // kNar: the narrow tiles behind all the waves' wide ones
+  float* nslots = fs_lds + (kFsThreads / 64) * kSlots * kFsSlotFloats + wave * kSlots * kFsNarFloats;
+  const unsigned nslot_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)nslots);
+  unsigned lpn = 0u;
+  if (kNar) {
+    // lane L: row (L >> 4) of an instruction's four, channel 64 + 4 (pos ^ ((row >> 2) & 3)) + (L & 3);
+    // (row >> 2) & 3 = m & 3 for row 4m + (L >> 4): the instruction's number, added at issue
+    lpn = (unsigned)((lane >> 4) * ldb + 256 + 4 * (lane & 3));
+  }
   const int row_b = (int)(ts - p.pre);                          // first input row of the strip
   const int n_tiles = 2 * ((st_len + nl - 1 + 63) / 64);        // whole pairs
   auto issue = [&](int t) {
     const unsigned tb = (unsigned)((row_b + 32 * t) * ldb);     // (negative rows wrap: out of range)
-    unsigned v[8];
+    if constexpr (kDw) {
+      const unsigned slot = slot_addr + (unsigned)(t & (kSlots - 1)) * (kFsSlotFloats * 4);
+      unsigned v[16];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = lpart[m] + tb;
-    fs_issue_tile(rs, slot_addr + (unsigned)(t & (kSlots - 1)) * (kFsSlotFloats * 4), v);
+      for (int k = 0; k < 16; ++k) v[k] = lpart[k] + tb;
+      fs_issue_half_dw(rs, slot, v);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] += 16u * (unsigned)ldb;
+      fs_issue_half_dw(rs, slot + 0x1000u, v);
+    } else {
+      unsigned v[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) v[m] = lpart[m] + tb;
+      fs_issue_tile(rs, slot_addr + (unsigned)(t & (kSlots - 1)) * (kFsSlotFloats * 4), v);
+    }
+    if constexpr (kNar) {
+      unsigned v[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int g = ((lane >> 2) & 3) ^ (m & 3);                 // channel granule of this lane's position
+        v[m] = 4 * g + (lane & 3) < p.cn ? lpn + 16u * g + tb + (unsigned)(4 * m * ldb) : 0x80000000u;
+      }
+      fs_issue_narrow(rs, nslot_addr + (unsigned)(t & (kSlots - 1)) * (kFsNarFloats * 4), v);
+    }
   };
   // the rows of tile t: wait for them, read them in operand order, refill the slot
+  float4 xn[2];                                        // kNar: the lane's 8 narrow channels of its row
   auto fetch = [&](int t, float4 (&xb)[8]) {
     // (tiles t+1 .. t+kSlots-1 may still be on their way: 8 DMA instructions each)
     const int ahead = n_tiles - 1 - t < kSlots - 1 ? n_tiles - 1 - t : kSlots - 1;
     if (FS_NODMA || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (kDw) {
+      // (32 instructions per tile, 40 with the narrow tile)
+      if (ahead == 1 && kNar) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    }
+    else if (ahead == 1 && kNar) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -1920,6 +2019,12 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       xb[k] = *reinterpret_cast<const float4*>(xt + 4 * ((8 * lh + k) ^ (li & 15)));
+    if constexpr (kNar) {
+      const float* nt = nslots + (t & (kSlots - 1)) * kFsNarFloats + li * 16;
+      const int sw = (li >> 2) & 3;
+      xn[0] = *reinterpret_cast<const float4*>(nt + 4 * ((2 * lh) ^ sw));
+      xn[1] = *reinterpret_cast<const float4*>(nt + 4 * ((2 * lh + 1) ^ sw));
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   auto refill = [&](int t) {
@@ -1933,6 +2038,13 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
     for (int k = 0; k < 8; ++k) {
       mx = fmaxf(fmaxf(fabsf(xb[k].x), fabsf(xb[k].y)), mx);       // (v_max3_f32 with |.| modifiers)
       mx = fmaxf(fmaxf(fabsf(xb[k].z), fabsf(xb[k].w)), mx);
+    }
+    if constexpr (kNar) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        mx = fmaxf(fmaxf(fabsf(xn[k].x), fabsf(xn[k].y)), mx);
+        mx = fmaxf(fmaxf(fabsf(xn[k].z), fabsf(xn[k].w)), mx);
+      }
     }
     const auto ex = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
     mx = fmaxf(__uint_as_float(ex[0]), __uint_as_float(ex[1]));
@@ -1982,6 +2094,17 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
         a = td_mfma_f16(wh[j], al, a);
         a = td_mfma_f16(wh[j], ah, a);
       }
+      if constexpr (kNar) {
+        td_u32x4 ah, al;
+        unsigned hh, ll;
+        fs_split2(xn[0].x, xn[0].y, sa, hh, ll); ah[0] = hh; al[0] = ll;
+        fs_split2(xn[0].z, xn[0].w, sa, hh, ll); ah[1] = hh; al[1] = ll;
+        fs_split2(xn[1].x, xn[1].y, sa, hh, ll); ah[2] = hh; al[2] = ll;
+        fs_split2(xn[1].z, xn[1].w, sa, hh, ll); ah[3] = hh; al[3] = ll;
+        a = td_mfma_f16(wnl, ah, a);
+        a = td_mfma_f16(wnh, al, a);
+        a = td_mfma_f16(wnh, ah, a);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) a[r] *= ua;
       return;
@@ -1993,7 +2116,13 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
   float* orow = p.out + (st.out0 + ts) * p.ldout + p.q0;
   auto emit = [&](int pair, float v) {
     const int o = 64 * pair + lane;
-    if (o < st_len) orow[(long long)o * p.ldout] = v + bias;
+    if (o < st_len) {
+      float* dst = orow + (long long)o * p.ldout;
+      // (a later slice adds with a fire-and-forget atomic: a load here would make the wave wait for
+      // every DMA in flight; one lane per output and launch, launches in stream order: deterministic)
+      if (p.accum) __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *dst = v + bias;
+    }
   };
 
 #pragma unroll
@@ -2005,7 +2134,8 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
     const int lag = 16 * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3);
 #pragma unroll
     for (int i = 0; i < 32; ++i)
-      wreg[i] = lag < nl && 32 * lh + i < p.c ? p.w[((size_t)lag * p.c + 32 * lh + i) * p.d + p.q0] : 0.f;
+      wreg[i] = lag < nl && 32 * lh + i < p.c
+                    ? p.w[((size_t)(p.lag0 + lag) * p.c_all + p.ch0 + 32 * lh + i) * p.d + p.q0] : 0.f;
   }
   // kF16: the weights as two float16 pieces under ONE power-of-two scale (largest magnitude in
   // [2^13, 2^14)): k-step j multiplies channels 32 g + 8 j .. + 7
@@ -2013,6 +2143,17 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
     float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) mx = fmaxf(mx, fabsf(wreg[i]));
+    float wn[8];
+    if (kNar) {
+      // lane (lag row li, half lh): W[lag][ch0 + 64 + 8 lh + i]
+      const int lag = 16 * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        wn[i] = lag < nl && 8 * lh + i < p.cn
+                    ? p.w[((size_t)(p.lag0 + lag) * p.c_all + p.ch0 + 64 + 8 * lh + i) * p.d + p.q0] : 0.f;
+        mx = fmaxf(mx, fabsf(wn[i]));
+      }
+    }
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft, 64));
     unsigned e = __float_as_uint(mx) >> 23;
@@ -2028,6 +2169,15 @@ __global__ __launch_bounds__(kFsThreads, kOcc) void fir_stream_kernel(FirStreamP
         wh[j][q] = hh;
         wl[j][q] = ll;
       }
+    if (kNar) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned hh, ll;
+        td_split2_f16(wn[2 * q] * ws, wn[2 * q + 1] * ws, hh, ll);
+        wnh[q] = hh;
+        wnl[q] = ll;
+      }
+    }
   }
   float low_prev = 0.f;
   if (TD_FS_ABL == 5) { emit(0, wreg[0] + __uint_as_float(wh[0][0])); return; }
@@ -2386,9 +2536,12 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     return TD_OK;
   }
   {
-    // one output, 4..64 channels in whole 16-byte granules, <= 32 lags, every recording below 2 GB: the
-    // DMA-streamed kernel
-    bool stream_ok = !w_file_stride && d == 1 && nl <= 32 && c >= 4 && c <= 64 && vec4 && ldx < (1 << 20);
+    // one output, up to 128 channels and 64 lags, every recording below 2 GB: the DMA-streamed kernel,
+    // in slices of <= 64 channels x <= 32 lags (the first writes, the others add); rows of whole aligned
+    // 16-byte granules by 16-byte DMA, any other row shape by 4-byte DMA (a row per instruction).
+    // (ldx <= 8192: the out-of-range marks of absent granules / rows rely on a tile's offsets staying
+    // far below 2^31)
+    bool stream_ok = !w_file_stride && d == 1 && nl <= 64 && c >= 1 && c <= 128 && ldx <= 8192;
     for (int f = 0; f < num_files && stream_ok; ++f)
       stream_ok = (offs[f + 1] - offs[f]) * ldx * 4 < (int64_t)0x7fc00000;
 #ifdef TD_DEV_SWITCHES
@@ -2435,6 +2588,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       fp.n_files = num_files; fp.n_strips = n_strips; fp.strip = 0;
       fp.c = c; fp.pre = pre; fp.post = post; fp.w = w; fp.bias = bias; fp.d = d; fp.q0 = 0;
       fp.out = out; fp.ldout = ldout;
+      fp.ch0 = 0; fp.c_all = c; fp.lag0 = 0; fp.accum = 0;
       fp.dbg = nullptr;
 #ifdef TD_FS_TIMING
       static long long* dbg_dev = nullptr;
@@ -2472,20 +2626,37 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
       }
 #endif
       constexpr size_t kLds = sizeof(float) * (kFsThreads / 64) * kFsSlots * kFsSlotFloats;
+      constexpr size_t kLdsNar = kLds + sizeof(float) * (kFsThreads / 64) * kFsSlots * kFsNarFloats;
       if (!h->lds_opt_fir_stream) {
-        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_stream_kernel<true, kFsSlots, kFsOcc>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_stream_kernel<false, kFsSlots, kFsOcc>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+#define TD_FS_OPT(F, D, N)                                                                                \
+        TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_stream_kernel<F, kFsSlots, kFsOcc, D, N>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((N) ? kLdsNar : kLds)))
+        TD_FS_OPT(true, false, false); TD_FS_OPT(false, false, false); TD_FS_OPT(true, true, false);
+        TD_FS_OPT(false, true, false); TD_FS_OPT(true, false, true); TD_FS_OPT(true, true, true);
+#undef TD_FS_OPT
         h->lds_opt_fir_stream = true;
       }
       const dim3 grid((unsigned)td_ceil_div(n_strips, kFsThreads / 64)), block(kFsThreads);
       // (TD_ACC_F32: exact float32 products on the float32 matrix instruction; otherwise each as three
       // float16 products -- the rule of the accumulate)
-      if (h->acc_mode == TD_ACC_F32)
-        hipLaunchKernelGGL((fir_stream_kernel<false, kFsSlots, kFsOcc>), grid, block, kLds, h->stream, fp);
-      else
-        hipLaunchKernelGGL((fir_stream_kernel<true, kFsSlots, kFsOcc>), grid, block, kLds, h->stream, fp);
+      const bool f32 = h->acc_mode == TD_ACC_F32;
+      // (65 .. 80 channels, float16 form: the channels past 64 ride along as a fifth k-step)
+      const bool nar = !f32 && c > 64 && c <= 80;
+      for (int lag0 = 0; lag0 < nl; lag0 += 32)
+        for (int ch0 = 0; ch0 < c; ch0 += 64) {
+          fp.lag0 = lag0; fp.ch0 = ch0;
+          fp.c = c - ch0 < 64 ? c - ch0 : 64;
+          fp.cn = nar ? c - 64 : 0;
+          const int nls = nl - lag0 < 32 ? nl - lag0 : 32;
+          fp.pre = pre - lag0; fp.post = nls - 1 - fp.pre;
+          fp.accum = (lag0 || ch0) ? 1 : 0;
+          const bool dw = !((ldx % 4 == 0) && (fp.c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x + ch0) & 15) == 0));
+#define TD_FS_GO(F, D, N) hipLaunchKernelGGL((fir_stream_kernel<F, kFsSlots, kFsOcc, D, N>), grid, block, (N) ? kLdsNar : kLds, h->stream, fp)
+          if (nar) { if (dw) TD_FS_GO(true, true, true); else TD_FS_GO(true, false, true); break; }
+          if (f32) { if (dw) TD_FS_GO(false, true, false); else TD_FS_GO(false, false, false); }
+          else     { if (dw) TD_FS_GO(true, true, false); else TD_FS_GO(true, false, false); }
+#undef TD_FS_GO
+        }
       TD_HIP(h, hipGetLastError());
       return TD_OK;
     }
