@@ -517,6 +517,243 @@ def loso_leg(eeg, env):
   }
 
 
+# ---- progress marks + watchdog ------------------------------------------------------------------
+# Every rank writes what it is about to do (the next collective, the next leg) into its own log
+# file when the launcher gave it a directory (TD_BENCH_LOG_DIR), and a watchdog thread of the rank
+# ends the process (exit code 124, the last mark on stderr) when no mark has been written for
+# --watchdog-seconds: a collective that never returns -- the first contact of this code with an
+# 8-GPU node -- becomes a diagnosis instead of a hang.  (os._exit from the rank itself; nothing is
+# re-executed.)
+_PROGRESS = {'t': time.time(), 'msg': 'start', 'rank': 0, 'file': None}
+
+
+def progress(msg):
+  _PROGRESS['t'] = time.time()
+  _PROGRESS['msg'] = msg
+  f = _PROGRESS['file']
+  if f is not None:
+    f.write('%.3f rank %d: %s\n' % (_PROGRESS['t'], _PROGRESS['rank'], msg))
+    f.flush()
+
+
+def start_watchdog(rank, seconds):
+  import threading
+  _PROGRESS['rank'] = rank
+  log_dir = os.environ.get('TD_BENCH_LOG_DIR')
+  if log_dir:
+    _PROGRESS['file'] = open(os.path.join(log_dir, 'rank%d.log' % rank), 'a')
+  progress('watchdog armed (%d s)' % seconds)
+  if seconds <= 0:
+    return
+
+  def watch():
+    while True:
+      time.sleep(2.0)
+      idle = time.time() - _PROGRESS['t']
+      if idle > seconds:
+        sys.stderr.write('bench.py: rank %d made no progress for %.0f s; last mark: %s\n'
+                         % (rank, idle, _PROGRESS['msg']))
+        sys.stderr.flush()
+        os._exit(124)
+  threading.Thread(target=watch, daemon=True).start()
+
+
+def shapes_leg(h, device):
+  """The accumulate call (targets + lag kernel + finalize) at the shapes the reference documents and
+  the ones around them -- 63 ch (Telluride4, notebook :613), 69 ch x 37 lags (doc/DecodingCodelab.md:709),
+  32 x 32, 16 x 4, 128 x 32 -- at 1e6 samples against the headline's 64 x 32 in the same process, and
+  td_decode_fused at the C4 shape with 63 and 69 channels.  hipEvents on the launching stream, median of
+  three loops.  (VERDICT r4 #1: the fast paths existed for one shape family.)"""
+  import torch
+  n = 1000000
+  offs = np.array([0, n], np.int64)
+  gen = torch.Generator(device='cuda')
+  gen.manual_seed(5)
+
+  def median3(fn, reps):
+    for _ in range(3):
+      fn()
+    ts = []
+    for _ in range(3):
+      h.synchronize()
+      h.timer_start()
+      for _ in range(reps):
+        fn()
+      ts.append(h.timer_stop() / reps)
+    return float(np.median(ts)), [float(t) for t in ts]
+
+  def acc_ms(c, lags, reps=20):
+    x = torch.randn(n, c, device='cuda', generator=gen)
+    y = torch.randn(n, 1, device='cuda', generator=gen)
+    st = device.LagStats(c, 0, lags - 1, d=1, handle=h)
+
+    def call():
+      st.reset()
+      st.accumulate(x, None, y, offs)
+    ms, loops = median3(call, reps)
+    del st, x, y
+    return ms, loops
+
+  base, base_loops = acc_ms(64, 32)
+  out = {'what': ('accumulate call at 1e6 samples, one recording, one target; `ratio` = time / (the 64 x 32 time of '
+                  'this process x C^2 L / (64^2 32)) -- 1.0 = flops-proportional to the headline shape'),
+         '64x32': {'ms': base, 'loops_ms': base_loops}}
+  for c, lags in ((63, 32), (69, 37), (32, 32), (16, 4), (128, 32), (96, 32), (16, 32), (21, 32)):
+    ms, loops = acc_ms(c, lags, 20 if c * lags > 600 else 50)
+    prop = base * (c * c * lags) / (64.0 * 64 * 32)
+    out['%dx%d' % (c, lags)] = {
+        'ms': ms, 'loops_ms': loops, 'flops_proportional_ms': prop, 'ratio': ms / prop,
+        'algorithmic_tflops': 2.0 * c * c * lags * n / (ms * 1e-3) / 1e12,
+        'hbm_frac': n * 4.0 * (c + 1) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+  # the decode at the reference's channel counts
+  n_trials, frames = 200, 6000
+  doffs = np.arange(n_trials + 1, dtype=np.int64) * frames
+  rows = n_trials * frames
+  dec = {}
+  for c in (63, 69):
+    sets = [(torch.randn(rows, c, device='cuda', generator=gen), torch.randn(rows, 2, device='cuda', generator=gen))
+            for _ in range(3)]
+    w = torch.randn(c * 32, 1, device='cuda', generator=gen) * 0.01
+    b = torch.zeros(1, device='cuda')
+    corr = [0.0, 0.0, 1.0, 0.0, 0.0, 1.0]
+    state = {'i': 0}
+
+    def call():
+      xs, es = sets[state['i'] % 3]
+      state['i'] += 1
+      device.decode_fused(xs, es, doffs, w, b, 0, 31, 1000, 100, corr, handle=h)
+    ms, loops = median3(call, 100)
+    gb = rows * 4.0 * (c + 2) / (ms * 1e-3) / 1e9
+    dec['%dch' % c] = {'ms': ms, 'loops_ms': loops, 'windows_per_s': 10200 / ms * 1e3,
+                       'hbm_gbps_algorithmic': gb, 'hbm_frac': gb / PEAK_HBM_GBPS}
+    del sets
+  out['decode_c4_shape'] = dict(dec, what='td_decode_fused, 200 trials x 6000 frames, W = 1000 / hop 100, 32 lags, inputs '
+                                           'rotated over three copies; algorithmic bytes = frames x 4 (C + 2)')
+  return out
+
+
+def loso_multi_leg(rank, world, dist, h, barrier):
+  """Config C5 as BASELINE.json defines it: the 32 subjects dealt to the N ranks (4 per GPU at N = 8),
+  ONE all-reduce of the per-subject packed statistics, the 32 folds dealt round-robin, the 32 x 20
+  held-out scores gathered (regression.jackknife_over_regularizations(rank, world_size);
+  regression.py:326-420).  Every rank holds the same host data (seed 0); the recordings a rank
+  touches stay on its device between sweeps.  Rank 0 also runs the one-GPU sweep and checks the
+  gathered table against it."""
+  import torch
+  from telluride_decoding_amd import brain_data, distributed, regression
+  progress('C5 leg: synthetic data')
+  eeg, env, _ = make_workload(0)
+  n_subj, n = 32, 31250
+  att = np.zeros((n, 1), np.float32)
+  files = [(eeg[i * n:(i + 1) * n], env[i * n:(i + 1) * n], env[i * n:(i + 1) * n], att)
+           for i in range(n_subj)]
+  ds = brain_data.Dataset(files, 1000, pre_context=PRE, post_context=POST)
+  lams = list(np.logspace(-6, 3, 20))
+  times = []
+  res = None
+  for it in range(4):
+    progress('C5 leg: sweep %d (all-reduce of the statistics table, gather of the scores)' % it)
+    gc.collect()
+    barrier()
+    t0 = time.perf_counter()
+    res = regression.jackknife_over_regularizations(ds, lams, rank=rank, world_size=world)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    times.append(float(t.item()))
+  route = dict(distributed.LAST_COLLECTIVE)
+  solver = dict(regression.LAST_SWEEP)
+  out = None
+  if rank == 0:
+    progress('C5 leg: the one-GPU sweep of rank 0 for the comparison')
+    one = regression.jackknife_over_regularizations(ds, lams)
+    diff = float(np.max(np.abs(one['all_runs'] - res['all_runs'])))
+    top = max((v[0], k) for k, v in res.items() if k != 'all_runs')
+    out = {
+        'workload': 'C5: LOSO x 20 lambdas, 32 subjects x 31 250 samples x 64 ch, 32 lags: subjects dealt to %d ranks, '
+                    'one all-reduce of the packed per-subject statistics, folds round-robin, scores gathered' % world,
+        'ranks': world, 'seconds': min(times[1:]), 'seconds_first_sweep': times[0], 'sweeps_s': times,
+        'fits': n_subj * len(lams), 'fits_per_s': n_subj * len(lams) / min(times[1:]),
+        'collective': route, 'solver': solver,
+        'best_lambda': float(top[1]), 'best_mean_r': float(top[0]),
+        'max_abs_diff_vs_one_gpu': diff, 'matches_one_gpu_to_2e-6': bool(diff <= 2e-6),
+        'timing': 'host clock between barriers, MAX over ranks; the recordings a rank touches resident in its HBM '
+                  '(sweeps after the first)',
+    }
+  barrier()
+  return out
+
+
+def decode_multi_leg(rank, world, dist, h, device, barrier, iters=100):
+  """Config C4 over N ranks: pure replicas -- the 200 trials dealt in contiguous blocks (25 per GPU at
+  N = 8; infer.py:376-407 decodes trial by trial), no data-path collective, the 10 200 decisions gathered.
+  Every rank builds the same trials (seed 4) and the same decoder (fit + global correlation statistics on all
+  200 trials, untimed); the timed region is `iters` td_decode_fused calls on the rank's own trials between
+  barriers, MAX over ranks.  Rank 0 checks the gathered decisions against its own decode of all trials:
+  bit for bit."""
+  import torch
+  from telluride_decoding_amd import distributed, synth
+  progress('C4 leg: synthetic trials')
+  n_trials, frames, width, hop = 200, 6000, 1000, 100
+  trials = synth.make_trials(4, n_trials, frames, C, switch_half=True)
+  eeg = np.concatenate([t[0] for t in trials])
+  env = np.concatenate([t[1] for t in trials])
+  att = np.concatenate([t[2] for t in trials])
+  offs = np.arange(n_trials + 1, dtype=np.int64) * frames
+  attended = np.where(att > 0.5, env[:, 1:2], env[:, 0:1]).astype(np.float32)
+  xd, envd = h.to_device(eeg), h.to_device(env)
+  st = device.LagStats(C, PRE, POST, d=1, handle=h)
+  st.accumulate(xd, None, h.to_device(attended), offs)
+  w, b = st.ridge_solve([LAMBDA])
+  w, b = w[0].contiguous(), b[0].contiguous()
+  pred = device.predict_fir(xd, offs, w, b, PRE, POST, handle=h)
+  n = eeg.shape[0]
+  corr = []
+  for spk in (0, 1):
+    s = device.window_sums(envd[:, spk:spk + 1], pred, [0, n], n, n, handle=h).cpu().numpy()[0, 0]
+    corr += [s[0] / n, s[1] / n, np.sqrt((s[2] - s[0] ** 2 / n) * (s[3] - s[1] ** 2 / n)) / n]
+  del pred, st
+  mine = np.array_split(np.arange(n_trials), world)[rank]
+  t0_, t1_ = int(mine[0]), int(mine[-1]) + 1
+  xs = xd[t0_ * frames:t1_ * frames].clone()
+  es = envd[t0_ * frames:t1_ * frames].clone()
+  loffs = np.arange(t1_ - t0_ + 1, dtype=np.int64) * frames
+  per_trial = (frames - width) // hop + 1
+  for _ in range(3):
+    out = device.decode_fused(xs, es, loffs, w, b, PRE, POST, width, hop, corr, handle=h)
+  progress('C4 leg: timed decodes (no collective inside; barrier at both ends)')
+  gc.collect()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    out = device.decode_fused(xs, es, loffs, w, b, PRE, POST, width, hop, corr, handle=h)
+  barrier()
+  t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  elapsed = float(t.item())
+  progress('C4 leg: gather of the decisions')
+  local = out[1].cpu().numpy().reshape(t1_ - t0_, per_trial).astype(np.float64)
+  gathered = distributed.gather_rows(local, n_trials, list(range(t0_, t1_))).reshape(-1)
+  res = None
+  if rank == 0:
+    whole = device.decode_fused(xd, envd, offs, w, b, PRE, POST, width, hop, corr, handle=h)[1].cpu().numpy()
+    same = bool(np.array_equal(gathered.astype(whole.dtype), whole))
+    ms = elapsed / iters * 1e3
+    res = {
+        'workload': 'C4: 200 trials x 60 s x 64 ch dealt to %d ranks in contiguous blocks (%d on rank 0), '
+                    'W = 1000 / hop 100, replicas: no data-path collective, decisions gathered' % (world, t1_ - t0_),
+        'ranks': world, 'windows': n_trials * per_trial, 'ms': ms,
+        'windows_per_s': n_trials * per_trial / ms * 1e3, 'seconds': elapsed, 'iters': iters,
+        'collective': {'route': 'none in the timed region; decisions gathered by one all-reduce of disjoint rows',
+                       'ranks': world},
+        'decisions_identical_to_one_gpu': same,
+        'timing': 'host clock over %d back-to-back calls between barriers, MAX over ranks (one input copy per rank: '
+                  'replayed, not rotated)' % iters,
+    }
+  barrier()
+  return res
+
+
 def launch_ranks(args, argv):
   """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver calls it
   when it does not go through torch.distributed.run): this process touches no GPU; it starts N
@@ -536,11 +773,25 @@ def launch_ranks(args, argv):
   with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
+  import tempfile
+  log_dir = tempfile.mkdtemp(prefix='td_bench_')
+
+  def last_marks():
+    lines = []
+    for r in range(n):
+      try:
+        with open(os.path.join(log_dir, 'rank%d.log' % r)) as f:
+          rows = f.read().strip().splitlines()
+        lines.append(rows[-1] if rows else 'rank %d: (no mark)' % r)
+      except OSError:
+        lines.append('rank %d: (no log)' % r)
+    return lines
   procs = []
   for r in range(n):
     env = dict(os.environ)
     env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TD_BENCH_LAUNCHER='self')
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TD_BENCH_LAUNCHER='self',
+               TD_BENCH_LOG_DIR=log_dir)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
@@ -552,14 +803,25 @@ def launch_ranks(args, argv):
   reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
   reader.start()
   failed = None
+  t_start = time.time()
   while True:
     codes = [p.poll() for p in procs]
     bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+    # (the whole launch has a limit of its own: a rank whose watchdog thread cannot run any more --
+    # stuck inside a driver call -- still ends here)
+    if failed is None and not bad and time.time() - t_start > args.launch_timeout:
+      bad = [(r, -1) for r, c in enumerate(codes) if c is None][:1]
+      sys.stderr.write('bench.py: the launch exceeded --launch-timeout (%d s)\n' % args.launch_timeout)
     if bad and failed is None:
       failed = bad[0]
       for p in procs:
         if p.poll() is None:
           p.terminate()                                 # exactly the PIDs started above
+      t_kill = time.time() + 10
+    if failed is not None and time.time() > t_kill:
+      for p in procs:
+        if p.poll() is None:
+          p.kill()
     if all(c is not None for c in codes):
       break
     time.sleep(0.05)
@@ -568,7 +830,9 @@ def launch_ranks(args, argv):
   sys.stdout.write(text)
   sys.stdout.flush()
   if failed is not None:
-    sys.stderr.write('bench.py: rank %d exited with code %d; no result\n' % failed)
+    sys.stderr.write('bench.py: rank %d exited with code %d; no result.  Last mark of every rank:\n' % failed)
+    for row in last_marks():
+      sys.stderr.write('  ' + row + '\n')
     return 1
   last = text.strip().splitlines()[-1] if text.strip() else ''
   try:
@@ -589,6 +853,8 @@ def dry_launch(args, rank, local_rank, world):
   import torch
   import torch.distributed as dist
   from telluride_decoding_amd import distributed
+  start_watchdog(rank, args.watchdog_seconds)
+  progress('dry launch: rendezvous (gloo)')
   dist.init_process_group('gloo', rank=rank, world_size=world)
   if os.environ.get('TD_BENCH_DRY_FAIL_RANK') == str(rank):      # tests: a worker that dies
     os._exit(7)
@@ -609,6 +875,26 @@ def dry_launch(args, rank, local_rank, world):
   seen = dist.get_world_size()
   ok = bool((buf[:, 2] == 1).all()) and int(buf[:, 0].sum()) == FILES_PER_GPU * FRAMES_PER_FILE * world \
       and int(buf[:, 1].sum()) == FILES_PER_GPU * FRAMES_PER_FILE
+  # the sharding and gathers of the C5 / C4 legs (loso_multi_leg, decode_multi_leg), no compute: 32
+  # subjects dealt to the ranks, their table rows all-reduced, 32 folds round-robin, a score table
+  # and 200 trials' decisions gathered from disjoint rows
+  splan = distributed.ShardPlan([31250] * 32, world)
+  table = torch.zeros(32, 4, dtype=torch.float64)
+  for i in splan.files_of(rank):
+    table[i] = float(i + 1)
+  distributed.allreduce_packed(table)
+  ok = ok and bool((table[:, 0] == torch.arange(1, 33, dtype=torch.float64)).all())
+  folds = distributed.split_round_robin(list(range(32)), rank, world)
+  got = distributed.gather_rows(np.array([[f * 10.0 + k for k in range(20)] for f in folds]).reshape(len(folds), 20),
+                                32, folds)
+  ok = ok and bool(np.array_equal(got, np.arange(32)[:, None] * 10.0 + np.arange(20)[None, :]))
+  mine_t = np.array_split(np.arange(200), world)[rank]
+  dec = distributed.gather_rows(np.repeat(mine_t[:, None].astype(np.float64), 51, axis=1), 200, list(mine_t))
+  ok = ok and bool(np.array_equal(dec[:, 0], np.arange(200.0))) and dec.shape == (200, 51)
+  if os.environ.get('TD_BENCH_DRY_HANG_RANK') == str(rank):       # tests: a rank stuck in a collective
+    progress('dry launch: (test) this rank never reaches the barrier')
+    time.sleep(3600)
+  progress('dry launch: final barrier')
   dist.barrier()
   dist.destroy_process_group()
   if not ok:
@@ -621,7 +907,10 @@ def dry_launch(args, rank, local_rank, world):
         'launcher': os.environ.get('TD_BENCH_LAUNCHER', 'torch.distributed.run'),
         'backend': 'gloo', 'data': 'none (no compute: launch / rendezvous / collective plumbing only)',
         'weak_frames_per_rank': [int(v) for v in buf[:, 0]],
-        'strong_frames_per_rank': [int(v) for v in buf[:, 1]]}), flush=True)
+        'strong_frames_per_rank': [int(v) for v in buf[:, 1]],
+        'c5_subjects_per_rank': [len(splan.files_of(r)) for r in range(world)],
+        'c4_trials_per_rank': [len(a) for a in np.array_split(np.arange(200), world)],
+        'legs_plumbing_ok': True}), flush=True)
   return 0
 
 
@@ -659,6 +948,13 @@ def main():
   ap.add_argument('--share-gpu', action='store_true',
                   help='development: all N ranks on GPU 0 over gloo (RCCL needs a GPU per rank) -- '
                        'runs the N > 1 logic of this file on a one-GPU box; the numbers mean nothing')
+  ap.add_argument('--watchdog-seconds', type=int, default=600,
+                  help='a rank that writes no progress mark for this long (a collective that never returns) '
+                       'prints its last mark and exits with code 124; 0 = no watchdog')
+  ap.add_argument('--launch-timeout', type=int, default=3000,
+                  help='self-launched ranks (--gpus N without WORLD_SIZE): the launcher ends them all after '
+                       'this many seconds and prints every rank\'s last progress mark')
+  ap.add_argument('--no-shapes', action='store_true', help='skip the off-headline shapes leg (N = 1)')
   ap.add_argument('--dry-launch', action='store_true',
                   help='launch the ranks, rendezvous (gloo, CPU) and print the line without any '
                        'compute: checks the multi-rank plumbing where there is no GPU')
@@ -678,6 +974,7 @@ def main():
   if args.dry_launch:
     sys.exit(dry_launch(args, rank, local_rank, world))
   import torch
+  start_watchdog(rank, args.watchdog_seconds)
   if args.share_gpu:
     local_rank = 0
   if torch.cuda.device_count() <= local_rank:
@@ -687,6 +984,7 @@ def main():
   dist_on = world > 1 or args.force_dist      # --force-dist: the N > 1 code path on one rank
   if dist_on:
     import torch.distributed as dist
+    progress('rendezvous: init_process_group')
     if world == 1:
       os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
       os.environ.setdefault('MASTER_PORT', '29544')
@@ -713,8 +1011,10 @@ def main():
   def barrier():
     torch.cuda.synchronize()
     if dist_on:
+      progress('barrier')
       dist.barrier()
     torch.cuda.synchronize()
+    progress('past a barrier')
 
   def time_region(run, steps, warmup, after_warmup=None, collect=True):
     """The contract's timed region: warmup, barrier + sync, K steps, barrier + sync, MAX over
@@ -1035,15 +1335,34 @@ def main():
           'one_gpu_reference': 'strong_share_bound_one_gpu["8e+06_samples"].whole_job_ms of the N = 1 line',
       }
 
+  if world > 1 and args.scaling == 'weak' and not args.no_extra:
+    # BASELINE configs C5 and C4 over the N ranks (C5 is DEFINED as sharded over the GPUs of a node;
+    # the decode half of the metric is windows/s at 1 -> 8 GPUs)
+    leg = loso_multi_leg(rank, world, dist, h, barrier)
+    if rank == 0:
+      line['loso'] = leg
+    if not args.no_decode:
+      leg = decode_multi_leg(rank, world, dist, h, device, barrier)
+      if rank == 0:
+        line['decode'] = leg
   if rank == 0:
     eeg, env = host_data
     if world == 1 and not args.no_cpu:
+      progress('cpu baseline')
       line['cpu_baseline'] = cpu_baseline(eeg, env)
     if world == 1 and not args.no_decode:
+      progress('decode leg')
       line['decode'] = decode_leg(h, device)
     if world == 1 and not args.no_extra:
+      progress('cca leg')
       line['cca'] = cca_leg(h, device, eeg)
+      progress('loso leg')
       line['loso'] = loso_leg(eeg, env)
+      line['loso_first_sweep_s'] = line['loso']['seconds_first_sweep']
+    if world == 1 and not args.no_extra and not args.no_shapes:
+      progress('shapes leg')
+      line['shapes'] = shapes_leg(h, device)
+  progress('final barrier')
   if dist_on:
     dist.barrier()
     distributed.close_native_comms()

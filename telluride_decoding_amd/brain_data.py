@@ -229,6 +229,18 @@ class Dataset(object):
       self._device_cache = (handle, x, x2, y, offs)
     return self._device_cache[1:]
 
+  def device_file(self, handle, i):
+    """(x, y) of recording i alone on the device, kept by the dataset: a rank of a multi-rank
+    sweep touches only some of the recordings and uploads each of them once, not once per sweep."""
+    box = self._cache_box
+    if len(box) < 2:
+      box.append({})
+    key = (id(handle), int(i))
+    if key not in box[1]:
+      f = self.files[i]
+      box[1][key] = (handle.to_device(f[0]), handle.to_device(f[2]))
+    return box[1][key]
+
   def attention_host(self):
     """Attention labels of the zipped, batched stream (never shifted)."""
     used = self.rows_used()

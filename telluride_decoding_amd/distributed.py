@@ -324,16 +324,17 @@ def split_round_robin(items, rank, world_size):
   return [it for i, it in enumerate(items) if i % world_size == rank]
 
 
-def gather_rows(local_rows, n_total, index, group=None):
+def gather_rows(local_rows, n_total, index, group=None, local_only=False):
   """Each rank computed rows `index` of an [n_total, ...] result; returns the full
-  array on every rank (sum of disjoint contributions)."""
+  array on every rank (sum of disjoint contributions).  local_only: this caller holds every row
+  (a one-rank computation inside a multi-rank job): no collective."""
   import torch
   local_rows = np.asarray(local_rows, np.float64)
   full = np.zeros((n_total,) + local_rows.shape[1:], np.float64)
   for j, i in enumerate(index):
     full[i] = local_rows[j]
   dist = _dist()
-  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+  if not local_only and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
     t = torch.from_numpy(full)
     if dist.get_backend(group) == 'nccl':
       t = t.cuda()

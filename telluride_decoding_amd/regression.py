@@ -127,6 +127,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
       if whole is not None:
         x_all, _, y_all, offs = whole
         uploaded[i] = (x_all[int(offs[i]):int(offs[i + 1])], y_all[int(offs[i]):int(offs[i + 1])])
+      elif hasattr(dataset, 'device_file'):
+        uploaded[i] = dataset.device_file(h, i)          # (kept by the dataset across sweeps)
       else:
         f = dataset.files[i]
         uploaded[i] = (h.to_device(f[0]), h.to_device(f[2]))
@@ -150,7 +152,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   table = h.zeros((n_files, plen), 'float64')
   for i, st in per_file.items():
     table[i] = st.pack(1, 0)
-  distributed.allreduce_packed(table, group, handle=h)
+  if world_size > 1:        # (a one-rank sweep inside a multi-rank job must not enter a collective)
+    distributed.allreduce_packed(table, group, handle=h)
   stats = []
   for i in range(n_files):
     if i in per_file and world_size == 1:
@@ -321,7 +324,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   import torch
   rows = (torch.stack(scores).cpu().numpy() if scores else np.zeros((0, n_lam)))   # one copy
   # 5. gather
-  all_folds = distributed.gather_rows(rows, n_files, my_folds, group)[fold_list]     # [F, Lambda]
+  all_folds = distributed.gather_rows(rows, n_files, my_folds, group,
+                                      local_only=world_size == 1)[fold_list]         # [F, Lambda]
   results = collections.OrderedDict()
   for li, lam in enumerate(lambdas):
     results[lam] = calculate_stats(all_folds[:, li])
@@ -350,7 +354,7 @@ def jackknife_one_model(dataset, regularization_lambda, max_test_count=-1, test_
   n_files = len(dataset.files)
   if test_file is not None:
     folds = [int(test_file)]
-  elif max_test_count is not None and max_test_count >= 0:
+  elif max_test_count is not None and max_test_count > 0:   # (0, like -1: every file; brain_data.py:208)
     folds = list(range(min(int(max_test_count), n_files)))
   else:
     folds = list(range(n_files))

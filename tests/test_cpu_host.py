@@ -357,6 +357,9 @@ def test_bench_gpus_n_starts_n_ranks_itself():
   assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launcher'] == 'self'
   assert line['weak_frames_per_rank'] == [1000000, 1000000]
   assert line['strong_frames_per_rank'] == [500000, 500000]
+  # the sharding / all-reduce / gathers of the C5 and C4 legs of an N > 1 run (no compute)
+  assert line['c5_subjects_per_rank'] == [16, 16] and line['c4_trials_per_rank'] == [100, 100]
+  assert line['legs_plumbing_ok'] is True
   # the same through torch.distributed.run (how the driver launches N > 1)
   port = 31500 + (os.getpid() % 2000)
   env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE')}
@@ -380,6 +383,21 @@ def test_bench_never_runs_fewer_ranks_than_asked():
   assert res.returncode != 0 and 'rank 1 exited with code 7' in res.stderr
   res = _bench(['--gpus', '2', '--dry-launch'], {'WORLD_SIZE': '4', 'RANK': '0'})
   assert res.returncode != 0 and 'WORLD_SIZE=4' in (res.stderr + res.stdout)
+
+
+def test_bench_watchdog_turns_a_hung_collective_into_a_diagnosis():
+  """first contact with a multi-GPU node must be diagnosable.  A rank that never
+  reaches a collective (here: sleeps in front of the final barrier of the dry launch) leaves the
+  others waiting inside it; every rank's watchdog thread ends its process after --watchdog-seconds
+  without a progress mark (exit code 124), and the launcher prints the last mark of EVERY rank --
+  which collective each was in -- and exits non-zero.  Nothing is re-executed."""
+  res = _bench(['--gpus', '2', '--steps', '1', '--dry-launch', '--watchdog-seconds', '5'],
+               {'TD_BENCH_DRY_HANG_RANK': '1'}, timeout=120)
+  assert res.returncode != 0
+  assert 'exited with code 124' in res.stderr and 'Last mark of every rank' in res.stderr
+  assert 'rank 0: dry launch: final barrier' in res.stderr
+  assert 'rank 1: dry launch: (test) this rank never reaches the barrier' in res.stderr
+  assert '"n_gpus"' not in res.stdout
 
 
 def test_streaming_attention_is_host_arithmetic_and_matches_goldens():
