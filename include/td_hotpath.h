@@ -266,6 +266,15 @@ int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_
  * 2 not converged / not positive definite, 3 aborted) when it was tried.  Any pointer may be NULL. */
 enum { TD_SOLVER_AUTO = 0, TD_SOLVER_CHOLESKY = 1, TD_SOLVER_CG = 2 };
 int td_set_solver(td_handle* h, int mode);
+/* Named options of a handle (the library reads no TD_* environment variable except TD_RCCL_LIB):
+ *   "cca_whitening"   0 (default) td_cca_solve whitens the large side by its Cholesky factor when the
+ *                     inertia certificate allows; 1 = always the eigen-decomposition the reference calls
+ *                     (cca.py:345-360);
+ *   "cg_limit_ticks"  the conjugate-gradient kernel's wait limit per launch in 10 ns ticks (< 0: the
+ *                     default, 20 ms; 0: every workgroup gives up at its first empty poll -- the abort /
+ *                     drain / Cholesky-fallback route, for tests).
+ * Unknown names are TD_ERR_INVALID. */
+int td_set_option(td_handle* h, const char* name, int64_t value);
 int td_last_solve_info(td_handle* h, int* solver, int* iterations, int* cg_status);
 /* The same without waiting for the device.  *singular_flag_host points at a pinned host int
  * owned by the handle (a ring of 8: read it before the 8th later call; a call that would reuse a

@@ -86,6 +86,7 @@ SIGNATURES = {
     'td_stats_moments': [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'td_ridge_solve': [_vp, _vp, _pd, _i, _vp, _vp],
     'td_set_solver': [_vp, _i],
+    'td_set_option': [_vp, _c.c_char_p, _i64],
     'td_last_solve_info': [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)],
     'td_ridge_solve_async': [_vp, _vp, _pd, _i, _vp, _vp, _vp],
     'td_ridge_solve_multi': [_vp, _c.POINTER(_vp), _i, _pd, _i, _vp, _vp, _vp],

@@ -56,6 +56,7 @@ struct CgParams {
   int* status;            // [0] = 0 ok / 2 not converged or not positive definite / 3 aborted, [1] = iterations (max over systems)
   double inv;             // 1 / frames
   double tol2;            // (relative residual)^2
+  double accept;          // the TRUE residual of the answer may be accept * tol2 (squared, relative)
   int n, ld, d, n_lambda, k, rows, max_iter;
   unsigned epoch;         // round numbers of this launch start above it
   long long limit_ticks;  // wall_clock64 ticks (100 MHz) a wait may last
@@ -286,6 +287,9 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
       int polls = 0;
       bool gave_up = false;
       __builtin_amdgcn_s_sleep(24);
+      // (the limit is per WAIT: a healthy grid that works through many systems / iterations must not run
+      // out of a budget for the whole launch -- 6 systems x 400 iterations x 8 us exceeded the 20 ms)
+      const long long t_wait = wall_clock64();
       {
         int j0 = (t >> 5) & (kCgMaxCols - 1);
         if (cg_col(t, j0) >= k) j0 = 0;
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
           while (!ll_try(pp, round, dummy)) {
             if ((++polls & 15) == 0 || P.limit_ticks < 16) {
               if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.epoch + 1u) { gave_up = true; break; }
-              if (wall_clock64() - t_start > P.limit_ticks) {
+              if (wall_clock64() - t_wait > P.limit_ticks) {
                 __hip_atomic_store(P.abort_word, P.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 gave_up = true;
                 break;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
         if (all) break;
         if ((++polls & 15) == 0 || P.limit_ticks < 16) {
           if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.epoch + 1u) { gave_up = true; break; }
-          if (wall_clock64() - t_start > P.limit_ticks) {
+          if (wall_clock64() - t_wait > P.limit_ticks) {
             __hip_atomic_store(P.abort_word, P.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             gave_up = true;
             break;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
       const double sw = wave_parts(part_b, 4, 2);
       TD_CG_T(4);
       if (check_pass) {
-        if (!(gamma <= 100.0 * P.tol2 * bnorm2)) status = 2;      // (also catches NaN)
+        if (!(gamma <= P.accept * P.tol2 * bnorm2)) status = 2;   // (also catches NaN)
         break;
       }
       if (gamma <= P.tol2 * bnorm2) {       // r (whose product just came back) is small: x is the answer;
@@ -410,13 +414,19 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
 }
 
 template <int R>
-int launch_cg(td_handle* h, const CgParams& p, int wgs, size_t lds_bytes) {
+int launch_cg(td_handle* h, const CgParams& p, int wgs, size_t lds_bytes, int cus) {
   static bool opted[64] = {};
   if (lds_bytes > 65536 && !opted[h->device & 63]) {
     TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(cg_resident_kernel<R>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     opted[h->device & 63] = true;
   }
+  // The grid spins on packets of ALL its workgroups: every one of them must be resident at once.  Ask
+  // the runtime how many fit a CU with this LDS and register footprint BEFORE launching (the abort
+  // clock inside the kernel is the net under another process's grid, which no query sees).
+  int per_cu = 0;
+  TD_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_resident_kernel<R>, kCgThreads, lds_bytes));
+  if ((long long)per_cu * cus < wgs) return TD_CG_NOT_RESIDENT;
   hipLaunchKernelGGL(cg_resident_kernel<R>, dim3((unsigned)wgs), dim3(kCgThreads), lds_bytes, h->stream, p);
   return TD_OK;
 }
@@ -437,7 +447,7 @@ int td_cg_rows(int k, int cus) {
 // xty [n][d] already on the device) on h->stream.  status_dev[0..1] receive status and iterations.
 int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const double* xty, int d, double inv,
                       const double* lams_dev, int n_lambda, int cus, int max_iter, double tol, float* w_dev,
-                      float* b_dev, int* status_dev) {
+                      float* b_dev, int* status_dev, double accept) {
   const int k = n - 1;
   const int rows = td_cg_rows(k, cus);
   TD_REQUIRE(h, rows > 0, "td_cg_solve_dense: %d unknowns do not fit the LDS of %d workgroups", k, cus);
@@ -459,25 +469,27 @@ int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const doub
   p.packets = h->cg_packets;
   p.abort_word = reinterpret_cast<unsigned*>(h->cg_packets + 2 * 2 * kCgThreads * kCgMaxCols);
   p.w = w_dev; p.bias = b_dev; p.status = status_dev;
-  p.inv = inv; p.tol2 = tol * tol;
+  p.inv = inv; p.tol2 = tol * tol; p.accept = accept;
   p.n = n; p.ld = ld; p.d = d; p.n_lambda = n_lambda; p.k = k; p.rows = rows; p.max_iter = max_iter;
   p.epoch = h->cg_epoch;
   p.limit_ticks = 100000LL * 20;          // 20 ms at 100 MHz
-  if (const char* e = getenv("TD_CG_LIMIT_TICKS")) p.limit_ticks = atoll(e);      // development: 0 = abort at the first empty poll
+  if (h->cg_limit_ticks >= 0) p.limit_ticks = h->cg_limit_ticks;      // td_set_option("cg_limit_ticks"): 0 = give up at the first empty poll
   h->cg_epoch += rounds;
   // (the abort word holds the launch number -- epoch + 1, never 0 -- of the last aborted launch: no reset)
   const int wgs = (k + rows - 1) / rows;
   const size_t lds = sizeof(double) * ((size_t)rows * ((k + 1) & ~1) + 14 * kCgWaves + 16);
+  int rc = TD_OK;
   switch (rows) {
-    case 1: TD_TRY(launch_cg<1>(h, p, wgs, lds)); break;
-    case 2: TD_TRY(launch_cg<2>(h, p, wgs, lds)); break;
-    case 3: TD_TRY(launch_cg<3>(h, p, wgs, lds)); break;
-    case 4: TD_TRY(launch_cg<4>(h, p, wgs, lds)); break;
-    case 5: TD_TRY(launch_cg<5>(h, p, wgs, lds)); break;
-    case 6: TD_TRY(launch_cg<6>(h, p, wgs, lds)); break;
-    case 7: TD_TRY(launch_cg<7>(h, p, wgs, lds)); break;
-    default: TD_TRY(launch_cg<8>(h, p, wgs, lds)); break;
+    case 1: rc = launch_cg<1>(h, p, wgs, lds, cus); break;
+    case 2: rc = launch_cg<2>(h, p, wgs, lds, cus); break;
+    case 3: rc = launch_cg<3>(h, p, wgs, lds, cus); break;
+    case 4: rc = launch_cg<4>(h, p, wgs, lds, cus); break;
+    case 5: rc = launch_cg<5>(h, p, wgs, lds, cus); break;
+    case 6: rc = launch_cg<6>(h, p, wgs, lds, cus); break;
+    case 7: rc = launch_cg<7>(h, p, wgs, lds, cus); break;
+    default: rc = launch_cg<8>(h, p, wgs, lds, cus); break;
   }
+  if (rc != TD_OK) return rc;              // (TD_CG_NOT_RESIDENT: nothing was queued)
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

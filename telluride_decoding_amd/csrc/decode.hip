@@ -2545,7 +2545,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
     for (int f = 0; f < num_files && stream_ok; ++f)
       stream_ok = (offs[f + 1] - offs[f]) * ldx * 4 < (int64_t)0x7fc00000;
 #ifdef TD_DEV_SWITCHES
-    if (getenv("TD_FIR_STREAM_OFF")) stream_ok = false;
+    if (td_dev_env("TD_FIR_STREAM_OFF")) stream_ok = false;
 #endif
     if (stream_ok) {
       const int cus = h->cu_count > 0 ? h->cu_count : 256;
@@ -2664,7 +2664,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   // (Measured at C4, decode step: 90.1 us with fir_tile16_kernel against 86.3 us with
   // predict_fir_mfma_kernel -- its split + MFMA cost 26 us and its loads 19 us that overlap only
   // partly (ablations: DESIGN 8) -- so the P-tile kernel stays the default and this one is opt-in.)
-  static const bool tile16 = getenv("TD_FIR_TILE16") != nullptr;          // development: A/B runs
+  static const bool tile16 = td_dev_env("TD_FIR_TILE16") != nullptr;          // development: A/B runs
   if (!w_file_stride && d == 1 && nl <= 32 && c >= 4 && c <= 64 && vec4 && tile16 && h->acc_mode != TD_ACC_F32) {
     // one output: the barrier-free 16-row kernel (fir_tile16_kernel); 12 waves per CU, one round
     const int cus = h->cu_count > 0 ? h->cu_count : 256;
@@ -2855,7 +2855,7 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
   const int k1 = c1 * (pre1 + 1 + post1), k2 = c2 * (pre2 + 1 + post2);
   // no context on either view, aligned rows, at most 16 outputs: one fused pass (cca_project_kernel)
 #ifdef TD_DEV_SWITCHES
-  static const bool old_proj = getenv("TD_PROJECT_F32") != nullptr;        // development: A/B runs
+  static const bool old_proj = td_dev_env("TD_PROJECT_F32") != nullptr;        // development: A/B runs
 #else
   constexpr bool old_proj = false;
 #endif
@@ -2875,7 +2875,7 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
       stream_ok = n * ldx * 4 < (int64_t)0x7fc00000 && n * ldx2 * 4 < (int64_t)0x7fc00000;
     }
 #ifdef TD_DEV_SWITCHES
-    if (getenv("TD_PROJECT_STREAM_OFF")) stream_ok = false;
+    if (td_dev_env("TD_PROJECT_STREAM_OFF")) stream_ok = false;
 #endif
     if (stream_ok) {
       // one strip per resident wave (kPsOcc workgroups of four waves per CU), a multiple of 32 rows

@@ -506,7 +506,7 @@ int sym_eig(td_handle* h, const double* a, int lda, int n, double* vals, double*
   hipLaunchKernelGGL(pad_sym_kernel, dim3(grid_for((long long)np * np)), dim3(256), 0, h->stream, a,
                      lda, n, np, ap, vp);
   P.a = ap; P.lda = np; P.n = np; P.direct = 0; P.nblocks = nblocks; P.jout = jm; P.vals = nullptr;
-  P.skip = skip; P.max_sweeps = getenv("TD_EIG_INNER") ? atoi(getenv("TD_EIG_INNER")) : kMaxInnerSweeps;
+  P.skip = skip; P.max_sweeps = td_dev_env("TD_EIG_INNER") ? atoi(td_dev_env("TD_EIG_INNER")) : kMaxInnerSweeps;
   BlockUpd U;
   U.a = ap; U.v = vp; U.np = np; U.nblocks = nblocks; U.j = jm; U.skip = skip;
   int sweep = 0;
@@ -530,7 +530,7 @@ int sym_eig(td_handle* h, const double* a, int lda, int n, double* vals, double*
     TD_HIP(h, hipMemcpyAsync(&rotated, counter, sizeof(unsigned int), hipMemcpyDeviceToHost,
                              h->stream));
     TD_HIP(h, hipStreamSynchronize(h->stream));
-    if (getenv("TD_EIG_TRACE")) fprintf(stderr, "eig n=%d sweep %d: %u rotations\n", n, sweep, rotated);
+    if (td_dev_env("TD_EIG_TRACE")) fprintf(stderr, "eig n=%d sweep %d: %u rotations\n", n, sweep, rotated);
     if (rotated == 0) break;
   }
   if (sweeps_out) *sweeps_out = sweep + 1;
@@ -818,7 +818,7 @@ int jacobi_svd(td_handle* h, double* g, int ldg, int k, int m, int dim, double* 
     if (sweeps_out) *sweeps_out = 0;
     return TD_OK;
   }
-  static const bool no_gram = getenv("TD_SVD_JACOBI") != nullptr;         // development: A/B runs
+  static const bool no_gram = td_dev_env("TD_SVD_JACOBI") != nullptr;         // development: A/B runs
   if (k <= NB && k > 1 && m >= 4 * k && !no_gram) {
     double* gg = norms + k;                              // [k][k]
     double* vals = gg + (size_t)k * k;                   // [k]; eigenvectors -> vt
@@ -1057,9 +1057,8 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   // (every pivot above the rounding tolerance of td_chol_factor) the reference's filter keeps
   // every eigenvalue.  One extra factorisation (4 ms at K1 = 2553) instead of the Jacobi
   // eigen-decomposition (0.2-0.3 s) -- which still decides whenever the certificate fails.
-  // (development A/B switch, read per call so that one process can compare both routes; a
-  // getenv is ~50 ns against a dense stage of >= 0.28 ms that ends in a stream synchronisation)
-  const bool force_eig = getenv("TD_CCA_EIG") != nullptr;
+  // (td_set_option(h, "cca_whitening", 1): always the reference's eigen route)
+  const bool force_eig = h->cca_whitening == 1;
   bool use_chol = k2 <= 64 && cols && !force_eig;
   const bool psd_proof = regularization > 2.0 * eps_eig && denom <= (double)frames;
   if (use_chol) {

@@ -2571,7 +2571,7 @@ static void lag_slab_counts(const td_handle* h, const std::vector<LagSeg>& segs,
                             long long per_item_wgs, bool split, std::vector<long long>* out,
                             long long want_items = 0) {
   long long kMaxSlab = split ? 8192 : 2048;
-  if (const char* e = getenv("TD_MAX_SLAB")) kMaxSlab = atoll(e);   // development
+  if (const char* e = td_dev_env("TD_MAX_SLAB")) kMaxSlab = atoll(e);   // development
   std::vector<long long>& n_slabs = *out;
   n_slabs.assign(segs.size(), 0);
   long long min_items = 0, max_items = 0;
@@ -2635,7 +2635,7 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   // with the operands swapped -- force_small -- instead of as padded 64 x 64 tiles)
   // both operands narrow and enough lags to fill a workgroup's 32: the VALU kernel with a row of
   // outputs per thread (lagcov_narrow_kernel); it shares the skinny kernel's slab layout
-  static const bool no_narrow = getenv("TD_LAG_NO_NARROW") != nullptr;     // development: A/B runs
+  static const bool no_narrow = td_dev_env("TD_LAG_NO_NARROW") != nullptr;     // development: A/B runs
   const bool narrow = !a_ones && ca <= 8 && cb <= 8 && e_count >= 8 && !no_narrow;
   plan->narrow = narrow;
   const bool small = narrow || ((a_ones || plan->force_small) && ca_eff <= 8);
@@ -2663,7 +2663,7 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   // The split kernels (lagcov_split_kernel): the same stream and channel tile on both sides,
   // lags 0 .. <= 63, 33 .. 64 channels.
   // (the environment switches are for A/B runs inside one process tree; td_set_accumulate_mode is the API)
-  static const bool env_f32 = getenv("TD_LAGCOV_F32") != nullptr;
+  static const bool env_f32 = td_dev_env("TD_LAGCOV_F32") != nullptr;
   const bool force_f32 = env_f32 || h->acc_mode == TD_ACC_F32;
   bool split = !small && !few && (a == b) && (lda == ldb) && (ca == cb) && !a_ones && e_min == 0 &&
                ca > 32 && ca <= 64 && e_count <= 64 && !force_f32;
@@ -2677,7 +2677,7 @@ int td_lagcov_plan(td_handle* h, const float* a, int64_t lda, int ca, bool a_one
   plan->small = small; plan->few = few; plan->split = split; plan->few_g = few_g;
   // the two-piece float16 form of the split kernel (half the matrix instructions): for callers
   // that reduce through the finalize launch, which divides the channel scales out (allow_f16)
-  static const bool env_bf16 = getenv("TD_LAGCOV_BF16X3") != nullptr;
+  static const bool env_bf16 = td_dev_env("TD_LAGCOV_BF16X3") != nullptr;
   plan->f16 = split && plan->allow_f16 && !env_bf16 && h->acc_mode == TD_ACC_F16X2;
 
   // Slab plan.  Every slab is ONE f32 accumulation chain (relative error ~ eps/2 *
@@ -2883,7 +2883,7 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
       // More work items than CUs (the C2 plan: three slabs per CU): one workgroup per CU walks its
       // share and leaves one partial slab (LagParams::n_part).  Not with the riding target column.
       long long grid_wgs = nwg;
-      static const bool no_persist = getenv("TD_LAG_ONE_ITEM") != nullptr;   // development: A/B runs
+      static const bool no_persist = td_dev_env("TD_LAG_ONE_ITEM") != nullptr;   // development: A/B runs
       {
         const int cus = h->cu_count > 0 ? h->cu_count : 256;
         const long long per_round = (long long)(cus / p.n_groups) * p.n_groups;
@@ -3646,7 +3646,7 @@ int td_gram(td_handle* h, const float* x, int64_t ldx, int c1, const float* x2, 
                     (ldx2 % 4 == 0) && (c2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(x2) & 15) == 0);
   // the bf16x3 kernel (aligned rows): slabs of whole 32-row chunks, two 4-wave workgroups per CU
   // (211 registers), a wave's MFMA chain <= 16 chunks
-  static const bool old_gram = getenv("TD_GRAM_F32") != nullptr;          // development: A/B runs
+  static const bool old_gram = td_dev_env("TD_GRAM_F32") != nullptr;          // development: A/B runs
   const bool bf = vec4 && !old_gram && h->acc_mode != TD_ACC_F32;
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
   // float32 kernel: slabs of whole 64-row tiles, at most 2048 rows (f32 chains of 512 row quads

@@ -980,7 +980,7 @@ int lagcov_auto(td_handle* h, const float* x, int64_t ldx, int c, const std::vec
   }
   if (c <= 64 || c > 128)
     return td_lagcov(h, x, ldx, c, false, x, ldx, c, segs, 0, l, g, true, 0, 0, false, true);
-  static const bool blocks = getenv("TD_AUTO_BLOCKS") != nullptr;          // development: A/B runs
+  static const bool blocks = td_dev_env("TD_AUTO_BLOCKS") != nullptr;          // development: A/B runs
   long long lo = 0, hi = 0;
   bool any = false, same = true;
   for (const LagSeg& sg : segs) {
@@ -1060,7 +1060,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   // 49 us pre-pass; as a pass of their own -- which is HBM-bound, has the matrix pipe to spare
   // and measures the channel maxima on the way -- they cost 62 us in all.  So the folded form is
   // opt-in: TD_ACC_FOLDED.)
-  static const bool want_fold = getenv("TD_ACC_FOLDED") != nullptr;      // development: A/B runs
+  static const bool want_fold = td_dev_env("TD_ACC_FOLDED") != nullptr;      // development: A/B runs
   const bool folded = do_main && !virt && do_targets && s->d == 1 && s->pre1 == 0 && want_fold &&
                       td_lagcov_plan_targets(&mp);
   if (folded) {
@@ -1283,7 +1283,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
   // (td_gram), done by MAIN; TARGETS then has nothing left to add.
   const bool one_pass = stats_one_pass(s);
 
-  static const bool no_fuse = getenv("TD_ACC_UNFUSED") != nullptr;     // development: A/B runs
+  static const bool no_fuse = td_dev_env("TD_ACC_UNFUSED") != nullptr;     // development: A/B runs
   if (stats_fusable(s) && new_frames > 0 && !no_fuse)
     return accumulate_fused(h, s, x_dev, ldx, y_dev, ldy, sxx, syx, j1, num_files, new_frames,
                             first_slot, do_main, do_targets, tgt_first);
@@ -1364,7 +1364,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
       // matrix-core targets kernel in windows of 32 lags, td_lagcov_column, instead of a padded
       // 64-channel tile for its auto-covariance (0.14 ms at the codelab's shape) and the skinny
       // VALU kernel for the cross-covariance (0.28 ms); `TD_LAG_NO_COLUMN` keeps those)
-      static const bool no_column = getenv("TD_LAG_NO_COLUMN") != nullptr;
+      static const bool no_column = td_dev_env("TD_LAG_NO_COLUMN") != nullptr;
       const bool column = s->c2 == 1 && !no_column;
       if (column)
         TD_TRY(td_lagcov_column(h, x2_dev, ldx2, x2_dev, ldx2, 1, syy, 0, s->l2, s->g + s->off_fyy));
@@ -1381,7 +1381,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
       const int e_min_xy = -(s->post1 + s->pre2), e_cnt_xy = s->l1 + s->l2 - 1;
       bool swap = s->c2 <= 8 && s->c1 > 8;
       for (const LagSeg& sg : sxy) if (sg.u_begin != 0) swap = false;
-      static const bool no_swap = getenv("TD_GXY_DIRECT") != nullptr;      // development: A/B runs
+      static const bool no_swap = td_dev_env("TD_GXY_DIRECT") != nullptr;      // development: A/B runs
       if (swap && !no_swap) {
         const int e_max_xy = e_min_xy + e_cnt_xy - 1;
         std::vector<LagSeg> sw(sxy.size());
@@ -1444,7 +1444,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
     // general float32 matrix kernel on [y | 1] padded to 128 rows -- 3.4 ms per 1e6 samples for
     // 8 features x 32 lags against 64 targets, 1.3 ms for 64 channels against 8 targets -- and a
     // column sum that read the targets once per column.)
-    static const bool wide_general = getenv("TD_TARGETS_GENERAL") != nullptr;   // development: A/B runs
+    static const bool wide_general = td_dev_env("TD_TARGETS_GENERAL") != nullptr;   // development: A/B runs
     bool wide_done = false;
     if (s->d > 4 && !wide_general) {
       bool from_start = true;

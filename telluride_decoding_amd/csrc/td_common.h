@@ -13,6 +13,17 @@
 
 #include "td_hotpath.h"
 
+// Development switches (A/B runs of kernels inside one process tree, ablations) are read from the
+// environment ONLY in a -DTD_DEV_SWITCHES build (tools/build_variant.sh); the shipped library reads
+// TD_RCCL_LIB (comm.hip) and nothing else: a stray TD_* variable in a user's environment cannot change
+// which kernel runs.
+#ifdef TD_DEV_SWITCHES
+#include <cstdlib>
+static inline const char* td_dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* td_dev_env(const char*) { return nullptr; }
+#endif
+
 constexpr int kChanShards = 16;
 constexpr int kChanTab = (kChanShards + 1) * 128;     // unsigned per table
 
@@ -81,6 +92,10 @@ struct td_handle {
   unsigned cg_epoch = 0;
   int* cg_status = nullptr;
   int solver_mode = 0;          // TD_SOLVER_AUTO
+  // td_set_option: "cca_whitening" (0 automatic, 1 always the reference's eigen route) and
+  // "cg_limit_ticks" (< 0: the default wait limit of the conjugate-gradient kernel's polls)
+  int cca_whitening = 0;
+  long long cg_limit_ticks = -1;
   int last_solver = 0, last_iterations = 0, last_cg_status = 0;
   // Optional per-kernel hipEvent timing of the dominant kernel (td_profile_*):
   // event pairs recorded on h->stream around every lagcov MFMA launch.
@@ -122,9 +137,12 @@ int td_scratch(td_handle* h, size_t bytes, void** out);
 
 // cg.hip: rows per workgroup of the LDS-resident conjugate-gradient solve (0: does not fit), and the solve itself
 int td_cg_rows(int k, int cus);
+// (accept: the true residual the answer is accepted with, as a factor on tol^2.  Returns
+// TD_CG_NOT_RESIDENT -- nothing queued -- when the grid's workgroups cannot all be resident at once.)
+constexpr int TD_CG_NOT_RESIDENT = 1;
 int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const double* xty, int d, double inv,
                       const double* lams_dev, int n_lambda, int cus, int max_iter, double tol, float* w_dev,
-                      float* b_dev, int* status_dev);
+                      float* b_dev, int* status_dev, double accept = 100.0);
 
 // Solver workspace: like td_scratch, a separate arena.
 int td_workspace(td_handle* h, size_t bytes, void** out);

@@ -76,6 +76,10 @@ class Handle(object):
     gradients first), 'cholesky' or 'cg': td_set_solver."""
     self.check(self.lib.td_set_solver(self.ptr, self.SOLVERS[mode]))
 
+  def set_option(self, name, value):
+    """td_set_option: 'cca_whitening' (0 automatic / 1 eigen route), 'cg_limit_ticks' (< 0 default)."""
+    self.check(self.lib.td_set_option(self.ptr, name.encode(), int(value)))
+
   def last_solve_info(self):
     """What the last synchronous ridge solve on this handle did: {'solver': 'cholesky' | 'cg',
     'iterations': n, 'cg_status': 0 converged / 2 not converged / 3 aborted} (td_last_solve_info)."""

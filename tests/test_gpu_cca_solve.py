@@ -216,9 +216,9 @@ def test_cca_solve_matches_float64_lapack(dev, c1, l1, c2, l2, n, reg):
   np.testing.assert_allclose(my.cpu().numpy(), sy, atol=1e-6)
 
 
-def test_cholesky_and_eigen_whitening_agree(dev, monkeypatch):
+def test_cholesky_and_eigen_whitening_agree(dev):
   """With reg > 0 nothing can be filtered and td_cca_solve whitens the x side with its Cholesky
-  factor (no Jacobi sweeps on cov_xx); TD_CCA_EIG forces the reference's eigen route: same
+  factor (no Jacobi sweeps on cov_xx); td_set_option('cca_whitening', 1) forces the reference's eigen route: same
   canonical correlations and rotations.  With reg = 0 the shortcut is taken only with a proof that
   nothing would be filtered."""
   rng = np.random.default_rng(77)
@@ -232,10 +232,12 @@ def test_cholesky_and_eigen_whitening_agree(dev, monkeypatch):
   dim = 4
   ra, rb, _, _, e, sweeps = st.cca_solve(n - 1, 0.05, dim)
   assert sweeps[0] == 0, 'the Cholesky route was not taken'
-  monkeypatch.setenv('TD_CCA_EIG', '1')
-  ra2, rb2, _, _, e2, sweeps2 = st.cca_solve(n - 1, 0.05, dim)
-  assert sweeps2[0] > 0, 'TD_CCA_EIG did not force the eigen route'
-  monkeypatch.delenv('TD_CCA_EIG')
+  h.set_option('cca_whitening', 1)
+  try:
+    ra2, rb2, _, _, e2, sweeps2 = st.cca_solve(n - 1, 0.05, dim)
+  finally:
+    h.set_option('cca_whitening', 0)
+  assert sweeps2[0] > 0, 'td_set_option(cca_whitening, 1) did not force the eigen route'
   np.testing.assert_allclose(e.cpu().numpy(), e2.cpu().numpy(), rtol=1e-6)
   a, b = _aligned(ra.cpu().numpy().astype(np.float64), rb.cpu().numpy().astype(np.float64),
                   ra2.cpu().numpy().astype(np.float64), rb2.cpu().numpy().astype(np.float64))
@@ -247,9 +249,11 @@ def test_cholesky_and_eigen_whitening_agree(dev, monkeypatch):
   # sweeps on cov_xx, same answer as the eigen route ...
   ra0, rb0, _, _, e0, sweeps0 = st.cca_solve(n - 1, 0.0, dim)
   assert st.last_cca_route == 'cholesky' and sweeps0[0] == 0
-  monkeypatch.setenv('TD_CCA_EIG', '1')
-  ra1, rb1, _, _, e1, _ = st.cca_solve(n - 1, 0.0, dim)
-  monkeypatch.delenv('TD_CCA_EIG')
+  h.set_option('cca_whitening', 1)
+  try:
+    ra1, rb1, _, _, e1, _ = st.cca_solve(n - 1, 0.0, dim)
+  finally:
+    h.set_option('cca_whitening', 0)
   np.testing.assert_allclose(e0.cpu().numpy(), e1.cpu().numpy(), rtol=1e-6)
   a, b = _aligned(ra0.cpu().numpy().astype(np.float64), rb0.cpu().numpy().astype(np.float64),
                   ra1.cpu().numpy().astype(np.float64), rb1.cpu().numpy().astype(np.float64))
