@@ -43,3 +43,17 @@ def evaluate_mean_over_batches(metric, pred_batches, true_batches):
   (TensorFlow semantics, not in the reference tree; SURVEY.md 8c iii)."""
   vals = [metric(t, p) for p, t in zip(pred_batches, true_batches)]
   return float(np.mean(vals))
+
+
+def pearson_correlation_loss(x, y):
+  """brain_model.PearsonCorrelationLoss.call (reference brain_model.py:104-126): the per-frame
+  NEGATIVE correlation contributions, summed over the columns -- their sum over the frames is minus
+  the sum of the columns' Pearson correlations."""
+  x, y = np.asarray(x), np.asarray(y)
+  if x.shape != y.shape:
+    raise ValueError('Two correlation arrays must have the same size, not '
+                     ' %s vs %s.' % ((x.shape, y.shape)))
+  x_m = x - np.mean(x, axis=0)
+  y_m = y - np.mean(y, axis=0)
+  power = np.sqrt(np.sum(np.square(x_m), axis=0) * np.sum(np.square(y_m), axis=0))
+  return -np.sum(x_m * y_m / power, axis=-1)

@@ -62,6 +62,31 @@ def pearson_correlation_second(x, y):
   return pearson_correlation(x, y)[1]
 
 
+class PearsonCorrelationLoss(object):
+  """The Pearson correlation as a per-frame loss (reference brain_model.py:94-126): `call(x, y)`
+  returns one NEGATIVE correlation contribution per frame, summed over the columns; their sum over
+  the frames is minus the sum of the columns' correlations.  (The reference subclasses
+  tf.keras.losses.Loss; there is no Keras here, the arithmetic is the class.)  Column means and
+  powers are the five float64 window sums of the HIP window-sums kernel over the whole block, the
+  per-frame products td_frame_scores."""
+
+  def call(self, x, y):
+    h = device.default_handle()
+    if tuple(np.shape(x)) != tuple(np.shape(y)):
+      raise ValueError('Two correlation arrays must have the same size, not '
+                       ' %s vs %s.' % ((tuple(np.shape(x)), tuple(np.shape(y)))))
+    xd, yd = _as_2d_device(h, x), _as_2d_device(h, y)
+    rows, cols = int(xd.shape[0]), int(xd.shape[1])
+    s = device.window_sums(xd, yd, [0, rows], rows, rows, handle=h).cpu().numpy()[0]   # [cols, 5]
+    mean_x, mean_y = s[:, 0] / rows, s[:, 1] / rows
+    power = np.sqrt((s[:, 2] - s[:, 0] ** 2 / rows) * (s[:, 3] - s[:, 1] ** 2 / rows))
+    per_frame = device.frame_scores(xd, yd, 'mean', mean_x, mean_y, power, handle=h).cpu().numpy()
+    out = -cols * per_frame
+    return out.astype(np.float32 if str(xd.dtype) == 'torch.float32' else np.float64)
+
+  __call__ = call
+
+
 def _dataset_stats(dataset, want_y=True, want_x2=False, handle=None):
   """LagStats of a Dataset via the raw-array fast path."""
   h = handle or device.default_handle()

@@ -76,6 +76,22 @@ def _window_results(decoded, window_size):
   return [float(v) for v in full_results], [float(v) for v in label_means]
 
 
+def calculate_time_axis(data, window_step, window_width, frame_rate):
+  """Time (in minutes) of the CENTRE of every analysis window of a windowed signal (reference
+  infer.py:173-199): `data` is the number of windows, or a list / array with one entry (row) per
+  window."""
+  import numbers
+  if isinstance(data, numbers.Number):
+    num_points = int(data)
+  elif isinstance(data, list):
+    num_points = len(data)
+  elif isinstance(data, np.ndarray):
+    num_points = data.shape[0]
+  else:
+    raise TypeError('Unknown type passed as input argument.')
+  return (np.arange(num_points) * window_step + window_width / 2.0) / frame_rate / 60.0
+
+
 def find_first_segment(labels):
   """Index of the first window whose label differs from the first one's -- the end of the stretch
   the state-space decoder's priors are tuned on -- or 0 when the label never changes

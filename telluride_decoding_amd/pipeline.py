@@ -36,6 +36,13 @@ class _MaskedStreams(object):
       pass
 
 
+class _Done(object):
+  """An event that has already been waited for."""
+
+  def synchronize(self):
+    pass
+
+
 class FitPipeline(object):
   """submit() queues one fit and returns the solution of an earlier one (None while the
   pipeline fills).
@@ -227,11 +234,24 @@ class FitPipeline(object):
         self.h_full = device.Handle()
     with torch.cuda.stream(self.s_full):
       self.s_full.wait_event(self.ev_acc[buf])
-      w, b = self.stats[buf].ridge_solve(lambdas, handle=self.h_full)     # (synchronises s_full)
+      # the persistent conjugate-gradient grid needs every CU: it starts exchanging only when the
+      # chains still queued on the 64-CU solve streams have drained -- wait for them on the device,
+      # in front of the launch, not inside its spin loops (where a loaded device meets the abort clock)
+      for ev_prev in self.ev_solved:
+        if ev_prev is not None:
+          self.s_full.wait_event(ev_prev)
+      try:
+        w, b = self.stats[buf].ridge_solve(lambdas, handle=self.h_full)     # (synchronises s_full)
+        flag = (lambda: 0)
+      except np.linalg.LinAlgError:
+        # a singular LAST fit is reported in order, like the asynchronous ones: through its flag when the
+        # result is popped -- the earlier fits' solutions are handed out first
+        w = b = None
+        flag = (lambda: 1)
       ev = torch.cuda.Event()
       ev.record(self.s_full)
       self.ev_solved[buf] = ev
-    self._results.append((w, b, (lambda: 0), ev))
+    self._results.append((w, b, flag, ev))
 
   def flush(self):
     """Solves the last submitted fit and returns every solution not yet handed out (a list,
@@ -239,14 +259,21 @@ class FitPipeline(object):
     if self.pending is not None:
       plain = (self.allreduce is None and self.solves is None and not self.targets_on_solve and
                self.latency_flush)
+      pending, self.pending = self.pending, None      # (cleared first: a failing solve is not retried by the next flush)
       if plain:
-        self._solve_last(*self.pending)
+        self._solve_last(*pending)
       else:
-        self._solve(*self.pending)
-      self.pending = None
+        self._solve(*pending)
     out = []
-    while self._results:
-      out.append(self._pop())
+    try:
+      while self._results:
+        out.append(self._pop())
+    except np.linalg.LinAlgError:
+      # the singular fit is consumed by its report; the solutions popped before it go back to the
+      # front of the queue (already waited for): the next flush() hands them and the later ones out
+      done = [(r[0], r[1], (lambda: 0), _Done()) if r is not None else (None, None, None, _Done()) for r in out]
+      self._results[:0] = done
+      raise
     return out
 
   def __del__(self):

@@ -576,6 +576,26 @@ def g11_decode_harness():
 
 
 # ----------------------------------------------------------------- G12 BASELINE config C1 exactly
+def g13_loss_and_time_axis():
+  """brain_model.PearsonCorrelationLoss (brain_model.py:94-126) on the 6-point known answer of
+  test/brain_model_test.py:1083-1090 (sum -0.5298) and on a seeded [frames, dims] block, and
+  infer.calculate_time_axis (infer.py:173-199) for a count, a list and an array
+  (test/infer_test.py:46-53)."""
+  from telluride_decoding import infer as ref_infer
+  kat = np.array([[1, 43, 99], [2, 21, 65], [3, 25, 79], [4, 42, 75],
+                  [5, 57, 87], [6, 59, 81]], dtype=np.float32)
+  pcl = ref_bm.PearsonCorrelationLoss()
+  loss_kat = np.asarray(pcl.call(kat[:, 1:2], kat[:, 2:3]))
+  rng = np.random.default_rng(13)
+  x = rng.standard_normal((300, 3)).astype(np.float32)
+  y = (0.4 * x + rng.standard_normal((300, 3))).astype(np.float32)
+  loss = np.asarray(pcl.call(x, y))
+  save('g13_loss_time_axis', kat=kat, loss_kat=loss_kat, x=x, y=y, loss=loss,
+       axis_count=ref_infer.calculate_time_axis(7, 50, 100, 100.0),
+       axis_list=ref_infer.calculate_time_axis([0.0] * 4, 500, 1000, 100.0),
+       axis_array=ref_infer.calculate_time_axis(np.zeros((5, 2)), 1, 2, 1))
+
+
 def g12_c1_10k():
   """BASELINE.json configs[0] as stated: ONE 16-channel x 10 000-sample recording -> 1-channel
   envelope, batch 100, lambda = 0.1 (regression_test.py-sized), without lags and with 4 lags."""
@@ -607,3 +627,4 @@ if __name__ == '__main__':
   g10_decoder_train()
   g11_decode_harness()
   g12_c1_10k()
+  g13_loss_and_time_axis()

@@ -618,6 +618,24 @@ def test_pearson_functions(dev):
     cca.cca_pearson_correlation(None, yy[:, :7])
 
 
+def test_pearson_correlation_loss(dev):
+  """brain_model.PearsonCorrelationLoss (reference brain_model.py:94-126): the per-frame
+  negative correlations of the reference's own code (golden G13, generate_golden.py) -- the six-point
+  known answer of test/brain_model_test.py:1083-1090 (sum -0.5298) and a seeded [300, 3] block -- from the
+  window-sums and frame-scores kernels; a shape mismatch is the reference's ValueError."""
+  from telluride_decoding_amd import brain_model
+  g = golden('g13_loss_time_axis')
+  pcl = brain_model.PearsonCorrelationLoss()
+  got = pcl.call(g['kat'][:, 1:2], g['kat'][:, 2:3])
+  np.testing.assert_allclose(got, g['loss_kat'], rtol=2e-5, atol=2e-7)
+  assert abs(float(np.sum(got)) + 0.5298) < 1e-4
+  got = pcl(g['x'], g['y'])
+  assert got.shape == g['loss'].shape and got.dtype == np.float32
+  np.testing.assert_allclose(got, g['loss'], rtol=2e-5, atol=2e-6)
+  with pytest.raises(ValueError, match='must have the same size'):
+    pcl.call(g['x'], g['y'][:, :2])
+
+
 def _aligned(a, ref):
   """Fix the per-component sign ambiguity of CCA rotations."""
   sign = np.sign(np.sum(a * ref, axis=0))

@@ -497,6 +497,16 @@ def test_pipelined_fits_equal_serial_fits(dev):
     assert len(rest) == streams + 1
     for k in range(streams + 1):
       np.testing.assert_array_equal(rest[k][0].cpu().numpy(), want[k][0])
+    # a singular LAST fit (solved synchronously by flush's latency solver) is reported in order too:
+    # the earlier fits' solutions are not lost, and a second flush does not solve it again
+    assert pipe.submit(data[0][0], data[0][1], offs, [0.1, 1.0]) is None
+    assert pipe.submit(zx, zy, offs, [0.0]) is None
+    with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
+      pipe.flush()
+    assert pipe.pending is None
+    kept = pipe.flush()
+    assert len(kept) == 1 and pipe.flush() == []
+    np.testing.assert_array_equal(kept[0][0].cpu().numpy(), want[0][0])
     del pipe
   # both placements of the y^T x part: on the solve stream (default) and on the accumulate stream
   for on_solve in (True, False):
