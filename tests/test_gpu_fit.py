@@ -634,6 +634,87 @@ def test_c3_full_size_cca_moments(dev):
   assert float((m['xtx'][64, :64] - xd.sum(0)).abs().max()) < 5e-6 * n ** 0.5
 
 
+def test_c3_full_size_fit_and_transform_vs_oracle(dev):
+  """BASELINE config C3 END TO END at full size (only its moments were tested, the dense
+  stage and the transform at 1e6 ran in bench.py alone): 64-ch EEG against an 8-band envelope, 1e6
+  frames in minibatches of 1000, reg = 0.1, 5 components -- cca.BrainModelCCA.fit (one-pass Gram
+  kernel + td_cca_solve) and .predict (cca_project_stream_kernel) against the reference's procedure
+  in float64 (oracle/cca.py: per-minibatch moments, eig, whitening, svd; cca.py:272-369): canonical
+  correlations, rotations up to the joint sign of a component, and a seeded sample of 10 000 rows of the
+  transform (cca.py:157-161)."""
+  from oracle import cca as o_cca
+  from telluride_decoding_amd import brain_data, cca
+  rng = np.random.default_rng(33)
+  n, c1, c2, dim, batch = 1000000, 64, 8, 5, 1000
+  src = rng.standard_normal((n, c2)).astype(np.float32)
+  mix = (rng.standard_normal((c2, c1)) * np.linspace(1.0, 0.1, c2)[:, None]).astype(np.float32)
+  x = (src @ mix + rng.standard_normal((n, c1)).astype(np.float32)).astype(np.float32)
+  x2 = (src + 0.5 * rng.standard_normal((n, c2)).astype(np.float32)).astype(np.float32) + 3.0
+  bd = brain_data.TestBrainData('input_1', 'input_2', 100.0, final_batch_size=batch)
+  bd.preserve_test_data(x, np.ones((n, 1), np.float32), x2)
+  ds = bd.create_dataset('program_test', temporal_context=False)
+  model = cca.BrainModelCCA(ds, cca_dims=dim, regularization_lambda=0.1)
+  assert model.fit(ds) == {}
+  x64, y64 = x.astype(np.float64), x2.astype(np.float64)
+  batches = (({'input_1': x64[s:s + batch], 'input_2': y64[s:s + batch]}, None) for s in range(0, n, batch))
+  ra, rb, mx, my, e = o_cca.cca_parameters_from_batches(batches, dim, regularization=0.1, mini_batch_count=0)
+  np.testing.assert_allclose(model.eigenvalues, e, rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(model.mean_x, mx, atol=2e-6)
+  np.testing.assert_allclose(model.mean_y, my, atol=2e-6)
+  sign = np.sign(np.sum(np.asarray(model.rot_x, np.float64) * ra, axis=0))
+  assert np.all(sign != 0)
+  # (a canonical DIRECTION moves by (moment rounding) / (gap to the neighbouring canonical correlations):
+  # the last components here are 0.02 apart, so the float32-product moments' 1e-7 shows as ~2e-5 in
+  # them -- the reference's own float32 accumulation as much; 1e-4 of the largest entry)
+  np.testing.assert_allclose(np.asarray(model.rot_x) * sign, ra, atol=1e-4 * np.max(np.abs(ra)))
+  np.testing.assert_allclose(np.asarray(model.rot_y) * sign, rb, atol=1e-4 * np.max(np.abs(rb)))
+  out = model.predict(ds)
+  assert out.shape == (n, 2 * dim)
+  rows = np.sort(rng.choice(n, 10000, replace=False))
+  # the transform kernel against float64 with the rotations the fit returned (isolates the kernel) ...
+  same = o_cca.cca_transform(x64[rows], y64[rows], model.mean_x, model.mean_y,
+                             np.asarray(model.rot_x, np.float64), np.asarray(model.rot_y, np.float64))
+  assert float(np.max(np.abs(out[rows] - same)) / np.max(np.abs(same))) < 2e-6
+  # ... and end to end against the oracle's own rotations
+  want = o_cca.cca_transform(x64[rows], y64[rows], mx, my, ra, rb)
+  got = out[rows].astype(np.float64) * np.concatenate((sign, sign))
+  err = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+  parity_log.record('c3_full_fit_transform', e_rel=float(np.max(np.abs(model.eigenvalues - e) / e)), transform_rel=err)
+  assert err < 1e-4
+
+
+def test_c5_full_subjects_sampled_folds_vs_oracle_refit(dev):
+  """BASELINE config C5 with all 32 subjects and all 20 lambdas on a 20 000-frame slice of every
+  subject (at full size the sweep was only compared with itself -- PCG against the direct
+  solves; the oracle comparison was 5 files x 1 200 frames): three sampled (held-out subject, lambda)
+  pairs refit FROM SCRATCH by the reference's procedure in float64 (oracle: lag matrix of the 31
+  training subjects in minibatches of 1000, x^T x per minibatch, np.linalg.solve; held-out
+  pearson_correlation_first per minibatch, Keras mean; regression.py:151-242, brain_model.py:422-481)
+  against the sweep's entries."""
+  from oracle import pearson as o_pear
+  from telluride_decoding_amd import brain_data, regression, synth
+  n_subj, n, c, pre, post, batch = 32, 20000, 64, 0, 31, 1000
+  trials = synth.make_trials(9, n_subj, n, c)
+  files = [(eeg, env, env[:, 0:1].astype(np.float32), att) for eeg, env, att in trials]
+  ds = brain_data.Dataset(files, batch, pre_context=pre, post_context=post)
+  lams = list(np.logspace(-6, 3, 20))
+  got = regression.jackknife_over_regularizations(ds, lams)
+  assert got['all_runs'].shape == (20, n_subj) and np.all(np.isfinite(got['all_runs']))
+  f64 = [tuple(a.astype(np.float64) for a in f) for f in files]
+  worst = 0.0
+  for fold, li in ((0, 12), (17, 7), (31, 18)):            # lambda = 0.48, 2e-3, 336
+    train = [f64[g] for g in range(n_subj) if g != fold]
+    w, b, _, _, _ = o_reg.linear_regressor_from_batches(
+        o_lag.minibatches(train, batch, pre=pre, post=post), lamb=lams[li])
+    test_b = list(o_lag.minibatches([f64[fold]], batch, pre=pre, post=post))
+    preds = [o_reg.dense_forward(bx['input_1'], w, b) for bx, _ in test_b]
+    want = o_pear.evaluate_mean_over_batches(o_pear.pearson_correlation_first, preds, [by for _, by in test_b])
+    err = abs(float(got['all_runs'][li, fold]) - float(want))
+    worst = max(worst, err)
+    assert err < 2e-5, (fold, lams[li], float(got['all_runs'][li, fold]), float(want))
+  parity_log.record('c5_32_subjects_sampled_refits', max_abs_r_err=worst, pairs=3)
+
+
 def test_loso_lambda_sweep_matches_refit_from_scratch(dev):
   """Row A10 (config C5's shape, small): regression.jackknife_over_regularizations -- one
   accumulate per file, fold = sum of the others, all lambdas in one batched solve -- against the
