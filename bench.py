@@ -154,12 +154,14 @@ def _decode_cpu_rate(trials, wn, bn, corr, dtype):
 
 def _pmc_bytes(kernel_key):
   """HBM bytes per launch of one kernel from this round's PMC pass (profiles/), or None."""
-  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_lagcov_pmc.json')
-  try:
-    with open(path) as f:
-      return json.load(f).get(kernel_key, {}).get('hbm_bytes_per_launch')
-  except (OSError, ValueError):
-    return None
+  for name in ('r05_lagcov_pmc.json', 'r04_lagcov_pmc.json'):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', name)
+    try:
+      with open(path) as f:
+        return json.load(f).get(kernel_key, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+      continue
+  return None
 
 
 def decode_leg(h, device, iters=200):
@@ -209,13 +211,15 @@ def decode_leg(h, device, iters=200):
         loops.append(t)
         best = t if best is None or t < best else best
       timed.loops = loops
-      return best, out
+      timed.best = best
+      return float(np.median(loops)), out
     finally:
       gc.enable()
 
   ms, (scores, dec) = timed(1000, 100, False)
   ms_rot, (scores_r, dec_r) = timed(1000, 100, True)
   loops_rot = list(timed.loops)
+  best_rot = timed.best
   assert bool((dec == dec_r).all())
 
   def two_streams():
@@ -308,14 +312,15 @@ def decode_leg(h, device, iters=200):
   return {
       'workload': 'C4: 200 distinct trials x 60 s x 64 ch, two envelopes, W=1000/hop=100 (10 s / 1 s)',
       'windows': n_win, 'ms': ms_rot, 'windows_per_s': n_win / ms_rot * 1e3, 'loops_ms': loops_rot,
-      'timing': ('hipEvents around %d back-to-back td_decode_fused calls (best of three such loops) ROTATING over three copies of the '
+      'best_loop_ms': best_rot, 'best_loop_windows_per_s': n_win / best_rot * 1e3,
+      'timing': ('hipEvents around %d back-to-back td_decode_fused calls (MEDIAN of three such loops; the best beside it) ROTATING over three copies of the '
                  'input at different addresses (951 MB > the 256 MiB Infinity Cache); `replayed` = the '
                  'same call on one copy back to back' % iters),
       'algorithmic_bytes': int(n) * 4 * (C + 2), 'hbm_gbps_algorithmic': gbps_rot,
       'roofline': {'bound': 'hbm', 'achieved': gbps_rot, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                    'frac': gbps_rot / PEAK_HBM_GBPS, 'inputs': 'rotated',
                    'traffic_fir_kernel': _pmc_bytes('fir_stream_kernel'),
-                   'traffic_source': 'profiles/r04_lagcov_pmc.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE '
+                   'traffic_source': 'profiles/r05_lagcov_pmc.json or r04 (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE '
                                      'of fir_stream_kernel, a separate run; the per-trial tail reads 14 MB more)'},
       'replayed': {'ms': ms, 'windows_per_s': n_win / ms * 1e3, 'hbm_gbps_algorithmic': gbps,
                    'frac': gbps / PEAK_HBM_GBPS},
@@ -1139,13 +1144,16 @@ def main():
     avg_s = kernel_ms / max(launches, 1) / 1e3
     achieved = flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
     traffic, traffic_source = None, None
-    for name in ('r04_lagcov_pmc.json', 'r03_lagcov_pmc.json'):
+    for name in ('r05_lagcov_pmc.json', 'r04_lagcov_pmc.json', 'r03_lagcov_pmc.json'):
       pmc = os.path.join(ROOT, 'profiles', name)
       if os.path.exists(pmc) and args.scaling == 'weak':
         with open(pmc) as f:
           traffic = json.load(f).get('hbm_bytes_per_launch')
-        traffic_source = ('profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over the same '
-                          'kernel and launch shape (a separate run; not measured in this one)' % name)
+        traffic_source = ('profiles/%s: rocprofv3 --pmc FETCH_SIZE (x 2, the gfx950 correction) + WRITE_SIZE of a '
+                          'SEPARATE run over the same kernel and launch shape -- a constant in this line, not a '
+                          'measurement of this run; the counters under-count (below the 256 MB the kernel must '
+                          'read + its partial slabs).  Per fit x is read TWICE: by the targets pass (HBM-bound) and '
+                          'by this kernel (MFMA-bound)' % name)
         break
     line = {
         'metric': 'TRF-fit samples/sec', 'value': value, 'unit': 'samples/s',
@@ -1282,6 +1290,17 @@ def main():
     line['f32_mode'] = {'samples_per_s': samples_per_step * 20 / e_f, 'ms_per_step': e_f / 20 * 1e3,
                         'what': 'the same pipelined fit with td_set_accumulate_mode(TD_ACC_F32): every product '
                                 'on v_mfma_f32_32x32x2_f32 (20 steps)'}
+    # ... and with the three-piece bfloat16 split (six products, each float32 product exact to 2^-27:
+    # not narrower than float32 arithmetic)
+    run_b, hp_b, pipe_b = make_runner(shard, reduce_fn, solves, False)
+    hp_b.set_accumulate_mode('bf16x3')
+    e_b, _ = time_region(run_b, 20, 3)
+    hp_b.set_accumulate_mode('f16x2')
+    del pipe_b, run_b
+    torch.cuda.synchronize()
+    line['bf16x3_mode'] = {'samples_per_s': samples_per_step * 20 / e_b, 'ms_per_step': e_b / 20 * 1e3,
+                           'what': 'the same pipelined fit with td_set_accumulate_mode(TD_ACC_BF16X3): every float32 '
+                                   'product as six bfloat16 products, exact to 2^-27 (20 steps)'}
   if rank == 0:
     line['collective'] = (dict(distributed.LAST_COLLECTIVE) if distributed.LAST_COLLECTIVE else
                           {'route': 'none (one rank, no exchange)', 'ranks': 1})

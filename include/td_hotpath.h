@@ -273,6 +273,10 @@ int td_set_solver(td_handle* h, int mode);
  *   "cg_limit_ticks"  the conjugate-gradient kernel's wait limit per launch in 10 ns ticks (< 0: the
  *                     default, 20 ms; 0: every workgroup gives up at its first empty poll -- the abort /
  *                     drain / Cholesky-fallback route, for tests).
+ *   "async_cg"        1: td_ridge_solve_async may solve by conjugate gradients on the compact statistics
+ *                     (one launch of one workgroup per channel: fits a 64-CU partition); its flag is
+ *                     then 2 when the solver gave up -- the caller solves again (td_ridge_solve) -- as
+ *                     well as 0 / 1.  0 (default): the factorisation, flags 0 / 1 only.
  * Unknown names are TD_ERR_INVALID. */
 int td_set_option(td_handle* h, const char* name, int64_t value);
 int td_last_solve_info(td_handle* h, int* solver, int* iterations, int* cg_status);
@@ -280,7 +284,8 @@ int td_last_solve_info(td_handle* h, int* solver, int* iterations, int* cg_statu
  * owned by the handle (a ring of 8: read it before the 8th later call; a call that would reuse a
  * slot whose solve has not finished yet -- more than 8 solves outstanding, nobody can have read
  * that flag -- returns TD_ERR_STATE instead of overwriting it) that becomes 0, or 1 if
- * some cov_x was not positive definite (w_dev / b_dev are then meaningless), once the work queued
+ * some cov_x was not positive definite (w_dev / b_dev are then meaningless), or -- only with
+ * td_set_option(h, "async_cg", 1) -- 2 if the conjugate-gradient solver gave up, once the work queued
  * by this call has completed -- wait for an event recorded after the call, then read it.  For
  * callers that pipeline fits: a host that waits for every solve cannot queue the next fit's
  * work in time (pipeline.FitPipeline). */

@@ -431,6 +431,355 @@ int launch_cg(td_handle* h, const CgParams& p, int wgs, size_t lds_bytes, int cu
   return TD_OK;
 }
 
+
+// ---- conjugate gradients on the COMPACT statistics (round 5) --------------------------------------
+// The resident kernel above needs the LDS of the whole chip (33 MB at C2), so the solves of a pipelined
+// fit -- which run on a 64-CU partition beside the next accumulate -- stayed with the ~100-launch
+// Cholesky chain.  But the moment matrix of files that were summed whole is block-Toeplitz up to their
+// HEAD windows (stats.hip):
+//   M[(a,i),(b,j)] = G[b - a][i][j] - sum_files sum_{s < a} x_f[s][i] x~_f[s + b - a][j]        (pre = 0)
+// with G[e] = fxx[e] (e >= 0), fxx[-e]^T (e < 0), so a product M p needs 0.5 MB of statistics instead of
+// the 33 MB matrix:
+//   (T p)[(a,i)] = sum_{b,j} G[b - a][i][j] p[(b,j)]
+//   (E p)[(a,i)] = - sum_f sum_{s<a} x_f[s][i] q_f[s - a],   q_f[m] = sum_{b,j} x~_f[m + b][j] p[(b,j)]
+// ONE workgroup per CHANNEL i (64 at C2: the solve partition's 64 CUs) owns the rows (a, i), a = 0..L-1:
+// wave w the rows 4w..4w+3, lane j the columns (., j) -- the 35 values G[e][i][j] a lane needs live in
+// its registers for the whole solve, the multiplied vector is read from an LDS copy: no matrix traffic at
+// all.  The q_f[m] (files x post numbers: "predictions" at the virtual rows in front of a recording) are
+// dealt to the waves of the grid (their window rows in registers too), published and polled like the rows
+// of the product: TWO exchanges per iteration, the T part computed while the first is in flight.
+// Everything else -- Chronopoulos-Gear recurrences, the bias unknown eliminated, the true-residual check,
+// the abort clock -- is the resident kernel's.  An extra exchange in front of the first system sums the
+// trace: a lambda below 1e-6 trace(cov) is not attempted (status 4; the promise of the automatic route).
+constexpr int kCgtMaxQ = 512;           // q numbers (files x post) at most: one per wave of the 64 workgroups
+constexpr int kCgtRowPackets = 2 * kCgThreads * kCgMaxCols;   // per buffer
+
+struct CgtParams {
+  const double* fxx;      // [L][C][C] sums
+  const double* gxo;      // [L][d + 1][C] sums
+  const double* sy;       // [d]
+  const float* win;       // [F][2][2 hw][C]
+  const double* lams;
+  unsigned long long* packets;   // rows [2][2048][2] | q [2][kCgtMaxQ][2] | trace [64][2]
+  unsigned* abort_word;
+  float* w;
+  float* bias;
+  int* status;
+  int* flag;              // may be null: 0 converged / 2 gave up
+  double inv, tol2, accept;
+  int C, L, d, n_lambda, k, hw, n_files, nq, max_iter, gate;
+  unsigned epoch;
+  long long limit_ticks;
+};
+
+// spins until the packet carries `round` (value in v); false = gave up (abort word / clock)
+__device__ __forceinline__ bool cgt_wait(const unsigned long long* pk, unsigned round, double& v,
+                                         unsigned* abort_word, unsigned abort_id, long long limit_ticks,
+                                         long long t_wait) {
+  int polls = 0;
+  while (!ll_try(pk, round, v)) {
+    if ((++polls & 15) == 0 || limit_ticks < 16) {
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_id) return false;
+      if (wall_clock64() - t_wait > limit_ticks) {
+        __hip_atomic_store(abort_word, abort_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
+  __shared__ __attribute__((aligned(16))) double vec[kCgThreads * kCgMaxCols];   // the multiplied vector
+  __shared__ double gi[66 * 64];           // my channel's rows of the block-Toeplitz part
+  __shared__ double qv[kCgtMaxQ];          // the q numbers of this iteration
+  __shared__ double wi[kCgtMaxQ];          // - x_f[s][i] / n: my channel's column of the head windows
+  __shared__ double rowsum[32], part_a[kCgWaves], part_b[4 * kCgWaves], trs[64];
+  __shared__ int s_abort;
+  const int C = P.C, L = P.L, k = P.k, post = L - 1, nq = P.nq, D1 = P.d + 1;
+  const int t = threadIdx.x, lane = t & 63, i = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double inv = P.inv;
+  const unsigned abort_id = P.epoch + 1u;
+  unsigned long long* const row_pk = P.packets;
+  unsigned long long* const q_pk = P.packets + 2 * 2 * kCgtRowPackets;
+  unsigned long long* const tr_pk = q_pk + 2 * 2 * kCgtMaxQ;
+  if (t == 0) s_abort = 0;
+
+  // -- the lagged covariances against my channel, gi[(e + L + 2) * 64 + j] = G[e][i][j] / n for
+  // e = -(L - 1) - 3 .. L - 1 (three rows of zeros in front: the sliding window below starts there)
+  for (int idx = t; idx < (2 * L + 2) * 64; idx += kCgThreads) {
+    const int e = idx / 64 - L - 2, j = idx % 64;
+    const int ae = e < 0 ? -e : e;
+    double v = 0.0;
+    if (j < C && ae < L)
+      v = (e >= 0 ? P.fxx[((size_t)ae * C + i) * C + j] : P.fxx[((size_t)ae * C + j) * C + i]) * inv;
+    gi[idx] = v;
+  }
+  // -- the window rows of the (at most two) q numbers this wave computes: q index = f post + mi,
+  // q_f[mi - post] = sum_b sum_j x~_f[mi - post + b][j] p[(b, j)] over the rows of the recording (>= 0)
+  const int gw = i * kCgWaves + wave;
+  float wreg[32];
+  {
+    const int qi = gw;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+      float v = 0.f;
+      if (qi < nq && b < L && lane < C) {
+        // x~_f[m + b], m = mi - post: head-window row m + b + hw, a row of the recording when m + b >= 0
+        const int f = qi / post, mi = qi % post, u = mi - post + b;
+        if (u >= 0) v = P.win[(((size_t)f * 2) * 2 * P.hw + (u + P.hw)) * C + lane];
+      }
+      wreg[b] = v;
+    }
+  }
+  for (int q = t; q < nq; q += kCgThreads) {
+    const int f = q / post, sr = q % post;
+    wi[q] = -(double)P.win[(((size_t)f * 2) * 2 * P.hw + (sr + P.hw)) * C + i] * inv;   // (E is a part of M / n)
+  }
+  // -- the bias column
+  double s_reg[kCgMaxCols];
+#pragma unroll
+  for (int j = 0; j < kCgMaxCols; ++j) {
+    const int c = cg_col(t, j);
+    s_reg[j] = c < k ? P.gxo[((size_t)(c / C) * D1 + P.d) * C + (c % C)] * inv : 0.0;
+  }
+  const double srow_t = t < L ? P.gxo[((size_t)t * D1 + P.d) * C + i] * inv : 0.0;
+  const double a_kk = 1.0;                 // frames / frames
+  unsigned round = P.epoch + 1u;
+  int status = 0, iters_max = 0;
+  bool aborted = false;
+  __syncthreads();
+
+  // -- trace(cov) ~ L sum_i G[0][i][i] / n: one exchange in front of everything
+  double trace = 0.0;
+  if (P.gate) {
+    if (t == 0) ll_store(tr_pk + 2 * i, P.fxx[((size_t)i) * C + i] * inv * L, round);
+    const long long t_wait = wall_clock64();
+    bool ok = true;
+    if (t < C) {
+      double v = 0.0;
+      ok = cgt_wait(tr_pk + 2 * t, round, v, P.abort_word, abort_id, P.limit_ticks, t_wait);
+      trs[t] = v;
+    }
+    if (!ok) s_abort = 1;
+    __syncthreads();
+    if (s_abort) aborted = true;
+    for (int c = 0; c < C; ++c) trace += trs[c];
+  }
+
+  for (int sys = 0; sys < P.n_lambda * P.d && !aborted && status == 0; ++sys) {
+    const int li = sys / P.d, qo = sys % P.d;
+    const double lam = P.lams[li];
+    if (P.gate && !(lam >= 1e-6 * trace)) { status = 4; break; }
+    const double ckk = a_kk + lam;
+    const double inv_ckk = 1.0 / ckk;
+    const double bk = P.sy[qo] * inv;
+    double x[kCgMaxCols], r_[kCgMaxCols], p[kCgMaxCols], v[kCgMaxCols], b[kCgMaxCols], wq[kCgMaxCols];
+#pragma unroll
+    for (int j = 0; j < kCgMaxCols; ++j) {
+      const int c = cg_col(t, j);
+      b[j] = c < k ? P.gxo[((size_t)(c / C) * D1 + qo) * C + (c % C)] * inv - s_reg[j] * (bk * inv_ckk) : 0.0;
+      x[j] = 0.0; r_[j] = b[j]; p[j] = 0.0; v[j] = 0.0; wq[j] = 0.0;
+    }
+    double sdot, bnorm2;
+    {
+      double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) { e0 += s_reg[j] * b[j]; e1 += b[j] * b[j]; }
+      e0 = wave_sum(e0);
+      e1 = wave_sum(e1);
+      if (lane == 0) { part_b[4 * wave] = e0; part_b[4 * wave + 1] = e1; }
+      __syncthreads();
+      sdot = wave_parts(part_b, 4, 0);
+      bnorm2 = wave_parts(part_b, 4, 1);
+      __syncthreads();
+    }
+    double gamma_old = 1.0, denom_old = 1.0, sv = 0.0;
+    int it = 0;
+    bool check_pass = false;
+    const bool done = bnorm2 == 0.0;
+    while (!done) {
+      // -- the multiplied vector (r, or x in the check pass) -> LDS
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        const int c = cg_col(t, j);
+        if (c < k) vec[c] = r_[j];
+      }
+      double sx = 0.0;
+      if (check_pass) {
+#pragma unroll
+        for (int j = 0; j < kCgMaxCols; ++j) sx = fma(s_reg[j], x[j], sx);
+        sx = wave_sum(sx);
+        if (lane == 0) part_a[wave] = sx;
+      } else {
+        ++it;
+      }
+      __syncthreads();
+      if (check_pass) sdot = wave_parts(part_a, 1, 0);
+      ++round;
+      // -- my q numbers: published first, the T part runs while they travel
+      unsigned long long* const qbuf = q_pk + (size_t)(round & 1u) * 2 * kCgtMaxQ;
+      if (gw < nq) {                       // (wave-uniform: one q number per wave of the grid)
+        double a = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < 32; ++bb)
+          if (bb < L) a = fma((double)wreg[bb], lane < C ? vec[bb * C + lane] : 0.0, a);
+        a = wave_sum(a);
+        if (lane == 0) ll_store(qbuf + 2 * gw, a, round);
+      }
+      // -- T part of my rows a = 4 wave + r: lane j multiplies the columns (., j)
+      // (row a = 4 wave + r needs G[l2 - a] against the column block l2: a window of four table rows
+      // that slides by one per block -- one new 8-byte read per lane and block)
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (4 * wave < L) {
+        const double* gp = gi + (size_t)(L + 2 - 4 * wave) * 64 + lane;      // e = -4 wave (l2 = 0, r = 0)
+        double w0 = gp[0], w1 = gp[-64], w2 = gp[-128], w3 = gp[-192];
+        for (int l2 = 0; l2 < L; ++l2) {
+          const double pv = lane < C ? vec[l2 * C + lane] : 0.0;
+          acc[0] = fma(w0, pv, acc[0]);
+          acc[1] = fma(w1, pv, acc[1]);
+          acc[2] = fma(w2, pv, acc[2]);
+          acc[3] = fma(w3, pv, acc[3]);
+          w3 = w2; w2 = w1; w1 = w0;
+          w0 = l2 + 1 < L ? gp[(l2 + 1) * 64] : 0.0;
+        }
+      }
+      // -- every q number
+      {
+        const long long t_wait = wall_clock64();
+        bool ok = true;
+        for (int q = t; q < nq && ok; q += kCgThreads) {
+          double val = 0.0;
+          ok = cgt_wait(qbuf + 2 * q, round, val, P.abort_word, abort_id, P.limit_ticks, t_wait);
+          qv[q] = val;
+        }
+        if (!ok) s_abort = 1;
+      }
+      __syncthreads();
+      // -- E part: row a takes - sum_f sum_{s < a} x_f[s][i] q_f[s - a]  (wi holds the sign)
+      if (4 * wave < L && !s_abort) {
+        for (int q = lane; q < nq; q += 64) {
+          const int f = q / post, sr = q % post;
+          const double wv_ = wi[q];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a = 4 * wave + r;
+            if (sr < a && a < L) acc[r] = fma(wv_, qv[f * post + (sr - a + post)], acc[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double tot = wave_sum(acc[r]);
+          if (lane == 0) rowsum[4 * wave + r] = tot;
+        }
+      }
+      __syncthreads();
+      // -- publish my L rows: one contiguous run of packets (workgroup-major packet order)
+      unsigned long long* const buf = row_pk + (size_t)(round & 1u) * 2 * kCgtRowPackets;
+      if (t < L) {
+        const int c = t * C + i;
+        ll_store(buf + 2 * (i * L + t), rowsum[t] + lam * vec[c] - srow_t * (sdot * inv_ckk), round);
+      }
+      // -- every entry of the product
+      {
+        const long long t_wait = wall_clock64();
+        bool ok = !s_abort;
+        __builtin_amdgcn_s_sleep(16);
+#pragma unroll
+        for (int j = 0; j < kCgMaxCols; ++j) {
+          const int c = cg_col(t, j);
+          double val = 0.0;
+          if (c < k && ok) ok = cgt_wait(buf + 2 * ((c % C) * L + c / C), round, val, P.abort_word, abort_id,
+                                         P.limit_ticks, t_wait);
+          wq[j] = c < k ? val : 0.0;
+        }
+        if (!ok) s_abort = 1;
+      }
+#ifdef TD_CGT_DEBUG      // development: the first product (and the vector it was taken with) instead of a solve
+      if (i == 0) {
+#pragma unroll
+        for (int j = 0; j < kCgMaxCols; ++j) {
+          const int c = cg_col(t, j);
+          if (c < k) { P.w[c] = (float)wq[j]; P.w[k + c] = (float)r_[j]; }
+        }
+      }
+      status = 5;
+      break;
+#endif
+      // -- ONE reduction: r^T r, w^T r, s^T w (in the check pass: |b - A x|^2)
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        const double dj = b[j] - wq[j];
+        e0 += check_pass ? dj * dj : r_[j] * r_[j];
+        e1 += wq[j] * r_[j];
+        e2 += s_reg[j] * wq[j];
+      }
+      e0 = wave_sum(e0);
+      e1 = wave_sum(e1);
+      e2 = wave_sum(e2);
+      if (lane == 0) { part_b[4 * wave] = e0; part_b[4 * wave + 1] = e1; part_b[4 * wave + 2] = e2; }
+      __syncthreads();
+      if (s_abort) { aborted = true; break; }
+      const double gamma = wave_parts(part_b, 4, 0);
+      const double delta = wave_parts(part_b, 4, 1);
+      const double sw = wave_parts(part_b, 4, 2);
+      if (check_pass) {
+        if (!(gamma <= P.accept * P.tol2 * bnorm2)) status = 2;
+        break;
+      }
+      if (gamma <= P.tol2 * bnorm2) {
+        check_pass = true;
+        --it;
+#pragma unroll
+        for (int j = 0; j < kCgMaxCols; ++j) r_[j] = x[j];
+        continue;
+      }
+      if (it >= P.max_iter) { status = 2; break; }
+      const double beta = it == 1 ? 0.0 : gamma / gamma_old;
+      const double denom = it == 1 ? delta : delta - beta * beta * denom_old;
+      if (!(denom > 0.0)) { status = 2; break; }
+      const double alpha = gamma / denom;
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        p[j] = r_[j] + beta * p[j];
+        v[j] = wq[j] + beta * v[j];
+        x[j] += alpha * p[j];
+        r_[j] -= alpha * v[j];
+      }
+      sv = sw + beta * sv;
+      sdot -= alpha * sv;
+      gamma_old = gamma;
+      denom_old = denom;
+    }
+    iters_max = it > iters_max ? it : iters_max;
+    if (aborted || status != 0) break;
+    __syncthreads();
+    double e0 = 0.0;
+#pragma unroll
+    for (int j = 0; j < kCgMaxCols; ++j) e0 += s_reg[j] * x[j];
+    e0 = wave_sum(e0);
+    if (lane == 0) part_a[wave] = e0;
+    __syncthreads();
+    const double sxx = wave_parts(part_a, 1, 0);
+    if (i == 0) {
+#pragma unroll
+      for (int j = 0; j < kCgMaxCols; ++j) {
+        const int c = cg_col(t, j);
+        if (c < k) P.w[((size_t)li * k + c) * P.d + qo] = (float)x[j];
+      }
+      if (t == 0) P.bias[(size_t)li * P.d + qo] = (float)((bk - sxx) * inv_ckk);
+    }
+    __syncthreads();
+  }
+  if (i == 0 && t == 0) {
+    P.status[0] = aborted ? 3 : status;
+    P.status[1] = iters_max;
+    if (P.flag) *P.flag = (aborted || status != 0) ? 2 : 0;
+  }
+}
+
 }  // namespace
 
 // Plan: rows per workgroup for k unknowns on `cus` compute units; 0 when the matrix does not fit
@@ -490,6 +839,49 @@ int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const doub
     default: rc = launch_cg<8>(h, p, wgs, lds, cus); break;
   }
   if (rc != TD_OK) return rc;              // (TD_CG_NOT_RESIDENT: nothing was queued)
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
+
+int td_cg_solve_compact(td_handle* h, const StatsCompact& sc, const double* lams_dev, const double* lams_host,
+                        int n_lambda, int max_iter, double tol, double accept, float* w_dev, float* b_dev,
+                        int* status_dev, int* flag_dev) {
+  const int C = sc.c, L = sc.l, k = C * L, post = L - 1;
+  const long long nq = (long long)sc.n_files * post;
+  if (!sc.ok || C < 2 || C > 64 || (C & 1) || L < 1 || L > 32 || k > kCgThreads * kCgMaxCols ||
+      (post > 0 && sc.hw < post) || nq > (long long)kCgWaves * C || nq > kCgtMaxQ || n_lambda < 1)
+    return TD_CG_NOT_RESIDENT;
+  for (int i = 0; i < n_lambda; ++i)
+    if (!(lams_host[i] > 0.0)) return TD_CG_NOT_RESIDENT;
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  int per_cu = 0;
+  TD_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_toeplitz_kernel, kCgThreads, 0));
+  if ((long long)per_cu * cus < C) return TD_CG_NOT_RESIDENT;
+  const size_t words = (size_t)2 * 2 * kCgtRowPackets + (size_t)2 * 2 * kCgtMaxQ + 2 * 64;
+  const size_t bytes = sizeof(unsigned long long) * words + 256;
+  if (!h->cgt_packets) {
+    TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->cgt_packets), bytes));
+    TD_HIP(h, hipMemsetAsync(h->cgt_packets, 0, bytes, h->stream));
+    h->cgt_epoch = 0;
+  }
+  const unsigned rounds = (unsigned)(n_lambda * sc.d) * (unsigned)(max_iter + 4) + 8u;
+  if (h->cgt_epoch > 0xffffffffu - rounds - 16u) {
+    TD_HIP(h, hipMemsetAsync(h->cgt_packets, 0, bytes, h->stream));
+    h->cgt_epoch = 0;
+  }
+  CgtParams p;
+  p.fxx = sc.fxx; p.gxo = sc.gxo; p.sy = sc.sy; p.win = sc.win; p.lams = lams_dev;
+  p.packets = h->cgt_packets;
+  p.abort_word = reinterpret_cast<unsigned*>(h->cgt_packets + words);
+  p.w = w_dev; p.bias = b_dev; p.status = status_dev; p.flag = flag_dev;
+  p.inv = 1.0 / (double)sc.frames; p.tol2 = tol * tol; p.accept = accept;
+  p.C = C; p.L = L; p.d = sc.d; p.n_lambda = n_lambda; p.k = k; p.hw = sc.hw; p.n_files = (int)sc.n_files;
+  p.nq = (int)nq; p.max_iter = max_iter; p.gate = 1;
+  p.epoch = h->cgt_epoch;
+  p.limit_ticks = 100000LL * 20;
+  if (h->cg_limit_ticks >= 0) p.limit_ticks = h->cg_limit_ticks;
+  h->cgt_epoch += rounds;
+  hipLaunchKernelGGL(cg_toeplitz_kernel, dim3((unsigned)C), dim3(kCgThreads), 0, h->stream, p);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

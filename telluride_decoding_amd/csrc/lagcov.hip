@@ -525,12 +525,16 @@ __device__ __forceinline__ void bf_ksteps(const unsigned* __restrict__ ap,
 #else
 #define TD_KOFF(s) (8 * (s))
 #endif
+#ifdef TD_F16_LONGCHAIN   // experiment: ONE chain per slab (the kernel zeroes acc per work item and adds it to total there)
+    bf_kstep<false, kBfPieceDw, kF16>(ap + TD_KOFF(s), bp + TD_KOFF(s), nullptr, acc);
+#else
     if (s % kChain == 0) bf_kstep<true, kBfPieceDw, kF16>(ap + TD_KOFF(s), bp + TD_KOFF(s), nullptr, acc);
     else                 bf_kstep<false, kBfPieceDw, kF16>(ap + TD_KOFF(s), bp + TD_KOFF(s), nullptr, acc);
     if ((s + 1) % kChain == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) total[r] += acc[r];
     }
+#endif
     // (without a fence hipcc hoists the LDS reads of all the unrolled steps to the top; fences
     // after every step, every other step or none at all time the same)
     __builtin_amdgcn_sched_barrier(0);
@@ -988,6 +992,12 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   store(w.u_begin, buf0);
   store_y(ybuf);
   __syncthreads();
+#ifdef TD_F16_LONGCHAIN
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+#endif
 
   // (virtual images: the tile loop of a recording's last slab runs past its end, where only the
   // shifted copies of the A-only channels are not zero; the other tasks stop at u_end)
@@ -1019,10 +1029,12 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     } else {
       // the last, cut tile of a slab: A stops at nk
       const int nk = (int)left;
+#ifndef TD_F16_LONGCHAIN
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+#endif
       for (int t0 = 0; t0 < nk; t0 += 16) {
         const int cnt = nk - t0 - 8 * lg;              // may be <= 0 or >= 8
         unsigned mask[4];
@@ -1031,8 +1043,10 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
           mask[d] = cnt >= 2 * d + 2 ? 0xffffffffu : cnt == 2 * d + 1 ? 0x0000ffffu : 0u;
         bf_kstep<false, kBfPieceDw, kF16>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc);
       }
+#ifndef TD_F16_LONGCHAIN
 #pragma unroll
       for (int r = 0; r < 4; ++r) total[r] += acc[r];
+#endif
     }
     if constexpr (kTgt) {
       if (t_on)
@@ -1043,6 +1057,10 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     if (more) __syncthreads();
 #endif
   }
+#ifdef TD_F16_LONGCHAIN
+#pragma unroll
+  for (int r = 0; r < 4; ++r) total[r] += acc[r];
+#endif
   }   // work items of this workgroup
 
   // Epilogue: the wave's 32 x 32 block of its four lags in the workgroup's partial slab.

@@ -1676,14 +1676,46 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
   double* xtx = reinterpret_cast<double*>(base);
   double* xty = xtx + nn;
   const SolveWs w = carve(reinterpret_cast<char*>(base) + head, np, n_lambda);
-  TD_TRY(td_stats_moments_ld(h, s, xtx, np, xty, nullptr, nullptr, nullptr));
   TD_TRY(td_upload_async(h, lambdas_host, sizeof(double) * n_lambda, w.lams));
+  h->last_solver = TD_SOLVER_CHOLESKY; h->last_iterations = 0; h->last_cg_status = 0;
+  {
+    // Conjugate gradients on the COMPACT statistics (cg.hip: one workgroup per channel, no dense matrix,
+    // no expansion): the route of a handle whose CUs cannot hold the dense matrix in LDS (the solve
+    // partition of a pipelined fit) and of asynchronous solves that asked for it (td_set_option
+    // "async_cg"): an asynchronous caller finds 2 in its flag when the solver gave up (not converged,
+    // ill-conditioned for the promise, aborted) and solves again with the factorisation.
+    const int cus_c = h->cu_count > 0 ? h->cu_count : 256;
+    bool positive = true;
+    for (int i = 0; i < n_lambda; ++i) positive = positive && lambdas_host[i] > 0.0;
+    const bool want = h->solver_mode != TD_SOLVER_CHOLESKY && positive && n_lambda * d <= kCgAutoSystems &&
+                      (flag_dev ? h->async_cg != 0 : (td_cg_rows(n - 1, cus_c) == 0 && n >= kCgAutoMinN1));
+    StatsCompact sc;
+    sc.ok = false;
+    if (want) TD_TRY(td_stats_compact(s, &sc));
+    if (want && sc.ok) {
+      if (!h->cg_status) TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->cg_status), sizeof(int) * 16));
+      const bool by_choice = h->solver_mode == TD_SOLVER_CG;
+      const int rc_c = td_cg_solve_compact(h, sc, w.lams, lambdas_host, n_lambda,
+                                           by_choice ? kCgMaxIter : kCgAutoMaxIter, kCgTol, by_choice ? 100.0 : 4.0,
+                                           w_dev, b_dev, h->cg_status, flag_dev);
+      if (rc_c != TD_OK && rc_c != TD_CG_NOT_RESIDENT) return rc_c;
+      if (rc_c == TD_OK) {
+        if (flag_dev) { h->last_solver = TD_SOLVER_CG; return TD_OK; }      // (the flag says how it went)
+        int st[2] = {0, 0};
+        TD_HIP(h, hipMemcpyAsync(st, h->cg_status, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));
+        TD_HIP(h, hipStreamSynchronize(h->stream));
+        h->last_iterations = st[1]; h->last_cg_status = st[0];
+        if (st[0] == 0) { h->last_solver = TD_SOLVER_CG; return TD_OK; }
+        if (st[0] == 5) return td_fail(h, TD_ERR_STATE, "cg_toeplitz_kernel: debug build (first product dumped)");
+      }
+    }
+  }
+  TD_TRY(td_stats_moments_ld(h, s, xtx, np, xty, nullptr, nullptr, nullptr));
   const double inv = 1.0 / (double)frames;
   // A few large systems, synchronous caller, the whole matrix fits the LDS of the CUs this handle runs
   // on: conjugate gradients in ONE launch (cg.hip) instead of the ~100 launches of the factorisation.
   // Anything but "converged, true residual checked" falls through to the Cholesky below, which also
   // owns the "Singular matrix" report.
-  h->last_solver = TD_SOLVER_CHOLESKY; h->last_iterations = 0; h->last_cg_status = 0;
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
   const int systems = n_lambda * d;
   const bool cg_auto = systems <= kCgAutoSystems &&
@@ -1772,6 +1804,9 @@ int td_set_option(td_handle* h, const char* name, int64_t value) {
     h->cca_whitening = (int)value;
   } else if (!strcmp(name, "cg_limit_ticks")) {
     h->cg_limit_ticks = value;
+  } else if (!strcmp(name, "async_cg")) {
+    TD_REQUIRE(h, value == 0 || value == 1, "td_set_option: async_cg is 0 or 1");
+    h->async_cg = (int)value;
   } else {
     return td_fail(h, TD_ERR_INVALID, "td_set_option: unknown option '%s'", name);
   }

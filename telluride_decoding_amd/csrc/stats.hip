@@ -39,6 +39,12 @@ struct td_stats {
   float* win2 = nullptr;
   int64_t n_files = 0, cap_files = 0;
   int64_t frames = 0;
+  // Every file so far was summed whole -- rows [0, N') with N' = the rows that exist, both ends owned:
+  // its tail window holds zeros from row hw on and the moment matrix is block-Toeplitz but for the
+  // HEAD windows (td_stats_compact: the solver that works on the compact statistics).  False after a
+  // dropped remainder, a time range, an input offset that leaves rows behind the sums, an unpack or a
+  // combine (conservative: their sources are not inspected).
+  bool whole_files = true;
   // A reset that has not been written yet (regression statistics only, see stats_fusable): the
   // next accumulate call's finalize launch OVERWRITES its half of `g` instead of adding to it --
   // `fresh_main` covers fxx and n, `fresh_tgt` gxo and sy -- and no memset is queued.  Every
@@ -782,6 +788,16 @@ int td_stats_layout(const td_stats* s, int* k1, int* d, int64_t* frames) {
   return TD_OK;
 }
 
+int td_stats_compact(const td_stats* s, StatsCompact* out) {
+  out->ok = s->c2 == 0 && s->d >= 1 && s->pre1 == 0 && s->whole_files && s->frames > 0 && !s->fresh_main &&
+            !s->fresh_tgt;
+  out->fxx = s->g + s->off_fxx; out->gxo = s->g + s->off_gxo; out->sy = s->g + s->off_sy;
+  out->win = s->win1;
+  out->c = s->c1; out->l = s->l1; out->d = s->d; out->hw = s->hw;
+  out->n_files = s->n_files; out->frames = s->frames;
+  return TD_OK;
+}
+
 // Used by eig.hip.
 int td_stats_dims(const td_stats* s, int* k1, int* k2, int64_t* frames) {
   *k1 = s->k1;
@@ -860,6 +876,7 @@ int td_stats_reset(td_handle* h, td_stats* s) {
   s->n_files = 0;
   s->frames = 0;
   s->tab_ready = false;
+  s->whole_files = true;
   return TD_OK;
 }
 
@@ -1269,6 +1286,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
     e.u_begin = ub; e.u_end = ue;
     sxy.push_back(e);
     const int flags = edge_flags_host ? edge_flags_host[f] : 3;
+    if (do_main && !(ub == 0 && ue == np && np == vx && flags == 3)) s->whole_files = false;
     j1[f].row0 = r0 + dx; j1[f].valid = vx; j1[f].nprime = np;
     j1[f].head = flags & 1; j1[f].tail = flags & 2;
     j2[f].row0 = r0 + dy; j2[f].valid = vy; j2[f].nprime = np;
@@ -1639,6 +1657,7 @@ int td_stats_combine(td_handle* h, td_stats* dst, td_stats* const* srcs, int n) 
   }
   dst->n_files = files;
   dst->frames = frames;
+  dst->whole_files = false;
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
@@ -1696,6 +1715,7 @@ int td_stats_unpack_known(td_handle* h, td_stats* s, const double* buf_dev, int6
     TD_HIP(h, hipGetLastError());
   }
   s->n_files = total_file_slots;
+  s->whole_files = false;
   if (total_frames >= 0) {
     s->frames = total_frames;
   } else {

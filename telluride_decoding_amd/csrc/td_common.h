@@ -89,13 +89,15 @@ struct td_handle {
   // status block {status, iterations}, the solver selection (td_set_solver) and what the last
   // td_ridge_solve on this handle did (td_last_solve_info).
   unsigned long long* cg_packets = nullptr;
-  unsigned cg_epoch = 0;
+  unsigned long long* cgt_packets = nullptr;   // the compact-statistics solver's packets (rows | q | trace)
+  unsigned cg_epoch = 0, cgt_epoch = 0;
   int* cg_status = nullptr;
   int solver_mode = 0;          // TD_SOLVER_AUTO
   // td_set_option: "cca_whitening" (0 automatic, 1 always the reference's eigen route) and
   // "cg_limit_ticks" (< 0: the default wait limit of the conjugate-gradient kernel's polls)
   int cca_whitening = 0;
   long long cg_limit_ticks = -1;
+  int async_cg = 0;             // "async_cg": td_ridge_solve_async may use the compact-statistics CG (flag 2 = gave up)
   int last_solver = 0, last_iterations = 0, last_cg_status = 0;
   // Optional per-kernel hipEvent timing of the dominant kernel (td_profile_*):
   // event pairs recorded on h->stream around every lagcov MFMA launch.
@@ -135,6 +137,25 @@ int td_fail(td_handle* h, int code, const char* fmt, ...);
 // needs more room (stream-ordered reuse is safe: one stream per handle).
 int td_scratch(td_handle* h, size_t bytes, void** out);
 
+// The compact regression statistics as the solver that never expands them sees them (stats.hip): the
+// lagged covariance blocks fxx [l][c][c] (sums), [y | 1]^T x~ gxo [l][d + 1][c], sum y [d], the boundary
+// windows win [file][head | tail][2 hw][c] float32.  ok: regression statistics without pre-context whose
+// files were all summed whole -- the moment matrix is then block-Toeplitz but for the head windows.
+struct StatsCompact {
+  bool ok;
+  const double *fxx, *gxo, *sy;
+  const float* win;
+  int c, l, d, hw;
+  int64_t n_files, frames;
+};
+int td_stats_compact(const td_stats* s, StatsCompact* out);
+// cg.hip: conjugate gradients on the compact statistics (one workgroup per channel, <= 64 CUs): queues
+// the launch on h->stream; flag_dev (may be null) receives 0 converged / 2 gave up (not converged, not
+// positive definite, ill-conditioned for the promise, aborted) behind it; status_dev as td_cg_solve_dense.
+// Returns TD_CG_NOT_RESIDENT (nothing queued) when the shape or the handle's CUs do not fit.
+int td_cg_solve_compact(td_handle* h, const StatsCompact& sc, const double* lams_dev, const double* lams_host,
+                        int n_lambda, int max_iter, double tol, double accept, float* w_dev, float* b_dev,
+                        int* status_dev, int* flag_dev);
 // cg.hip: rows per workgroup of the LDS-resident conjugate-gradient solve (0: does not fit), and the solve itself
 int td_cg_rows(int k, int cus);
 // (accept: the true residual the answer is accepted with, as a factor on tol^2.  Returns

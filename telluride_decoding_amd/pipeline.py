@@ -55,7 +55,8 @@ class FitPipeline(object):
   """
 
   def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=64, targets_on_solve=False,
-               buffers=None, solves=None, solve_streams=2, latency_flush=True, targets_ahead=False):
+               buffers=None, solves=None, solve_streams=2, latency_flush=True, targets_ahead=False,
+               cg_solves=True):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -131,6 +132,15 @@ class FitPipeline(object):
       with torch.cuda.stream(st):
         self.h_solves.append(device.Handle())
     self.s_solve, self.h_solve = self.s_solves[0], self.h_solves[0]
+    # cg_solves: the asynchronous solves may run as ONE launch of conjugate gradients on the compact
+    # statistics (cg.hip: a workgroup per channel -- it fits the solve partition, where the resident
+    # kernel of a lone fit does not) instead of the ~100-launch Cholesky chain; a solve that gives up
+    # (flag 2: not converged, lambda too small for the promise) is repeated with the factorisation when
+    # its result is due.
+    self.cg_solves = bool(cg_solves)
+    if self.cg_solves:
+      for hs in self.h_solves:
+        hs.set_option('async_cg', 1)
     if self._masked:
       # the accumulate plans its work items for the CUs it really has
       self.h_acc.check(lib.td_set_cu_count(self.h_acc.ptr, n_cu - solve_cus))
@@ -182,15 +192,30 @@ class FitPipeline(object):
       ev = torch.cuda.Event()
       ev.record(s_solve)
       self.ev_solved[buf] = ev
-    self._results.append((w, b, flag, ev))
+    self._results.append((w, b, flag, ev, (buf, lambdas, index)))
 
   def _pop(self):
     """Oldest queued solution, waited for and checked."""
-    w, b, flag, ev = self._results.pop(0)
+    entry = self._results.pop(0)
+    w, b, flag, ev = entry[:4]
     ev.synchronize()
     if flag is None:
       return None
-    if flag():
+    state = flag()
+    if state == 2 and len(entry) > 4:
+      # the conjugate-gradient solve gave up: the factorisation, synchronously, from the statistics of
+      # that fit (its buffer is not reused before this result has been handed out)
+      buf, lambdas, index = entry[4]
+      hs = self.h_solves[index % len(self.s_solves)]
+      with self.torch.cuda.stream(self.s_solves[index % len(self.s_solves)]):
+        hs.set_solver('cholesky')
+        try:
+          w, b = self.stats[buf].ridge_solve(lambdas, handle=hs)
+        finally:
+          hs.set_solver('auto')
+      self.cg_fallbacks = getattr(self, 'cg_fallbacks', 0) + 1
+      return w, b
+    if state:
       raise np.linalg.LinAlgError('Singular matrix: covariance is not positive definite')
     return w, b
 

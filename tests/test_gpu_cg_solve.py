@@ -236,3 +236,146 @@ def test_async_flag_ring_overrun_is_an_error(dev):
   w, b, flag = st.ridge_solve_async([0.1], handle=h)
   h.synchronize()
   assert flag() == 0 and np.all(np.isfinite(w.cpu().numpy()))
+
+
+def _masked_handle(dev, cus=64):
+  """A handle on a stream masked to the first `cus` CUs (the solve partition of a pipelined fit)."""
+  import ctypes
+  import torch
+  from telluride_decoding_amd import _lib
+  lib = _lib.load()
+  p = ctypes.c_void_p()
+  assert lib.td_stream_create_masked(0, 0, cus, ctypes.byref(p)) == 0
+  stream = torch.cuda.ExternalStream(p.value)
+  with torch.cuda.stream(stream):
+    h = dev.Handle()
+  h.check(lib.td_set_cu_count(h.ptr, cus))
+  return h, stream, (lib, p)
+
+
+@pytest.mark.parametrize('c,post,frames,files,lams,d', [
+    (64, 31, 6000, 3, [0.1], 1),              # the C2 shape: 64 workgroups x 32 rows, 93 q numbers
+    (64, 31, 2500, 10, [0.05, 2.0], 1),       # ten recordings (310 q numbers), two lambdas in one launch
+    (64, 15, 4000, 2, [0.1], 2),              # two outputs
+    (32, 7, 3000, 4, [0.1], 1),               # 32 workgroups, 8 lags
+    (16, 3, 3000, 2, [0.5], 1),               # 64 unknowns
+    (64, 0, 3000, 2, [0.1], 1),               # no lags: no edge term at all
+])
+def test_compact_cg_on_a_masked_handle_matches_cholesky_and_oracle(dev, c, post, frames, files, lams, d):
+  """cg_toeplitz_kernel (cg.hip): conjugate gradients on the COMPACT statistics -- one workgroup per channel,
+  the block-Toeplitz part from fxx, the head-window term through the q exchange, no dense matrix -- the
+  route td_ridge_solve takes on a handle whose CUs cannot hold the dense matrix in LDS (the 64-CU solve
+  partition).  Against the blocked Cholesky on the same handle (brain_model.py:447-477 either way) and the
+  float64 oracle."""
+  import torch
+  from telluride_decoding_amd import synth
+  h, stream, keep = _masked_handle(dev)
+  with torch.cuda.stream(stream):
+    trials = synth.make_trials(3 + c, files, frames, c)
+    eeg = np.concatenate([t[0] for t in trials])
+    env = np.concatenate([t[1][:, :d] for t in trials])
+    offs = np.arange(files + 1, dtype=np.int64) * frames
+    st = dev.LagStats(c, 0, post, d=d, handle=h)
+    st.accumulate(h.to_device(eeg), None, h.to_device(env), offs, handle=h)
+    h.set_solver('cholesky')
+    wc, bc = (t.cpu().numpy().astype(np.float64) for t in st.ridge_solve(lams, handle=h))
+    h.set_solver('auto')
+    wg, bg = (t.cpu().numpy().astype(np.float64) for t in st.ridge_solve(lams, handle=h))
+    info = h.last_solve_info()
+  if c * (post + 1) + 1 >= 128:
+    assert info['solver'] == 'cg' and info['cg_status'] == 0 and 0 < info['iterations'] <= 160, info
+  scale = np.max(np.abs(wc))
+  assert np.max(np.abs(wg - wc)) / scale < 2e-6
+  assert np.max(np.abs(bg - bc)) < 2e-6 * max(1.0, np.max(np.abs(bc)))
+  wo, bo = _oracle_weights(eeg, env, offs, post, lams[0])
+  assert np.max(np.abs(wg[0] - wo)) / np.max(np.abs(wo)) < 1e-5
+  lib, p = keep
+  del st, h
+  torch.cuda.synchronize()
+  lib.td_stream_destroy(p)
+
+
+def test_compact_cg_refuses_what_it_cannot_promise(dev):
+  """The compact solver is taken only for statistics whose files were summed whole (the matrix is then
+  block-Toeplitz but for the head windows): a dropped remainder leaves rows behind the sums -> the
+  factorisation; so does a lambda below 1e-6 trace(cov) (status 4: not attempted), lambda = 0, and more
+  recordings than the grid has waves for their q numbers.  The answers are the factorisation's, bit for bit."""
+  import torch
+  from telluride_decoding_amd import synth
+  h, stream, keep = _masked_handle(dev)
+  with torch.cuda.stream(stream):
+    trials = synth.make_trials(8, 3, 3100, 64)
+    eeg = np.concatenate([t[0] for t in trials])
+    env = np.concatenate([t[1][:, :1] for t in trials])
+    offs = np.arange(4, dtype=np.int64) * 3100
+    xd, yd = h.to_device(eeg), h.to_device(env)
+
+    def both(st, lam):
+      h.set_solver('auto')
+      wa = st.ridge_solve([lam], handle=h)[0].cpu().numpy()
+      info = h.last_solve_info()
+      h.set_solver('cholesky')
+      wc = st.ridge_solve([lam], handle=h)[0].cpu().numpy()
+      h.set_solver('auto')
+      return wa, wc, info
+    st = dev.LagStats(64, 0, 31, d=1, handle=h)
+    st.accumulate(xd, None, yd, offs, rows_used=[3000, 3000, 3000], handle=h)       # 100 rows dropped per file
+    wa, wc, info = both(st, 0.1)
+    assert info['solver'] == 'cholesky' and info['cg_status'] == 0 and np.array_equal(wa, wc), info
+    st.reset()
+    st.accumulate(xd, None, yd, offs, handle=h)
+    wa, wc, info = both(st, 1e-7)
+    assert info['solver'] == 'cholesky' and info['cg_status'] == 4 and np.array_equal(wa, wc), info
+    wa, wc, info = both(st, 0.0)
+    assert info['solver'] == 'cholesky' and np.array_equal(wa, wc), info
+    wa, wc, info = both(st, 0.1)
+    assert info['solver'] == 'cg', info
+    # 20 recordings of 155 frames: 620 q numbers > 512 waves
+    st.reset()
+    st.accumulate(xd[:3100], None, yd[:3100], np.arange(21, dtype=np.int64) * 155, handle=h)
+    wa, wc, info = both(st, 0.1)
+    assert info['solver'] == 'cholesky' and np.array_equal(wa, wc), info
+  lib, p = keep
+  del st, h
+  torch.cuda.synchronize()
+  lib.td_stream_destroy(p)
+
+
+def test_pipeline_cg_solves_fall_back_in_order(dev):
+  """pipeline.FitPipeline(cg_solves=True): the asynchronous solves run as the one-launch compact solver
+  (flag 0) and give the weights of back-to-back factorised fits to 5e-6 of the largest; a fit whose lambda the solver
+  does not attempt (flag 2) is solved again with the factorisation when its result is due -- the caller
+  sees the factorisation's answer at the right position."""
+  import torch
+  from telluride_decoding_amd import pipeline, synth
+  h = dev.default_handle()
+  trials = synth.make_trials(12, 2, 4000, 64)
+  eeg = np.concatenate([t[0] for t in trials])
+  env = np.concatenate([t[1][:, :1] for t in trials])
+  offs = np.arange(3, dtype=np.int64) * 4000
+  xd, yd = h.to_device(eeg), h.to_device(env)
+  st = dev.LagStats(64, 0, 31, d=1)
+  lam_seq = [0.1, 1e-7, 0.3, 0.1]
+  want = []
+  h.set_solver('cholesky')
+  for lam in lam_seq:
+    st.reset(); st.accumulate(xd, None, yd, offs)
+    want.append(st.ridge_solve([lam])[0].cpu().numpy())
+  h.set_solver('auto')
+  pipe = pipeline.FitPipeline(64, 0, 31, d=1, cg_solves=True)
+  got = []
+  for lam in lam_seq:
+    r = pipe.submit(xd, yd, offs, [lam])
+    if r is not None:
+      got.append(r)
+  got.extend(pipe.flush())
+  assert len(got) == len(lam_seq)
+  assert getattr(pipe, 'cg_fallbacks', 0) >= 1            # the 1e-7 fit
+  for k, (w, _) in enumerate(got):
+    # (the lambda = 1e-7 system has a condition number ~1e8: the pipeline's accumulate runs on a 192-CU
+    # partition with another slab plan, its moments differ from the serial fit's in the last float32 bits
+    # and the weights amplify that; both are factorisations of their own moments)
+    tol = 5e-6 if lam_seq[k] > 1e-3 else 5e-2
+    got_w = w.cpu().numpy()
+    assert np.all(np.isfinite(got_w))
+    assert np.max(np.abs(got_w - want[k])) <= tol * np.max(np.abs(want[k])), (k, lam_seq[k])
