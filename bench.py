@@ -1169,8 +1169,10 @@ def main():
         'config': {
             'workload': ('C2: 64-ch x 1e6-sample ridge TRF fit%s (10 recordings x 100k frames), '
                          '32 lags (K = 2048 + bias), lambda = 0.1, D = 1: lagged-covariance MFMA '
-                         'accumulate + float64 solve (blocked Cholesky on the solve streams of the pipeline; '
-                         'one-launch conjugate gradients where a fit runs alone: serial_ms_per_step, single_fit)'
+                         'accumulate + float64 solve (one-launch conjugate gradients: on the compact statistics, a '
+                         'workgroup per channel, on the solve partition of the pipeline -- cg_toeplitz_kernel; with the '
+                         'dense matrix resident in LDS where a fit runs alone: serial_ms_per_step, single_fit; the blocked '
+                         'Cholesky is the fallback of both)'
                          % (' per GPU' if args.scaling == 'weak' else ', ONE job shared by all GPUs')),
             'samples_per_step': samples_per_step, 'channels': C, 'lags': POST + 1,
             'parallelism': ('single GPU' if world == 1 else

@@ -250,20 +250,25 @@ int td_stats_moments(td_handle* h, td_stats* s, double* xtx_dev, double* xty_dev
 int td_ridge_solve(td_handle* h, td_stats* s, const double* lambdas_host, int n_lambda,
                    float* w_dev, float* b_dev);
 /* How td_ridge_solve solves (brain_model.py:477 is one dense np.linalg.solve):
- *   TD_SOLVER_AUTO (default) a synchronous call with at most 4 (lambda, output) systems, every lambda > 0, of
+ *   TD_SOLVER_AUTO (default) a synchronous call with at most 4 (lambda, output) systems of
  *                  n >= 128 / 192 / 512 (one / two / three or four systems: where one launch measures faster than the
- *                  factorisation's chain) whose matrix fits the LDS of the CUs the handle runs on (td_set_cu_count;
- *                  n = 2049 on the 256 CUs of an MI355X does) runs conjugate gradients in ONE persistent
- *                  launch -- the matrix resident in LDS, one packet exchange per iteration -- and takes the
- *                  blocked Cholesky only when that does not converge to a relative residual of 1e-12
- *                  (checked on the TRUE residual), meets a non-positive curvature, or its workgroups are
- *                  not all resident within 20 ms (another persistent grid on the device: the launch aborts
- *                  itself and drains); everything else takes the Cholesky directly;
+ *                  factorisation's chain), every lambda >= 1e-6 trace(cov_x) (condition number <= 1e6: the answer
+ *                  stands in for np.linalg.solve, and a residual bound must be a weight bound) runs conjugate
+ *                  gradients in ONE persistent launch: with the dense matrix resident in the LDS of the CUs the
+ *                  handle runs on when it fits (td_set_cu_count; n = 2049 on the 256 CUs of an MI355X does), else
+ *                  -- statistics whose files were summed whole, no pre-context -- on the compact statistics, one
+ *                  workgroup per channel (64 CUs suffice).  The blocked Cholesky follows only when that does not
+ *                  converge in 160 iterations to a relative residual of 1e-12 (the TRUE residual checked within
+ *                  2e-12), meets a non-positive curvature, cannot have all its workgroups resident (asked of the
+ *                  runtime BEFORE the launch) or aborts itself (a wait longer than 20 ms: another process's
+ *                  persistent grid); everything else takes the Cholesky directly;
  *   TD_SOLVER_CHOLESKY       always the blocked float64 Cholesky (~100 launches per system);
- *   TD_SOLVER_CG             conjugate gradients first for any system count / size that fits (lambda > 0).
+ *   TD_SOLVER_CG             conjugate gradients first for any system count / size that fits (lambda > 0; 400
+ *                            iterations, true residual within 1e-11, no conditioning gate for the resident kernel).
  * td_last_solve_info: what the last td_ridge_solve on this handle did -- solver (TD_SOLVER_CHOLESKY or
  * TD_SOLVER_CG), iterations of the slowest system, and the conjugate-gradient status (0 converged,
- * 2 not converged / not positive definite, 3 aborted) when it was tried.  Any pointer may be NULL. */
+ * 2 not converged / not positive definite, 3 aborted, 4 not attempted: lambda below 1e-6 trace) when it was
+ * tried.  Any pointer may be NULL. */
 enum { TD_SOLVER_AUTO = 0, TD_SOLVER_CHOLESKY = 1, TD_SOLVER_CG = 2 };
 int td_set_solver(td_handle* h, int mode);
 /* Named options of a handle (the library reads no TD_* environment variable except TD_RCCL_LIB):

@@ -18,7 +18,7 @@ def counter(path, kernel, name):
 
 out = {}
 for key, kernel, algo, note in (
-    ('lagcov', 'lagcov_split_kernel<true, 83, true, false>', 256000000,
+    ('lagcov', 'lagcov_split_kernel<true, 83, true, false, false>', 256000000,
      'reads the 256 MB of input (the four lag-group workgroups of a time slab share one XCD L2); '
      'writes 33 MB = 64 float32 partial slabs of 512 KB (one workgroup per CU and lag group walks '
      'three <= 8192-sample slabs and leaves one partial slab), summed in float64 by '
@@ -29,7 +29,7 @@ for key, kernel, algo, note in (
      'C3 one-pass CCA moments: every input byte read once; 512 partial slabs of 15 KB'),
     ('project', 'cca_project_stream_kernel<3>', 328000000,
      'C3 transform: x and x2 read once, 40 MB of outputs written'),
-    ('fir', 'fir_stream_kernel<true, 2, 2>', 312000000,
+    ('fir', 'fir_stream_kernel<true, 2, 2, false, false>', 312000000,
      'C4 decode, the FIR prediction: 307.2 MB of EEG read once (+ the 31 halo rows of every strip, '
      'mostly L2 hits) and 4.8 MB of predictions written')):
   name, fetch = counter(os.path.join(root, tag + '_hotkernels_pmc1.txt'), kernel, 'FETCH_SIZE')

@@ -20,7 +20,7 @@ i=0
 for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   # (without the CCA dense stage: its small lagged accumulate runs the same lagcov template and
   # would dilute the per-launch averages of the C2-sized launches)
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc$i -o p -- python3 tools/prof_kernels.py fit cg cca decode > $out/pmc$i.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc$i -o p -- python3 tools/prof_kernels.py fit cg cgt shapes cca decode > $out/pmc$i.log 2>&1
   python3 tools/prof_summary.py $out/pmc$i --pmc > $out/${tag}_hotkernels_pmc$i.txt
   i=$((i+1))
 done

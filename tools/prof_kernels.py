@@ -1,12 +1,12 @@
 """Runs only the hot kernels a few times (for rocprofv3 kernel-trace / PMC passes):
-   python tools/prof_kernels.py [fit] [cg] [cca] [ccasolve] [decode]"""
+   python tools/prof_kernels.py [fit] [cg] [cgt] [shapes] [cca] [ccasolve] [decode]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from telluride_decoding_amd import device
 
-what = sys.argv[1:] or ['fit', 'cg', 'cca', 'ccasolve', 'decode']
+what = sys.argv[1:] or ['fit', 'cg', 'cgt', 'shapes', 'cca', 'ccasolve', 'decode']
 h = device.default_handle()
 torch.manual_seed(0)
 if 'fit' in what:
@@ -24,12 +24,57 @@ if 'cg' in what:
   trials = synth.make_trials(2, 10, 20000, 64)
   eeg = np.concatenate([t[0] for t in trials]); env = np.concatenate([t[1][:, 0:1] for t in trials])
   st = device.LagStats(64, 0, 31, d=1)
+  # (accumulated by the bf16x3 form: a kernel of another name -- the per-launch PMC averages of the float16
+  # kernel then cover the C2-sized launches of `fit` only)
+  h.set_accumulate_mode('bf16x3')
   st.accumulate(h.to_device(eeg), None, h.to_device(env), np.arange(11, dtype=np.int64) * 20000)
+  h.set_accumulate_mode('f16x2')
   for mode in ('cg', 'cholesky'):
     h.set_solver(mode)
     for rep in range(3):
       st.ridge_solve([0.1])
   h.set_solver('auto')
+  torch.cuda.synchronize()
+if 'cgt' in what:
+  # the compact-statistics conjugate gradients (cg_toeplitz_kernel) on a stream masked to 64 CUs: the solve of
+  # a pipelined fit
+  import ctypes
+  from telluride_decoding_amd import synth, _lib
+  lib = _lib.load()
+  pm = ctypes.c_void_p()
+  assert lib.td_stream_create_masked(0, 0, 64, ctypes.byref(pm)) == 0
+  s64 = torch.cuda.ExternalStream(pm.value)
+  with torch.cuda.stream(s64):
+    h64 = device.Handle()
+    h64.check(lib.td_set_cu_count(h64.ptr, 64))
+    trials = synth.make_trials(2, 10, 20000, 64)
+    eeg = np.concatenate([t[0] for t in trials]); env = np.concatenate([t[1][:, 0:1] for t in trials])
+    st = device.LagStats(64, 0, 31, d=1, handle=h64)
+    h64.set_accumulate_mode('bf16x3')
+    st.accumulate(h64.to_device(eeg), None, h64.to_device(env), np.arange(11, dtype=np.int64) * 20000, handle=h64)
+    h64.set_accumulate_mode('f16x2')
+    for rep in range(3):
+      st.ridge_solve([0.1], handle=h64)
+    assert h64.last_solve_info()['solver'] == 'cg'
+  torch.cuda.synchronize()
+  del st, h64          # (the handle before its stream: a masked stream left to interpreter exit crashes in teardown)
+  lib.td_stream_destroy(pm)
+if 'shapes' in what:
+  # the accumulate on virtual images (lagcov_split_kernel<..., kVirt>) at 32 x 32, 69 x 37, 128 x 32, and the
+  # streamed FIR at 63 / 69 channels
+  n = 1000000
+  offs1 = np.array([0, n], np.int64)
+  for c, lags in ((32, 32), (69, 37), (128, 32)):
+    x = torch.randn(n, c, device='cuda'); y = torch.randn(n, 1, device='cuda')
+    st = device.LagStats(c, 0, lags - 1, d=1)
+    for rep in range(3):
+      st.reset(); st.accumulate(x, None, y, offs1)
+    del st, x, y
+  for c in (63, 69):
+    xd = torch.randn(200 * 6000, c, device='cuda')
+    w = torch.randn(32 * c, 1, device='cuda') * 0.01
+    for rep in range(3):
+      device.predict_fir(xd, np.arange(201, dtype=np.int64) * 6000, w, None, 0, 31, handle=h)
   torch.cuda.synchronize()
 if 'cca' in what:
   # C3: 64-ch EEG vs 8-band envelope, 1e6 samples, no context: one-pass Gram + transform

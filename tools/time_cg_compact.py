@@ -36,3 +36,6 @@ with torch.cuda.stream(s64):
     wc, bc = res[('cholesky', lam)]; wg, bg = res[('auto', lam)]
     print('lambda %g: max |w_cg - w_chol| / max |w| = %.3e, bias diff %.3e' %
           (lam, np.max(np.abs(wc - wg)) / np.max(np.abs(wc)), float(np.max(np.abs(bc - bg)))))
+del st, h
+torch.cuda.synchronize()
+lib.td_stream_destroy(p)
