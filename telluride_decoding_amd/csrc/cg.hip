@@ -58,6 +58,8 @@ struct CgParams {
   double tol2;            // (relative residual)^2
   double accept;          // the TRUE residual of the answer may be accept * tol2 (squared, relative)
   int n, ld, d, n_lambda, k, rows, max_iter;
+  int gate;               // 1: a lambda below 1e-6 trace(cov) is not attempted (status 4)
+  unsigned long long* trace_pk;   // [workgroups][2]: the workgroups' shares of the trace
   unsigned epoch;         // round numbers of this launch start above it
   long long limit_ticks;  // wall_clock64 ticks (100 MHz) a wait may last
 };
@@ -162,14 +164,52 @@ __global__ __launch_bounds__(kCgThreads) void cg_resident_kernel(CgParams P) {
   const double a_kk = P.xtx[(size_t)k * P.ld + k] * inv;
   __syncthreads();
 
-  const long long t_start = wall_clock64();
   unsigned round = P.epoch;
   int status = 0, iters_max = 0;
   bool aborted = false;
 
+  // -- the conditioning gate of the automatic route: trace(cov) from the diagonal entries of the resident
+  // rows, one exchange in front of the first system (it was a kernel + a read-back + a host wait)
+  double trace = 0.0;
+  if (P.gate) {
+    ++round;
+    if (t == 0) {
+      double tr = 0.0;
+      for (int r = 0; r < R; ++r)
+        if (i0 + r < k) tr += rows[(size_t)r * ks + i0 + r];
+      ll_store(P.trace_pk + 2 * w, tr, round);
+    }
+    const long long t_wait = wall_clock64();
+    bool gave_up = false;
+    double mine = 0.0;
+    for (int wg = t; wg < (int)gridDim.x && !gave_up; wg += kCgThreads) {
+      double v = 0.0;
+      int polls = 0;
+      while (!ll_try(P.trace_pk + 2 * wg, round, v)) {
+        if ((++polls & 15) == 0 || P.limit_ticks < 16) {
+          if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.epoch + 1u) { gave_up = true; break; }
+          if (wall_clock64() - t_wait > P.limit_ticks) {
+            __hip_atomic_store(P.abort_word, P.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
+            break;
+          }
+        }
+      }
+      mine += v;
+    }
+    if (gave_up) s_abort = 1;
+    mine = wave_sum(mine);
+    if (lane == 0) part_a[wave] = mine;
+    __syncthreads();
+    trace = wave_parts(part_a, 1, 0);
+    if (s_abort) aborted = true;
+    __syncthreads();
+  }
+
   for (int sys = 0; sys < P.n_lambda * P.d && !aborted && status == 0; ++sys) {
     const int li = sys / P.d, qo = sys % P.d;
     const double lam = P.lams[li];
+    if (P.gate && !(lam >= 1e-6 * trace)) { status = 4; break; }
     const double ckk = a_kk + lam;
     const double inv_ckk = 1.0 / ckk;
     const double bk = P.xty[(size_t)k * P.d + qo] * inv;
@@ -489,16 +529,28 @@ __device__ __forceinline__ bool cgt_wait(const unsigned long long* pk, unsigned 
   return true;
 }
 
+// kCpw: channels per workgroup -- 1: a workgroup per channel (64 CUs at C2); 2: two channels per workgroup
+// (wave w: channel w >> 2, rows 8 (w & 3) .. + 7; two q numbers per wave), for a 32-CU partition.
+template <int kCpw>
 __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
-  __shared__ __attribute__((aligned(16))) double vec[kCgThreads * kCgMaxCols];   // the multiplied vector
-  __shared__ double gi[66 * 64];           // my channel's rows of the block-Toeplitz part
-  __shared__ double qv[kCgtMaxQ];          // the q numbers of this iteration
-  __shared__ double wi[kCgtMaxQ];          // - x_f[s][i] / n: my channel's column of the head windows
-  __shared__ double rowsum[32], part_a[kCgWaves], part_b[4 * kCgWaves], trs[64];
+  constexpr int kRw = 4 * kCpw;            // rows of the product per wave
+  extern __shared__ __attribute__((aligned(16))) double cgt_lds[];
+  double* const vec = cgt_lds;                               // [2048] the multiplied vector
+  double* const gi_all = vec + kCgThreads * kCgMaxCols;      // [kCpw][66 * 64] my channels' rows of the block-Toeplitz part
+  double* const qv = gi_all + kCpw * 66 * 64;                // [kCgtMaxQ] the q numbers of this iteration
+  double* const wi_all = qv + kCgtMaxQ;                      // [kCpw][kCgtMaxQ] - x_f[s][i] / n: my channels' columns of the head windows
+  double* const rowsum = wi_all + kCpw * kCgtMaxQ;           // [kCpw][32]
+  double* const part_a = rowsum + kCpw * 32;                 // [waves]
+  double* const part_b = part_a + kCgWaves;                  // [4 waves]
+  double* const trs = part_b + 4 * kCgWaves;                 // [64]
   __shared__ int s_abort;
   const int C = P.C, L = P.L, k = P.k, post = L - 1, nq = P.nq, D1 = P.d + 1;
-  const int t = threadIdx.x, lane = t & 63, i = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ci = kCpw == 2 ? wave >> 2 : 0;                  // the wave's channel of the workgroup's
+  const int i0 = blockIdx.x * kCpw, i = i0 + ci;
+  const int a0 = kCpw == 2 ? (wave & 3) * kRw : wave * kRw;  // its first row (lag)
+  const bool has_rows = a0 < L && i < C;
   const double inv = P.inv;
   const unsigned abort_id = P.epoch + 1u;
   unsigned long long* const row_pk = P.packets;
@@ -506,22 +558,25 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
   unsigned long long* const tr_pk = q_pk + 2 * 2 * kCgtMaxQ;
   if (t == 0) s_abort = 0;
 
-  // -- the lagged covariances against my channel, gi[(e + L + 2) * 64 + j] = G[e][i][j] / n for
-  // e = -(L - 1) - 3 .. L - 1 (three rows of zeros in front: the sliding window below starts there)
-  for (int idx = t; idx < (2 * L + 2) * 64; idx += kCgThreads) {
-    const int e = idx / 64 - L - 2, j = idx % 64;
+  // -- the lagged covariances against my channels, gi[(e + L + 2) * 64 + j] = G[e][i][j] / n for
+  // e = -(L - 1) - 3 .. L - 1 (zero rows in front: the sliding windows below start there)
+  for (int idx = t; idx < kCpw * 66 * 64; idx += kCgThreads) {
+    const int cc = idx / (66 * 64), rem = idx % (66 * 64);
+    const int e = rem / 64 - L - 2, j = rem % 64, ic = i0 + cc;
     const int ae = e < 0 ? -e : e;
     double v = 0.0;
-    if (j < C && ae < L)
-      v = (e >= 0 ? P.fxx[((size_t)ae * C + i) * C + j] : P.fxx[((size_t)ae * C + j) * C + i]) * inv;
-    gi[idx] = v;
+    if (j < C && ae < L && ic < C && rem < (2 * L + 2) * 64)
+      v = (e >= 0 ? P.fxx[((size_t)ae * C + ic) * C + j] : P.fxx[((size_t)ae * C + j) * C + ic]) * inv;
+    gi_all[idx] = v;
   }
-  // -- the window rows of the (at most two) q numbers this wave computes: q index = f post + mi,
+  // -- the window rows of the kCpw q numbers this wave computes: q index = f post + mi,
   // q_f[mi - post] = sum_b sum_j x~_f[mi - post + b][j] p[(b, j)] over the rows of the recording (>= 0)
-  const int gw = i * kCgWaves + wave;
-  float wreg[32];
-  {
-    const int qi = gw;
+  const int n_waves = kCgWaves * (int)gridDim.x;
+  const int gw = (int)blockIdx.x * kCgWaves + wave;
+  float wreg[kCpw][32];
+#pragma unroll
+  for (int sl = 0; sl < kCpw; ++sl) {
+    const int qi = gw + sl * n_waves;
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
       float v = 0.f;
@@ -530,12 +585,14 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
         const int f = qi / post, mi = qi % post, u = mi - post + b;
         if (u >= 0) v = P.win[(((size_t)f * 2) * 2 * P.hw + (u + P.hw)) * C + lane];
       }
-      wreg[b] = v;
+      wreg[sl][b] = v;
     }
   }
-  for (int q = t; q < nq; q += kCgThreads) {
-    const int f = q / post, sr = q % post;
-    wi[q] = -(double)P.win[(((size_t)f * 2) * 2 * P.hw + (sr + P.hw)) * C + i] * inv;   // (E is a part of M / n)
+  for (int idx = t; idx < kCpw * nq; idx += kCgThreads) {
+    const int cc = idx / nq, q = idx % nq;
+    const int f = q / post, sr = q % post, ic = i0 + cc;
+    wi_all[cc * kCgtMaxQ + q] =
+        ic < C ? -(double)P.win[(((size_t)f * 2) * 2 * P.hw + (sr + P.hw)) * C + ic] * inv : 0.0;   // (E is a part of M / n)
   }
   // -- the bias column
   double s_reg[kCgMaxCols];
@@ -544,7 +601,10 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
     const int c = cg_col(t, j);
     s_reg[j] = c < k ? P.gxo[((size_t)(c / C) * D1 + P.d) * C + (c % C)] * inv : 0.0;
   }
-  const double srow_t = t < L ? P.gxo[((size_t)t * D1 + P.d) * C + i] * inv : 0.0;
+  // (thread t < kCpw L publishes row (t % L, i0 + t / L))
+  const int pub_c = t / L, pub_l = t % L, pub_i = i0 + pub_c;
+  const bool pub = t < kCpw * L && pub_i < C;
+  const double srow_t = pub ? P.gxo[((size_t)pub_l * D1 + P.d) * C + pub_i] * inv : 0.0;
   const double a_kk = 1.0;                 // frames / frames
   unsigned round = P.epoch + 1u;
   int status = 0, iters_max = 0;
@@ -554,7 +614,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
   // -- trace(cov) ~ L sum_i G[0][i][i] / n: one exchange in front of everything
   double trace = 0.0;
   if (P.gate) {
-    if (t == 0) ll_store(tr_pk + 2 * i, P.fxx[((size_t)i) * C + i] * inv * L, round);
+    if (t < kCpw && i0 + t < C) ll_store(tr_pk + 2 * (i0 + t), P.fxx[((size_t)(i0 + t)) * C + i0 + t] * inv * L, round);
     const long long t_wait = wall_clock64();
     bool ok = true;
     if (t < C) {
@@ -620,29 +680,36 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       ++round;
       // -- my q numbers: published first, the T part runs while they travel
       unsigned long long* const qbuf = q_pk + (size_t)(round & 1u) * 2 * kCgtMaxQ;
-      if (gw < nq) {                       // (wave-uniform: one q number per wave of the grid)
-        double a = 0.0;
 #pragma unroll
-        for (int bb = 0; bb < 32; ++bb)
-          if (bb < L) a = fma((double)wreg[bb], lane < C ? vec[bb * C + lane] : 0.0, a);
-        a = wave_sum(a);
-        if (lane == 0) ll_store(qbuf + 2 * gw, a, round);
+      for (int sl = 0; sl < kCpw; ++sl) {
+        const int qi = gw + sl * n_waves;
+        if (qi < nq) {                     // (wave-uniform: kCpw q numbers per wave of the grid)
+          double a = 0.0;
+#pragma unroll
+          for (int bb = 0; bb < 32; ++bb)
+            if (bb < L) a = fma((double)wreg[sl][bb], lane < C ? vec[bb * C + lane] : 0.0, a);
+          a = wave_sum(a);
+          if (lane == 0) ll_store(qbuf + 2 * qi, a, round);
+        }
       }
       // -- T part of my rows a = 4 wave + r: lane j multiplies the columns (., j)
-      // (row a = 4 wave + r needs G[l2 - a] against the column block l2: a window of four table rows
-      // that slides by one per block -- one new 8-byte read per lane and block)
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      if (4 * wave < L) {
-        const double* gp = gi + (size_t)(L + 2 - 4 * wave) * 64 + lane;      // e = -4 wave (l2 = 0, r = 0)
-        double w0 = gp[0], w1 = gp[-64], w2 = gp[-128], w3 = gp[-192];
+      // (row a = a0 + r needs G[l2 - a] against the column block l2: a window of kRw table rows that
+      // slides by one per block -- one new 8-byte read per lane and block)
+      double acc[kRw];
+#pragma unroll
+      for (int r = 0; r < kRw; ++r) acc[r] = 0.0;
+      if (has_rows) {
+        const double* gp = gi_all + (size_t)ci * 66 * 64 + (size_t)(L + 2 - a0) * 64 + lane;      // e = -a0 (l2 = 0, r = 0)
+        double wnd[kRw];
+#pragma unroll
+        for (int r = 0; r < kRw; ++r) wnd[r] = (L + 2 - a0 - r) >= 0 ? gp[-64 * r] : 0.0;
         for (int l2 = 0; l2 < L; ++l2) {
           const double pv = lane < C ? vec[l2 * C + lane] : 0.0;
-          acc[0] = fma(w0, pv, acc[0]);
-          acc[1] = fma(w1, pv, acc[1]);
-          acc[2] = fma(w2, pv, acc[2]);
-          acc[3] = fma(w3, pv, acc[3]);
-          w3 = w2; w2 = w1; w1 = w0;
-          w0 = l2 + 1 < L ? gp[(l2 + 1) * 64] : 0.0;
+#pragma unroll
+          for (int r = 0; r < kRw; ++r) acc[r] = fma(wnd[r], pv, acc[r]);
+#pragma unroll
+          for (int r = kRw - 1; r > 0; --r) wnd[r] = wnd[r - 1];
+          wnd[0] = l2 + 1 < L ? gp[(l2 + 1) * 64] : 0.0;
         }
       }
       // -- every q number
@@ -658,28 +725,29 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       }
       __syncthreads();
       // -- E part: row a takes - sum_f sum_{s < a} x_f[s][i] q_f[s - a]  (wi holds the sign)
-      if (4 * wave < L && !s_abort) {
+      if (has_rows && !s_abort) {
+        const double* wi = wi_all + ci * kCgtMaxQ;
         for (int q = lane; q < nq; q += 64) {
           const int f = q / post, sr = q % post;
           const double wv_ = wi[q];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int a = 4 * wave + r;
+          for (int r = 0; r < kRw; ++r) {
+            const int a = a0 + r;
             if (sr < a && a < L) acc[r] = fma(wv_, qv[f * post + (sr - a + post)], acc[r]);
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < kRw; ++r) {
           const double tot = wave_sum(acc[r]);
-          if (lane == 0) rowsum[4 * wave + r] = tot;
+          if (lane == 0 && a0 + r < 32) rowsum[ci * 32 + a0 + r] = tot;
         }
       }
       __syncthreads();
       // -- publish my L rows: one contiguous run of packets (workgroup-major packet order)
       unsigned long long* const buf = row_pk + (size_t)(round & 1u) * 2 * kCgtRowPackets;
-      if (t < L) {
-        const int c = t * C + i;
-        ll_store(buf + 2 * (i * L + t), rowsum[t] + lam * vec[c] - srow_t * (sdot * inv_ckk), round);
+      if (pub) {
+        const int c = pub_l * C + pub_i;
+        ll_store(buf + 2 * (pub_i * L + pub_l), rowsum[pub_c * 32 + pub_l] + lam * vec[c] - srow_t * (sdot * inv_ckk), round);
       }
       // -- every entry of the product
       {
@@ -697,7 +765,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
         if (!ok) s_abort = 1;
       }
 #ifdef TD_CGT_DEBUG      // development: the first product (and the vector it was taken with) instead of a solve
-      if (i == 0) {
+      if (blockIdx.x == 0) {
 #pragma unroll
         for (int j = 0; j < kCgMaxCols; ++j) {
           const int c = cg_col(t, j);
@@ -763,7 +831,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
     if (lane == 0) part_a[wave] = e0;
     __syncthreads();
     const double sxx = wave_parts(part_a, 1, 0);
-    if (i == 0) {
+    if (blockIdx.x == 0) {
 #pragma unroll
       for (int j = 0; j < kCgMaxCols; ++j) {
         const int c = cg_col(t, j);
@@ -773,7 +841,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
     }
     __syncthreads();
   }
-  if (i == 0 && t == 0) {
+  if (blockIdx.x == 0 && t == 0) {
     P.status[0] = aborted ? 3 : status;
     P.status[1] = iters_max;
     if (P.flag) *P.flag = (aborted || status != 0) ? 2 : 0;
@@ -796,20 +864,20 @@ int td_cg_rows(int k, int cus) {
 // xty [n][d] already on the device) on h->stream.  status_dev[0..1] receive status and iterations.
 int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const double* xty, int d, double inv,
                       const double* lams_dev, int n_lambda, int cus, int max_iter, double tol, float* w_dev,
-                      float* b_dev, int* status_dev, double accept) {
+                      float* b_dev, int* status_dev, double accept, bool gate) {
   const int k = n - 1;
   const int rows = td_cg_rows(k, cus);
   TD_REQUIRE(h, rows > 0, "td_cg_solve_dense: %d unknowns do not fit the LDS of %d workgroups", k, cus);
   if (!h->cg_packets) {
     TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->cg_packets),
-                        sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192));
-    TD_HIP(h, hipMemsetAsync(h->cg_packets, 0, sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192,
+                        sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192 + 4096));
+    TD_HIP(h, hipMemsetAsync(h->cg_packets, 0, sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192 + 4096,
                              h->stream));
     h->cg_epoch = 0;
   }
   const unsigned rounds = (unsigned)(n_lambda * d) * (unsigned)(max_iter + 4) + 8u;
   if (h->cg_epoch > 0xffffffffu - rounds - 16u) {          // the 32-bit round numbers wrap: start over
-    TD_HIP(h, hipMemsetAsync(h->cg_packets, 0, sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192,
+    TD_HIP(h, hipMemsetAsync(h->cg_packets, 0, sizeof(unsigned long long) * 2 * 2 * kCgThreads * kCgMaxCols + 256 + 8192 + 4096,
                              h->stream));
     h->cg_epoch = 0;
   }
@@ -820,6 +888,8 @@ int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const doub
   p.w = w_dev; p.bias = b_dev; p.status = status_dev;
   p.inv = inv; p.tol2 = tol * tol; p.accept = accept;
   p.n = n; p.ld = ld; p.d = d; p.n_lambda = n_lambda; p.k = k; p.rows = rows; p.max_iter = max_iter;
+  p.gate = gate ? 1 : 0;
+  p.trace_pk = h->cg_packets + 2 * 2 * kCgThreads * kCgMaxCols + (256 + 8192) / 8;      // behind the abort word and the timing area
   p.epoch = h->cg_epoch;
   p.limit_ticks = 100000LL * 20;          // 20 ms at 100 MHz
   if (h->cg_limit_ticks >= 0) p.limit_ticks = h->cg_limit_ticks;      // td_set_option("cg_limit_ticks"): 0 = give up at the first empty poll
@@ -849,14 +919,36 @@ int td_cg_solve_compact(td_handle* h, const StatsCompact& sc, const double* lams
   const int C = sc.c, L = sc.l, k = C * L, post = L - 1;
   const long long nq = (long long)sc.n_files * post;
   if (!sc.ok || C < 2 || C > 64 || (C & 1) || L < 1 || L > 32 || k > kCgThreads * kCgMaxCols ||
-      (post > 0 && sc.hw < post) || nq > (long long)kCgWaves * C || nq > kCgtMaxQ || n_lambda < 1)
+      (post > 0 && sc.hw < post) || nq > kCgtMaxQ || n_lambda < 1)
     return TD_CG_NOT_RESIDENT;
   for (int i = 0; i < n_lambda; ++i)
     if (!(lams_host[i] > 0.0)) return TD_CG_NOT_RESIDENT;
+  // one workgroup per channel when the handle's CUs hold them all at once, else two channels each
+  // (every workgroup must be resident: asked of the runtime before the launch)
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
-  int per_cu = 0;
-  TD_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_toeplitz_kernel, kCgThreads, 0));
-  if ((long long)per_cu * cus < C) return TD_CG_NOT_RESIDENT;
+  auto lds_bytes = [](int cpw) {
+    return sizeof(double) * ((size_t)kCgThreads * kCgMaxCols + (size_t)cpw * 66 * 64 + kCgtMaxQ + (size_t)cpw * kCgtMaxQ +
+                             (size_t)cpw * 32 + kCgWaves + 4 * kCgWaves + 64);
+  };
+  static bool opted[64] = {};
+  if (!opted[h->device & 63]) {
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(cg_toeplitz_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(1)));
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(cg_toeplitz_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(2)));
+    opted[h->device & 63] = true;
+  }
+  int cpw = 0;
+  for (int cand = 1; cand <= 2 && !cpw; ++cand) {
+    const int wgs = (C + cand - 1) / cand;
+    int per_cu = 0;
+    if (cand == 1)
+      TD_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_toeplitz_kernel<1>, kCgThreads, lds_bytes(1)));
+    else
+      TD_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_toeplitz_kernel<2>, kCgThreads, lds_bytes(2)));
+    if ((long long)per_cu * cus >= wgs && nq <= (long long)cand * kCgWaves * wgs) cpw = cand;
+  }
+  if (!cpw) return TD_CG_NOT_RESIDENT;
   const size_t words = (size_t)2 * 2 * kCgtRowPackets + (size_t)2 * 2 * kCgtMaxQ + 2 * 64;
   const size_t bytes = sizeof(unsigned long long) * words + 256;
   if (!h->cgt_packets) {
@@ -881,7 +973,10 @@ int td_cg_solve_compact(td_handle* h, const StatsCompact& sc, const double* lams
   p.limit_ticks = 100000LL * 20;
   if (h->cg_limit_ticks >= 0) p.limit_ticks = h->cg_limit_ticks;
   h->cgt_epoch += rounds;
-  hipLaunchKernelGGL(cg_toeplitz_kernel, dim3((unsigned)C), dim3(kCgThreads), 0, h->stream, p);
+  if (cpw == 1)
+    hipLaunchKernelGGL(cg_toeplitz_kernel<1>, dim3((unsigned)C), dim3(kCgThreads), lds_bytes(1), h->stream, p);
+  else
+    hipLaunchKernelGGL(cg_toeplitz_kernel<2>, dim3((unsigned)((C + 1) / 2)), dim3(kCgThreads), lds_bytes(2), h->stream, p);
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

@@ -1010,21 +1010,6 @@ constexpr int kLosoRows = 32;      // right-hand-side rows per workgroup
 // n = 129 / 513 / 769 / 2049 against 0.20 / 0.39 / 0.51 / 1.15 for the factorisation; the systems run one
 // after another, the batched factorisation shares its chain: two systems win from n = 129 by little and
 // from 257 clearly, four only from n = 513 -- 0.40 against 0.47)
-// sum of the diagonal of the dense moment matrix (n x n, row stride ld) -- the conditioning gate of the
-// automatic conjugate-gradient route
-__global__ __launch_bounds__(256) void trace_kernel(const double* __restrict__ a, int n, int ld, double* out) {
-  __shared__ double part[256];
-  double t = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) t += a[(size_t)i * ld + i];
-  part[threadIdx.x] = t;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *out = part[0];
-}
-
 constexpr int kCgAutoSystems = 4;     // (lambda, output) systems at most
 constexpr int kCgAutoMinN1 = 128;     // smallest n for one system,
 constexpr int kCgAutoMinN2 = 192;     // two,
@@ -1729,27 +1714,18 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
                 all_positive && n >= 3 && td_cg_rows(n - 1, cus) > 0;
   const bool by_choice = h->solver_mode == TD_SOLVER_CG;
   if (try_cg && !h->cg_status) TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->cg_status), sizeof(int) * 16));
-  if (try_cg && !by_choice) {
-    // The AUTOMATIC route answers for np.linalg.solve (brain_model.py:477), so it is taken only where a
-    // residual bound is a weight bound: a true relative residual of 2e-12 leaves the weights within
-    // cond(A) x 2e-12 of the factorisation's, and cond(A) <= trace(cov) / lambda + 1 -- with
-    // lambda >= 1e-6 trace(cov) that is 2e-6, inside the 1e-5 the fit promises.  Smaller lambdas (low-pass
-    // EEG with a tiny ridge) take the factorisation; td_set_solver(TD_SOLVER_CG) remains the explicit choice.
-    double* tr_dev = reinterpret_cast<double*>(h->cg_status + 8);
-    hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, h->stream, xtx, n, np, tr_dev);
-    double tr = 0.0;
-    TD_HIP(h, hipMemcpyAsync(&tr, tr_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    TD_HIP(h, hipStreamSynchronize(h->stream));
-    double lam_min = lambdas_host[0];
-    for (int i = 1; i < n_lambda; ++i) lam_min = lambdas_host[i] < lam_min ? lambdas_host[i] : lam_min;
-    if (!(lam_min >= 1e-6 * tr * inv)) try_cg = false;         // (also a NaN trace)
-  }
+  // The AUTOMATIC route answers for np.linalg.solve (brain_model.py:477), so it is taken only where a
+  // residual bound is a weight bound: a true relative residual of 2e-12 leaves the weights within
+  // cond(A) x 2e-12 of the factorisation's, and cond(A) <= trace(cov) / lambda + 1 -- with
+  // lambda >= 1e-6 trace(cov) that is 2e-6, inside the 1e-5 the fit promises.  The kernel sums the trace
+  // itself (one exchange in front of the first system) and reports status 4 for a smaller lambda (low-pass
+  // EEG with a tiny ridge): the factorisation follows; td_set_solver(TD_SOLVER_CG) remains the explicit choice.
   if (try_cg) {
     // (automatic: at most ~3x the iterations of a well-conditioned system of this kind -- C2: 55 -- and
     // the answer's TRUE residual within 2 tol; by choice: 400 iterations, 10 tol)
     const int rc_cg = td_cg_solve_dense(h, xtx, n, np, xty, d, inv, w.lams, n_lambda, cus,
                                         by_choice ? kCgMaxIter : kCgAutoMaxIter, kCgTol, w_dev, b_dev,
-                                        h->cg_status, by_choice ? 100.0 : 4.0);
+                                        h->cg_status, by_choice ? 100.0 : 4.0, !by_choice);
     if (rc_cg == TD_CG_NOT_RESIDENT) { h->last_cg_status = 3; try_cg = false; }
     else if (rc_cg != TD_OK) return rc_cg;
   }

@@ -163,7 +163,7 @@ int td_cg_rows(int k, int cus);
 constexpr int TD_CG_NOT_RESIDENT = 1;
 int td_cg_solve_dense(td_handle* h, const double* xtx, int n, int ld, const double* xty, int d, double inv,
                       const double* lams_dev, int n_lambda, int cus, int max_iter, double tol, float* w_dev,
-                      float* b_dev, int* status_dev, double accept = 100.0);
+                      float* b_dev, int* status_dev, double accept = 100.0, bool gate = false);
 
 // Solver workspace: like td_scratch, a separate arena.
 int td_workspace(td_handle* h, size_t bytes, void** out);

@@ -9,11 +9,12 @@ files = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 lib = _lib.load()
 p = ctypes.c_void_p()
-assert lib.td_stream_create_masked(0, 0, 64, ctypes.byref(p)) == 0
+CUS = int(os.environ.get("CUS", "64"))
+assert lib.td_stream_create_masked(0, 0, CUS, ctypes.byref(p)) == 0
 s64 = torch.cuda.ExternalStream(p.value)
 with torch.cuda.stream(s64):
   h = device.Handle()
-  h.check(lib.td_set_cu_count(h.ptr, 64))
+  h.check(lib.td_set_cu_count(h.ptr, CUS))
   trials = synth.make_trials(3, files, frames, 64)
   eeg = np.concatenate([t[0] for t in trials]); env = np.concatenate([t[1][:, 0:1] for t in trials])
   offs = np.arange(files + 1, dtype=np.int64) * frames
