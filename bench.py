@@ -942,6 +942,9 @@ def main():
   ap.add_argument('--targets-on-solve', action='store_true',
                   help='run the y^T x part of the accumulate on the solve streams (the round-2 '
                        'arrangement; the accumulate then measures its channel maxima in a pass of its own)')
+  ap.add_argument('--targets-ahead', action='store_true',
+                  help='run the y^T x / channel-maximum pass of fit i + 1 on a stream of its own on the solve '
+                       'partition (TD_ACC_TARGETS_FIRST), beside the matrix kernel of fit i')
   ap.add_argument('--solve-streams', type=int, default=2,
                   help='solve streams of the pipeline (fit i on stream i mod n, same CU partition)')
   ap.add_argument('--solve-cus', type=int, default=64,
@@ -1100,7 +1103,8 @@ def main():
       return run, h, None
     pipe = pipeline.FitPipeline(C, PRE, POST, d=D, solve_cus=args.solve_cus,
                                 targets_on_solve=args.targets_on_solve, allreduce=reduce_fn,
-                                solves=solves, solve_streams=args.solve_streams)
+                                solves=solves, solve_streams=args.solve_streams,
+                                targets_ahead=args.targets_ahead)
 
     fill_stats = []
 

@@ -601,6 +601,11 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
     const int c = cg_col(t, j);
     s_reg[j] = c < k ? P.gxo[((size_t)(c / C) * D1 + P.d) * C + (c % C)] * inv : 0.0;
   }
+  // s = q % post of this lane's q numbers q = lane + 64 it (5 bits each; post <= 31)
+  unsigned long long sr_pack = 0ull;
+#pragma unroll
+  for (int it8 = 0; it8 < kCgtMaxQ / 64; ++it8)
+    sr_pack |= (unsigned long long)(post > 0 ? (lane + 64 * it8) % post : 0) << (5 * it8);
   // (thread t < kCpw L publishes row (t % L, i0 + t / L))
   const int pub_c = t / L, pub_l = t % L, pub_i = i0 + pub_c;
   const bool pub = t < kCpw * L && pub_i < C;
@@ -659,6 +664,13 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
     int it = 0;
     bool check_pass = false;
     const bool done = bnorm2 == 0.0;
+#ifdef TD_CGT_TIMING
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = wall_clock64();
+#define TD_CGT_T(i) do { const long long now_ = wall_clock64(); tph[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define TD_CGT_T(i)
+#endif
     while (!done) {
       // -- the multiplied vector (r, or x in the check pass) -> LDS
 #pragma unroll
@@ -678,21 +690,32 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       __syncthreads();
       if (check_pass) sdot = wave_parts(part_a, 1, 0);
       ++round;
+      TD_CGT_T(0);
       // -- my q numbers: published first, the T part runs while they travel
       unsigned long long* const qbuf = q_pk + (size_t)(round & 1u) * 2 * kCgtMaxQ;
 #pragma unroll
       for (int sl = 0; sl < kCpw; ++sl) {
         const int qi = gw + sl * n_waves;
         if (qi < nq) {                     // (wave-uniform: kCpw q numbers per wave of the grid)
-          double a = 0.0;
+          // (unconditional reads -- a branch per term made every LDS read wait for the one before it:
+          // 2.3 us for this block; the window rows past L and the lanes past C hold zeros -- and two
+          // chains of additions)
+          const int lq = lane < C ? lane : 0;
+          double pvq[32];
 #pragma unroll
-          for (int bb = 0; bb < 32; ++bb)
-            if (bb < L) a = fma((double)wreg[sl][bb], lane < C ? vec[bb * C + lane] : 0.0, a);
-          a = wave_sum(a);
+          for (int bb = 0; bb < 32; ++bb) pvq[bb] = vec[(bb < L ? bb : 0) * C + lq];
+          double a = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int bb = 0; bb < 32; bb += 2) {
+            a = fma((double)wreg[sl][bb], pvq[bb], a);
+            a2 = fma((double)wreg[sl][bb + 1], pvq[bb + 1], a2);
+          }
+          a = wave_sum(a + a2);
           if (lane == 0) ll_store(qbuf + 2 * qi, a, round);
         }
       }
       // -- T part of my rows a = 4 wave + r: lane j multiplies the columns (., j)
+      TD_CGT_T(1);
       // (row a = a0 + r needs G[l2 - a] against the column block l2: a window of kRw table rows that
       // slides by one per block -- one new 8-byte read per lane and block)
       double acc[kRw];
@@ -703,15 +726,38 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
         double wnd[kRw];
 #pragma unroll
         for (int r = 0; r < kRw; ++r) wnd[r] = (L + 2 - a0 - r) >= 0 ? gp[-64 * r] : 0.0;
-        for (int l2 = 0; l2 < L; ++l2) {
-          const double pv = lane < C ? vec[l2 * C + lane] : 0.0;
+        // (eight column blocks per trip: their sixteen LDS reads are in flight together -- one block per
+        // trip was a chain of read latencies, ~1.8 us of a 10 us iteration)
+        const int lc = lane < C ? lane : 0;
+        const double keep = lane < C ? 1.0 : 0.0;
+        int l2 = 0;
+        for (; l2 + 8 <= L; l2 += 8) {
+          double pv[8], gn[8];
 #pragma unroll
-          for (int r = 0; r < kRw; ++r) acc[r] = fma(wnd[r], pv, acc[r]);
+          for (int u = 0; u < 8; ++u) {
+            pv[u] = vec[(l2 + u) * C + lc];
+            gn[u] = l2 + u + 1 < L ? gp[(l2 + u + 1) * 64] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double pu = pv[u] * keep;
+#pragma unroll
+            for (int r = 0; r < kRw; ++r) acc[r] = fma(wnd[r], pu, acc[r]);
+#pragma unroll
+            for (int r = kRw - 1; r > 0; --r) wnd[r] = wnd[r - 1];
+            wnd[0] = gn[u];
+          }
+        }
+        for (; l2 < L; ++l2) {
+          const double pu = vec[l2 * C + lc] * keep;
+#pragma unroll
+          for (int r = 0; r < kRw; ++r) acc[r] = fma(wnd[r], pu, acc[r]);
 #pragma unroll
           for (int r = kRw - 1; r > 0; --r) wnd[r] = wnd[r - 1];
           wnd[0] = l2 + 1 < L ? gp[(l2 + 1) * 64] : 0.0;
         }
       }
+      TD_CGT_T(2);
       // -- every q number
       {
         const long long t_wait = wall_clock64();
@@ -724,16 +770,31 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
         if (!ok) s_abort = 1;
       }
       __syncthreads();
+      TD_CGT_T(3);
       // -- E part: row a takes - sum_f sum_{s < a} x_f[s][i] q_f[s - a]  (wi holds the sign)
       if (has_rows && !s_abort) {
         const double* wi = wi_all + ci * kCgtMaxQ;
-        for (int q = lane; q < nq; q += 64) {
-          const int f = q / post, sr = q % post;
-          const double wv_ = wi[q];
+        // (q = f post + s pairs with row a when s < a; its partner q_f[s - a] is entry q + post - a: no
+        // division in the loop -- s of this lane's q numbers was taken at set-up)
 #pragma unroll
-          for (int r = 0; r < kRw; ++r) {
-            const int a = a0 + r;
-            if (sr < a && a < L) acc[r] = fma(wv_, qv[f * post + (sr - a + post)], acc[r]);
+        for (int it8 = 0; it8 < kCgtMaxQ / 64; ++it8) {
+          const int q = lane + 64 * it8;
+          if (64 * it8 < nq) {               // (wave-uniform)
+            const int sr = (sr_pack >> (5 * it8)) & 31;
+            const int qc = q < nq ? q : 0;
+            const double wv_ = q < nq ? wi[qc] : 0.0;
+            // (the kRw partners read unconditionally, at a clamped index, and selected afterwards)
+            double qq[kRw];
+#pragma unroll
+            for (int r = 0; r < kRw; ++r) {
+              const int idx = qc + post - (a0 + r);
+              qq[r] = qv[idx < 0 ? 0 : (idx >= kCgtMaxQ ? kCgtMaxQ - 1 : idx)];
+            }
+#pragma unroll
+            for (int r = 0; r < kRw; ++r) {
+              const int a = a0 + r;
+              acc[r] = fma((sr < a && a < L) ? wv_ : 0.0, qq[r], acc[r]);
+            }
           }
         }
 #pragma unroll
@@ -743,6 +804,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
         }
       }
       __syncthreads();
+      TD_CGT_T(4);
       // -- publish my L rows: one contiguous run of packets (workgroup-major packet order)
       unsigned long long* const buf = row_pk + (size_t)(round & 1u) * 2 * kCgtRowPackets;
       if (pub) {
@@ -751,18 +813,38 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       }
       // -- every entry of the product
       {
+        // (every pass loads all four packets with no branch between the loads: one round trip per pass,
+        // not one per packet -- as the resident kernel)
         const long long t_wait = wall_clock64();
-        bool ok = !s_abort;
-        __builtin_amdgcn_s_sleep(16);
+        bool gave_up = s_abort != 0;
+        int pidx[kCgMaxCols];
 #pragma unroll
         for (int j = 0; j < kCgMaxCols; ++j) {
-          const int c = cg_col(t, j);
-          double val = 0.0;
-          if (c < k && ok) ok = cgt_wait(buf + 2 * ((c % C) * L + c / C), round, val, P.abort_word, abort_id,
-                                         P.limit_ticks, t_wait);
-          wq[j] = c < k ? val : 0.0;
+          const int c = cg_col(t, j) < k ? cg_col(t, j) : k - 1;
+          pidx[j] = 2 * ((c % C) * L + c / C);
         }
-        if (!ok) s_abort = 1;
+        __builtin_amdgcn_s_sleep(16);
+        int polls = 0;
+        while (!gave_up) {
+          bool all = true;
+#pragma unroll
+          for (int j = 0; j < kCgMaxCols; ++j) {
+            double val;
+            const bool got = ll_try(buf + pidx[j], round, val);
+            wq[j] = cg_col(t, j) < k ? val : 0.0;
+            all = all && got;
+          }
+          if (all) break;
+          if ((++polls & 15) == 0 || P.limit_ticks < 16) {
+            if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == abort_id) { gave_up = true; break; }
+            if (wall_clock64() - t_wait > P.limit_ticks) {
+              __hip_atomic_store(P.abort_word, abort_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              gave_up = true;
+              break;
+            }
+          }
+        }
+        if (gave_up) s_abort = 1;
       }
 #ifdef TD_CGT_DEBUG      // development: the first product (and the vector it was taken with) instead of a solve
       if (blockIdx.x == 0) {
@@ -775,6 +857,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       status = 5;
       break;
 #endif
+      TD_CGT_T(5);
       // -- ONE reduction: r^T r, w^T r, s^T w (in the check pass: |b - A x|^2)
       double e0 = 0.0, e1 = 0.0, e2 = 0.0;
 #pragma unroll
@@ -790,6 +873,7 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       if (lane == 0) { part_b[4 * wave] = e0; part_b[4 * wave + 1] = e1; part_b[4 * wave + 2] = e2; }
       __syncthreads();
       if (s_abort) { aborted = true; break; }
+      TD_CGT_T(6);
       const double gamma = wave_parts(part_b, 4, 0);
       const double delta = wave_parts(part_b, 4, 1);
       const double sw = wave_parts(part_b, 4, 2);
@@ -821,6 +905,9 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       gamma_old = gamma;
       denom_old = denom;
     }
+#ifdef TD_CGT_TIMING
+    if (blockIdx.x == 0 && t == 0) for (int ii = 0; ii < 7; ++ii) P.status[2 + ii] = (int)tph[ii];
+#endif
     iters_max = it > iters_max ? it : iters_max;
     if (aborted || status != 0) break;
     __syncthreads();
@@ -978,5 +1065,14 @@ int td_cg_solve_compact(td_handle* h, const StatsCompact& sc, const double* lams
   else
     hipLaunchKernelGGL(cg_toeplitz_kernel<2>, dim3((unsigned)((C + 1) / 2)), dim3(kCgThreads), lds_bytes(2), h->stream, p);
   TD_HIP(h, hipGetLastError());
+#ifdef TD_CGT_TIMING
+  {
+    int st[9] = {0};
+    hipStreamSynchronize(h->stream);
+    hipMemcpy(st, status_dev, sizeof(st), hipMemcpyDeviceToHost);
+    fprintf(stderr, "cgt phases (10 ns ticks over %d iterations): vec+barrier %d q %d T %d poll-q+barrier %d E+sums+barrier %d publish+poll-rows %d reduction %d\n",
+            st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8]);
+  }
+#endif
   return TD_OK;
 }
