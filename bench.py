@@ -26,7 +26,7 @@ measured after the timed region and reported as `serial_ms_per_step`.
 
 Before the W warm-up steps, --spinup-steps (default 40, untimed, reported in the line) bring the
 device out of the idle of the set-up phase: after an idle moment the chip answers a burst of
-matrix work with a power / clock transient of ~25 launches, which W = 3 warm-up
+matrix work with a power / clock transient of ~25 launches (profiles/NOTES.md 6), which W = 3 warm-up
 steps do not outlast; and --drain-fill (default 2, untimed, reported) accumulate-only calls run
 while the last warm-up solves drain, so that the barrier is reached under load.  The timed region
 is still exactly K steps between barrier + synchronise.

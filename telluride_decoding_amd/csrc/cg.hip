@@ -10,7 +10,7 @@
 // a few dot products -- and the matrix of a ridge TRF fit is benign (lambda and the sensor noise
 // floor bound the smallest eigenvalue; the large ones are the few dozen directions the stimulus
 // drives): the C2 system converges to 1e-12 in 54-56 iterations (block-circulant, Kronecker and
-// coarse-space preconditioners make it WORSE or cost more exchanges than they save: DESIGN.md 8).
+// coarse-space preconditioners make it WORSE or cost more exchanges than they save: profiles/NOTES.md 8).
 // What an iteration costs on a GPU is not arithmetic (2 n^2 = 8.4 MFLOP) but the exchange between
 // workgroups.  So:
 //   * ONE persistent launch of W <= (CUs) workgroups, workgroup w owning R = ceil(k / W) rows of the

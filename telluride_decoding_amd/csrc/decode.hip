@@ -2663,7 +2663,7 @@ int launch_fir(td_handle* h, const float* x, int64_t ldx, const int64_t* offs, i
   }
   // (Measured at C4, decode step: 90.1 us with fir_tile16_kernel against 86.3 us with
   // predict_fir_mfma_kernel -- its split + MFMA cost 26 us and its loads 19 us that overlap only
-  // partly (ablations: DESIGN 8) -- so the P-tile kernel stays the default and this one is opt-in.)
+  // partly (ablations: profiles/NOTES.md 8) -- so the P-tile kernel stays the default and this one is opt-in.)
   static const bool tile16 = td_dev_env("TD_FIR_TILE16") != nullptr;          // development: A/B runs
   if (!w_file_stride && d == 1 && nl <= 32 && c >= 4 && c <= 64 && vec4 && tile16 && h->acc_mode != TD_ACC_F32) {
     // one output: the barrier-free 16-row kernel (fir_tile16_kernel); 12 waves per CU, one round

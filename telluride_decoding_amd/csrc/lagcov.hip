@@ -475,7 +475,7 @@ __device__ __forceinline__ void bf_kstep(const unsigned* __restrict__ ap,
   for (int pc = 0; pc < kP; ++pc)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#ifdef TD_ABL_NOALIGN   // timing ablations (wrong sums; tools/README.md): no operand VALU
+#ifdef TD_ABL_NOALIGN   // timing ablations (wrong sums; tools/README.md, profiles/NOTES.md 8): no operand VALU
       b[0][pc][i] = d[pc][i]; b[1][pc][i] = a[pc][i]; b[2][pc][i] = d[pc][i + 2]; b[3][pc][i] = a[kP - 1 - pc][i];
 #else
       b[0][pc][i] = d[pc][i];
