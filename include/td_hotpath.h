@@ -282,6 +282,8 @@ int td_set_solver(td_handle* h, int mode);
  *                     (one launch of one workgroup per channel: fits a 64-CU partition); its flag is
  *                     then 2 when the solver gave up -- the caller solves again (td_ridge_solve) -- as
  *                     well as 0 / 1.  0 (default): the factorisation, flags 0 / 1 only.
+ *   "narrow16"        1 (default): regression statistics of <= 16 channels x <= 16 lags are accumulated by
+ *                     the one-kernel streaming form (float32 products); 0: the tiled kernels (A/B runs).
  * Unknown names are TD_ERR_INVALID. */
 int td_set_option(td_handle* h, const char* name, int64_t value);
 int td_last_solve_info(td_handle* h, int* solver, int* iterations, int* cg_status);

@@ -1109,6 +1109,214 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   }
 }
 
+// ---- <= 16 channels: one streaming kernel for the matrix AND the targets (round 5) ----------------
+// With 16 channels the lagged covariance is HBM-bound if nothing gets in the way: 64 bytes of input and
+// l1 x 256 multiply-adds per sample.  The float32 matrix instruction v_mfma_f32_16x16x4_f32 takes
+// A = x~[u .. u+3][i] and B = x~[u+e .. u+e+3][j] with lane = channel + 16 k -- for a dense 16-channel
+// array that is 64 consecutive floats, ONE coalesced dword load per operand, straight from global
+// memory (the l1 overlapping loads of a step hit the vector L1): no LDS, no barrier, no staging, no
+// split (the products are float32 products).  A wave walks a slab of one recording four samples at a
+// time with <= 8 lags in its accumulators; the four waves of a workgroup are four sub-slabs (<= 8 lags)
+// or two sub-slabs x two lag groups (<= 16 lags; beyond that the float16 kernel on virtual images is
+// faster).  The targets ride along on the vector pipe (y[u] x~[u + e - pre][j]: d x lags FMAs per step),
+// and so do the column sums of x and y that the bias moments need -- what lagcov_targets_mfma_kernel does
+// for the wide shapes in a pass of its own.  A workgroup's sums (chains of a few hundred steps, added over
+// its sub-slabs in a fixed order) leave as ONE float32 partial slab, reduced in float64 by the finalize
+// launch like every other kernel's.
+struct Narrow16Params {
+  const float* x;
+  const float* y;
+  long long ldx, ldy;
+  int c, d, pre, l1;
+  const LagWork* works;      // a = the y stream, b = x; [u_begin, u_end) = the workgroup's slab
+  int n_lg, lpw;             // lag groups per workgroup (1 or 2), lags per wave (<= 8)
+  int do_main, do_tgt;       // the parts this call carries
+  float* part;               // [workgroup][l1][16][16]
+  float* tpart;              // [d][workgroup][l1][16]
+  double* csum;              // [workgroup][16]
+  double* ysum;              // [d][workgroup]
+  long long n_part;
+};
+
+typedef float n16_f32x4 __attribute__((ext_vector_type(4)));
+
+// Rows of a recording through a buffer descriptor over exactly its valid rows: a row past the end -- or
+// before the start: the 32-bit byte offset wraps far past the range -- reads as zero, which is x~.  A
+// lane of a channel that does not exist carries 0x80000000 in its offset (the host keeps a recording's
+// bytes well below that).
+__device__ __forceinline__ float n16_load(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+}
+
+// kLpw: lags per wave (the last lag group may reach past l1: those lags are computed and dropped -- no
+// condition inside the loop); kD: target columns carried (>= d; the columns past d multiply by what
+// the y buffer holds there and are dropped); kPre: the targets' lags start before 0 (their own loads).
+template <bool kMain, bool kTgt, int kLpw, int kD, bool kPre>
+__global__ __launch_bounds__(256) void lagcov_narrow16_kernel(Narrow16Params p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave % p.n_lg, sub = wave / p.n_lg, n_sub = 4 / p.n_lg;
+  const LagWork w = p.works[blockIdx.x];
+  const long long len = w.u_end - w.u_begin;
+  const long long sub_len = ((len + n_sub - 1) / n_sub + 3) / 4 * 4;
+  const long long ub = w.u_begin + sub * sub_len;
+  const long long ue = ub + sub_len < w.u_end ? ub + sub_len : w.u_end;
+  const int j = lane & 15, k = lane >> 4;
+  const int e0 = g * kLpw;
+  const int ne = p.l1 - e0 < kLpw ? p.l1 - e0 : kLpw;          // lags of this wave that exist (<= 0: none)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x + w.b_row0 * p.ldx), 0,
+      w.b_valid > 0 ? (int)(((w.b_valid - 1) * p.ldx + p.c) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.y + w.a_row0 * p.ldy), 0,
+      w.a_valid > 0 ? (int)(((w.a_valid - 1) * p.ldy + p.d) * 4) : 0, 0x00020000);
+  const unsigned row_x = (unsigned)(p.ldx * 4), row_y = (unsigned)(p.ldy * 4);
+  const unsigned lane_x = j < p.c ? (unsigned)k * row_x + 4u * j : 0x80000000u;
+  const unsigned lane_y = (unsigned)k * row_y;
+  const unsigned lag0 = (unsigned)e0 * row_x, pre_x = (unsigned)p.pre * row_x;
+  n16_f32x4 acc[kLpw];
+  float tacc[kD][kLpw];
+#pragma unroll
+  for (int q = 0; q < kLpw; ++q) {
+    acc[q] = n16_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int col = 0; col < kD; ++col) tacc[col][q] = 0.f;
+  }
+  float cs = 0.f, ys[kD];
+#pragma unroll
+  for (int col = 0; col < kD; ++col) ys[col] = 0.f;
+  // kU steps of four samples per iteration: every load of the iteration first (they are what the wave
+  // waits for), then the arithmetic.  Steps past the slab's end load rows that exist or zeros and are
+  // masked out of A and y.
+  constexpr int kU = kLpw >= 8 ? 2 : 4;
+  for (long long u = ub; u < ue; u += 4 * kU) {
+    const unsigned vx = lane_x + (unsigned)u * row_x;            // row u + k, this lane's channel
+    const unsigned vy = lane_y + (unsigned)u * row_y;
+    float a[kU], b[kU][kLpw], bt[kU][kLpw], yv[kU][kD];
+#pragma unroll
+    for (int st = 0; st < kU; ++st) {
+      const unsigned vs = vx + (unsigned)(4 * st) * row_x;
+      a[st] = n16_load(rx, vs);
+#pragma unroll
+      for (int q = 0; q < kLpw; ++q) b[st][q] = n16_load(rx, vs + lag0 + (unsigned)q * row_x);
+      if (kTgt) {
+#pragma unroll
+        for (int col = 0; col < kD; ++col) yv[st][col] = n16_load(ry, vy + (unsigned)(4 * st) * row_y + 4u * col);
+        if (kPre) {
+#pragma unroll
+          for (int q = 0; q < kLpw; ++q) bt[st][q] = n16_load(rx, vs + lag0 + (unsigned)q * row_x - pre_x);
+        }
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < kU; ++st) {
+      const bool in_slab = k + 4 * st < ue - u;
+      const float av = in_slab ? a[st] : 0.f;
+#pragma unroll
+      for (int q = 0; q < kLpw; ++q) {
+        if (kMain) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[st][q], acc[q], 0, 0, 0);
+        if (kTgt) {
+#pragma unroll
+          for (int col = 0; col < kD; ++col) {
+            const float yc = in_slab ? yv[st][col] : 0.f;
+            tacc[col][q] += yc * (kPre ? bt[st][q] : b[st][q]);   // (the targets' lag of index e0 + q is e0 + q - pre)
+          }
+        }
+      }
+      if (kTgt) {
+        cs += av;
+#pragma unroll
+        for (int col = 0; col < kD; ++col) ys[col] += in_slab ? yv[st][col] : 0.f;
+      }
+    }
+  }
+  // The sub-slabs of the workgroup are summed here, in a fixed order (the float32 sums must not depend on
+  // which wave finishes first): the waves of sub-slabs 1.. leave theirs in LDS, the wave of sub-slab 0 of
+  // each lag group adds them and writes the workgroup's ONE partial slab.
+  constexpr int kSlot = kLpw * 256 + kD * kLpw * 16 + 16 + 16;      // floats a wave leaves
+  __shared__ float red[3 * kSlot];
+  if (kTgt) {
+    // the k groups of a lane's column: lanes l, l + 16, l + 32, l + 48 (every lane ends up with the sum)
+#pragma unroll
+    for (int col = 0; col < kD; ++col) {
+#pragma unroll
+      for (int q = 0; q < kLpw; ++q) {
+        float t = tacc[col][q];
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        tacc[col][q] = t;
+      }
+      float t = ys[col];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      ys[col] = t;
+    }
+    cs += __shfl_xor(cs, 16);
+    cs += __shfl_xor(cs, 32);
+  }
+  if (sub > 0) {
+    float* slot = red + ((sub - 1) * p.n_lg + g) * kSlot;
+    if (kMain) {
+#pragma unroll
+      for (int q = 0; q < kLpw; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[(q * 4 + r) * 64 + lane] = acc[q][r];
+    }
+    if (kTgt && k == 0) {
+#pragma unroll
+      for (int col = 0; col < kD; ++col) {
+#pragma unroll
+        for (int q = 0; q < kLpw; ++q) slot[kLpw * 256 + (col * kLpw + q) * 16 + j] = tacc[col][q];
+        if (j == 0) slot[kLpw * 256 + kD * kLpw * 16 + 16 + col] = ys[col];
+      }
+      slot[kLpw * 256 + kD * kLpw * 16 + j] = cs;
+    }
+  }
+  __syncthreads();
+  if (sub > 0) return;
+  for (int o = 1; o < n_sub; ++o) {
+    const float* slot = red + ((o - 1) * p.n_lg + g) * kSlot;
+    if (kMain) {
+#pragma unroll
+      for (int q = 0; q < kLpw; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] += slot[(q * 4 + r) * 64 + lane];
+    }
+    if (kTgt && k == 0) {
+#pragma unroll
+      for (int col = 0; col < kD; ++col) {
+#pragma unroll
+        for (int q = 0; q < kLpw; ++q) tacc[col][q] += slot[kLpw * 256 + (col * kLpw + q) * 16 + j];
+        ys[col] += slot[kLpw * 256 + kD * kLpw * 16 + 16 + col];
+      }
+      cs += slot[kLpw * 256 + kD * kLpw * 16 + j];
+    }
+  }
+  const long long pidx = blockIdx.x;
+  // D of the 16 x 16 x 4 instruction: register r of lane l is (i = 4 (l / 16) + r, j = l % 16)
+  if (kMain) {
+#pragma unroll
+    for (int q = 0; q < kLpw; ++q) {
+      if (q < ne) {
+        float* dst = p.part + ((size_t)pidx * p.l1 + (e0 + q)) * 256 + (4 * k) * 16 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r * 16] = acc[q][r];
+      }
+    }
+  }
+  if (!kTgt || k != 0) return;
+#pragma unroll
+  for (int col = 0; col < kD; ++col) {
+    if (col < p.d) {
+#pragma unroll
+      for (int q = 0; q < kLpw; ++q)
+        if (q < ne) p.tpart[(((size_t)col * p.n_part + pidx) * p.l1 + (e0 + q)) * 16 + j] = tacc[col][q];
+      if (g == 0 && j == 0) p.ysum[(size_t)col * p.n_part + pidx] = (double)ys[col];
+    }
+  }
+  if (g == 0) p.csum[pidx * 16 + j] = (double)cs;
+}
+
 // Largest magnitude of every channel over the rows [row0, row1) of a time x channel array, as
 // float bits (non-negative floats order like unsigned integers; a NaN is "larger" than
 // everything) atomically maxed into tab[channel]: the scales of the float16 kernel above.
@@ -3353,6 +3561,105 @@ __global__ __launch_bounds__(256) void virt_reduce_kernel(LagReduceJob jb) {
   }
 }
 }  // namespace
+
+int td_narrow16_plan(td_handle* h, int c, int d, int pre, int l1, int64_t ldx, int64_t ldy,
+                     const std::vector<LagSeg>& syx, Narrow16Plan* plan) {
+  (void)h;
+  plan->ok = false;
+  // (measured at 1e6 samples x 16 channels: 4 / 8 / 16 lags 0.055 / 0.09 / 0.15 ms against 0.19 / 0.17 / 0.17 on the
+  // tiled kernels; at 32 lags the virtual-image float16 kernel wins, 0.16 against 0.27)
+  if (c < 1 || c > 16 || d < 1 || d > 4 || l1 < 1 || l1 > 16 || pre < 0 || pre >= l1) return TD_OK;
+  plan->c = c; plan->d = d; plan->pre = pre; plan->l1 = l1;
+  plan->n_lg = l1 <= 8 ? 1 : 2;
+  const int need = (int)td_ceil_div(l1, plan->n_lg);
+  plan->lpw = need <= 2 ? 2 : need <= 4 ? 4 : 8;
+  const int n_sub = 4 / plan->n_lg;
+  long long total = 0;
+  for (const LagSeg& sg : syx) total += sg.u_end > sg.u_begin ? sg.u_end - sg.u_begin : 0;
+  if (total <= 0) return TD_OK;
+  // the buffer descriptors address a recording with 32-bit byte offsets (margin: the rows a lag reaches
+  // past either end, and the 0x80000000 of the lanes without a channel)
+  for (const LagSeg& sg : syx)
+    if ((sg.b_valid + 128) * ldx * 4 >= (1LL << 31) || (sg.a_valid + 128) * ldy * 4 >= (1LL << 31)) return TD_OK;
+  // ~16 waves per CU of the whole chip; a sub-slab of at least 64 samples.  (Not the handle's CU count: the
+  // slabs -- and with them the float32 rounding of the sums -- must not depend on the stream a call runs on.)
+  const long long want = 1024;
+  long long per = td_ceil_div(total, want);
+  if (per < 64LL * n_sub) per = 64LL * n_sub;
+  per = td_round_up(per, 4 * n_sub);
+  plan->works.clear();
+  for (const LagSeg& sg : syx) {
+    for (long long u = sg.u_begin; u < sg.u_end; u += per) {
+      LagWork wk;
+      wk.a_row0 = sg.a_row0; wk.a_valid = sg.a_valid; wk.b_row0 = sg.b_row0; wk.b_valid = sg.b_valid;
+      wk.u_begin = u; wk.u_end = u + per < sg.u_end ? u + per : sg.u_end;
+      plan->works.push_back(wk);
+    }
+  }
+  plan->n_part = (long long)plan->works.size();
+  plan->part_bytes = (size_t)td_round_up((int64_t)(sizeof(float) * plan->n_part * l1 * 256), 256);
+  plan->tpart_bytes = (size_t)td_round_up((int64_t)(sizeof(float) * d * plan->n_part * l1 * 16), 256);
+  plan->cs_bytes = (size_t)td_round_up((int64_t)(sizeof(double) * plan->n_part * 16), 256);
+  plan->ys_bytes = (size_t)td_round_up((int64_t)(sizeof(double) * d * plan->n_part), 256);
+  plan->scratch_bytes = plan->part_bytes + plan->tpart_bytes + plan->cs_bytes + plan->ys_bytes;
+  plan->ok = true;
+  return TD_OK;
+}
+
+int td_narrow16_launch(td_handle* h, Narrow16Plan* plan, const float* x, int64_t ldx, const float* y, int64_t ldy,
+                       void* scratch, bool do_main, bool do_targets, double* g_xx, bool acc_main, double* g_xo,
+                       bool acc_tgt, LagReduceJob* job, TargetsOutputs* out) {
+  Narrow16Params p;
+  memset(&p, 0, sizeof(p));
+  char* base = reinterpret_cast<char*>(scratch);
+  p.x = x; p.y = y; p.ldx = ldx; p.ldy = ldy;
+  p.c = plan->c; p.d = plan->d; p.pre = plan->pre; p.l1 = plan->l1;
+  p.n_lg = plan->n_lg; p.lpw = plan->lpw; p.n_part = plan->n_part;
+  p.part = reinterpret_cast<float*>(base);
+  p.tpart = reinterpret_cast<float*>(base + plan->part_bytes);
+  p.csum = reinterpret_cast<double*>(base + plan->part_bytes + plan->tpart_bytes);
+  p.ysum = reinterpret_cast<double*>(base + plan->part_bytes + plan->tpart_bytes + plan->cs_bytes);
+  const void* works_dev = nullptr;
+  TD_TRY(td_table_upload(h, plan->works.data(), plan->works.size() * sizeof(LagWork), &works_dev));
+  p.works = reinterpret_cast<const LagWork*>(works_dev);
+  TD_TRY(td_profile_mark(h, true, 0.0));
+  p.do_main = do_main ? 1 : 0; p.do_tgt = do_targets ? 1 : 0;
+  const dim3 grid((unsigned)plan->works.size());
+#define TD_N16(M, T, L, D, P) \
+  hipLaunchKernelGGL((lagcov_narrow16_kernel<M, T, L, D, P>), grid, dim3(256), 0, h->stream, p)
+#define TD_N16_P(M, T, L, D) do { if (plan->pre && (T)) TD_N16(M, T, L, D, true); else TD_N16(M, T, L, D, false); } while (0)
+#define TD_N16_D(M, T, L) do { if (!(T) || plan->d == 1) TD_N16_P(M, T, L, 1); else TD_N16_P(M, T, L, 4); } while (0)
+#define TD_N16_L(M, T) do { if (plan->lpw == 2) TD_N16_D(M, T, 2); else if (plan->lpw == 4) TD_N16_D(M, T, 4); else TD_N16_D(M, T, 8); } while (0)
+  if (do_main && do_targets) TD_N16_L(true, true);
+  else if (do_main) TD_N16_L(true, false);
+  else TD_N16_L(false, true);
+#undef TD_N16_L
+#undef TD_N16_D
+#undef TD_N16_P
+#undef TD_N16
+  TD_HIP(h, hipGetLastError());
+  TD_TRY(td_profile_mark(h, false, 0.0));
+  const int c = plan->c, l1 = plan->l1, d = plan->d;
+  *job = LagReduceJob{};
+  job->partial = p.part; job->is_f64 = 0;
+  job->n_work = (int)plan->n_part; job->e_pad = l1; job->ca_pad = 16; job->cb_pad = 16;
+  job->e_count = l1; job->ca_eff = c; job->cb = c;
+  job->g = g_xx; job->accumulate = acc_main ? 1 : 0; job->ca_dst = c; job->ldg = c;
+  job->mirror = 0;
+  out->csum = p.csum; out->n_work = (int)plan->n_part; out->cb_pad = 16;
+  for (int i = 0; i < 4; ++i) out->ysum[i] = nullptr;
+  for (int i = 0; i < d; ++i) {
+    LagReduceJob& tj = out->jobs[i];
+    tj = LagReduceJob{};
+    tj.partial = p.tpart + (size_t)i * plan->n_part * l1 * 16; tj.is_f64 = 0;
+    tj.n_work = (int)plan->n_part; tj.e_pad = l1; tj.ca_pad = 1; tj.cb_pad = 16;
+    tj.e_count = l1; tj.ca_eff = 1; tj.cb = c;
+    tj.g = g_xo + (size_t)i * c; tj.accumulate = acc_tgt ? 1 : 0; tj.ca_dst = d + 1; tj.ldg = c;
+    tj.mirror = 0;
+    out->ysum[i] = p.ysum + (size_t)i * plan->n_part;
+  }
+  return TD_OK;
+}
 
 int td_chan_max(td_handle* h, const float* x, int64_t ldx, int c, long long row0, long long row1, unsigned* tab) {
   TD_REQUIRE(h, c >= 1 && c <= 128, "td_chan_max: 1 .. 128 channels");

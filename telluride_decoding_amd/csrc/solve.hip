@@ -1780,6 +1780,9 @@ int td_set_option(td_handle* h, const char* name, int64_t value) {
     h->cca_whitening = (int)value;
   } else if (!strcmp(name, "cg_limit_ticks")) {
     h->cg_limit_ticks = value;
+  } else if (!strcmp(name, "narrow16")) {
+    TD_REQUIRE(h, value == 0 || value == 1, "td_set_option: narrow16 is 0 or 1");
+    h->narrow16 = (int)value;
   } else if (!strcmp(name, "async_cg")) {
     TD_REQUIRE(h, value == 0 || value == 1, "td_set_option: async_cg is 0 or 1");
     h->async_cg = (int)value;

@@ -1061,13 +1061,17 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   TargetsPlan tp;
   PrepassPlan pp;
   VirtPlan vp;                   // <= 32 channels: the float16 kernel on virtual images (lagcov.hip)
-  if (do_main) {
+  Narrow16Plan np16;             // <= 16 channels: matrix + targets in one streaming kernel (lagcov.hip)
+  if (h->narrow16) TD_TRY(td_narrow16_plan(h, s->c1, s->d, s->pre1, s->l1, ldx, ldy, syx, &np16));
+  const bool n16 = np16.ok;
+  if (do_main && n16) TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
+  if (do_main && !n16) {
     TD_TRY(ensure_window_capacity(h, s, s->n_files + num_files));
     TD_TRY(td_lagcov_virt_plan(h, x_dev, ldx, s->c1, sxx, s->l1, &vp));
     mp.allow_f16 = true;         // the finalize launch divides the channel scales out
     if (!vp.ok) TD_TRY(td_lagcov_plan(h, x_dev, ldx, s->c1, false, x_dev, ldx, s->c1, sxx, 0, s->l1, &mp));
   }
-  const bool virt = do_main && vp.ok;
+  const bool virt = do_main && !n16 && vp.ok;
   // Two forms, 3 launches and two reads of x each:
   //   default: targets kernel (yT x~, column sums, channel maxima) -> lag kernel -> finalize;
   //   FOLDED (one target column, no pre-context, the float16 kernel): a streaming pre-pass
@@ -1078,17 +1082,18 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   // and measures the channel maxima on the way -- they cost 62 us in all.  So the folded form is
   // opt-in: TD_ACC_FOLDED.)
   static const bool want_fold = td_dev_env("TD_ACC_FOLDED") != nullptr;      // development: A/B runs
-  const bool folded = do_main && !virt && do_targets && s->d == 1 && s->pre1 == 0 && want_fold &&
+  const bool folded = do_main && !virt && !n16 && do_targets && s->d == 1 && s->pre1 == 0 && want_fold &&
                       td_lagcov_plan_targets(&mp);
   if (folded) {
     TD_TRY(td_chan_prepass_plan(h, syx, &pp));
-  } else if (do_targets) {
+  } else if (do_targets && !n16) {
     TD_TRY(td_lagcov_targets_plan(h, y_dev, ldy, s->d, x_dev, ldx, s->c1, syx, -s->pre1, s->l1, &tp));
     TD_REQUIRE(h, tp.handled && tp.n_work > 0, "accumulate_fused: the targets kernel refused the shape");
   }
-  const size_t main_bytes = virt ? vp.scratch_bytes : do_main ? mp.scratch_bytes + (folded ? mp.tpartial_bytes : 0) : 0;
+  const size_t main_bytes = n16 ? np16.scratch_bytes : virt ? vp.scratch_bytes
+                            : do_main ? mp.scratch_bytes + (folded ? mp.tpartial_bytes : 0) : 0;
   void* scratch = nullptr;
-  TD_TRY(td_scratch(h, main_bytes + (folded ? pp.scratch_bytes : do_targets ? tp.scratch_bytes : 0),
+  TD_TRY(td_scratch(h, main_bytes + (folded ? pp.scratch_bytes : do_targets && !n16 ? tp.scratch_bytes : 0),
                     &scratch));
   char* base = reinterpret_cast<char*>(scratch);
   FinalizeParams fp;
@@ -1127,7 +1132,14 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   // of them also measures the channel maxima the float16 lag kernel scales by (no pre-context:
   // with one the lag kernel reaches further past a range's end than the targets do, and it
   // measures for itself: chan_max_kernel).
-  if (do_targets && !folded) {
+  LagReduceJob job16;
+  if (n16) {
+    // one launch for whichever parts this call carries (the same sums whether they come together or apart)
+    to.maxtab = nullptr;
+    TD_TRY(td_narrow16_launch(h, &np16, x_dev, ldx, y_dev, ldy, base, do_main, do_targets, s->g + s->off_fxx,
+                              !s->fresh_main, s->g + s->off_gxo, !s->fresh_tgt, &job16, &to));
+  }
+  if (do_targets && !folded && !n16) {
     to.maxtab = nullptr;
     if (do_main && (mp.f16 || virt) && s->pre1 == 0) {
       TD_TRY(td_chan_tab(h, &to.maxtab));
@@ -1153,7 +1165,9 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     if (ahead) mp.tab = s->chan_tab;
     s->tab_ready = false;
     bool own_tab = false;
-    if (virt) {
+    if (n16) {
+      job = job16;
+    } else if (virt) {
       unsigned* tab = mp.tab;
       if (!tab) {
         // nobody measured the channel maxima on the way (a pre-context, a MAIN-only call): a pass of

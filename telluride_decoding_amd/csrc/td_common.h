@@ -98,6 +98,7 @@ struct td_handle {
   int cca_whitening = 0;
   long long cg_limit_ticks = -1;
   int async_cg = 0;             // "async_cg": td_ridge_solve_async may use the compact-statistics CG (flag 2 = gave up)
+  int narrow16 = 1;             // "narrow16": <= 16 channels take the one-kernel streaming accumulate (0: the tiled kernels)
   int last_solver = 0, last_iterations = 0, last_cg_status = 0;
   // Optional per-kernel hipEvent timing of the dominant kernel (td_profile_*):
   // event pairs recorded on h->stream around every lagcov MFMA launch.
@@ -528,6 +529,21 @@ struct TargetsOutputs {
 };
 int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, double* g_dev,
                              bool accumulate, TargetsOutputs* out);
+
+// <= 16 channels, <= 32 lags, 1..4 targets: ONE streaming kernel for the lagged covariance, the targets,
+// the column sums (lagcov_narrow16_kernel).  plan->ok = false when the shape is not its.
+struct Narrow16Plan {
+  bool ok = false;
+  int c = 0, d = 0, pre = 0, l1 = 0, n_lg = 1, lpw = 0;
+  std::vector<LagWork> works;
+  long long n_part = 0;
+  size_t part_bytes = 0, tpart_bytes = 0, cs_bytes = 0, ys_bytes = 0, scratch_bytes = 0;
+};
+int td_narrow16_plan(td_handle* h, int c, int d, int pre, int l1, int64_t ldx, int64_t ldy,
+                     const std::vector<LagSeg>& syx, Narrow16Plan* plan);
+int td_narrow16_launch(td_handle* h, Narrow16Plan* plan, const float* x, int64_t ldx, const float* y, int64_t ldy,
+                       void* scratch, bool do_main, bool do_targets, double* g_xx, bool acc_main, double* g_xo,
+                       bool acc_tgt, LagReduceJob* job, TargetsOutputs* out);
 
 int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, const float* b,
               int64_t ldb, int cb, const std::vector<LagSeg>& segs, int e_min, int e_count,

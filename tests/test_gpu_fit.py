@@ -135,6 +135,16 @@ def _rel(a, b):
     (80, 16, 15, 0, 0, 0, 1, 0, (2600,), 7),
     (112, 0, 15, 0, 0, 0, 1, 0, (1400, 300), 0),
     (20, 0, 11, 8, 3, 3, 0, 0, (1500, 5, 700), 11),
+    # <= 16 channels x <= 16 lags: ONE streaming kernel for matrix and targets (float32 16 x 16 x 4 matrix
+    # instruction, lagcov_narrow16_kernel): the C1 shape, odd channel counts, 2 .. 4 targets, a pre-context
+    # (the targets' lags start before 0), offsets of either sign, a recording shorter than the context,
+    # dropped remainders, one lag, one channel, both lag-group layouts (<= 8 and 9 .. 16 lags)
+    (16, 0, 3, 0, 0, 0, 1, 0, (5000, 4096, 300), 96),
+    (13, 2, 5, 0, 0, 0, 3, -2, (700, 5, 1300), 31),
+    (1, 0, 15, 0, 0, 0, 4, 1, (900, 40), 0),
+    (9, 7, 8, 0, 0, 0, 2, 0, (130, 129, 2050), 77),
+    (16, 0, 0, 0, 0, 0, 1, 0, (1000, 7), 0),
+    (5, 1, 1, 0, 0, 0, 2, 3, (64, 65, 63, 9), 0),
 ])
 def test_moments_match_dense_lag_matrix(dev, c1, pre, post, c2, pre2, post2, d, off, lens, drop):
   rng = np.random.default_rng(1234 + c1 + pre * 7 + post)
@@ -1098,7 +1108,7 @@ def test_general_solve_indefinite_and_singular(dev, n, nrhs):
 
 
 @pytest.mark.parametrize('world,shape', [(2, 'narrow'), (3, 'narrow'), (8, 'narrow'),
-                                         (2, 'c2'), (8, 'c2'), (5, 'wide')])
+                                         (2, 'c2'), (8, 'c2'), (5, 'wide'), (3, 'n16')])
 def test_time_range_shards_equal_whole_recordings(dev, world, shape):
   """Strong-scaling unit of SURVEY 8e: ranks share long recordings by TIME RANGE (piece = range
   + halo; zero extension and edge corrections only at true ends; one packed all-reduce with
@@ -1109,6 +1119,9 @@ def test_time_range_shards_equal_whole_recordings(dev, world, shape):
   rng = np.random.default_rng(40 + world)
   if shape == 'narrow':        # float32 accumulate kernel, lagged CCA moments too
     c1, pre, post, c2, pre2, post2, d = 8, 2, 5, 3, 1, 2, 2
+    lens = (1900, 130, 2777, 640)
+  elif shape == 'n16':         # the <= 16-channel streaming kernel (ranges that begin inside a recording)
+    c1, pre, post, c2, pre2, post2, d = 12, 1, 6, 0, 0, 0, 2
     lens = (1900, 130, 2777, 640)
   elif shape == 'c2':          # the bf16x3 accumulate kernel at the C2 channel / lag counts
     c1, pre, post, c2, pre2, post2, d = 64, 0, 31, 0, 0, 0, 1
@@ -1156,6 +1169,53 @@ def test_time_range_shards_equal_whole_recordings(dev, world, shape):
   w1, b1 = merged.ridge_solve([0.1])
   w0, b0 = whole.ridge_solve([0.1])
   np.testing.assert_allclose(w1.cpu().numpy(), w0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_narrow16_strided_inputs_parts_and_tiled_path(dev):
+  """The <= 16-channel streaming accumulate (lagcov_narrow16_kernel): inputs that are column slices of
+  wider arrays (row pitch > channels), the covariance part and the targets part of a call queued apart
+  (bit-identical to the call that carries both), and the tiled kernels it replaces (td_set_option
+  "narrow16" 0) agree with it to float32-chain rounding."""
+  import torch
+  rng = np.random.default_rng(77)
+  h = dev.default_handle()
+  c, pre, post, d = 11, 2, 9, 3
+  lens = (1500, 37, 4100)
+  n = sum(lens)
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  wide = h.to_device(rng.standard_normal((n, 24)).astype(np.float32))
+  wide_y = h.to_device(rng.standard_normal((n, 7)).astype(np.float32))
+  x, y = wide[:, 5:5 + c], wide_y[:, 2:2 + d]
+  assert x.stride(0) == 24 and y.stride(0) == 7
+  both = dev.LagStats(c, pre, post, d=d)
+  both.accumulate(x, None, y, offs, input_offset=1)
+  m3 = both.moments()
+  dense = dev.LagStats(c, pre, post, d=d)
+  dense.accumulate(x.contiguous(), None, y.contiguous(), offs, input_offset=1)
+  md = dense.moments()
+  apart = dev.LagStats(c, pre, post, d=d)
+  apart.accumulate(x, None, y, offs, input_offset=1, parts=1)
+  apart.accumulate(x, None, y, offs, input_offset=1, parts=2)
+  ma = apart.moments()
+  for key in ('xtx', 'xty'):
+    np.testing.assert_array_equal(m3[key].cpu().numpy(), md[key].cpu().numpy(), err_msg=key)
+    np.testing.assert_array_equal(m3[key].cpu().numpy(), ma[key].cpu().numpy(), err_msg=key)
+  h.set_option('narrow16', 0)
+  try:
+    tiled = dev.LagStats(c, pre, post, d=d)
+    tiled.accumulate(x, None, y, offs, input_offset=1)
+    mt = tiled.moments()
+  finally:
+    h.set_option('narrow16', 1)
+  scale = float(m3['xtx'].abs().max())
+  for key in ('xtx', 'xty'):
+    np.testing.assert_allclose(m3[key].cpu().numpy(), mt[key].cpu().numpy(), rtol=0, atol=3e-7 * scale,
+                               err_msg=key)
+  # ... and a second accumulate call adds to the first (the finalize launch accumulates)
+  both.accumulate(x, None, y, offs, input_offset=1)
+  m6 = both.moments()
+  np.testing.assert_allclose(m6['xtx'].cpu().numpy(), 2 * m3['xtx'].cpu().numpy(), rtol=1e-12, atol=0)
+  np.testing.assert_allclose(m6['xty'].cpu().numpy(), 2 * m3['xty'].cpu().numpy(), rtol=1e-12, atol=0)
 
 
 def test_ridge_solve_multi_equals_single_solves(dev):

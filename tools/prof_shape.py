@@ -1,5 +1,5 @@
 """One accumulate shape (and optionally the decode at that channel count) for rocprofv3:
-   python tools/prof_shape.py C LAGS [D] [N] [decode]
+   python tools/prof_shape.py C LAGS [D] [N] [decode] [n16=0]      (n16=0: without the <= 16-channel streaming kernel)
 Prints the hipEvent time per accumulate call; under rocprofv3 the kernel stats say which kernels it is."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,8 @@ d = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 1000000
 h = device.default_handle()
 h.use_torch_stream()
+if 'n16=0' in sys.argv:
+  h.set_option('narrow16', 0)
 torch.manual_seed(0)
 x = torch.randn(n, c, device='cuda'); y = torch.randn(n, d, device='cuda')
 offs = np.array([0, n], np.int64)
