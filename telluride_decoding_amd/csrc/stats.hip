@@ -138,6 +138,10 @@ inline void launch_ones_rows(td_handle* h, double* g, int rows, int row, int c, 
 // `fresh` statistics (td_stats_reset pending) every job overwrites instead of adding and the
 // memset of the reset goes away too.
 constexpr int kFinThreads = 1024;
+#ifndef TD_FIN_VEC_PHASES
+#define TD_FIN_VEC_PHASES 8
+#endif
+constexpr int kFinVecPhases = TD_FIN_VEC_PHASES;   // slab phases of the float4 reduction (fin_reduce4)
 constexpr int kFinMaxReduce = 5;      // F'xx + up to 4 target columns
 
 struct FinalizeParams {
@@ -244,7 +248,7 @@ __device__ __forceinline__ void fin_reduce(const LagReduceJob& jb, int q_phases,
 // per workgroup.  The lag-0 mirror needs no transposed reads here: the thread that holds (i, j),
 // j > i, of a symmetric block also writes (j, i), and the lower half's own sums are dropped.
 __device__ __forceinline__ void fin_reduce4(const LagReduceJob& jb, int block, double* part) {
-  constexpr int Q = 8, kGroups = kFinThreads / Q;       // 128 groups of 4 outputs
+  constexpr int Q = kFinVecPhases, kGroups = kFinThreads / Q;       // groups of 4 outputs
   const int ol = threadIdx.x % kGroups, q = threadIdx.x / kGroups;
   const long long total = (long long)jb.e_count * jb.ca_eff * jb.cb;
   const size_t slab = (size_t)jb.e_pad * jb.ca_pad * jb.cb_pad;
@@ -1107,7 +1111,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     fp.red[fp.n_red] = job;
     fp.red_q[fp.n_red] = q;
     fp.red_block0[fp.n_red] = blocks;
-    blocks += (int)td_ceil_div(outs, vec ? 512 : kFinThreads / q);
+    blocks += (int)td_ceil_div(outs, vec ? 4 * (kFinThreads / kFinVecPhases) : kFinThreads / q);
     fp.red_block0[++fp.n_red] = blocks;
   };
   const void* jobs_dev = nullptr;
