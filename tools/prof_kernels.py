@@ -60,11 +60,11 @@ if 'cgt' in what:
   del st, h64          # (the handle before its stream: a masked stream left to interpreter exit crashes in teardown)
   lib.td_stream_destroy(pm)
 if 'shapes' in what:
-  # the accumulate on virtual images (lagcov_split_kernel<..., kVirt>) at 32 x 32, 69 x 37, 128 x 32, and the
-  # streamed FIR at 63 / 69 channels
+  # the accumulate on virtual images (lagcov_split_kernel<..., kVirt>) at 32 x 32, 69 x 37, 128 x 32, the one-kernel
+  # streaming accumulate (lagcov_narrow16_kernel) at 16 x 4 and 16 x 16, and the streamed FIR at 63 / 69 channels
   n = 1000000
   offs1 = np.array([0, n], np.int64)
-  for c, lags in ((32, 32), (69, 37), (128, 32)):
+  for c, lags in ((32, 32), (69, 37), (128, 32), (16, 4), (16, 16)):
     x = torch.randn(n, c, device='cuda'); y = torch.randn(n, 1, device='cuda')
     st = device.LagStats(c, 0, lags - 1, d=1)
     for rep in range(3):
