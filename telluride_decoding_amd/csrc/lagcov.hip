@@ -2390,7 +2390,9 @@ __device__ __forceinline__ void tgt_stage_targets(const LagParams& p, const LagW
 // it also measures the largest magnitude of every channel for the float16 lag kernel that runs
 // next (maxtab: atomic max of float bits, td_f16_scale_exp) -- the pre-pass that kernel needs
 // costs nothing here.  The four waves' sums meet in LDS (fixed order): one slab per strip.
-template <bool kVec2>
+// kHalf (<= 32 channels): a lane holds ONE channel and the second matrix instruction of a step, its
+// accumulators and its float64 sums are not there (half the matrix work of the 64-channel form).
+template <bool kVec2, bool kHalf = false>
 __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams p,
                                                                        double* __restrict__ part64,
                                                                        double* csum, double* ysum,
@@ -2431,8 +2433,8 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   }
 
   const int n = lane & 31, g = lane >> 5;
-  const int c0 = cbt * 64 + 2 * n;                    // this lane's channels: c0 (tile 0), c0 + 1
-  const bool ok0 = c0 < p.cb, ok1 = c0 + 1 < p.cb;
+  const int c0 = kHalf ? cbt * 64 + n : cbt * 64 + 2 * n;   // this lane's channels: c0 (tile 0), c0 + 1
+  const bool ok0 = c0 < p.cb, ok1 = !kHalf && c0 + 1 < p.cb;
   const int off0 = ok0 ? c0 : 0, off1 = ok1 ? c0 + 1 : off0;
   // this wave's fast bodies: b0, b0 + 4, ... (fast bodies are a contiguous run of the strip)
   int b0 = wave, nb = 0;
@@ -2449,7 +2451,9 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   if (nb > 0) {
     float xr[P][2];
     auto load_step = [&](const float* bp, int s, float& x0, float& x1) {
-      if (kVec2) {
+      if (kHalf) {
+        x0 = bp[s * 2 * ts.ldb32]; x1 = 0.f;
+      } else if (kVec2) {
         const float2 v = *reinterpret_cast<const float2*>(bp + s * 2 * ts.ldb32);
         x0 = v.x; x1 = v.y;
       } else {
@@ -2473,7 +2477,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
         mx0 = fmaxf(mx0, fabsf(x0)); mx1 = fmaxf(mx1, fabsf(x1));
         const float a = yp[(b * kTgtBody + s) * 2];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);
+        if (!kHalf) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);
         // the slot is free once the MFMAs have read it: refill it for the wave's next body
         load_step(bp, s, xr[s % P][0], xr[s % P][1]);
       }
@@ -2482,7 +2486,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         big0[r] += (double)acc0[r]; acc0[r] = 0.f;
-        big1[r] += (double)acc1[r]; acc1[r] = 0.f;
+        if (!kHalf) { big1[r] += (double)acc1[r]; acc1[r] = 0.f; }
       }
     }
   }
@@ -2498,7 +2502,9 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
       const int r = (b * kTgtBody + s) * 2 + g;
       const int rc = min(max(r, ts.r_lo), ts.r_hi) - ts.r_lo;
       const float* rowp = ts.strip + rc * ts.ldb32;
-      if (kVec2) {
+      if (kHalf) {
+        xe[s][0] = rowp[off0]; xe[s][1] = 0.f;
+      } else if (kVec2) {
         const float2 v = *reinterpret_cast<const float2*>(rowp + off0);
         xe[s][0] = v.x; xe[s][1] = v.y;
       } else {
@@ -2515,14 +2521,14 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
       c0s = fmaf(in, x0, c0s); c1s = fmaf(in, x1, c1s);
       const float a = yp[(b * kTgtBody + s) * 2];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);
+      if (!kHalf) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x1, acc1, 0, 0, 0);
     }
     cs0 += (double)c0s;
     cs1 += (double)c1s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       big0[r] += (double)acc0[r]; acc0[r] = 0.f;
-      big1[r] += (double)acc1[r]; acc1[r] = 0.f;
+      if (!kHalf) { big1[r] += (double)acc1[r]; acc1[r] = 0.f; }
     }
   }
   // the two row parities of a channel sit in lanes n and n + 32
@@ -2539,6 +2545,7 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
   // the four waves' sums -> wave 0 (fixed order), 16 registers at a time: big0, big1, column sums
 #pragma unroll
   for (int round = 0; round < 3; ++round) {
+    if (kHalf && round == 1) continue;
     __syncthreads();
     if (wave > 0) {
 #pragma unroll
@@ -2565,12 +2572,12 @@ __global__ __launch_bounds__(kThreads) void lagcov_targets_mfma_kernel(LagParams
     const int k = e_lo + (r & 3) + 8 * (r >> 2) + 4 * g;
     if (k < p.e_count) {
       slab[(size_t)k * p.ca_pad * p.cb_pad + c0] = big0[r];
-      slab[(size_t)k * p.ca_pad * p.cb_pad + c0 + 1] = big1[r];
+      if (!kHalf) slab[(size_t)k * p.ca_pad * p.cb_pad + c0 + 1] = big1[r];
     }
   }
   if (g == 0 && csum) {
     csum[(size_t)slab_i * p.cb_pad + c0] = cs0;
-    csum[(size_t)slab_i * p.cb_pad + c0 + 1] = cs1;
+    if (!kHalf) csum[(size_t)slab_i * p.cb_pad + c0 + 1] = cs1;
   }
 }
 
@@ -3869,7 +3876,10 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
       double* part64 = reinterpret_cast<double*>(col);
       double* ysum = reinterpret_cast<double*>(col + plan->part_bytes);
       unsigned* maxtab = i == 0 ? out->maxtab : nullptr;        // (one column's pass is enough)
-      if (vec2)
+      if (cb <= 32)
+        hipLaunchKernelGGL((lagcov_targets_mfma_kernel<false, true>), grid, dim3(kThreads), 0, h->stream,
+                           pi, part64, csum, ysum, maxtab);
+      else if (vec2)
         hipLaunchKernelGGL((lagcov_targets_mfma_kernel<true>), grid, dim3(kThreads), 0, h->stream,
                            pi, part64, csum, ysum, maxtab);
       else

@@ -1107,7 +1107,9 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     const long long outs = (long long)job.e_count * job.ca_eff * job.cb;
     const bool vec = !job.is_f64 && !job.vmap && outs >= 32768 && job.cb % 4 == 0 && job.cb_pad % 4 == 0 &&
                      (reinterpret_cast<uintptr_t>(job.partial) & 15) == 0;
-    const int q = vec ? 0 : outs < 32768 ? 16 : 4;
+    // (16 slab phases x 64 outputs per workgroup for small jobs -- and for virtual-image slabs up to 32 x 32 x 32,
+    // whose reduction was the long pole of the 32-channel call: 35 us with 4 phases)
+    const int q = vec ? 0 : (outs < 32768 || (job.vmap && outs <= 65536)) ? 16 : 4;
     fp.red[fp.n_red] = job;
     fp.red_q[fp.n_red] = q;
     fp.red_block0[fp.n_red] = blocks;
