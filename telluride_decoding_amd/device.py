@@ -157,43 +157,6 @@ def default_handle():
   return h
 
 
-_side = {}
-
-
-def side_handles(n):
-  """n (handle, torch stream) pairs of the current device besides its default handle, kept for the
-  process: independent short jobs (the per-recording statistics of a jackknife sweep: 3 launches of
-  ~100 workgroups each) queued round-robin on them run beside each other instead of in a chain.  The
-  caller orders them against its own stream with events (fork_to / join_from)."""
-  torch = _torch()
-  dev = torch.cuda.current_device()
-  pool = _side.setdefault(dev, [])
-  while len(pool) < n:
-    st = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(st):
-      pool.append((Handle(dev), st))
-  return pool[:n]
-
-
-def fork_to(side, main_stream=None):
-  """The side streams wait for everything queued so far on the main (torch current) stream."""
-  torch = _torch()
-  ev = torch.cuda.Event()
-  ev.record(main_stream or torch.cuda.current_stream())
-  for _, st in side:
-    st.wait_event(ev)
-
-
-def join_from(side, main_stream=None):
-  """The main (torch current) stream waits for everything queued on the side streams."""
-  torch = _torch()
-  main = main_stream or torch.cuda.current_stream()
-  for _, st in side:
-    ev = torch.cuda.Event()
-    ev.record(st)
-    main.wait_event(ev)
-
-
 def _ptr(t):
   return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 

@@ -48,8 +48,6 @@ def calculate_stats(values):
 # The preconditioned-CG solve of the whole sweep (td_ridge_solve_loso); False = always the direct
 # batched Cholesky.
 USE_PCG = True
-# Side streams for the per-recording statistics of a sweep (1 = the caller's stream only).
-STATS_STREAMS = 4
 # How the last sweep of this process was solved: {'solver': 'pcg' | 'direct', 'iterations': n}
 LAST_SWEEP = {}
 SOLVE_WORKSPACE_BYTES = 6 << 30
@@ -139,29 +137,14 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   def new_stats():
     return dev.LagStats(dataset.c1, dataset.pre, dataset.post, 0, 0, 0, dataset.d, handle=h)
 
-  def file_stats(i, rows, handle=None, st=None):
-    st = st or new_stats()
+  def file_stats(i, rows):
+    st = new_stats()
     x, y = file_arrays(i)
-    st.accumulate(x, None, y, [0, lengths[i]], input_offset=off, rows_used=[rows], handle=handle)
+    st.accumulate(x, None, y, [0, lengths[i]], input_offset=off, rows_used=[rows])
     return st
 
-  # 1. per-file statistics (every zipped frame) of this rank's files.  A recording's accumulate is three
-  # dependent launches of ~100 workgroups: queued round-robin on a few side streams they run beside each
-  # other (C5, 32 recordings on one GPU: 2.1 ms of launches in a chain -> see DESIGN 8).
-  mine = list(plan.files_of(rank))
-  side = dev.side_handles(STATS_STREAMS) if (hasattr(dev, 'side_handles') and len(mine) > 2 and
-                                             STATS_STREAMS > 1) else None
-  if side:
-    fresh = {}
-    for i in mine:
-      file_arrays(i)                                       # (uploads, if any, on the main stream)
-      fresh[i] = new_stats()                               # (and whatever creating statistics queues)
-    dev.fork_to(side)
-    per_file = {i: file_stats(i, zipped[i], handle=side[k % len(side)][0], st=fresh[i])
-                for k, i in enumerate(mine)}
-    dev.join_from(side)
-  else:
-    per_file = {i: file_stats(i, zipped[i]) for i in mine}
+  # 1. per-file statistics (every zipped frame) of this rank's files
+  per_file = {i: file_stats(i, zipped[i]) for i in plan.files_of(rank)}
   # 2. make every file's statistics available on every rank: one all-reduce of
   #    [file][packed] with each rank filling only its own rows.
   proto = next(iter(per_file.values())) if per_file else new_stats()
