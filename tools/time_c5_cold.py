@@ -22,13 +22,24 @@ def wrap(obj, name, label):
     torch.cuda.synchronize(); marks.append((label, time.perf_counter() - t0))
     return out
   setattr(obj, name, staticmethod(timed) if isinstance(obj, type) and name == 'ridge_solve_loso' else timed)
+acc = {}
+def wrap_sum(cls, name, label):
+  orig = getattr(cls, name)
+  def timed(self, *a, **k):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = orig(self, *a, **k)
+    torch.cuda.synchronize(); acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
+    return out
+  setattr(cls, name, timed)
+for name in ('__init__', 'accumulate', 'combine', 'like'):
+  wrap_sum(dev.LagStats, name, name)
 wrap(dev.LagStats, 'ridge_solve_loso', 'solve')
 if hasattr(dev, 'side_handles'):
-  wrap(dev, 'side_handles', 'side handles')
+  pass
 wrap(dev, 'predict_fir_per_file', 'evaluate: fir')
 for rep in range(3):
-  del marks[:]
+  del marks[:]; acc.clear()
   torch.cuda.synchronize(); t0 = time.perf_counter()
   res = regression.jackknife_over_regularizations(ds, lams)
   torch.cuda.synchronize(); t1 = time.perf_counter()
-  print('sweep %d: %.1f ms; %s' % (rep, 1e3 * (t1 - t0), ', '.join('%s %.1f' % (k, 1e3 * v) for k, v in marks)))
+  print('sweep %d: %.1f ms; %s' % (rep, 1e3 * (t1 - t0), ', '.join('%s %.1f' % (k, 1e3 * v) for k, v in marks + sorted(acc.items()))))
