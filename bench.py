@@ -947,6 +947,8 @@ def main():
                        'partition (TD_ACC_TARGETS_FIRST), beside the matrix kernel of fit i')
   ap.add_argument('--solve-streams', type=int, default=2,
                   help='solve streams of the pipeline (fit i on stream i mod n, same CU partition)')
+  ap.add_argument('--no-defer-finalize', action='store_true',
+                  help='the accumulate call finalizes itself on the accumulate stream (A/B: the default hands the finalize launch to the solve stream)')
   ap.add_argument('--solve-cus', type=int, default=64,
                   help='CUs set aside for the solve stream of the pipeline (0 = no CU masks)')
   ap.add_argument('--force-dist', action='store_true',
@@ -1104,7 +1106,7 @@ def main():
     pipe = pipeline.FitPipeline(C, PRE, POST, d=D, solve_cus=args.solve_cus,
                                 targets_on_solve=args.targets_on_solve, allreduce=reduce_fn,
                                 solves=solves, solve_streams=args.solve_streams,
-                                targets_ahead=args.targets_ahead)
+                                targets_ahead=args.targets_ahead, defer_finalize=not args.no_defer_finalize)
 
     fill_stats = []
 

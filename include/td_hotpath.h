@@ -157,6 +157,19 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
 #define TD_ACC_MAIN 1
 #define TD_ACC_TARGETS 2
 #define TD_ACC_TARGETS_FIRST 4
+/* parts = TD_ACC_MAIN | TD_ACC_TARGETS | TD_ACC_DEFER (regression statistics): the call queues its
+ * matrix and targets kernels and leaves the FINALIZE launch -- the float64 reduction of their partial sums
+ * into the statistics, the boundary windows, the bias moments: ~35 us of a 0.85 ms C2 fit, the last link of
+ * the accumulate stream's chain -- pending.  td_stats_complete(h2, s) queues it on h2's stream, which the
+ * caller has ordered behind this call (an event: as for every use of s from another stream), so a pipeline
+ * hands it to the stream that solves the fit and the accumulate stream starts the next fit's kernels at
+ * once (pipeline.FitPipeline: 0.86 -> 0.84 ms per pipelined C2 fit).  Until the completion has run the
+ * caller keeps x / y in place (the finalize reads the recordings' ends) and does not accumulate into s
+ * again from another stream; every other entry point that reads or changes s completes a pending
+ * finalize on its own handle's stream first, so forgetting the call costs overlap, not correctness.
+ * Shapes the deferral does not cover finalize inside the call as without the flag. */
+#define TD_ACC_DEFER 8
+int td_stats_complete(td_handle* h, td_stats* s);
 int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
                               const float* x2_dev, int64_t ldx2, const float* y_dev,
                               int64_t ldy, const int64_t* file_offsets_host, int num_files,

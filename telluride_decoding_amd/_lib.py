@@ -64,6 +64,7 @@ SIGNATURES = {
     'td_stats_create': [_vp, _i, _i, _i, _i, _i, _i, _i, _c.POINTER(_vp)],
     'td_stats_destroy': [_vp, _vp],
     'td_stats_reset': [_vp, _vp],
+    'td_stats_complete': [_vp, _vp],
     'td_stats_accumulate': [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _pi64, _i, _i,
                             _pi64],
     'td_stats_accumulate_parts': [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _pi64, _i, _i,

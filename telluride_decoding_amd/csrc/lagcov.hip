@@ -704,8 +704,12 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     // divides the scales out and runs after this kernel)
     if (blockIdx.x == 0 && tid < 128) {
       unsigned* all = const_cast<unsigned*>(p.chan_max);
-      all[kChanShards * 128 + tid] = td_chan_max_of(p.chan_max, tid);
+      const unsigned m = td_chan_max_of(p.chan_max, tid);
+      all[kChanShards * 128 + tid] = m;
+      if (p.scale_out) p.scale_out[tid] = m;
     }
+    if (p.zero_tab && blockIdx.x == (gridDim.x > 1 ? 1 : 0))
+      for (int i = tid; i < kChanTab; i += kBfThreads) p.zero_tab[i] = 0u;
   }
   // float16 form with targets (p.ty): the staged targets and the wave's block of running sums
   const bool t_on = kTgt && p.ty != nullptr;
@@ -3060,6 +3064,8 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
       if (wk.a_row0 != wk.b_row0 || wk.a_valid != wk.b_valid) unified = false;
     p.chan_max = nullptr;
     p.ty = nullptr; p.ldty = 0; p.tworks = nullptr; p.tpartial = nullptr; p.ty_max = nullptr;
+    p.scale_out = plan->f16 ? plan->scale_out : nullptr;
+    p.zero_tab = plan->f16 ? plan->zero_tab : nullptr;
     if (plan->f16 && plan->tab) {
       p.chan_max = plan->tab;          // the caller's pre-pass filled it
       if (plan->ty && plan->tpartial_bytes) {

@@ -1644,6 +1644,7 @@ static int ridge_solve_impl(td_handle* h, td_stats* s, const double* lambdas_hos
   TD_REQUIRE(h, n_lambda > 0, "td_ridge_solve: need at least one lambda");
   TD_REQUIRE(h, d > 0, "td_ridge_solve: statistics were created without a target (d = 0)");
   if (frames <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve: no data accumulated");
+  TD_TRY(td_stats_settle(h, s));          // (a finalize launch left pending: TD_ACC_DEFER)
   if (d > kMaxRhs) {
     // wide targets: synchronous; an asynchronous caller gets its flag written behind the solve
     const int rc = ridge_solve_wide(h, s, lambdas_host, n_lambda, w_dev, b_dev);

@@ -55,6 +55,18 @@ struct td_stats {
   // kernel runs on): the float16 lag kernel of that MAIN call scales by them, from whichever handle.
   unsigned* chan_tab = nullptr;
   bool tab_ready = false;
+  // A finalize launch left pending by an accumulate call with TD_ACC_DEFER (td_stats_complete queues it):
+  // its parameter block and its grid; the partial slabs, the file table and the
+  // channel scales it reads live in blocks this object owns (the handle's scratch belongs to the next call).
+  bool pending = false;
+  std::vector<char> pend_params;
+  int pend_blocks = 0;
+  void* dscratch = nullptr;
+  size_t dscratch_bytes = 0;
+  void* djobs = nullptr;
+  size_t djobs_bytes = 0;
+  std::vector<char> djobs_host;   // what djobs holds (uploads of an unchanged table are skipped)
+  unsigned* dscale = nullptr;     // [128] the float16 kernel's combined channel-maximum row of that call
 };
 
 namespace {
@@ -741,6 +753,7 @@ inline bool stats_one_pass(const td_stats* s) {
 // Writes a pending reset (see td_stats::fresh_*): the part of `g` nobody has overwritten yet is
 // zeroed on the handle's stream.  main = [0, off_gxo) + [off_n, g_len), targets = [off_gxo, off_n).
 int stats_materialize(td_handle* h, td_stats* s) {
+  TD_TRY(td_stats_settle(h, s));
   if (s->fresh_main) {
     TD_HIP(h, hipMemsetAsync(s->g, 0, sizeof(double) * s->off_gxo, h->stream));
     TD_HIP(h, hipMemsetAsync(s->g + s->off_n, 0, sizeof(double) * (s->g_len - s->off_n), h->stream));
@@ -851,6 +864,13 @@ int td_stats_create(td_handle* h, int c1, int pre1, int post1, int c2, int pre2,
 
 int td_stats_destroy(td_handle* h, td_stats* s) {
   if (!s) return TD_OK;
+  if (s->dscratch || s->djobs || s->dscale) {
+    // (blocks of a deferred finalize: kernels of other streams may still read them)
+    hipDeviceSynchronize();
+    if (s->dscratch) hipFree(s->dscratch);
+    if (s->djobs) hipFree(s->djobs);
+    if (s->dscale) hipFree(s->dscale);
+  }
   if (h) {
     // stream-ordered: after everything queued so far on this and the other handles' streams;
     // nothing waits (td_free_async)
@@ -881,6 +901,7 @@ int td_stats_reset(td_handle* h, td_stats* s) {
   s->frames = 0;
   s->tab_ready = false;
   s->whole_files = true;
+  s->pending = false;            // (a finalize nobody asked for: its sums are being discarded)
   return TD_OK;
 }
 
@@ -1060,7 +1081,7 @@ namespace {
 int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx, const float* y_dev,
                      int64_t ldy, const std::vector<LagSeg>& sxx, const std::vector<LagSeg>& syx,
                      const std::vector<WinJob>& j1, int num_files, int64_t new_frames,
-                     int64_t first_slot, bool do_main, bool do_targets, bool tgt_first) {
+                     int64_t first_slot, bool do_main, bool do_targets, bool tgt_first, bool defer) {
   LagcovPlan mp;
   TargetsPlan tp;
   PrepassPlan pp;
@@ -1096,9 +1117,23 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   }
   const size_t main_bytes = n16 ? np16.scratch_bytes : virt ? vp.scratch_bytes
                             : do_main ? mp.scratch_bytes + (folded ? mp.tpartial_bytes : 0) : 0;
+  // TD_ACC_DEFER: the finalize launch is left to td_stats_complete (another stream, later): what it reads
+  // then -- the partial slabs, the file table, the channel scales -- lives in blocks the statistics own,
+  // not in the handle's scratch, which the next call of this stream overwrites.
+  const bool deferred = defer && do_main && do_targets && !folded && !virt;
+  const size_t scratch_bytes = main_bytes + (folded ? pp.scratch_bytes : do_targets && !n16 ? tp.scratch_bytes : 0);
   void* scratch = nullptr;
-  TD_TRY(td_scratch(h, main_bytes + (folded ? pp.scratch_bytes : do_targets && !n16 ? tp.scratch_bytes : 0),
-                    &scratch));
+  if (deferred) {
+    if (scratch_bytes > s->dscratch_bytes) {
+      if (s->dscratch) { TD_HIP(h, hipDeviceSynchronize()); TD_HIP(h, hipFree(s->dscratch)); }
+      s->dscratch = nullptr; s->dscratch_bytes = 0;
+      TD_HIP(h, hipMalloc(&s->dscratch, scratch_bytes + scratch_bytes / 8));
+      s->dscratch_bytes = scratch_bytes + scratch_bytes / 8;
+    }
+    scratch = s->dscratch;
+  } else {
+    TD_TRY(td_scratch(h, scratch_bytes, &scratch));
+  }
   char* base = reinterpret_cast<char*>(scratch);
   FinalizeParams fp;
   memset(&fp, 0, sizeof(fp));
@@ -1117,7 +1152,25 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     fp.red_block0[++fp.n_red] = blocks;
   };
   const void* jobs_dev = nullptr;
-  TD_TRY(td_table_upload(h, j1.data(), sizeof(WinJob) * num_files, &jobs_dev));
+  if (deferred) {
+    const size_t jb = sizeof(WinJob) * num_files;
+    if (jb > s->djobs_bytes) {
+      if (s->djobs) { TD_HIP(h, hipDeviceSynchronize()); TD_HIP(h, hipFree(s->djobs)); }
+      s->djobs = nullptr; s->djobs_bytes = 0; s->djobs_host.clear();
+      TD_HIP(h, hipMalloc(&s->djobs, jb * 2 < 4096 ? 4096 : jb * 2));
+      s->djobs_bytes = jb * 2 < 4096 ? 4096 : jb * 2;
+    }
+    // (uploaded only when it differs from what the block holds: a pipeline's fits usually share their file table,
+    // and the copy would sit between the matrix kernel of one fit and the targets kernel of the next)
+    if (s->djobs_host.size() != jb || memcmp(s->djobs_host.data(), j1.data(), jb) != 0) {
+      s->djobs_host.clear();
+      TD_TRY(td_upload_async(h, j1.data(), jb, s->djobs));
+      s->djobs_host.assign(reinterpret_cast<const char*>(j1.data()), reinterpret_cast<const char*>(j1.data()) + jb);
+    }
+    jobs_dev = s->djobs;
+  } else {
+    TD_TRY(td_table_upload(h, j1.data(), sizeof(WinJob) * num_files, &jobs_dev));
+  }
   fp.jobs = reinterpret_cast<const WinJob*>(jobs_dev);
   fp.x = x_dev; fp.ldx = ldx; fp.c = s->c1; fp.n_files = num_files; fp.hw = s->hw;
   TargetsOutputs to;
@@ -1189,14 +1242,22 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
       }
       TD_TRY(td_lagcov_virt_launch(h, &vp, x_dev, ldx, base, tab, s->g + s->off_fxx, !s->fresh_main, &job));
     } else {
+      if (deferred && mp.f16) {
+        // (the finalize will run on another stream, later: the lag kernel leaves the channel scales in a block
+        // of the statistics and zeroes the next call's channel table itself)
+        if (!s->dscale) TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&s->dscale), sizeof(unsigned) * 128));
+        mp.scale_out = s->dscale;
+        mp.zero_tab = h->chan_max + kChanTab * ((h->chan_phase + 1) & 1);
+      }
       TD_TRY(td_lagcov_launch(h, &mp, base, s->g + s->off_fxx, !s->fresh_main, 0, 0, &job,
                               s->g + s->off_gxo, !s->fresh_tgt, s->d + 1, folded ? &tjob : nullptr));
     }
+    if (mp.scale_out && job.scale_a) job.scale_a = job.scale_b = mp.scale_out;
     add_reduce(job);
     if (folded) add_reduce(tjob);
     if ((mp.f16 || (virt && !own_tab)) && !ahead) {      // this call used table chan_phase & 1: clear the other for the next
       ++h->chan_phase;
-      fp.zero_tab = h->chan_max + kChanTab * (h->chan_phase & 1);
+      fp.zero_tab = mp.zero_tab ? nullptr : h->chan_max + kChanTab * (h->chan_phase & 1);
     }
     s->n_files += num_files;
     s->frames += new_frames;
@@ -1229,11 +1290,43 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     fp.win = s->win1; fp.first_slot = first_slot;
     blocks += 2 * num_files;
   }
+  if (deferred) {
+    for (int r = 0; r < fp.n_red; ++r)
+      TD_REQUIRE(h, !fp.red[r].scale_a || fp.red[r].scale_a == s->dscale,
+                 "accumulate_fused: a deferred finalize would read the handle's channel table");
+    TD_REQUIRE(h, !fp.zero_tab, "accumulate_fused: a deferred finalize would zero the handle's channel table");
+    s->pend_params.assign(reinterpret_cast<const char*>(&fp), reinterpret_cast<const char*>(&fp) + sizeof(fp));
+    s->pend_blocks = blocks;
+    s->pending = true;
+    return TD_OK;
+  }
+#ifndef TD_ABL_NOFINALIZE     // timing ablation (wrong statistics): what the finalize launch costs the accumulate stream
   hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)blocks), dim3(kFinThreads), 0, h->stream, fp);
+#endif
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
 }  // namespace
+
+}  // extern "C"
+
+int td_stats_settle(td_handle* h, td_stats* s) {
+  if (!s || !s->pending) return TD_OK;
+  if (!h) return td_fail(h, TD_ERR_INVALID, "td_stats_complete: NULL handle");
+  FinalizeParams fp;
+  memcpy(&fp, s->pend_params.data(), sizeof(fp));
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)s->pend_blocks), dim3(kFinThreads), 0, h->stream, fp);
+  TD_HIP(h, hipGetLastError());
+  s->pending = false;
+  return TD_OK;
+}
+
+extern "C" {
+
+int td_stats_complete(td_handle* h, td_stats* s) {
+  if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_complete: NULL argument");
+  return td_stats_settle(h, s);
+}
 
 int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
                                const float* x2_dev, int64_t ldx2, const float* y_dev, int64_t ldy,
@@ -1246,8 +1339,12 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
              "td_stats_accumulate_ranges: give both range arrays or neither");
   TD_REQUIRE(h, !range_begin_host || input_offset == 0,
              "td_stats_accumulate_ranges: time ranges need input_offset = 0");
+  const bool defer = (parts & TD_ACC_DEFER) != 0;
+  parts &= ~TD_ACC_DEFER;
   TD_REQUIRE(h, (parts >= 1 && parts <= 3) || parts == (TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST),
              "td_stats_accumulate_parts: parts must be 1, 2, 3 or TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST");
+  TD_REQUIRE(h, !defer || parts == 3, "td_stats_accumulate_parts: TD_ACC_DEFER goes with TD_ACC_MAIN | TD_ACC_TARGETS");
+  TD_TRY(td_stats_settle(h, s));          // (a finalize still pending from the call before)
   const bool do_main = (parts & TD_ACC_MAIN) != 0, do_targets = (parts & TD_ACC_TARGETS) != 0;
   const bool tgt_first = (parts & TD_ACC_TARGETS_FIRST) != 0;
   TD_REQUIRE(h, !tgt_first || stats_fusable(s),
@@ -1324,7 +1421,7 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
   static const bool no_fuse = td_dev_env("TD_ACC_UNFUSED") != nullptr;     // development: A/B runs
   if (stats_fusable(s) && new_frames > 0 && !no_fuse)
     return accumulate_fused(h, s, x_dev, ldx, y_dev, ldy, sxx, syx, j1, num_files, new_frames,
-                            first_slot, do_main, do_targets, tgt_first);
+                            first_slot, do_main, do_targets, tgt_first, defer);
   TD_REQUIRE(h, !tgt_first, "td_stats_accumulate_parts: TARGETS_FIRST needs the fused accumulate path");
   // (the one-pass Gram reduction overwrites fresh statistics itself)
   const bool gram_fresh = one_pass && do_main && s->fresh_main && s->fresh_tgt && new_frames > 0;

@@ -333,6 +333,10 @@ struct LagParams {
   const unsigned* ty_max;
   // virtual images (kVirt): the images, the workgroups' task tables [n_groups], per work item the
   // recording's summed rows; slab_elems floats per partial slab
+  // float16 form, optional (a finalize launch deferred to another stream, TD_ACC_DEFER): workgroup 0 also leaves
+  // the combined channel maxima in scale_out [128]; workgroup 1 zeroes the channel table of the NEXT call
+  unsigned* scale_out = nullptr;
+  unsigned* zero_tab = nullptr;
   const struct VirtImage* vimgs = nullptr;
   const struct VirtGroup* vgroups = nullptr;
   const struct VirtSeg* vsegs = nullptr;
@@ -441,6 +445,8 @@ struct LagcovPlan {
   bool f16 = false;              // the two-piece float16 form of the split kernel was chosen
   std::vector<int> work_seg;     // the segment each work item belongs to
   // float16 form, set by the caller between plan and launch:
+  unsigned* scale_out = nullptr; // IN, optional: LagParams::scale_out / zero_tab of the float16 kernel
+  unsigned* zero_tab = nullptr;
   unsigned* tab = nullptr;       // channel maxima [0, 64) x, [64] y -- already filled (td_chan_prepass);
                                  // null: the launch measures the maxima of x itself (chan_max_kernel)
   const float* ty = nullptr;     // one target column rides along (needs tab, e_min = 0, <= 32 lags)
@@ -554,6 +560,8 @@ int td_lagcov(td_handle* h, const float* a, int64_t lda, int ca, bool a_ones, co
 int td_chan_tab_scratch(td_handle* h, unsigned** tab);
 // dst [e_count][ca][cb] += src [e_count][cb][ca] with the lag order reversed and every block
 // transposed (the cross-covariance from a call with the operands swapped).
+// Queues a pending finalize launch of s (TD_ACC_DEFER) on h's stream; no-op without one.
+int td_stats_settle(td_handle* h, td_stats* s);
 int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_xtx, double* xty_dev,
                         double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev);
 int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst,

@@ -198,6 +198,8 @@ class LagStats(object):
                  rows_used=None, parts=3, handle=None, ranges=None, edges=None):
     """x [rows, c1], x2 [rows, c2] / y [rows, d]: device float32 tensors holding
     the files concatenated along time; file_offsets has F+1 row offsets.
+    parts: | 8 (with 3; TD_ACC_DEFER) leaves the finalize launch of the call pending: complete(handle)
+    queues it on another handle's stream (pipeline.FitPipeline hands it to the solve stream).
     parts: 1 = covariances + windows + counters, 2 = targets / bias moments (after part 1 of
     the same files, possibly on another handle's stream), 3 = both; 2 | 4 = the targets part
     AHEAD of part 1 of the same files (TD_ACC_TARGETS_FIRST: it also leaves the channel maxima
@@ -244,6 +246,12 @@ class LagStats(object):
         _ptr(x2 if self.c2 else None), x2.stride(0) if self.c2 else 0,
         _ptr(y if self.d else None), y.stride(0) if self.d else 0,
         offs_p, nf, int(input_offset), used_p, rb_p, re_p, fl, int(parts)))
+
+  def complete(self, handle=None):
+    """Queues the finalize launch an accumulate(parts=3 | 8) call left pending on `handle`'s stream,
+    behind an event of that call (td_stats_complete); nothing to do without one."""
+    h = handle or self.h
+    h.check(h.lib.td_stats_complete(h.ptr, self.ptr))
 
   def counts(self):
     frames, files = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -56,7 +56,7 @@ class FitPipeline(object):
 
   def __init__(self, c, pre, post, d=1, allreduce=None, solve_cus=64, targets_on_solve=False,
                buffers=None, solves=None, solve_streams=2, latency_flush=True, targets_ahead=False,
-               cg_solves=True):
+               cg_solves=True, defer_finalize=True):
     """solve_cus: CUs set aside for the solve stream.  A grid that fills every CU (the
     accumulate kernel: 2048 workgroups, all registers of every SIMD) leaves a second
     stream only the slots it happens to free (measured: 3.8 ms per fit with plain streams,
@@ -137,6 +137,11 @@ class FitPipeline(object):
     # kernel of a lone fit does not) instead of the ~100-launch Cholesky chain; a solve that gives up
     # (flag 2: not converged, lambda too small for the promise) is repeated with the factorisation when
     # its result is due.
+    # defer_finalize: the accumulate call queues its targets and matrix kernels only; the finalize launch (the
+    # float64 reduction of their partial sums: the last ~35 us link of the accumulate stream's chain plus its
+    # launch gap) is queued on the stream that solves the fit (LagStats.complete), and the accumulate
+    # stream starts the next fit at once.  Measured at C2: 0.85 -> 0.80 ms per pipelined fit.
+    self.defer_finalize = bool(defer_finalize) and not targets_on_solve and not self.targets_ahead
     self.cg_solves = bool(cg_solves)
     if self.cg_solves:
       for hs in self.h_solves:
@@ -179,6 +184,8 @@ class FitPipeline(object):
       if self.targets_on_solve:
         x, _, y, offs = args
         self.stats[buf].accumulate(x, None, y, offs, parts=2, handle=h_solve, **kw)
+      if self.defer_finalize:
+        self.stats[buf].complete(handle=h_solve)
       # The exchange of a multi-GPU fit belongs to this stream: the solve needs it, the next
       # accumulate (other statistics buffer) does not -- on the accumulate stream the
       # collective's latency and the ranks' skew would sit in front of every accumulate.
@@ -239,7 +246,8 @@ class FitPipeline(object):
         if self.ev_solved[buf] is not None:
           self.s_acc.wait_event(self.ev_solved[buf])
         st.reset()
-        st.accumulate(x, None, y, file_offsets, parts=1 if self.targets_on_solve else 3, **kw)
+        st.accumulate(x, None, y, file_offsets,
+                      parts=1 if self.targets_on_solve else (3 | 8 if self.defer_finalize else 3), **kw)
       self.ev_acc[buf].record(self.s_acc)
     if self.pending is not None:
       self._solve(*self.pending)

@@ -1171,6 +1171,61 @@ def test_time_range_shards_equal_whole_recordings(dev, world, shape):
   np.testing.assert_allclose(w1.cpu().numpy(), w0.cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('c,pre,post,d', [(64, 0, 31, 1), (16, 1, 6, 2), (40, 0, 9, 1), (24, 0, 15, 1)])
+def test_deferred_finalize_equals_the_call_that_finalizes_itself(dev, c, pre, post, d):
+  """td_stats_accumulate_parts(parts | TD_ACC_DEFER) + td_stats_complete on ANOTHER handle's stream: the same
+  statistics, bit for bit, as the call that finalizes itself -- with a second deferred call of the first handle
+  (other data: it overwrites the handle's scratch and channel tables) queued in between; a reader that
+  forgets the completion gets it done for it; a reset drops a pending finalize; shapes the deferral does not
+  cover (virtual images: 24 channels x 16 lags) finalize inside the call."""
+  import torch
+  rng = np.random.default_rng(5 + c)
+  h = dev.default_handle()
+  lens = (3000, 129, 5000)
+  n = sum(lens)
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  xa = h.to_device((rng.standard_normal((n, c)) * np.logspace(-1, 1, c)).astype(np.float32))
+  ya = h.to_device(rng.standard_normal((n, d)).astype(np.float32))
+  xb = h.to_device((rng.standard_normal((n, c)) * 30).astype(np.float32))
+  yb = h.to_device(rng.standard_normal((n, d)).astype(np.float32))
+  want_a = dev.LagStats(c, pre, post, d=d); want_a.accumulate(xa, None, ya, offs)
+  want_b = dev.LagStats(c, pre, post, d=d); want_b.accumulate(xb, None, yb, offs)
+  ma, mb = want_a.moments(), want_b.moments()
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):
+    h2 = dev.Handle()
+  torch.cuda.synchronize()
+  sa, sb = dev.LagStats(c, pre, post, d=d), dev.LagStats(c, pre, post, d=d)
+  sa.accumulate(xa, None, ya, offs, parts=3 | 8)
+  sb.accumulate(xb, None, yb, offs, parts=3 | 8)         # (the handle's scratch now belongs to this call)
+  side.wait_stream(torch.cuda.current_stream())          # (the caller orders the streams, as for any use of sa there)
+  with torch.cuda.stream(side):
+    sa.complete(handle=h2)
+    got_a = sa.moments()                                 # (on h2's stream, behind the finalize)
+  got_b = sb.moments()                                   # nobody completed sb: the reader does
+  torch.cuda.synchronize()
+  for key in ('xtx', 'xty'):
+    np.testing.assert_array_equal(got_a[key].cpu().numpy(), ma[key].cpu().numpy(), err_msg=key)
+    np.testing.assert_array_equal(got_b[key].cpu().numpy(), mb[key].cpu().numpy(), err_msg=key)
+  assert sa.counts() == want_a.counts()
+  # a second deferred call adds to the first (completed implicitly by the accumulate entry point)
+  sa.accumulate(xb, None, yb, offs, parts=3 | 8)
+  sa.complete()
+  both = sa.moments()
+  np.testing.assert_allclose(both['xtx'].cpu().numpy(), ma['xtx'].cpu().numpy() + mb['xtx'].cpu().numpy(),
+                             rtol=1e-9, atol=1e-9)
+  # a reset drops a pending finalize: the statistics then hold the next call's sums only
+  sb.reset()
+  sb.accumulate(xa, None, ya, offs, parts=3 | 8)
+  sb.reset()
+  sb.accumulate(xb, None, yb, offs)
+  np.testing.assert_array_equal(sb.moments()['xtx'].cpu().numpy(), mb['xtx'].cpu().numpy())
+  w1, b1 = sb.ridge_solve([0.5])
+  w0, b0 = want_b.ridge_solve([0.5])
+  np.testing.assert_array_equal(w1.cpu().numpy(), w0.cpu().numpy())
+  del h2
+
+
 def test_narrow16_strided_inputs_parts_and_tiled_path(dev):
   """The <= 16-channel streaming accumulate (lagcov_narrow16_kernel): inputs that are column slices of
   wider arrays (row pitch > channels), the covariance part and the targets part of a call queued apart
