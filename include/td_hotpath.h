@@ -157,7 +157,7 @@ int td_stats_accumulate(td_handle* h, td_stats* s, const float* x_dev, int64_t l
 #define TD_ACC_MAIN 1
 #define TD_ACC_TARGETS 2
 #define TD_ACC_TARGETS_FIRST 4
-/* parts = TD_ACC_MAIN | TD_ACC_TARGETS | TD_ACC_DEFER (regression statistics): the call queues its
+/* parts = TD_ACC_MAIN [| TD_ACC_TARGETS] | TD_ACC_DEFER (regression statistics): the call queues its
  * matrix and targets kernels and leaves the FINALIZE launch -- the float64 reduction of their partial sums
  * into the statistics, the boundary windows, the bias moments: ~35 us of a 0.85 ms C2 fit, the last link of
  * the accumulate stream's chain -- pending.  td_stats_complete(h2, s) queues it on h2's stream, which the

@@ -1120,7 +1120,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   // TD_ACC_DEFER: the finalize launch is left to td_stats_complete (another stream, later): what it reads
   // then -- the partial slabs, the file table, the channel scales -- lives in blocks the statistics own,
   // not in the handle's scratch, which the next call of this stream overwrites.
-  const bool deferred = defer && do_main && do_targets && !folded && !virt;
+  const bool deferred = defer && do_main && !folded && !virt;
   const size_t scratch_bytes = main_bytes + (folded ? pp.scratch_bytes : do_targets && !n16 ? tp.scratch_bytes : 0);
   void* scratch = nullptr;
   if (deferred) {
@@ -1242,7 +1242,7 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
       }
       TD_TRY(td_lagcov_virt_launch(h, &vp, x_dev, ldx, base, tab, s->g + s->off_fxx, !s->fresh_main, &job));
     } else {
-      if (deferred && mp.f16) {
+      if (deferred && mp.f16 && !ahead) {
         // (the finalize will run on another stream, later: the lag kernel leaves the channel scales in a block
         // of the statistics and zeroes the next call's channel table itself)
         if (!s->dscale) TD_HIP(h, hipMalloc(reinterpret_cast<void**>(&s->dscale), sizeof(unsigned) * 128));
@@ -1292,7 +1292,8 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   }
   if (deferred) {
     for (int r = 0; r < fp.n_red; ++r)
-      TD_REQUIRE(h, !fp.red[r].scale_a || fp.red[r].scale_a == s->dscale,
+      TD_REQUIRE(h, !fp.red[r].scale_a || fp.red[r].scale_a == s->dscale ||
+                        (s->chan_tab && fp.red[r].scale_a == s->chan_tab + kChanShards * 128),
                  "accumulate_fused: a deferred finalize would read the handle's channel table");
     TD_REQUIRE(h, !fp.zero_tab, "accumulate_fused: a deferred finalize would zero the handle's channel table");
     s->pend_params.assign(reinterpret_cast<const char*>(&fp), reinterpret_cast<const char*>(&fp) + sizeof(fp));
@@ -1343,7 +1344,8 @@ int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, in
   parts &= ~TD_ACC_DEFER;
   TD_REQUIRE(h, (parts >= 1 && parts <= 3) || parts == (TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST),
              "td_stats_accumulate_parts: parts must be 1, 2, 3 or TD_ACC_TARGETS | TD_ACC_TARGETS_FIRST");
-  TD_REQUIRE(h, !defer || parts == 3, "td_stats_accumulate_parts: TD_ACC_DEFER goes with TD_ACC_MAIN | TD_ACC_TARGETS");
+  TD_REQUIRE(h, !defer || parts == 3 || parts == TD_ACC_MAIN,
+             "td_stats_accumulate_parts: TD_ACC_DEFER goes with TD_ACC_MAIN (| TD_ACC_TARGETS)");
   TD_TRY(td_stats_settle(h, s));          // (a finalize still pending from the call before)
   const bool do_main = (parts & TD_ACC_MAIN) != 0, do_targets = (parts & TD_ACC_TARGETS) != 0;
   const bool tgt_first = (parts & TD_ACC_TARGETS_FIRST) != 0;

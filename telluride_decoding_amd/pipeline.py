@@ -141,7 +141,7 @@ class FitPipeline(object):
     # float64 reduction of their partial sums: the last ~35 us link of the accumulate stream's chain plus its
     # launch gap) is queued on the stream that solves the fit (LagStats.complete), and the accumulate
     # stream starts the next fit at once.  Measured at C2: 0.85 -> 0.80 ms per pipelined fit.
-    self.defer_finalize = bool(defer_finalize) and not targets_on_solve and not self.targets_ahead
+    self.defer_finalize = bool(defer_finalize) and not targets_on_solve
     self.cg_solves = bool(cg_solves)
     if self.cg_solves:
       for hs in self.h_solves:
@@ -241,7 +241,7 @@ class FitPipeline(object):
     with torch.cuda.stream(self.s_acc):
       if self.targets_ahead:
         self.s_acc.wait_event(self.ev_tgt[buf])
-        st.accumulate(x, None, y, file_offsets, parts=1, **kw)
+        st.accumulate(x, None, y, file_offsets, parts=1 | 8 if self.defer_finalize else 1, **kw)
       else:
         if self.ev_solved[buf] is not None:
           self.s_acc.wait_event(self.ev_solved[buf])

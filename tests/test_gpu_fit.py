@@ -1657,7 +1657,10 @@ def test_targets_first_equals_the_fused_call(dev, c, post, lens, off, drop):
       st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=2 | 4, handle=h2)
       ev.record(side)
     torch.cuda.current_stream().wait_event(ev)
-    st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=1)
+    # (the second time with the MAIN call's finalize launch deferred: the pipeline's default)
+    st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=1 | (8 if rep else 0))
+    if rep:
+      st.complete()
     m = st.moments()
     assert st.counts() == ref.counts()
     assert torch.equal(m['xtx'], m_ref['xtx']) and torch.equal(m['xty'], m_ref['xty'])
