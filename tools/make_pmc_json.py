@@ -23,7 +23,7 @@ for key, kernel, algo, note in (
      'writes 33 MB = 64 float32 partial slabs of 512 KB (one workgroup per CU and lag group walks '
      'three <= 8192-sample slabs and leaves one partial slab), summed in float64 by '
      'stats_finalize_kernel'),
-    ('targets', 'lagcov_targets_mfma_kernel<true>', 260000000,
+    ('targets', 'lagcov_targets_mfma_kernel<true, false>', 260000000,
      'the second read of x (+ y): y^T x~, column sums and the channel maxima of the float16 kernel'),
     ('gram', 'gram_bf16x3_kernel<5>', 288000000,
      'C3 one-pass CCA moments: every input byte read once; 512 partial slabs of 15 KB'),
