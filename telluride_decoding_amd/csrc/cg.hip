@@ -573,20 +573,25 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
   // q_f[mi - post] = sum_b sum_j x~_f[mi - post + b][j] p[(b, j)] over the rows of the recording (>= 0)
   const int n_waves = kCgWaves * (int)gridDim.x;
   const int gw = (int)blockIdx.x * kCgWaves + wave;
-  float wreg[kCpw][32];
+  // kCpw = 1: one q number per wave, its 32 window rows in registers.  kCpw = 2 (half as many waves): a wave takes
+  // a PAIR of neighbours q_f[m], q_f[m + 1] of one recording -- their windows overlap in all but one row, 33
+  // registers where two separate numbers need 64 (which spilled: 5.3 us for this phase against 1.4).
+  constexpr int kW = kCpw == 2 ? 33 : 32;
+  const int hp = (post + 1) / 2;                                   // pairs per recording
+  const int pair_f = hp > 0 ? gw / hp : 0, pair_m = hp > 0 ? 2 * (gw % hp) : 0;
+  const bool q_on = kCpw == 2 ? (hp > 0 && pair_f < P.n_files) : gw < nq;
+  const int qi0 = kCpw == 2 ? pair_f * post + pair_m : gw;           // (its neighbour: qi0 + 1 when pair_m + 1 < post)
+  const bool q_two = kCpw == 2 && q_on && pair_m + 1 < post;
+  float wreg[kW];
 #pragma unroll
-  for (int sl = 0; sl < kCpw; ++sl) {
-    const int qi = gw + sl * n_waves;
-#pragma unroll
-    for (int b = 0; b < 32; ++b) {
-      float v = 0.f;
-      if (qi < nq && b < L && lane < C) {
-        // x~_f[m + b], m = mi - post: head-window row m + b + hw, a row of the recording when m + b >= 0
-        const int f = qi / post, mi = qi % post, u = mi - post + b;
-        if (u >= 0) v = P.win[(((size_t)f * 2) * 2 * P.hw + (u + P.hw)) * C + lane];
-      }
-      wreg[sl][b] = v;
+  for (int b = 0; b < kW; ++b) {
+    float v = 0.f;
+    if (q_on && b <= L && lane < C) {
+      // x~_f[m + b], m = mi - post: head-window row m + b + hw, a row of the recording when m + b >= 0
+      const int f = qi0 / post, mi = qi0 % post, u = mi - post + b;
+      if (u >= 0 && (b < L || kCpw == 2)) v = P.win[(((size_t)f * 2) * 2 * P.hw + (u + P.hw)) * C + lane];
     }
+    wreg[b] = v;
   }
   for (int idx = t; idx < kCpw * nq; idx += kCgThreads) {
     const int cc = idx / nq, q = idx % nq;
@@ -693,25 +698,34 @@ __global__ __launch_bounds__(kCgThreads) void cg_toeplitz_kernel(CgtParams P) {
       TD_CGT_T(0);
       // -- my q numbers: published first, the T part runs while they travel
       unsigned long long* const qbuf = q_pk + (size_t)(round & 1u) * 2 * kCgtMaxQ;
+      if (q_on) {                          // (wave-uniform)
+        // (unconditional reads -- a branch per term made every LDS read wait for the one before it:
+        // 2.3 us for this block; the window rows past L and the lanes past C hold zeros -- and two
+        // chains of additions)
+        const int lq = lane < C ? lane : 0;
+        double pvq[32];
 #pragma unroll
-      for (int sl = 0; sl < kCpw; ++sl) {
-        const int qi = gw + sl * n_waves;
-        if (qi < nq) {                     // (wave-uniform: kCpw q numbers per wave of the grid)
-          // (unconditional reads -- a branch per term made every LDS read wait for the one before it:
-          // 2.3 us for this block; the window rows past L and the lanes past C hold zeros -- and two
-          // chains of additions)
-          const int lq = lane < C ? lane : 0;
-          double pvq[32];
+        for (int bb = 0; bb < 32; ++bb) {
+          pvq[bb] = vec[(bb < L ? bb : 0) * C + lq];
+          if (kCpw == 2) pvq[bb] *= bb < L ? 1.0 : 0.0;        // (its window row L is not zero: the neighbour's)
+        }
+        double a = 0.0, a2 = 0.0;
 #pragma unroll
-          for (int bb = 0; bb < 32; ++bb) pvq[bb] = vec[(bb < L ? bb : 0) * C + lq];
-          double a = 0.0, a2 = 0.0;
+        for (int bb = 0; bb < 32; bb += 2) {
+          a = fma((double)wreg[bb], pvq[bb], a);
+          a2 = fma((double)wreg[bb + 1], pvq[bb + 1], a2);
+        }
+        a = wave_sum(a + a2);
+        if (lane == 0) ll_store(qbuf + 2 * qi0, a, round);
+        if (kCpw == 2 && q_two) {
+          double c1 = 0.0, c2 = 0.0;
 #pragma unroll
           for (int bb = 0; bb < 32; bb += 2) {
-            a = fma((double)wreg[sl][bb], pvq[bb], a);
-            a2 = fma((double)wreg[sl][bb + 1], pvq[bb + 1], a2);
+            c1 = fma((double)wreg[(bb + 1) % kW], pvq[bb], c1);
+            c2 = fma((double)wreg[(bb + 2) % kW], pvq[bb + 1], c2);
           }
-          a = wave_sum(a + a2);
-          if (lane == 0) ll_store(qbuf + 2 * qi, a, round);
+          c1 = wave_sum(c1 + c2);
+          if (lane == 0) ll_store(qbuf + 2 * (qi0 + 1), c1, round);
         }
       }
       // -- T part of my rows a = 4 wave + r: lane j multiplies the columns (., j)
@@ -1033,7 +1047,9 @@ int td_cg_solve_compact(td_handle* h, const StatsCompact& sc, const double* lams
       TD_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_toeplitz_kernel<1>, kCgThreads, lds_bytes(1)));
     else
       TD_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_toeplitz_kernel<2>, kCgThreads, lds_bytes(2)));
-    if ((long long)per_cu * cus >= wgs && nq <= (long long)cand * kCgWaves * wgs) cpw = cand;
+    // (q numbers: one per wave of the grid, or -- two channels per workgroup -- a pair of neighbours per wave)
+    const long long q_waves = cand == 1 ? nq : (long long)sc.n_files * ((post + 1) / 2);
+    if ((long long)per_cu * cus >= wgs && q_waves <= (long long)kCgWaves * wgs) cpw = cand;
   }
   if (!cpw) return TD_CG_NOT_RESIDENT;
   const size_t words = (size_t)2 * 2 * kCgtRowPackets + (size_t)2 * 2 * kCgtMaxQ + 2 * 64;
