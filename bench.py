@@ -1186,8 +1186,11 @@ def main():
                              'time ranges (+ halo) over %d GPUs, fit i solved by rank i mod N' % world)
                             + ', one all-reduce of the packed statistics per fit'),
             'pipelining': ('serial' if args.serial else
-                           'accumulate(i+1) || solves on %d streams (%d-CU partition)'
-                           % (args.solve_streams, args.solve_cus)),
+                           'accumulate(i+1) || solves on %d streams (%d-CU partition)%s'
+                           % (args.solve_streams, args.solve_cus,
+                              '' if args.no_defer_finalize else
+                              '; the finalize launch of fit i (float64 reduction of its partial sums) is queued on '
+                              'the solve stream: TD_ACC_DEFER + td_stats_complete')),
         },
         # The accumulate runs on the float16 matrix pipe: every float32 product is three float16
         # MFMA products (2-piece split with per-channel power-of-two scales, lagcov.hip).
