@@ -249,7 +249,9 @@ class FitPipeline(object):
         self.s_acc.wait_event(self.ev_tgt[buf])
         st.accumulate(x, None, y, file_offsets, parts=1 | 8 if self.defer_finalize else 1, **kw)
       else:
-        if self.ev_solved[buf] is not None:
+        # (the solve that last read this buffer: usually long done -- a wait queued for a finished event is still a
+        # barrier packet between the matrix kernel of one fit and the targets kernel of the next)
+        if self.ev_solved[buf] is not None and not self.ev_solved[buf].query():
           self.s_acc.wait_event(self.ev_solved[buf])
         st.reset()
         st.accumulate(x, None, y, file_offsets,
