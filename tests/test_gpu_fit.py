@@ -1226,6 +1226,21 @@ def test_deferred_finalize_equals_the_call_that_finalizes_itself(dev, c, pre, po
   del h2
 
 
+def test_pipeline_refuses_a_solve_partition_that_splits_an_xcd(dev):
+  """FitPipeline(solve_cus=...): a CU mask holds whole XCDs (a fraction of one runs the other partition at the
+  pace of that XCD's doubled-up CUs: 1.3-1.4 ms per pipelined C2 fit at 48 / 56 / 72 CUs against 0.83 at 64)."""
+  import torch
+  from telluride_decoding_amd import pipeline
+  n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+  if n_cu % 8:
+    pytest.skip('CU count %d is not 8 XCDs' % n_cu)
+  with pytest.raises(ValueError, match='whole number of XCDs'):
+    pipeline.FitPipeline(16, 0, 3, d=1, solve_cus=n_cu // 8 + n_cu // 16)
+  pipe = pipeline.FitPipeline(16, 0, 3, d=1, solve_cus=n_cu // 8)
+  assert pipe.defer_finalize
+  del pipe
+
+
 def test_narrow16_strided_inputs_parts_and_tiled_path(dev):
   """The <= 16-channel streaming accumulate (lagcov_narrow16_kernel): inputs that are column slices of
   wider arrays (row pitch > channels), the covariance part and the targets part of a call queued apart
