@@ -202,11 +202,19 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
       g -= 1
     train.combine(parts)
 
+  # The per-minibatch scores stay on the device until the sweep ends and are averaged on the host (they are a
+  # few kilobytes): `scores` holds (device tensor [minibatches of its folds, Lambda], minibatches per fold)
+  # -- no torch reduction, stack or repeat kernel in the sweep (their code objects cost the FIRST sweep of a
+  # process 80 ms to load: tools/torch_first_calls.py).
+  def tile_columns(y):
+    """y [rows, d] -> [rows, Lambda * d], the truth under every lambda's columns (a strided copy)."""
+    return y.unsqueeze(1).expand(-1, n_lam, -1).reshape(y.shape[0], n_lam * d).contiguous()
+
   def evaluate(f, w, b):
     """Held-out scores of fold f for its n_lam weight sets w [n_lam, K, d], b [n_lam, d]."""
     u = held_used[f]
     if u == 0:
-      scores.append(h.zeros((n_lam,), 'float64') + float('nan'))
+      scores.append((None, [0]))
       return
     k = int(w.shape[1])
     w_all = w.permute(1, 0, 2).reshape(k, n_lam * d).contiguous()
@@ -216,10 +224,10 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     # columns = (lambda, output); the truth repeats per lambda.  pearson_correlation_first =
     # output 0 of each model, with the zero rule taken over that model's d outputs
     p_all = pred[:u] if pred.shape[0] != u else pred
-    y_all = yf[dy:dy + u].repeat(1, n_lam)
+    y_all = tile_columns(yf[dy:dy + u])
     sums = dev.window_sums(y_all, p_all, [0, u], bsz, bsz, handle=h)
     r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)   # [minibatches, Lambda * d]
-    scores.append(r[:, ::d].mean(dim=0))
+    scores.append((r[:, ::d], [u // bsz]))
 
   def evaluate_folds(folds, w_all, b_all):
     """evaluate() for the folds of one solver call, w_all [folds, n_lam, K, d].  A run of
@@ -243,19 +251,12 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     w_f = w_all.permute(0, 2, 1, 3).reshape(len(folds), k, n_lam * d).contiguous()
     b_f = b_all.reshape(len(folds), n_lam * d).contiguous()
     pred = dev.predict_fir_per_file(x_all[r0:r1], sub, w_f, b_f, dataset.pre, dataset.post, handle=h)
-    truth = y_all[r0:r1].repeat(1, n_lam)
+    truth = tile_columns(y_all[r0:r1])
     # minibatches = the full windows of every recording (no offset: a recording's zipped stream
     # is the recording), each model scored on its own (groups of d columns)
     sums = dev.window_sums(truth, pred, sub, bsz, bsz, handle=h)
     r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)[:, ::d]    # [minibatches, Lambda]
-    counts = [held_used[f] // bsz for f in folds]
-    if all(cnt == counts[0] for cnt in counts):            # equal recordings: one mean launch
-      scores.extend(r.reshape(len(folds), counts[0], n_lam).mean(dim=1).unbind(0))
-      return
-    start = 0
-    for cnt in counts:
-      scores.append(r[start:start + cnt].mean(dim=0))
-      start += cnt
+    scores.append((r, [held_used[f] // bsz for f in folds]))
 
   # (1) All (fold, lambda) systems at once by preconditioned conjugate gradients: the folds'
   # covariances differ from the total's by 1 / folds, so ONE Cholesky factor per lambda (of the
@@ -322,8 +323,18 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     for fi, f in enumerate(folds):
       evaluate(f, w_all_folds[fi], b_all_folds[fi])
   check(keep=0)
-  import torch
-  rows = (torch.stack(scores).cpu().numpy() if scores else np.zeros((0, n_lam)))   # one copy
+  # Keras `evaluate` = the unweighted mean over a fold's minibatches (brain_model.py:206-253), on the host
+  fold_rows = []
+  for r, counts in scores:
+    if r is None:
+      fold_rows.append(np.full((n_lam,), np.nan))
+      continue
+    rh = np.asarray(r.cpu(), np.float64)
+    start = 0
+    for cnt in counts:
+      fold_rows.append(rh[start:start + cnt].mean(axis=0))
+      start += cnt
+  rows = np.stack(fold_rows) if fold_rows else np.zeros((0, n_lam))
   # 5. gather
   all_folds = distributed.gather_rows(rows, n_files, my_folds, group,
                                       local_only=world_size == 1)[fold_list]         # [F, Lambda]
