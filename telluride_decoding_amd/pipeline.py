@@ -101,7 +101,7 @@ class FitPipeline(object):
     # partition either.
     self.targets_ahead = bool(targets_ahead) and not targets_on_solve
     n_extra = 1 if self.targets_ahead else 0
-    if solve_cus and 0 < solve_cus < n_cu and n_cu % 8 == 0 and solve_cus % (n_cu // 8):
+    if solve_cus and 0 < solve_cus < n_cu and n_cu == 256 and solve_cus % (n_cu // 8):
       # (measured: 48 / 56 / 72 of 256 -> 1.3-1.4 ms per pipelined C2 fit against 0.83 at 64: a mask's CUs are
       # numbered XCD by XCD, workgroups are dealt to the XCDs in turn, so a partition that holds a fraction of
       # an XCD runs at the pace of that XCD's doubled-up CUs)
