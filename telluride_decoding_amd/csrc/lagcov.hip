@@ -3599,6 +3599,9 @@ int td_narrow16_plan(td_handle* h, int c, int d, int pre, int l1, int64_t ldx, i
   const long long want = 1024;
   long long per = td_ceil_div(total, want);
   if (per < 64LL * n_sub) per = 64LL * n_sub;
+  // (a wave's sums are ONE float32 accumulation chain: at most 2048 samples of it, as in the tiled kernels' slab
+  // plan -- very long inputs get more workgroups instead of longer chains)
+  if (per > 2048LL * n_sub) per = 2048LL * n_sub;
   per = td_round_up(per, 4 * n_sub);
   plan->works.clear();
   for (const LagSeg& sg : syx) {

@@ -550,6 +550,31 @@ def _lag_block_f64(torch, x, offs, a, b, rows_used=None):
   return out
 
 
+def test_narrow16_long_input_keeps_float32_chains_short(dev):
+  """The <= 16-channel streaming accumulate on 2e7 samples (one recording): a wave's sums are one float32
+  accumulation chain, capped at 2048 samples by giving long inputs more workgroups -- selected blocks of the
+  moments against direct float64 shifted products to 2e-7 of the diagonal, like every other kernel."""
+  import torch
+  h = dev.default_handle()
+  torch.manual_seed(11)
+  n, c, post = 20000000, 8, 7
+  x = torch.randn(n, c, device='cuda')
+  x += 0.4 * torch.roll(x, 1, 0) + 1.5            # correlated in time, not zero-mean: every product counts
+  y = (x[:, 2:3] * 0.7 + torch.randn(n, 1, device='cuda'))
+  offs = np.array([0, n], np.int64)
+  st = dev.LagStats(c, 0, post, d=1)
+  st.accumulate(x, None, y, offs)
+  m = st.moments()
+  xtx, xty = m['xtx'], m['xty']
+  scale = float(xtx.abs().max())
+  for (la, lb) in ((0, 0), (0, 7), (3, 5)):
+    want = _lag_block_f64(torch, x, offs, la, lb)
+    got = xtx[la * c:(la + 1) * c, lb * c:(lb + 1) * c]
+    assert float((got - want).abs().max()) / scale < 2e-7, (la, lb)
+  wy = x[3:].double().T @ y[:n - 3, 0].double()
+  assert float((xty[3 * c:4 * c, 0] - wy).abs().max()) / float(xty.abs().max()) < 2e-7
+
+
 def test_c2_full_size_moments_properties(dev):
   """BASELINE config C2 at full size (64 ch x 1e6 samples, 32 lags, 10 recordings): selected
   blocks of the 2049 x 2049 moment matrix against direct float64 shifted products, exact
