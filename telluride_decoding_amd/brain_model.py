@@ -275,8 +275,11 @@ class BrainModelLinearRegression(object):
     self._w_dev = self._b_dev = None
     self.metrics_names = ['loss', 'pearson_correlation_first']
 
-  def compile(self, *args, **kwargs):
-    del args, kwargs   # nothing to compile: closed-form model
+  def compile(self, optimizer=None, loss='mse', metrics=pearson_correlation_first,
+              learning_rate=1e-3, **kwargs):
+    """Accepted for drop-in use (brain_model.py:343-359); nothing to compile: the fit is closed
+    form, and `evaluate` always reports the reference's defaults (mse + pearson_correlation_first)."""
+    del optimizer, loss, metrics, learning_rate, kwargs
 
   def fit(self, input_dataset, **kwargs):
     del kwargs
@@ -306,14 +309,14 @@ class BrainModelLinearRegression(object):
       self._b_dev = h.to_device(self.b_estimate.reshape(1, -1)).reshape(-1)
     return self._w_dev, self._b_dev
 
-  def __call__(self, input_data):
-    return self.call(input_data)
+  def __call__(self, input_dataset):
+    return self.call(input_dataset)
 
-  def call(self, input_data):
-    """input_data: dict with an already-lagged 'input_1' [B, K] -> [B, D]."""
+  def call(self, input_dataset):
+    """input_dataset: dict with an already-lagged 'input_1' [B, K] -> [B, D] (brain_model.py:335-341)."""
     h = device.default_handle()
     w, b = self._device_weights(h)
-    x = _as_2d_device(h, input_data['input_1'])
+    x = _as_2d_device(h, input_dataset['input_1'])
     out = device.predict_fir(x, [0, int(x.shape[0])], w, b, 0, 0, handle=h)
     return brain_data._t(out.cpu().numpy())
 

@@ -177,8 +177,10 @@ class BrainModelCCA(object):
     self._dev = None
     self.metrics_names = ['loss', 'cca_pearson_correlation_first']
 
-  def compile(self, *args, **kwargs):
-    del args, kwargs
+  def compile(self, optimizer=None, loss=cca_pearson_correlation_first,
+              metrics=cca_pearson_correlation_first, learning_rate=1e-3, **kwargs):
+    """Accepted for drop-in use (cca.py:196-212); the fit is closed form, nothing to compile."""
+    del optimizer, loss, metrics, learning_rate, kwargs
 
   def fit(self, dataset, epochs=1):
     del epochs

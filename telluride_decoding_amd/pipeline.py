@@ -71,10 +71,14 @@ class FitPipeline(object):
       # one accumulating, one per solve in flight, one of slack: with fewer the stages end up
       # waiting for each other's jitter
       buffers = solve_streams + 2
-    if buffers < solve_streams + 1:
-      # with one buffer submit(i + 1) would reset the statistics before solve(i) is even queued
-      raise ValueError('FitPipeline needs at least %d statistics buffers for %d solve streams, '
-                       'not %d' % (solve_streams + 1, solve_streams, buffers))
+    # with one buffer submit(i + 1) would reset the statistics before solve(i) is even queued.  With the
+    # conjugate-gradient solves one more: a solve that gives up (flag 2) is repeated from its fit's statistics
+    # when its result is handed out -- at the END of the submit that has by then reset the buffer of the fit
+    # `buffers` submits back, which must therefore not be the oldest fit still outstanding.
+    need = solve_streams + (2 if cg_solves else 1)
+    if buffers < need:
+      raise ValueError('FitPipeline needs at least %d statistics buffers for %d solve streams%s, '
+                       'not %d' % (need, solve_streams, ' with cg_solves' if cg_solves else '', buffers))
     self.torch = torch
     self._masked = []
     # solves: optional callable(fit index) -> bool.  With several ranks sharing every fit
@@ -101,7 +105,7 @@ class FitPipeline(object):
     # partition either.
     self.targets_ahead = bool(targets_ahead) and not targets_on_solve
     n_extra = 1 if self.targets_ahead else 0
-    if solve_cus and 0 < solve_cus < n_cu and n_cu == 256 and solve_cus % (n_cu // 8):
+    if solve_cus and 0 < solve_cus < n_cu and n_cu % 8 == 0 and solve_cus % (n_cu // 8):
       # (measured: 48 / 56 / 72 of 256 -> 1.3-1.4 ms per pipelined C2 fit against 0.83 at 64: a mask's CUs are
       # numbered XCD by XCD, workgroups are dealt to the XCDs in turn, so a partition that holds a fraction of
       # an XCD runs at the pace of that XCD's doubled-up CUs)
@@ -165,6 +169,7 @@ class FitPipeline(object):
     self.ev_acc = [torch.cuda.Event() for _ in range(buffers)]
     self.ev_tgt = [torch.cuda.Event() for _ in range(buffers)]
     self.ev_solved = [None] * buffers
+    self._generation = [0] * buffers     # submits that have used a buffer (guards the flag-2 re-solve)
     self.pending = None          # (buffer index, lambdas) of the fit whose solve is not queued yet
     self._results = []           # queued solves: (w, b, flag reader, event)
     self.count = 0
@@ -205,7 +210,7 @@ class FitPipeline(object):
       ev = torch.cuda.Event()
       ev.record(s_solve)
       self.ev_solved[buf] = ev
-    self._results.append((w, b, flag, ev, (buf, lambdas, index)))
+    self._results.append((w, b, flag, ev, (buf, lambdas, index, self._generation[buf])))
 
   def _pop(self):
     """Oldest queued solution, waited for and checked."""
@@ -218,7 +223,10 @@ class FitPipeline(object):
     if state == 2 and len(entry) > 4:
       # the conjugate-gradient solve gave up: the factorisation, synchronously, from the statistics of
       # that fit (its buffer is not reused before this result has been handed out)
-      buf, lambdas, index = entry[4]
+      buf, lambdas, index, generation = entry[4]
+      if generation != self._generation[buf]:
+        raise RuntimeError('FitPipeline: the statistics of fit %d were reset before its solve was repeated'
+                           % index)
       hs = self.h_solves[index % len(self.s_solves)]
       with self.torch.cuda.stream(self.s_solves[index % len(self.s_solves)]):
         hs.set_solver('cholesky')
@@ -237,6 +245,7 @@ class FitPipeline(object):
     buf = self.count % len(self.stats)
     self.count += 1
     st = self.stats[buf]
+    self._generation[buf] += 1
     if self.targets_ahead:
       with torch.cuda.stream(self.s_tgt):
         if self.ev_solved[buf] is not None:

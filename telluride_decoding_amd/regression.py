@@ -31,16 +31,34 @@ from telluride_decoding_amd import device as _device
 from telluride_decoding_amd import distributed
 
 
-def parse_regularization_values(reg_string=None):
-  """Default grid 10^[-6..0] (reference regression.py:264-282)."""
-  if reg_string is None:
-    return list(np.power(10.0, np.arange(-6, 1)))
-  return [float(s) for s in str(reg_string).split(',')]
+def calculate_stats(run_results, axis=(1,)):
+  """Mean and standard deviation across the held-out files of a [#lambda, #test files] matrix of
+  results, one row per regularisation value (reference regression.py:245-261): two arrays, one
+  entry per lambda with the default axis."""
+  run_mean = np.mean(run_results, axis=axis)
+  run_std = np.std(run_results, axis=axis)
+  return run_mean, run_std
 
 
-def calculate_stats(values):
-  values = np.asarray(values, np.float64)
-  return float(np.mean(values)), float(np.std(values))
+def parse_regularization_values(mode_string):
+  """The regularisation values of a sweep (reference regression.py:264-282): a float stands for
+  itself, 'normal' is the default grid 10^[-6..0], 'test' the single value 1e-6, anything else a
+  comma-separated list of floats (returned as a float32 array like the reference does)."""
+  if isinstance(mode_string, float):
+    return [mode_string,]
+  if not isinstance(mode_string, str):
+    raise TypeError('Parse_regularization_values needs a comma-separated' +
+                    ' string, not a %s' % mode_string)
+  mode_string = mode_string.lower()
+  if mode_string == 'normal':
+    return np.power(10, np.arange(-6.0, 0.5, 1))
+  if mode_string == 'test':
+    return np.power(10, np.arange(-6.0, -5, 1))
+  try:
+    return np.array([float(tok) for tok in mode_string.split(',')], dtype=np.float32)
+  except Exception:
+    raise Exception('Could not parse regularization values: Want '
+                    'comma separated list of floats, not %s' % mode_string)
 
 
 # Workspace budget of one batched solve (bytes).  288 GB of HBM make a few GB free; the budget
@@ -102,7 +120,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   test_file); 'all_runs' and the statistics then cover those files only, in ascending order.
   """
   dev = device or _device
-  lambdas = parse_regularization_values() if regularization_list is None else list(regularization_list)
+  lambdas = (list(parse_regularization_values('normal')) if regularization_list is None
+             else list(regularization_list))
   n_files = len(dataset.files)
   if n_files < 2:
     raise ValueError('Need at least two files for a jackknife test.')
@@ -339,8 +358,9 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   all_folds = distributed.gather_rows(rows, n_files, my_folds, group,
                                       local_only=world_size == 1)[fold_list]         # [F, Lambda]
   results = collections.OrderedDict()
+  run_mean, run_std = calculate_stats(all_folds.T)          # [Lambda, F] like regression.py:416
   for li, lam in enumerate(lambdas):
-    results[lam] = calculate_stats(all_folds[:, li])
+    results[lam] = (float(run_mean[li]), float(run_std[li]))
   results['all_runs'] = all_folds.T
   return results
 

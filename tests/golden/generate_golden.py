@@ -40,6 +40,7 @@ from telluride_decoding import scaled_lda as ref_lda  # noqa: E402
 from oracle import lag as o_lag  # noqa: E402
 from oracle import regression as o_reg  # noqa: E402
 from telluride_decoding_amd import synth  # noqa: E402
+from tests.surface import module_surface  # noqa: E402
 
 
 def save(name, **arrays):
@@ -610,6 +611,45 @@ def g12_c1_10k():
   save('g12_c1_10k', **out)
 
 
+# ----------------------------------------------------------------- G14 sweep helpers + call surface
+SURFACE_MODULES = ('attention_decoder', 'brain_model', 'cca', 'infer_decoder', 'result_store',
+                   'scaled_lda', 'regression', 'infer')
+
+
+def g14_sweep_helpers_and_surface():
+  """regression.calculate_stats / parse_regularization_values (regression.py:245-282) on fixed
+  inputs, and `inspect.signature` of every public function, class and method the six hot-path
+  modules + regression + infer define -- the call surface as DATA (names, kinds, defaults)."""
+  import importlib
+  import json
+  from telluride_decoding import regression as ref_reg
+  rng = np.random.default_rng(14)
+  runs = rng.standard_normal((7, 5))
+  mean1, std1 = ref_reg.calculate_stats(runs)
+  mean0, std0 = ref_reg.calculate_stats(runs, axis=(0,))
+  out = dict(runs=runs, mean_axis1=mean1, std_axis1=std1, mean_axis0=mean0, std_axis0=std0,
+             parse_float=np.asarray(ref_reg.parse_regularization_values(0.25)),
+             parse_normal=ref_reg.parse_regularization_values('normal'),
+             parse_normal_upper=ref_reg.parse_regularization_values('NORMAL'),
+             parse_test=ref_reg.parse_regularization_values('test'),
+             parse_list=ref_reg.parse_regularization_values('0.1, 1,1e-3'),
+             parse_one=ref_reg.parse_regularization_values('3'))
+  errors = {}
+  for key, arg in (('int', 3), ('none', None), ('list', [0.1]), ('garbage', 'a,b'), ('empty', '')):
+    try:
+      ref_reg.parse_regularization_values(arg)
+      errors[key] = None
+    except BaseException as e:    # pylint: disable=broad-except
+      errors[key] = [type(e).__name__, str(e)]
+  save('g14_sweep_helpers', **out)
+  surface = {m: module_surface(importlib.import_module('telluride_decoding.' + m))
+             for m in SURFACE_MODULES}
+  path = os.path.join(HERE, 'g14_surface.json')
+  with open(path, 'w') as fp:
+    json.dump({'parse_errors': errors, 'surface': surface}, fp, indent=1, sort_keys=True)
+  print('wrote %s (%.1f kB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 if __name__ == '__main__':
   if len(sys.argv) > 1:           # python generate_golden.py g11_decode_harness ...
     for name in sys.argv[1:]:
@@ -628,3 +668,4 @@ if __name__ == '__main__':
   g11_decode_harness()
   g12_c1_10k()
   g13_loss_and_time_axis()
+  g14_sweep_helpers_and_surface()

@@ -188,9 +188,10 @@ def test_shard_plan_and_sweep_helpers():
   few = distributed.ShardPlan([5, 5], 4)
   assert sum(len(few.files_of(r)) for r in range(4)) == 2
   assert distributed.split_round_robin(list(range(10)), 1, 4) == [1, 5, 9]
-  np.testing.assert_allclose(regression.parse_regularization_values(), 10.0 ** np.arange(-6, 1))
-  assert regression.parse_regularization_values('0.1,1') == [0.1, 1.0]
-  assert regression.calculate_stats([1.0, 3.0]) == (2.0, 1.0)
+  np.testing.assert_allclose(regression.parse_regularization_values('normal'), 10.0 ** np.arange(-6, 1))
+  np.testing.assert_allclose(regression.parse_regularization_values('0.1,1'), [0.1, 1.0])
+  mean, std = regression.calculate_stats([[1.0, 3.0]])
+  assert list(mean) == [2.0] and list(std) == [1.0]
 
 
 def _loso_case():
