@@ -522,6 +522,107 @@ def loso_leg(eeg, env):
   }
 
 
+def _wall_median(fn, reps=5, warm=4):
+  """Median wall time (s) of a synchronous call, the device idle before and after."""
+  import torch
+  for _ in range(warm):
+    fn()
+  ts = []
+  for _ in range(reps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+  return float(np.median(ts))
+
+
+def decoder_train_leg(h, device):
+  """Row F1 at the C4 size: Decoder.train (reference infer_decoder.py:330-400 -- four passes over the two
+  datasets there: correlation statistics x 2, per-frame correlations x 2, then the scaled LDA of
+  scaled_lda.py:141-212) on 200 trials x 6000 frames x 64 ch, both speakers: data1 = the attended envelope as
+  truth, data0 = the unattended one, reduction 'lda'.  Here every dataset goes through the model ONCE (the
+  streamed FIR), the correlator sums, the per-frame correlations and the LDA class moments are one launch
+  each; nothing [frames, dims]-sized visits the host."""
+  import torch
+  from telluride_decoding_amd import brain_data, brain_model, infer_decoder, synth
+  trials = synth.make_trials(4, 200, 6000, C, switch_half=True)
+
+  def ds_of(attended):
+    files = []
+    for eeg, env, att in trials:
+      sel = (att > 0.5) if attended else (att <= 0.5)
+      truth = np.where(sel, env[:, 1:2], env[:, 0:1]).astype(np.float32)
+      files.append((eeg, env, truth, att))
+    return brain_data.Dataset(files, 1000, pre_context=PRE, post_context=POST)
+
+  data1, data0 = ds_of(True), ds_of(False)
+  model = brain_model.BrainModelLinearRegression(data1, regularization_lambda=LAMBDA)
+  model.fit(data1)
+  dec = infer_decoder.LinearRegressionDecoder(model, reduction='lda')
+  dprime = dec.train(data0, data1)
+  frames = sum(data1.file_lengths())
+  seconds = _wall_median(lambda: dec.train(data0, data1))
+  # the streaming part alone: the model's pass over one dataset (x read once, one prediction column written)
+  t_pred = _wall_median(lambda: model.predict_device(data1, handle=h))
+  x_d, _, y_d, offs = data1.device_arrays(h)
+  pred = model.predict_device(data1, handle=h)
+  t_sums = _wall_median(lambda: device.window_sums(y_d, pred, [0, frames], frames, frames, handle=h))
+  fir_bytes = 4.0 * frames * (C + 1)
+  # per dataset: x read + prediction written (FIR), truth + prediction read twice (statistics, per-frame
+  # correlations) + the correlations written and read again by the class moments
+  alg = 2.0 * (fir_bytes + 4.0 * frames * (2 + 2 + 1 + 1))
+  return {
+      'workload': 'F1: Decoder.train(data0 = unattended, data1 = attended), reduction lda, C4 data: 200 trials x '
+                  '6000 frames x 64 ch, 32 lags',
+      'seconds': seconds, 'frames': 2 * frames, 'frames_per_s': 2 * frames / seconds, 'dprime': float(dprime),
+      'algorithmic_bytes': alg, 'hbm_frac': alg / seconds / 1e9 / PEAK_HBM_GBPS,
+      'kernels': ['fir_stream_kernel (x2: one model pass per dataset)', 'block_sums / window sums (correlator statistics)',
+                  'frame_scores (per-frame correlations)', 'gram_bf16x3_kernel + stats_finalize_kernel (LDA class moments)',
+                  'td_general_solve (2 x 2 LDA eigenproblem: host-sized)'],
+      'streaming_parts': {
+          'model_pass_one_dataset': {'seconds': t_pred, 'bytes': fir_bytes,
+                                     'hbm_frac': fir_bytes / t_pred / 1e9 / PEAK_HBM_GBPS,
+                                     'what': 'predict_device: wall time of the synchronous call (launch + wait)'},
+          'correlator_sums_one_dataset': {'seconds': t_sums, 'bytes': 8.0 * frames,
+                                          'hbm_frac': 8.0 * frames / t_sums / 1e9 / PEAK_HBM_GBPS}},
+      'what': 'median wall time of the whole call (host logic included), inputs resident in HBM',
+  }
+
+
+def ledoit_wolf_leg(h, device, eeg, env):
+  """Row F2: the Ledoit-Wolf branch of calculate_linear_regressor_parameters_from_dataset (lamb = -1,
+  use_ridge = False: reference brain_model.py:440-444, 456-476) at the C1 and C2 shapes: the shrinkage
+  moment np.sum((xc ** 2)^T (xc ** 2)) as one streaming pass (shrink.hip: a scalar per lagged row, the
+  (K + 1)^2 matrix of the reference never exists), then the moments and the general solve."""
+  from telluride_decoding_amd import brain_data, brain_model
+  out = {}
+  att1 = np.zeros((10000, 1), np.float32)
+  rng = np.random.default_rng(12)
+  x1 = rng.standard_normal((10000, 16)).astype(np.float32)
+  y1 = (x1[:, :1] * 0.5 + rng.standard_normal((10000, 1))).astype(np.float32)
+  shapes = (('C1', [(x1, y1, y1, att1)], 16, 0, 3, 100),
+            ('C2', [(eeg[i * FRAMES_PER_FILE:(i + 1) * FRAMES_PER_FILE], env[i * FRAMES_PER_FILE:(i + 1) * FRAMES_PER_FILE],
+                     env[i * FRAMES_PER_FILE:(i + 1) * FRAMES_PER_FILE], np.zeros((FRAMES_PER_FILE, 1), np.float32))
+                    for i in range(FILES_PER_GPU)], C, PRE, POST, 1000))
+  for name, files, c, pre, post, batch in shapes:
+    ds = brain_data.Dataset(files, batch, pre_context=pre, post_context=post)
+    fit = lambda: brain_model.calculate_linear_regressor_parameters_from_dataset(ds, lamb=-1, use_ridge=False)
+    shrinkage = float(fit()[4])
+    seconds = _wall_median(fit, reps=3, warm=2)
+    x_d, _, _, offs = ds.device_arrays(h)
+    t_mom = _wall_median(lambda: device.shrinkage_moment(x_d, offs, pre, post, batch, handle=h), reps=5, warm=2)
+    frames = sum(ds.file_lengths())
+    out[name] = {
+        'shape': '%d ch x %d frames, %d lags, minibatches of %d' % (c, frames, pre + 1 + post, batch),
+        'seconds': seconds, 'shrinkage': shrinkage,
+        'moment': {'seconds': t_mom, 'bytes': 4.0 * frames * c, 'hbm_frac': 4.0 * frames * c / t_mom / 1e9 / PEAK_HBM_GBPS,
+                   'kernels': ['batch_colsum_kernel', 'running_mean_kernel', 'centred_square_kernel', 'partial_sum_kernel (shrink.hip)'],
+                   'what': 'td_shrinkage_moment, synchronous call: x read once'}}
+  out['what'] = 'median wall time of the fit with the automatic regulariser (accumulate + moment + solve), inputs in HBM'
+  return out
+
+
 # ---- progress marks + watchdog ------------------------------------------------------------------
 # Every rank writes what it is about to do (the next collective, the next leg) into its own log
 # file when the launcher gave it a directory (TD_BENCH_LOG_DIR), and a watchdog thread of the rank
@@ -1149,17 +1250,26 @@ def main():
     flops_per_launch = 2.0 * C * k * (kernel_samples / max(launches, 1))
     avg_s = kernel_ms / max(launches, 1) / 1e3
     achieved = flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
-    traffic, traffic_source = None, None
-    for name in ('r05_lagcov_pmc.json', 'r04_lagcov_pmc.json', 'r03_lagcov_pmc.json'):
+    traffic, traffic_source, traffic_per_fit = None, None, None
+    for name in ('r06_lagcov_pmc.json', 'r05_lagcov_pmc.json', 'r04_lagcov_pmc.json', 'r03_lagcov_pmc.json'):
       pmc = os.path.join(ROOT, 'profiles', name)
       if os.path.exists(pmc) and args.scaling == 'weak':
         with open(pmc) as f:
-          traffic = json.load(f).get('hbm_bytes_per_launch')
+          pmc_json = json.load(f)
+        traffic = pmc_json.get('hbm_bytes_per_launch')
         traffic_source = ('profiles/%s: rocprofv3 --pmc FETCH_SIZE (x 2, the gfx950 correction) + WRITE_SIZE of a '
                           'SEPARATE run over the same kernel and launch shape -- a constant in this line, not a '
-                          'measurement of this run; the counters under-count (below the 256 MB the kernel must '
-                          'read + its partial slabs).  Per fit x is read TWICE: by the targets pass (HBM-bound) and '
-                          'by this kernel (MFMA-bound)' % name)
+                          'measurement of this run: the 256 MB of input read once + the float32 partial slabs '
+                          '(1.16 x the algorithmic bytes)' % name)
+        tgt = pmc_json.get('lagcov_targets_mfma_kernel', {}).get('hbm_bytes_per_launch')
+        if traffic and tgt:
+          # per fit x is read TWICE: by the targets pass (HBM-bound) and by the matrix kernel (MFMA-bound)
+          alg = 4.0 * (C + D) * (kernel_samples / max(launches, 1))
+          traffic_per_fit = {'bytes': traffic + tgt, 'matrix_kernel': traffic, 'targets_pass': tgt,
+                             'algorithmic_bytes': alg, 'ratio': (traffic + tgt) / alg,
+                             'what': 'HBM bytes of the two passes of one fit (PMC, the same separate run): the targets '
+                                     'pass reads x and y again (y^T x~, column sums, the channel maxima of the float16 '
+                                     'split)'}
         break
     line = {
         'metric': 'TRF-fit samples/sec', 'value': value, 'unit': 'samples/s',
@@ -1201,7 +1311,7 @@ def main():
             'kernel': 'lagcov_split_kernel<float16 x 2>', 'bound': 'mfma',
             'achieved': achieved * SPLIT_PRODUCTS, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved * SPLIT_PRODUCTS / PEAK_BF16_MFMA_TFLOPS, 'traffic': traffic,
-            'traffic_source': traffic_source,
+            'traffic_source': traffic_source, 'traffic_per_fit': traffic_per_fit,
             'launches': launches, 'avg_launch_ms': kernel_ms / max(launches, 1),
             'algorithmic_flops_per_launch': flops_per_launch,
             'algorithmic_tflops': achieved,
@@ -1389,6 +1499,10 @@ def main():
       progress('loso leg')
       line['loso'] = loso_leg(eeg, env)
       line['loso_first_sweep_s'] = line['loso']['seconds_first_sweep']
+      progress('decoder_train leg')
+      line['decoder_train'] = decoder_train_leg(h, device)
+      progress('ledoit_wolf leg')
+      line['ledoit_wolf'] = ledoit_wolf_leg(h, device, eeg, env)
     if world == 1 and not args.no_extra and not args.no_shapes:
       progress('shapes leg')
       line['shapes'] = shapes_leg(h, device)

@@ -337,6 +337,18 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
                         const double* lambdas_host, int n_lambda, int max_iter, double tol,
                         float* w_dev, float* b_dev, int* status_host, int* iterations_host);
 
+/* The same sweep with the folds given as what they ARE (regression.py:326-420: fold f = every recording but
+ * f): fold f = total + sum over t in [term_begin[f], term_begin[f + 1]) of signs[t] * terms[t], signs +1 / -1,
+ * at most 4 terms a fold -- minus the held-out recording's statistics; for a fold whose minibatch stream
+ * drops a remainder (brain_data.py:369-370) minus the last training recording's and plus the same recording
+ * accumulated without its tail.  The statistics are linear in the recordings, so no fold's training
+ * statistics are ever summed and the dense moments of ALL folds come from the total's (expanded once, for the
+ * preconditioner) in one launch.  term_begin [n_folds + 1]; everything else as td_ridge_solve_loso. */
+int td_ridge_solve_loso_terms(td_handle* h, td_stats* total, td_stats* const* terms, const int* term_begin,
+                              const double* signs, int n_folds, const double* lambdas_host, int n_lambda,
+                              int max_iter, double tol, float* w_dev, float* b_dev, int* status_host,
+                              int* iterations_host);
+
 /* Generic SPD solve used by the above and by the shrinkage branch
  * (brain_model.py:456-477): a_dev [batch, n, n] float64 (destroyed),
  * rhs_dev [batch, n, nrhs] float64 (overwritten with the solution). */

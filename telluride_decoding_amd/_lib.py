@@ -93,6 +93,8 @@ SIGNATURES = {
     'td_ridge_solve_multi': [_vp, _c.POINTER(_vp), _i, _pd, _i, _vp, _vp, _vp],
     'td_ridge_solve_loso': [_vp, _vp, _c.POINTER(_vp), _i, _pd, _i, _i, _d, _vp, _vp, _c.POINTER(_i),
                             _c.POINTER(_i)],
+    'td_ridge_solve_loso_terms': [_vp, _vp, _c.POINTER(_vp), _c.POINTER(_i), _pd, _i, _pd, _i, _i, _d, _vp, _vp,
+                                  _c.POINTER(_i), _c.POINTER(_i)],
     'td_spd_solve': [_vp, _vp, _vp, _i, _i, _i],
     'td_general_solve': [_vp, _vp, _vp, _i, _i],
     'td_shrinkage_moment': [_vp, _vp, _i64, _i, _i, _i, _pi64, _i, _i, _pi64, _i64, _vp],

@@ -1906,10 +1906,13 @@ int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, 
 // system reached the relative residual `tol`, 1 when the preconditioner was not positive
 // definite or some system did not converge in max_iter iterations (the outputs are then not to
 // be used: the caller falls back to td_ridge_solve_multi).
-int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, int n_folds,
-                        const double* lambdas_host, int n_lambda, int max_iter, double tol,
-                        float* w_dev, float* b_dev, int* status_host, int* iterations_host) {
-  if (!h || !total || !folds || !lambdas_host || !w_dev || !b_dev || !status_host)
+// folds != NULL: the folds' training statistics; else fold f = total + sum of signs[t] * terms[t] over
+// t in [term_begin[f], term_begin[f + 1]).
+static int ridge_solve_loso_impl(td_handle* h, td_stats* total, td_stats* const* folds, td_stats* const* terms,
+                                 const int* term_begin, const double* signs, int n_folds,
+                                 const double* lambdas_host, int n_lambda, int max_iter, double tol,
+                                 float* w_dev, float* b_dev, int* status_host, int* iterations_host) {
+  if (!h || !total || (!folds && !(terms && term_begin && signs)) || !lambdas_host || !w_dev || !b_dev || !status_host)
     return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_loso: NULL argument");
   TD_REQUIRE(h, n_folds > 0 && n_lambda > 0 && max_iter > 0 && tol > 0.0, "td_ridge_solve_loso: bad sizes");
   int k1 = 0, d = 0;
@@ -1921,9 +1924,23 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
   for (int f = 0; f < n_folds; ++f) {
     int kf = 0, df = 0;
     int64_t ff = 0;
-    TD_REQUIRE(h, folds[f], "td_ridge_solve_loso: NULL statistics");
-    td_stats_layout(folds[f], &kf, &df, &ff);
-    TD_REQUIRE(h, kf == k1 && df == d, "td_ridge_solve_loso: layouts differ");
+    if (folds) {
+      TD_REQUIRE(h, folds[f], "td_ridge_solve_loso: NULL statistics");
+      td_stats_layout(folds[f], &kf, &df, &ff);
+      TD_REQUIRE(h, kf == k1 && df == d, "td_ridge_solve_loso: layouts differ");
+    } else {
+      double frames = (double)frames_total;
+      TD_REQUIRE(h, term_begin[f + 1] >= term_begin[f], "td_ridge_solve_loso_terms: term_begin must not decrease");
+      for (int t = term_begin[f]; t < term_begin[f + 1]; ++t) {
+        TD_REQUIRE(h, terms[t], "td_ridge_solve_loso_terms: NULL statistics");
+        int64_t ft = 0;
+        td_stats_layout(terms[t], &kf, &df, &ft);
+        TD_REQUIRE(h, kf == k1 && df == d, "td_ridge_solve_loso_terms: layouts differ");
+        TD_REQUIRE(h, signs[t] == 1.0 || signs[t] == -1.0, "td_ridge_solve_loso_terms: a sign is +1 or -1");
+        frames += signs[t] * (double)ft;
+      }
+      ff = (int64_t)frames;
+    }
     if (ff <= 0) return td_fail(h, TD_ERR_STATE, "td_ridge_solve_loso: a fold has no data");
     inv_n[f] = 1.0 / (double)ff;
   }
@@ -1974,8 +1991,13 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
     hipLaunchKernelGGL(loso_binv_kernel, dim3((unsigned)nbig, (unsigned)n_lambda, kBig), dim3(256), 0, h->stream,
                        pa, linv, xinv, np, nblk, nbig);
   // the folds' dense moments and right-hand sides
-  for (int f = 0; f < n_folds; ++f)
-    TD_TRY(td_stats_moments_ld(h, folds[f], af + (size_t)f * nn, np, xty + (size_t)f * n * d, nullptr, nullptr, nullptr));
+  if (folds) {
+    for (int f = 0; f < n_folds; ++f)
+      TD_TRY(td_stats_moments_ld(h, folds[f], af + (size_t)f * nn, np, xty + (size_t)f * n * d, nullptr, nullptr, nullptr));
+  } else {
+    // ONE launch for every fold: the total's dense matrix (mt, above) plus the folds' few signed terms
+    TD_TRY(td_stats_loso_moments(h, total, terms, term_begin, signs, n_folds, mt, np, af, xty));
+  }
   hipLaunchKernelGGL(loso_rhs_kernel, dim3(1024), dim3(256), 0, h->stream, xty, invn, n, d, np, n_folds,
                      n_lambda, B);
   LosoVec lv;
@@ -2065,6 +2087,23 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
   *status_host = flag == 2 ? 2 : flag ? 1 : 0;      // 0 converged, 1 not converged in max_iter, 2 not positive definite
   if (iterations_host) *iterations_host = it;
   return TD_OK;
+}
+
+int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, int n_folds,
+                        const double* lambdas_host, int n_lambda, int max_iter, double tol,
+                        float* w_dev, float* b_dev, int* status_host, int* iterations_host) {
+  if (!folds) return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_loso: NULL argument");
+  return ridge_solve_loso_impl(h, total, folds, nullptr, nullptr, nullptr, n_folds, lambdas_host, n_lambda, max_iter,
+                               tol, w_dev, b_dev, status_host, iterations_host);
+}
+
+int td_ridge_solve_loso_terms(td_handle* h, td_stats* total, td_stats* const* terms, const int* term_begin,
+                              const double* signs, int n_folds, const double* lambdas_host, int n_lambda,
+                              int max_iter, double tol, float* w_dev, float* b_dev, int* status_host,
+                              int* iterations_host) {
+  if (!terms || !term_begin || !signs) return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_loso_terms: NULL argument");
+  return ridge_solve_loso_impl(h, total, nullptr, terms, term_begin, signs, n_folds, lambdas_host, n_lambda, max_iter,
+                               tol, w_dev, b_dev, status_host, iterations_host);
 }
 
 }  // extern "C"

@@ -704,6 +704,168 @@ __global__ void bias_fill_kernel(const double* __restrict__ gxo, const double* _
   }
 }
 
+// ---- the dense moments of every fold of a leave-one-out sweep in ONE launch (round 6) -----------------
+// The moments are linear in the recordings: a fold's training statistics are the total's plus a few signed
+// terms (minus the held-out recording; a fold whose minibatch stream drops a remainder: minus the last
+// training recording, plus the same recording accumulated without its tail), each term the statistics of one
+// or two recordings.  So M_fold = M_total + sum_t sign_t (T(G_t) + E_t): the total's dense matrix -- which the
+// sweep solver expands anyway, for its preconditioner -- read once per fold and the terms' Toeplitz blocks and
+// edge products formed on the spot, like expand_kernel does for a statistic of one or two recordings.  Replaces,
+// per fold, a 31-member combine (16 MB of statistics summed), its window copy, an edge_outer pass over 31
+// recordings (32 MB of step tiles) and an expansion: 33 x 5 launches and 2.7 of the 15.5 ms of a C5 sweep.
+constexpr int kLosoMaxTerms = 4;
+struct LosoTermDev {
+  const double* g;      // the term's lagged auto-covariance blocks [l][c][c]
+  const float* win;     // its boundary windows [files][2][2 hw][c]
+  const double* gxo;    // [l][d + 1][c]
+  const double* sy;     // [d]
+  const double* n;      // [1]
+  long long n_files;
+  double sign;
+};
+struct LosoFoldDev {
+  int n_terms, pad;
+  LosoTermDev t[kLosoMaxTerms];
+};
+struct LosoExpandParams {
+  const double* mt;     // dense moments of the total, row stride ldm
+  const LosoFoldDev* folds;
+  int c, pre, post, l, hw, segs;
+  double* out;          // [folds][n][ldm]
+  long long ldm, fold_stride;
+};
+
+__global__ __launch_bounds__(256) void loso_expand_kernel(LosoExpandParams p) {
+  __shared__ double tr[32][33];
+  // (the fold is the fastest index: the workgroups that run together read the same tile of the total's matrix)
+  const int fold = blockIdx.x;
+  const int n_tj = (p.c + 31) / 32;
+  const int ti = blockIdx.y / n_tj, tj = blockIdx.y % n_tj;
+  const int seg = blockIdx.z % p.segs, e = blockIdx.z / p.segs;
+  const LosoFoldDev& fd = p.folds[fold];
+  double* out = p.out + (long long)fold * p.fold_stride;
+  const int ri = threadIdx.x >> 3, cj = (threadIdx.x & 7) * 4;   // 32 rows x 8 column quads
+  const int i = ti * 32 + ri, j0 = tj * 32 + cj;
+  const long long tile = (long long)p.c * p.c;
+  const bool row_ok = i < p.c;
+  const long long wsz = (long long)2 * p.hw * p.c;
+
+  double base[4] = {0.0, 0.0, 0.0, 0.0}, v[4];
+  for (int t = 0; t < fd.n_terms; ++t) {
+    const double* g = fd.t[t].g + (long long)e * tile;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (row_ok && j0 + q < p.c) base[q] += fd.t[t].sign * g[(long long)i * p.c + j0 + q];
+  }
+  auto emit = [&](int a) {
+    const int la = a + p.pre, lb = a + e + p.pre;
+    if (lb < 0 || lb >= p.l) return;                    // uniform per workgroup
+    const long long r = (long long)la * p.c + i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (row_ok && j0 + q < p.c) {
+        const long long at = r * p.ldm + (long long)lb * p.c + j0 + q;
+        out[at] = p.mt[at] + v[q];
+      }
+    if (e != 0) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tr[cj + q][ri] = v[q];
+      __syncthreads();
+      const int jm = tj * 32 + ri;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int im = ti * 32 + cj + q;
+        if (jm < p.c && im < p.c) {
+          const long long at = ((long long)lb * p.c + jm) * p.ldm + (long long)la * p.c + im;
+          out[at] = p.mt[at] + tr[ri][cj + q];
+        }
+      }
+    }
+  };
+  auto outer4 = [&](const LosoTermDev& tm, int which, int ra, int rb, double sign, double (&d)[4]) {
+    if (ra < 0 || ra >= 2 * p.hw || rb < 0 || rb >= 2 * p.hw) return;
+    const float* pa = tm.win + (long long)which * wsz + (long long)ra * p.c;
+    const float* pb = tm.win + (long long)which * wsz + (long long)rb * p.c;
+    for (long long f = 0; f < tm.n_files; ++f) {
+      const double av = row_ok ? (double)pa[f * 2 * wsz + i] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double bv = j0 + q < p.c ? (double)pb[f * 2 * wsz + j0 + q] : 0.0;
+        d[q] += sign * av * bv;
+      }
+    }
+  };
+  auto add_step = [&](int s) {
+    for (int t = 0; t < fd.n_terms; ++t) {
+      double d[4] = {0.0, 0.0, 0.0, 0.0};
+      if (s < p.post) {
+        outer4(fd.t[t], 0, s + p.hw, s + e + p.hw, -1.0, d);
+        outer4(fd.t[t], 1, s + p.hw, s + e + p.hw, +1.0, d);
+      } else {
+        const int aa = -(s - p.post + 1);
+        outer4(fd.t[t], 1, aa + p.hw, aa + e + p.hw, -1.0, d);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += fd.t[t].sign * d[q];
+    }
+  };
+  const int n_steps = p.post + p.pre;
+  const int s0 = p.segs == 1 ? 0 : seg * kExpandSeg;
+  const int s1 = p.segs == 1 ? n_steps : (s0 + kExpandSeg < n_steps ? s0 + kExpandSeg : n_steps);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = base[q];
+  if (seg == 0) emit(0);
+  if (s0 < s1) {
+    const int side0 = s0 < p.post ? 0 : p.post;
+    for (int sp = side0; sp < s0; ++sp) add_step(sp);
+    for (int st = s0; st < s1; ++st) {
+      if (st == p.post) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = base[q];
+      }
+      add_step(st);
+      emit(st < p.post ? st + 1 : -(st - p.post + 1));
+    }
+  }
+}
+
+// the bias row / column of every fold's XtX and its whole XtY: the total's plus the signed terms'
+struct LosoBiasParams {
+  const double* gxo; const double* sy; const double* n;      // the total's
+  const LosoFoldDev* folds;
+  int l, c, d;
+  double* out; long long ldm, fold_stride;
+  double* xty; long long xty_stride;
+};
+__global__ void loso_bias_kernel(LosoBiasParams p) {
+  const int k1 = p.l * p.c;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int fold = blockIdx.y;
+  if (idx > k1) return;
+  const LosoFoldDev& fd = p.folds[fold];
+  double* xtx = p.out + (long long)fold * p.fold_stride;
+  double* xty = p.xty + (long long)fold * p.xty_stride;
+  auto value = [&](const double* gxo, const double* sy, const double* n, int dd) -> double {
+    // dd < d: column dd of XtY; dd == d: the bias entry of XtX
+    if (idx < k1) {
+      const int l = idx / p.c, c = idx % p.c;
+      return gxo[((long long)l * (p.d + 1) + dd) * p.c + c];
+    }
+    return dd < p.d ? sy[dd] : n[0];
+  };
+  for (int dd = 0; dd <= p.d; ++dd) {
+    double s = value(p.gxo, p.sy, p.n, dd);
+    for (int t = 0; t < fd.n_terms; ++t) s += fd.t[t].sign * value(fd.t[t].gxo, fd.t[t].sy, fd.t[t].n, dd);
+    if (dd < p.d) {
+      xty[(long long)idx * p.d + dd] = s;
+    } else {
+      xtx[(long long)idx * p.ldm + k1] = s;
+      xtx[(long long)k1 * p.ldm + idx] = s;
+    }
+  }
+}
+
 __global__ void axpy_kernel(double* __restrict__ dst, const double* __restrict__ src, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
@@ -1899,5 +2061,57 @@ int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_x
       TD_HIP(h, hipMemcpyAsync(sum_x2_dev, s->g + s->off_gyo, sizeof(double) * s->k2,
                                hipMemcpyDeviceToDevice, h->stream));
   }
+  return TD_OK;
+}
+
+// Dense moments of the folds of a leave-one-out sweep (td_ridge_solve_loso_terms): fold f = total +
+// sum_{t in [term_begin[f], term_begin[f + 1])} signs[t] terms[t].  mt: the total's dense XtX (row stride ld), already
+// expanded; out [n_folds][n][ld] receives the folds' XtX, xty_out [n_folds][n][d] their XtY.  Regression
+// statistics without a second view; every fold at most kLosoMaxTerms terms.
+int td_stats_loso_moments(td_handle* h, td_stats* total, td_stats* const* terms, const int* term_begin,
+                          const double* signs, int n_folds, const double* mt, int64_t ld, double* out,
+                          double* xty_out) {
+  TD_REQUIRE(h, total && terms && term_begin && signs && mt && out && xty_out, "td_stats_loso_moments: NULL argument");
+  TD_REQUIRE(h, total->c2 == 0 && total->d >= 1, "td_stats_loso_moments: regression statistics only");
+  TD_TRY(stats_materialize(h, total));
+  std::vector<LosoFoldDev> folds((size_t)n_folds);
+  for (int f = 0; f < n_folds; ++f) {
+    const int nt = term_begin[f + 1] - term_begin[f];
+    TD_REQUIRE(h, nt >= 0 && nt <= kLosoMaxTerms, "td_stats_loso_moments: a fold has %d terms (at most %d)", nt,
+               kLosoMaxTerms);
+    memset(&folds[f], 0, sizeof(LosoFoldDev));
+    folds[f].n_terms = nt;
+    for (int t = 0; t < nt; ++t) {
+      td_stats* s = terms[term_begin[f] + t];
+      TD_REQUIRE(h, s, "td_stats_loso_moments: NULL statistics");
+      TD_REQUIRE(h, s->c1 == total->c1 && s->l1 == total->l1 && s->pre1 == total->pre1 && s->d == total->d &&
+                 s->c2 == 0 && s->hw == total->hw, "td_stats_loso_moments: layouts differ");
+      TD_TRY(stats_materialize(h, s));
+      LosoTermDev& td = folds[f].t[t];
+      td.g = s->g + s->off_fxx; td.win = s->win1; td.gxo = s->g + s->off_gxo; td.sy = s->g + s->off_sy;
+      td.n = s->g + s->off_n; td.n_files = s->n_files; td.sign = signs[term_begin[f] + t];
+    }
+  }
+  const void* folds_dev = nullptr;
+  TD_TRY(td_table_upload(h, folds.data(), folds.size() * sizeof(LosoFoldDev), &folds_dev));
+  const int n = total->k1 + 1;
+  LosoExpandParams p;
+  p.mt = mt; p.folds = reinterpret_cast<const LosoFoldDev*>(folds_dev);
+  p.c = total->c1; p.pre = total->pre1; p.post = total->post1; p.l = total->l1; p.hw = total->hw;
+  const int n_steps = total->pre1 + total->post1;
+  const int tiles = (int)(td_ceil_div(p.c, 32) * td_ceil_div(p.c, 32));
+  // (a workgroup walks its lag diagonal from the start -- a segment that starts later first repeats the steps in
+  //  front of it: segments only when the folds alone do not fill the chip)
+  p.segs = n_steps > 0 && (long long)n_folds * tiles * p.l < 2048 ? (int)td_ceil_div(n_steps, kExpandSeg) : 1;
+  p.out = out; p.ldm = ld; p.fold_stride = (long long)n * ld;
+  TD_REQUIRE(h, (long long)p.segs * p.l < 65536, "td_stats_loso_moments: too many lags");
+  hipLaunchKernelGGL(loso_expand_kernel, dim3((unsigned)n_folds, (unsigned)tiles, (unsigned)(p.segs * p.l)), dim3(256),
+                     0, h->stream, p);
+  LosoBiasParams b;
+  b.gxo = total->g + total->off_gxo; b.sy = total->g + total->off_sy; b.n = total->g + total->off_n;
+  b.folds = p.folds; b.l = total->l1; b.c = total->c1; b.d = total->d;
+  b.out = out; b.ldm = ld; b.fold_stride = p.fold_stride; b.xty = xty_out; b.xty_stride = (long long)n * total->d;
+  hipLaunchKernelGGL(loso_bias_kernel, dim3((unsigned)td_ceil_div(n, 256), (unsigned)n_folds), dim3(256), 0, h->stream, b);
+  TD_HIP(h, hipGetLastError());
   return TD_OK;
 }

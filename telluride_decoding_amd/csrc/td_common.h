@@ -564,6 +564,10 @@ int td_chan_tab_scratch(td_handle* h, unsigned** tab);
 int td_stats_settle(td_handle* h, td_stats* s);
 int td_stats_moments_ld(td_handle* h, td_stats* s, double* xtx_dev, int64_t ld_xtx, double* xty_dev,
                         double* x2tx2_dev, double* xtx2_dev, double* sum_x2_dev);
+// (stats.hip) the dense moments of the folds of a leave-one-out sweep from the total's and a few signed terms each
+int td_stats_loso_moments(td_handle* h, td_stats* total, td_stats* const* terms, const int* term_begin,
+                          const double* signs, int n_folds, const double* mt, int64_t ld, double* out,
+                          double* xty_out);
 int td_add_reversed_transposed(td_handle* h, const double* src, int e_count, int ca, int cb, double* dst,
                                int ca_dst = 0);
 int td_mirror_upper(td_handle* h, double* g_dev, int c, int ld);

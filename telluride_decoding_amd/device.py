@@ -368,6 +368,33 @@ class LagStats(object):
       return None
     return w, b, int(iters.value)
 
+  @staticmethod
+  def ridge_solve_loso_terms(total, fold_terms, lambdas, max_iter=40, tol=1e-12, handle=None):
+    """The same sweep with every fold given as total + a few signed terms (td_ridge_solve_loso_terms):
+    fold_terms[f] = [(LagStats, +1 or -1), ...] -- minus the held-out recording, and for a fold whose
+    minibatch stream drops a remainder minus the last training recording plus its truncated twin.  No fold
+    statistics are summed; the folds' dense moments come from the total's in one launch.  Returns as
+    ridge_solve_loso."""
+    h = handle or total.h
+    lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
+    n_folds = len(fold_terms)
+    w = h.empty((n_folds, len(lam), total.k1, total.d), 'float32')
+    b = h.empty((n_folds, len(lam), total.d), 'float32')
+    flat = [t for terms in fold_terms for t in terms]
+    arr = (ctypes.c_void_p * max(1, len(flat)))(*[s.ptr for s, _ in flat])
+    begin = np.concatenate(([0], np.cumsum([len(t) for t in fold_terms]))).astype(np.int32)
+    signs = np.asarray([float(sg) for _, sg in flat] or [0.0], np.float64)
+    status, iters = ctypes.c_int(0), ctypes.c_int(0)
+    h.check(h.lib.td_ridge_solve_loso_terms(
+        h.ptr, total.ptr, arr, begin.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+        signs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n_folds, lam_p, len(lam), int(max_iter), float(tol),
+        _ptr(w), _ptr(b), ctypes.byref(status), ctypes.byref(iters)))
+    LagStats.last_loso_status = {0: 'converged', 1: 'not converged', 2: 'preconditioner not positive definite'}.get(
+        status.value, 'status %d' % status.value)
+    if status.value:
+      return None
+    return w, b, int(iters.value)
+
   def cca_solve(self, denom, regularization, dim, eps_eig=1e-12, handle=None):
     """CCA dense stage on the device (td_cca_solve; reference cca.py:337-367): returns float32
     device tensors (rot_x [k1, dim], rot_y [k2, dim], mean_x [1, k1], mean_y [1, k2], e [dim])

@@ -261,11 +261,8 @@ class Decoder(object):
     correlations[0], class 2 = correlations[1]; d' = calculate_dprime of the scaled projections,
     from their class means and variances."""
     import torch
-    data = torch.cat([c.to(torch.float32) for c in correlations]).contiguous()
-    labels = np.concatenate((1 * np.ones(int(correlations[0].shape[0]),),
-                             2 * np.ones(int(correlations[1].shape[0]),)))
     self._lda = scaled_lda.ScaledLinearDiscriminantAnalysis()
-    self._lda.fit(data, labels)
+    self._lda.fit_device_classes(correlations[0].to(torch.float32), correlations[1].to(torch.float32))
     (m1, v1), (m2, v2) = self._lda.projected_class_stats()
     return (m2 - m1) / np.sqrt((v1 + v2) / 2.0)
 

@@ -66,6 +66,12 @@ def parse_regularization_values(mode_string):
 # The preconditioned-CG solve of the whole sweep (td_ridge_solve_loso); False = always the direct
 # batched Cholesky.
 USE_PCG = True
+# relative residual |b - A w| <= PCG_TOL |b| of every (fold, lambda) system of the sweep solver: the weights leave
+# as float32 (2^-24 = 6e-8); measured at C5: 4 iterations instead of the 6 of 1e-12, the held-out correlations 4e-11
+# from the direct solve's
+PCG_TOL = 1e-9
+# the folds of the sweep solver as signed terms of the total's statistics (False: a sum of 31 statistics per fold)
+USE_TERMS = True
 # How the last sweep of this process was solved: {'solver': 'pcg' | 'direct', 'iterations': n}
 LAST_SWEEP = {}
 SOLVE_WORKSPACE_BYTES = 6 << 30
@@ -287,18 +293,49 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   # folds of C5 are 1.1 GB; _pcg_chunk); a chunk that does not converge, or does not fit after
   # all, sends the REST of the sweep to (2).
   n_done = 0
+
+  def fold_terms(f):
+    """Fold f's training statistics as the total's plus signed terms: minus the held-out recording; when
+    batching drops a remainder from the end of the training stream, minus the last training recordings and
+    plus the same accumulated without the frames that fall off (fold_statistics says the same as a sum)."""
+    terms = [(stats[f], -1.0)]
+    members = [g for g in range(n_files) if g != f]
+    rem = (total_zipped - zipped[f]) % bsz
+    g = len(members) - 1
+    while rem > 0 and g >= 0:
+      last = members[g]
+      cut = min(rem, zipped[last])
+      key = (last, cut)
+      if key not in truncated:
+        truncated[key] = file_stats(last, zipped[last] - cut)
+      terms += [(stats[last], -1.0), (truncated[key], +1.0)]
+      rem -= cut
+      g -= 1
+    return terms
+
   # (the CG solver carries at most 8 outputs per system; wider targets take the direct solves)
   if hasattr(dev.LagStats, 'ridge_solve_loso') and my_folds and USE_PCG and d <= 8:
     per_call = _pcg_chunk(len(my_folds), n_lam, proto.k1 + 1, d)
     total = proto.like().combine(stats)
-    trains_all = [proto.like() for _ in range(per_call)]
+    # the folds as signed terms of the total (no fold's statistics are summed: td_ridge_solve_loso_terms) when
+    # the device layer has it and every fold is the total minus a few recordings; else a sum per fold
+    by_terms = hasattr(dev.LagStats, 'ridge_solve_loso_terms') and USE_TERMS
+    trains_all = [] if by_terms else [proto.like() for _ in range(per_call)]
     iters_max = 0
     while n_done < len(my_folds):
       folds = my_folds[n_done:n_done + per_call]
-      for train, f in zip(trains_all, folds):
-        fold_statistics(f, train)
+      terms = [fold_terms(f) for f in folds] if by_terms else None
+      if by_terms and max(len(t) for t in terms) > 4:
+        by_terms, terms = False, None
+        trains_all = [proto.like() for _ in range(per_call)]
+      if not by_terms:
+        for train, f in zip(trains_all, folds):
+          fold_statistics(f, train)
       try:
-        out = dev.LagStats.ridge_solve_loso(total, trains_all[:len(folds)], lambdas, handle=h)
+        if by_terms:
+          out = dev.LagStats.ridge_solve_loso_terms(total, terms, lambdas, tol=PCG_TOL, handle=h)
+        else:
+          out = dev.LagStats.ridge_solve_loso(total, trains_all[:len(folds)], lambdas, tol=PCG_TOL, handle=h)
       except MemoryError:
         out = None
       if out is None:
@@ -309,7 +346,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
       evaluate_folds(folds, w_all_folds, b_all_folds)
       n_done += len(folds)
     if n_done:
-      LAST_SWEEP.update(solver='pcg' if n_done == len(my_folds) else 'pcg+direct', iterations=iters_max)
+      LAST_SWEEP.update(solver='pcg' if n_done == len(my_folds) else 'pcg+direct', iterations=iters_max,
+                        folds_as='terms of the total' if by_terms else 'sums')
     del trains_all
   done = n_done == len(my_folds)
 

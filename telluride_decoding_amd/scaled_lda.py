@@ -41,10 +41,16 @@ def _class_moments_device(x, y):
   """_class_moments for a float32 CUDA tensor x [rows, dims]: count, sum and x^T x of every
   class from the accumulate kernels (LagStats without context: xtx = [[X^T X, sum], [sum^T, n]])."""
   import torch
-  from telluride_decoding_amd import device
   y = np.asarray(y).reshape(-1)
   labels = np.unique(y).tolist()
-  dims = int(x.shape[1])
+  members = [x[torch.from_numpy(y == label).to(x.device)].contiguous() for label in labels]   # device gather: plumbing
+  return _class_moments_of(labels, members)
+
+
+def _class_moments_of(labels, members):
+  """The same for classes that are already separate float32 CUDA tensors [rows_i, dims] (sorted labels)."""
+  from telluride_decoding_amd import device
+  dims = int(members[0].shape[1])
   h = device.default_handle()
   moments = []
   # The class scatter is X^T X - n m m^T, a difference: the moments are taken with the float32 matrix
@@ -54,11 +60,12 @@ def _class_moments_device(x, y):
   mode = h.accumulate_mode
   h.set_accumulate_mode('f32')
   try:
-    for label in labels:
-      rows = x[torch.from_numpy(y == label).to(x.device)].contiguous()       # device gather: plumbing
+    stats = []
+    for rows in members:
       st = device.LagStats(dims, handle=h)
       st.accumulate(rows, None, None, [0, int(rows.shape[0])])
-      moments.append(st.moments(want_xty=False)['xtx'].cpu().numpy())
+      stats.append(st.moments(want_xty=False)['xtx'])
+    moments = [m.cpu().numpy() for m in stats]          # (every class queued before the first wait)
   finally:
     h.set_accumulate_mode(mode)
   total = sum(m[dims, dims] for m in moments)
@@ -185,7 +192,10 @@ class LinearDiscriminantAnalysis(object):
   # ---- estimation ------------------------------------------------------------------
   def fit(self, x, y):
     x = _columns(x)
-    self._labels, self._mean_vectors, within, between, self._per_class = _class_moments(x, y)
+    self._fit_from_moments(_class_moments(x, y))
+
+  def _fit_from_moments(self, moments):
+    self._labels, self._mean_vectors, within, between, self._per_class = moments
     self._strengths, axes = _ranked_axes(within, between)
     if len(axes) < 2:
       self._w = np.ones((1, 1))
@@ -244,8 +254,18 @@ class ScaledLinearDiscriminantAnalysis(LinearDiscriminantAnalysis):
     self._import(values)
     self._slope, self._intercept = values.slope, values.intercept
 
+  def fit_device_classes(self, class0, class1, labels=(1, 2), y0=0, y1=1):
+    """fit() for two classes held as separate float32 device tensors [rows_i, dims] (labels sorted):
+    no label vector of one entry per row, no gather -- the class moments come straight from the
+    accumulate kernels (what Decoder.train needs at 1e6 frames per class)."""
+    self._fit_from_moments(_class_moments_of(list(labels), [class0.contiguous(), class1.contiguous()]))
+    self._scale(y0, y1)
+
   def fit(self, x, y, y0=0, y1=1):
     super(ScaledLinearDiscriminantAnalysis, self).fit(x, y)
+    self._scale(y0, y1)
+
+  def _scale(self, y0, y1):
     if len(self._labels) != 2:
       raise ValueError('Scaled LDA can only be done on two-class data.')
     # where the class means land along the first axis, through the CURRENT affine map

@@ -1713,3 +1713,58 @@ def test_targets_first_equals_the_fused_call(dev, c, post, lens, off, drop):
   st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=1)
   st.accumulate(xd, None, yd, offs, input_offset=off, rows_used=used, parts=2)
   assert torch.equal(st.moments()['xty'], m_ref['xty'])
+
+
+def test_loso_folds_as_terms_of_the_total(dev):
+  """td_ridge_solve_loso_terms (round 6): every fold given as the total's statistics plus signed terms (minus the
+  held-out recording; minus / plus the last training recording and its truncated twin when batching drops a
+  remainder) -- no fold statistics summed, the folds' dense moments from the total's in one launch.  Weights
+  against the direct batched factorisation of the SUMMED fold statistics, recordings of uneven length with
+  pre- and post-context and two outputs; then the whole sweep by both routes."""
+  from telluride_decoding_amd import brain_data, regression
+  rng = np.random.default_rng(3)
+  lengths = (1230, 1111, 987, 1300, 1045, 700)
+  files, stats = [], []
+  h = dev.default_handle()
+  c, pre, post, d = 40, 2, 5, 2
+  for nf in lengths:
+    x = rng.standard_normal((nf, c)).astype(np.float32)
+    y = (x[:, :2] * 0.5 + rng.standard_normal((nf, 2))).astype(np.float32)
+    files.append((x, y, y, np.zeros((nf, 1), np.float32)))
+    st = dev.LagStats(c, pre, post, d=d, handle=h)
+    st.accumulate(h.to_device(x), None, h.to_device(y), [0, nf])
+    stats.append(st)
+  # a truncated twin of the last recording (what a dropped remainder of 45 frames leaves of it)
+  cut = dev.LagStats(c, pre, post, d=d, handle=h)
+  cut.accumulate(h.to_device(files[-1][0]), None, h.to_device(files[-1][2]), [0, lengths[-1]],
+                 rows_used=[lengths[-1] - 45])
+  total = stats[0].like().combine(stats)
+  lambdas = [1e-4, 0.1, 10.0]
+  terms, sums = [], []
+  for f in range(len(files) - 1):
+    terms.append([(stats[f], -1.0), (stats[-1], -1.0), (cut, +1.0)])
+    sums.append(stats[0].like().combine([stats[g] for g in range(len(files) - 1) if g != f] + [cut]))
+  terms.append([(stats[-1], -1.0)])
+  sums.append(stats[0].like().combine(stats[:-1]))
+  out = dev.LagStats.ridge_solve_loso_terms(total, terms, lambdas, tol=1e-12, handle=h)
+  assert out is not None, dev.LagStats.last_loso_status
+  w, b, iters = out
+  w_ref, b_ref, flag = dev.LagStats.ridge_solve_multi(sums, lambdas, handle=h, wait=False)
+  w, b, w_ref, b_ref = (t.cpu().numpy().astype(np.float64) for t in (w, b, w_ref, b_ref))
+  assert flag() == 0 and 1 <= iters <= 40
+  assert np.max(np.abs(w - w_ref)) <= 2e-6 * np.max(np.abs(w_ref))
+  assert np.max(np.abs(b - b_ref)) <= 2e-6 * max(1.0, np.max(np.abs(b_ref)))
+  # the sweep: both routes of the solver, and the direct solves
+  ds = brain_data.Dataset(files, 100, pre_context=pre, post_context=post)
+  runs = {}
+  try:
+    for name, use_terms, pcg in (('terms', True, True), ('sums', False, True), ('direct', True, False)):
+      regression.USE_TERMS, regression.USE_PCG = use_terms, pcg
+      runs[name] = regression.jackknife_over_regularizations(ds, lambdas)['all_runs']
+      if pcg:
+        assert regression.LAST_SWEEP['solver'] == 'pcg'
+        assert regression.LAST_SWEEP['folds_as'] == ('terms of the total' if use_terms else 'sums')
+  finally:
+    regression.USE_TERMS, regression.USE_PCG = True, True
+  np.testing.assert_allclose(runs['terms'], runs['sums'], rtol=0, atol=1e-7)
+  np.testing.assert_allclose(runs['terms'], runs['direct'], rtol=0, atol=2e-6)

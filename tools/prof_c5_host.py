@@ -12,13 +12,15 @@ files = [(eeg, env, env[:, 0:1].astype(np.float32), att) for eeg, env, att in tr
 ds = brain_data.Dataset(files, 1000, pre_context=0, post_context=31)
 lams = list(np.logspace(-6, 3, 20))
 marks = []
-orig = dev.LagStats.ridge_solve_loso
-def timed(*a, **k):
-  torch.cuda.synchronize(); marks.append(('solve begins', time.perf_counter()))
-  out = orig(*a, **k)
-  torch.cuda.synchronize(); marks.append(('solve ends', time.perf_counter()))
-  return out
-dev.LagStats.ridge_solve_loso = staticmethod(timed)
+def timed_of(orig):
+  def timed(*a, **k):
+    torch.cuda.synchronize(); marks.append(('solve begins', time.perf_counter()))
+    out = orig(*a, **k)
+    torch.cuda.synchronize(); marks.append(('solve ends', time.perf_counter()))
+    return out
+  return timed
+dev.LagStats.ridge_solve_loso = staticmethod(timed_of(dev.LagStats.ridge_solve_loso))
+dev.LagStats.ridge_solve_loso_terms = staticmethod(timed_of(dev.LagStats.ridge_solve_loso_terms))
 for rep in range(4):
   del marks[:]
   torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -1,12 +1,12 @@
 """Runs only the hot kernels a few times (for rocprofv3 kernel-trace / PMC passes):
-   python tools/prof_kernels.py [fit] [cg] [cgt] [shapes] [cca] [ccasolve] [decode]"""
+   python tools/prof_kernels.py [fit] [cg] [cgt] [shapes] [cca] [ccasolve] [decode] [dtrain] [lw]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from telluride_decoding_amd import device
 
-what = sys.argv[1:] or ['fit', 'cg', 'cgt', 'shapes', 'cca', 'ccasolve', 'decode']
+what = sys.argv[1:] or ['fit', 'cg', 'cgt', 'shapes', 'cca', 'ccasolve', 'decode', 'dtrain', 'lw']
 h = device.default_handle()
 torch.manual_seed(0)
 if 'fit' in what:
@@ -109,4 +109,34 @@ if 'decode' in what:
   corr = [0.0, 0.0, 1.0, 0.0, 0.0, 1.0]
   for rep in range(3):
     scores, dec = device.decode_fused(x, env, offs, w, b, 0, 31, 1000, 100, corr, handle=h)
+  torch.cuda.synchronize()
+if 'dtrain' in what:
+  # F1: Decoder.train at the C4 size (40 trials here: the kernels are per-dataset passes, their time is linear)
+  from telluride_decoding_amd import brain_data, brain_model, infer_decoder, synth
+  trials = synth.make_trials(4, 40, 6000, 64, switch_half=True)
+  def ds_of(attended):
+    files = []
+    for eeg, env, att in trials:
+      sel = (att > 0.5) if attended else (att <= 0.5)
+      files.append((eeg, env, np.where(sel, env[:, 1:2], env[:, 0:1]).astype(np.float32), att))
+    return brain_data.Dataset(files, 1000, pre_context=0, post_context=31)
+  data1, data0 = ds_of(True), ds_of(False)
+  model = brain_model.BrainModelLinearRegression(data1, regularization_lambda=0.1)
+  model.fit(data1)
+  dec = infer_decoder.LinearRegressionDecoder(model, reduction='lda')
+  for rep in range(3):
+    dec.train(data0, data1)
+  torch.cuda.synchronize()
+if 'lw' in what:
+  # F2: the Ledoit-Wolf shrinkage moment + general solve at the C2 shape
+  from telluride_decoding_amd import brain_data, brain_model
+  n = 100000
+  files = []
+  for i in range(10):
+    xf = np.random.default_rng(i).standard_normal((n, 64)).astype(np.float32)
+    yf = (xf[:, :1] * 0.3 + np.random.default_rng(100 + i).standard_normal((n, 1))).astype(np.float32)
+    files.append((xf, yf, yf, np.zeros((n, 1), np.float32)))
+  ds = brain_data.Dataset(files, 1000, pre_context=0, post_context=31)
+  for rep in range(2):
+    brain_model.calculate_linear_regressor_parameters_from_dataset(ds, lamb=-1, use_ridge=False)
   torch.cuda.synchronize()
