@@ -241,9 +241,16 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
   a = h.to_device(cov_x, np.float64)
   rhs = h.to_device(cov_xy, np.float64)
   if ledoit_wolf:
-    # a negative estimated shrinkage (the reference's golden case has one) makes the matrix
-    # indefinite: LU like np.linalg.solve (:477), not the ridge path's Cholesky
-    rhs = device.general_solve(a, rhs, handle=h)
+    # (1 - s) cov + s mu I is positive definite for 0 <= s <= 1: the blocked Cholesky (2.5 ms at C2).  A negative
+    # estimated shrinkage (the reference's golden case has one; so has white-ish data at C2: -1e-6) can make
+    # the matrix indefinite: LU like np.linalg.solve (:477) -- one column per launch, 60 ms at C2
+    if 0.0 <= shrinkage <= 1.0:
+      try:
+        rhs = device.spd_solve(a, rhs, handle=h)
+      except np.linalg.LinAlgError:
+        rhs = device.general_solve(a, rhs, handle=h)
+    else:
+      rhs = device.general_solve(a, rhs, handle=h)
   else:
     rhs = device.spd_solve(a, rhs, handle=h)
   sol = rhs.cpu().numpy().astype(np.float32)
