@@ -175,6 +175,16 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
                               int64_t ldy, const int64_t* file_offsets_host, int num_files,
                               int input_offset, const int64_t* rows_used_host, int parts);
 
+/* The per-recording statistics of a leave-one-out sweep in one call (regression.jackknife_one_model,
+ * regression.py:151-242, refits on all files but one: every recording's statistics are needed on their own):
+ * the files of x / y as in td_stats_accumulate, but file f is summed into each[f] -- freshly created or reset
+ * regression statistics of one layout -- by ONE targets launch and ONE matrix launch over all the recordings
+ * and a finalize launch per recording.  *handled = 0: a shape this form does not take (<= 32 or > 64
+ * channels, statistics that already hold data); nothing was queued, call td_stats_accumulate per file. */
+int td_stats_accumulate_each(td_handle* h, td_stats* const* each, const float* x_dev, int64_t ldx,
+                             const float* y_dev, int64_t ldy, const int64_t* file_offsets_host, int num_files,
+                             int input_offset, const int64_t* rows_used_host, int* handled);
+
 /* The same for callers that share ONE long recording between ranks by time range
  * (third unit): the moments are sums over rows, so a call may sum only the rows
  * [range_begin[f], range_end[f]) of file f's zipped stream.  A "file" here is the piece of the

@@ -77,6 +77,7 @@ SIGNATURES = {
     'td_stats_pack': [_vp, _vp, _vp, _i64, _i64],
     'td_stats_unpack': [_vp, _vp, _vp, _i64],
     'td_stats_unpack_known': [_vp, _vp, _vp, _i64, _i64],
+    'td_stats_accumulate_each': [_vp, _c.POINTER(_vp), _vp, _i64, _vp, _i64, _pi64, _i, _i, _pi64, _c.POINTER(_i)],
     'td_stats_allreduce': [_vp, _vp, _vp, _i64, _i64, _i64],
     'td_allreduce_f64': [_vp, _vp, _i64, _vp],
     'td_rccl_available': [_vp],

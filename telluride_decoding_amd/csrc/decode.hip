@@ -647,6 +647,57 @@ __global__ __launch_bounds__(kThreads) void block_sums_kernel(
   }
 }
 
+// Many columns (the 20 lambdas of a sweep's held-out evaluation, regression.py:197-214): a lane is a COLUMN,
+// a wave step reads 64 / cols whole rows of both arrays -- contiguous -- where the kernel above gives every
+// column a pass of its own over lines it shares with the other columns (20 columns: 20 x the L2 traffic,
+// 290 us for 1e6 rows).  One wave per block, its row phases summed through LDS in a fixed order.
+__global__ __launch_bounds__(kThreads) void block_sums_cols_kernel(
+    const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
+    int cols, const FileDesc* __restrict__ trials, int n_trials, long long n_blocks,
+    int g, double* __restrict__ out) {
+  __shared__ double part[kThreads / 64][64][5];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long blk = blockIdx.x * (long long)(kThreads / 64) + wave;
+  if (blk >= n_blocks) return;                          // (wave-uniform; no workgroup barrier below)
+  const FileDesc tr = trials[find_file(trials, n_trials, blk)];
+  const long long r0 = tr.row0 + (blk - tr.first) * g;
+  const int per = 64 / cols;                            // rows per wave step (cols <= 64)
+  const int col = lane % cols, rs = lane / cols;
+  double s[5] = {0, 0, 0, 0, 0};
+  if (rs < per) {
+    int r = rs;
+    for (; r + 3 * per < g; r += 4 * per) {             // four loads of each array in flight
+      float av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        av[q] = a[(r0 + r + q * per) * lda + col];
+        bv[q] = b[(r0 + r + q * per) * ldb + col];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double x = (double)av[q], y = (double)bv[q];
+        s[0] += x; s[1] += y; s[2] += x * x; s[3] += y * y; s[4] += x * y;
+      }
+    }
+    for (; r < g; r += per) {
+      const double x = (double)a[(r0 + r) * lda + col], y = (double)b[(r0 + r) * ldb + col];
+      s[0] += x; s[1] += y; s[2] += x * x; s[3] += y * y; s[4] += x * y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) part[wave][lane][k] = s[k];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own LDS writes
+  if (rs == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      double v = s[k];
+      for (int q = 1; q < per; ++q) v += part[wave][q * cols + col][k];
+      out[(blk * cols + col) * 5 + k] = v;
+    }
+  }
+}
+
 // The fused decode's shape: two truth columns (the speakers' envelopes) against ONE shared
 // prediction column -- every frame is loaded once and 8 sums instead of 10 go through the tree.
 __global__ __launch_bounds__(kThreads) void block_sums_pair_kernel(
@@ -3015,6 +3066,11 @@ int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b
     double* bsums = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + 2 * tb);
     TD_TRY(td_upload_async(h, blk_tab.data(), sizeof(FileDesc) * num_trials, d_blk));
     TD_TRY(td_upload_async(h, win_tab.data(), sizeof(FileDesc) * num_trials, d_win));
+    if (cols >= 8 && cols <= 64)
+      hipLaunchKernelGGL(block_sums_cols_kernel, dim3((unsigned)td_ceil_div(n_blocks, kThreads / 64)), dim3(kThreads), 0,
+                         h->stream, a_dev, (long long)lda, b_dev, (long long)ldb, cols, d_blk, num_trials,
+                         (long long)n_blocks, g, bsums);
+    else
     hipLaunchKernelGGL(block_sums_kernel,
                        dim3((unsigned)td_ceil_div(n_blocks, kThreads / kBlockLanes), (unsigned)(cols < 64 ? cols : 64)),
                        dim3(kThreads), 0, h->stream, a_dev, (long long)lda, b_dev, (long long)ldb,

@@ -1060,6 +1060,9 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
 #ifndef TD_ABL_NOBAR      // timing ablation: no barrier per tile
     if (more) __syncthreads();
 #endif
+#ifdef TD_STAGGER         // experiment: the second wave of every SIMD starts each tile late (64 TD_STAGGER cycles)
+    if (more && wave >= 4) __builtin_amdgcn_s_sleep(TD_STAGGER);
+#endif
   }
 #ifdef TD_F16_LONGCHAIN
 #pragma unroll
@@ -3126,7 +3129,7 @@ int td_lagcov_launch(td_handle* h, LagcovPlan* plan, void* scratch, double* g_de
       {
         const int cus = h->cu_count > 0 ? h->cu_count : 256;
         const long long per_round = (long long)(cus / p.n_groups) * p.n_groups;
-        if (!(plan->f16 && p.ty) && !no_persist && per_round > 0 && nwg > per_round) {
+        if (!(plan->f16 && p.ty) && !no_persist && !plan->no_chains && per_round > 0 && nwg > per_round) {
           // ... but a chain of float32 slab sums stays short: at most kMaxItemsPerChain items
           // (~256 tiles) per partial slab -- 4e7 samples in one call gave every CU 76 items and the
           // sums of squares came out 3e-7 off -- so very long inputs run several rounds of

@@ -1483,6 +1483,125 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
   TD_HIP(h, hipGetLastError());
   return TD_OK;
 }
+
+// One accumulate over SEVERAL recordings that leaves every recording's statistics in an object of its own
+// (the per-recording statistics of a leave-one-out sweep, regression.py:151-242: 32 calls of three small
+// launches each were 2 of the 11.5 ms of a C5 sweep): ONE targets launch and ONE matrix launch over all the
+// recordings -- the work items of the matrix kernel each belong to one recording and keep a partial slab of
+// their own (no chains across items) -- and one finalize launch per recording over ITS slabs, target sums,
+// boundary windows and frame count.  each[f]: freshly reset regression statistics of one layout, 33..64
+// channels (the plain float16 / bfloat16 / float32 matrix kernels).  *handled = 0: not this shape, nothing
+// was queued -- the caller accumulates recording by recording.
+int accumulate_each(td_handle* h, td_stats* const* each, const float* x_dev, int64_t ldx, const float* y_dev,
+                    int64_t ldy, const std::vector<LagSeg>& sxx, const std::vector<LagSeg>& syx,
+                    const std::vector<WinJob>& j1, int num_files, const std::vector<int64_t>& frames,
+                    const std::vector<char>& whole, int* handled) {
+  *handled = 0;
+  td_stats* s0 = each[0];
+  for (int f = 0; f < num_files; ++f) {
+    td_stats* s = each[f];
+    if (!stats_fusable(s) || s->c1 != s0->c1 || s->pre1 != s0->pre1 || s->l1 != s0->l1 || s->d != s0->d ||
+        s->n_files != 0 || s->frames != 0 || s->pending || frames[f] <= 0) {   // (empty: every sum is overwritten)
+      *handled = -1;
+      return TD_OK;
+    }
+    for (int g = 0; g < f; ++g)
+      if (each[g] == s) { *handled = -2; return TD_OK; }
+  }
+  Narrow16Plan np16;
+  if (h->narrow16) TD_TRY(td_narrow16_plan(h, s0->c1, s0->d, s0->pre1, s0->l1, ldx, ldy, syx, &np16));
+  if (np16.ok) { *handled = -3; return TD_OK; }
+  VirtPlan vp;
+  TD_TRY(td_lagcov_virt_plan(h, x_dev, ldx, s0->c1, sxx, s0->l1, &vp));
+  if (vp.ok) { *handled = -4; return TD_OK; }
+  LagcovPlan mp;
+  mp.allow_f16 = true;
+  mp.no_chains = true;           // a partial slab per work item: the items of a recording are summed on their own
+  TD_TRY(td_lagcov_plan(h, x_dev, ldx, s0->c1, false, x_dev, ldx, s0->c1, sxx, 0, s0->l1, &mp));
+  TargetsPlan tp;
+  TD_TRY(td_lagcov_targets_plan(h, y_dev, ldy, s0->d, x_dev, ldx, s0->c1, syx, -s0->pre1, s0->l1, &tp));
+  if (!tp.handled || tp.n_work <= 0 || (int)mp.work_seg.size() != (int)mp.works.size()) { *handled = -5; return TD_OK; }
+  *handled = 1;
+  for (int f = 0; f < num_files; ++f) TD_TRY(ensure_window_capacity(h, each[f], 1));
+  const size_t main_bytes = mp.scratch_bytes;
+  void* scratch = nullptr;
+  TD_TRY(td_scratch(h, main_bytes + tp.scratch_bytes, &scratch));
+  char* base = reinterpret_cast<char*>(scratch);
+  const void* jobs_dev = nullptr;
+  TD_TRY(td_table_upload(h, j1.data(), sizeof(WinJob) * num_files, &jobs_dev));
+  TargetsOutputs to;
+  to.maxtab = nullptr;
+  if ((mp.f16) && s0->pre1 == 0) {
+    TD_TRY(td_chan_tab(h, &to.maxtab));
+    mp.tab = to.maxtab;
+  }
+  TD_TRY(td_lagcov_targets_launch(h, &tp, base + main_bytes, s0->g + s0->off_gxo, false, &to));
+  LagReduceJob job;
+  TD_TRY(td_lagcov_launch(h, &mp, base, s0->g + s0->off_fxx, false, 0, 0, &job, s0->g + s0->off_gxo, false,
+                          s0->d + 1, nullptr));
+  TD_REQUIRE(h, job.n_work == (int)mp.works.size() && !job.vmap, "accumulate_each: the matrix kernel merged work items");
+  bool zero_next = false;
+  if (mp.f16) { ++h->chan_phase; zero_next = true; }
+  // first work item of every recording (the items are in recording order)
+  std::vector<int> w0((size_t)num_files + 1, (int)mp.works.size());
+  for (int i = (int)mp.works.size() - 1; i >= 0; --i) w0[mp.work_seg[i]] = i;
+  for (int f = num_files - 1; f >= 0; --f) if (w0[f] > w0[f + 1]) w0[f] = w0[f + 1];
+  const size_t slab = (size_t)job.e_pad * job.ca_pad * job.cb_pad;
+  for (int f = 0; f < num_files; ++f) {
+    td_stats* s = each[f];
+    FinalizeParams fp;
+    memset(&fp, 0, sizeof(fp));
+    int blocks = 0;
+    auto add_reduce = [&](const LagReduceJob& jb) {
+      const long long outs = (long long)jb.e_count * jb.ca_eff * jb.cb;
+      const bool vec = !jb.is_f64 && outs >= 32768 && jb.cb % 4 == 0 && jb.cb_pad % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(jb.partial) & 15) == 0;
+      const int q = vec ? 0 : outs < 32768 ? 16 : 4;
+      fp.red[fp.n_red] = jb;
+      fp.red_q[fp.n_red] = q;
+      fp.red_block0[fp.n_red] = blocks;
+      blocks += (int)td_ceil_div(outs, vec ? 4 * (kFinThreads / kFinVecPhases) : kFinThreads / q);
+      fp.red_block0[++fp.n_red] = blocks;
+    };
+    LagReduceJob jf = job;
+    jf.partial = (job.is_f64 ? reinterpret_cast<const char*>(job.partial) + sizeof(double) * slab * w0[f]
+                             : reinterpret_cast<const char*>(job.partial) + sizeof(float) * slab * w0[f]);
+    jf.n_work = w0[f + 1] - w0[f];
+    jf.g = s->g + s->off_fxx; jf.accumulate = 0;
+    add_reduce(jf);
+    const int t0 = tp.seg_work0[f], t1 = tp.seg_work0[f + 1];
+    for (int i = 0; i < s->d; ++i) {
+      LagReduceJob jt = to.jobs[i];
+      const size_t tslab = (size_t)jt.e_pad * jt.ca_pad * jt.cb_pad;
+      jt.partial = reinterpret_cast<const char*>(jt.partial) + (jt.is_f64 ? sizeof(double) : sizeof(float)) * tslab * t0;
+      jt.n_work = t1 - t0;
+      jt.g = s->g + s->off_gxo + (jt.g - (s0->g + s0->off_gxo));     // the same row of THIS recording's [l][d + 1][c]
+      jt.accumulate = 0;
+      add_reduce(jt);
+    }
+    fp.jobs = reinterpret_cast<const WinJob*>(jobs_dev) + f;
+    fp.x = x_dev; fp.ldx = ldx; fp.c = s->c1; fp.n_files = 1; fp.hw = s->hw;
+    fp.b_ysum = blocks;
+    for (int i = 0; i < s->d; ++i) fp.ysum[i] = to.ysum[i] + t0;
+    fp.ys_n_work = t1 - t0; fp.ys_cols = s->d; fp.ys_accumulate = 0; fp.sy = s->g + s->off_sy;
+    blocks += s->d;
+    fp.b_ones = blocks;
+    fp.ones_l = s->l1; fp.csum = to.csum + (size_t)t0 * to.cb_pad; fp.cs_n_work = t1 - t0; fp.cs_pad = to.cb_pad;
+    fp.e_min = -s->pre1; fp.rows = s->d + 1; fp.row = s->d; fp.ones_accumulate = 0; fp.gxo = s->g + s->off_gxo;
+    blocks += s->l1;
+    fp.b_win = blocks;
+    fp.win = s->win1; fp.first_slot = 0;
+    blocks += 2;
+    fp.n_dst = s->g + s->off_n; fp.n_value = (double)frames[f];
+    if (zero_next && f == num_files - 1) fp.zero_tab = h->chan_max + kChanTab * (h->chan_phase & 1);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)blocks), dim3(kFinThreads), 0, h->stream, fp);
+    s->n_files = 1; s->frames = frames[f]; s->fresh_main = false; s->fresh_tgt = false;
+    s->tab_ready = false;
+    if (!whole[f]) s->whole_files = false;
+  }
+  TD_HIP(h, hipGetLastError());
+  return TD_OK;
+}
 }  // namespace
 
 }  // extern "C"
@@ -1503,6 +1622,48 @@ extern "C" {
 int td_stats_complete(td_handle* h, td_stats* s) {
   if (!h || !s) return td_fail(h, TD_ERR_INVALID, "td_stats_complete: NULL argument");
   return td_stats_settle(h, s);
+}
+
+int td_stats_accumulate_each(td_handle* h, td_stats* const* each, const float* x_dev, int64_t ldx,
+                             const float* y_dev, int64_t ldy, const int64_t* file_offsets_host, int num_files,
+                             int input_offset, const int64_t* rows_used_host, int* handled) {
+  if (!h || !each || !handled) return td_fail(h, TD_ERR_INVALID, "td_stats_accumulate_each: NULL argument");
+  *handled = 0;
+  TD_REQUIRE(h, x_dev && y_dev && file_offsets_host && num_files > 0, "td_stats_accumulate_each: NULL input");
+  for (int f = 0; f < num_files; ++f) {
+    TD_REQUIRE(h, each[f], "td_stats_accumulate_each: NULL statistics");
+    TD_TRY(td_stats_settle(h, each[f]));
+  }
+  TD_REQUIRE(h, ldx >= each[0]->c1 && ldy >= each[0]->d, "td_stats_accumulate_each: row pitch below the column count");
+  const int64_t dx = input_offset > 0 ? input_offset : 0, dy = input_offset < 0 ? -input_offset : 0;
+  std::vector<LagSeg> sxx, syx;
+  std::vector<WinJob> j1((size_t)num_files);
+  std::vector<int64_t> frames((size_t)num_files);
+  std::vector<char> whole((size_t)num_files);
+  for (int f = 0; f < num_files; ++f) {
+    const int64_t r0 = file_offsets_host[f], r1 = file_offsets_host[f + 1];
+    TD_REQUIRE(h, r1 >= r0, "file_offsets must be non-decreasing");
+    const int64_t nf = r1 - r0;
+    const int64_t vx = nf - dx > 0 ? nf - dx : 0, vy = nf - dy > 0 ? nf - dy : 0;
+    int64_t nz = vx < vy ? vx : vy;
+    if (nf < nz) nz = nf;
+    int64_t np = nz;
+    if (rows_used_host) {
+      TD_REQUIRE(h, rows_used_host[f] >= 0 && rows_used_host[f] <= nz, "rows_used[%d] = %lld outside [0, %lld]", f,
+                 (long long)rows_used_host[f], (long long)nz);
+      np = rows_used_host[f];
+    }
+    frames[f] = np;
+    LagSeg a;
+    a.a_row0 = r0 + dx; a.a_valid = vx; a.b_row0 = r0 + dx; a.b_valid = vx; a.u_begin = 0; a.u_end = np;
+    sxx.push_back(a);
+    LagSeg b;   // A = y stream, B = x
+    b.a_row0 = r0 + dy; b.a_valid = vy; b.b_row0 = r0 + dx; b.b_valid = vx; b.u_begin = 0; b.u_end = np;
+    syx.push_back(b);
+    whole[f] = np == vx ? 1 : 0;
+    j1[f].row0 = r0 + dx; j1[f].valid = vx; j1[f].nprime = np; j1[f].head = 1; j1[f].tail = 2;
+  }
+  return accumulate_each(h, each, x_dev, ldx, y_dev, ldy, sxx, syx, j1, num_files, frames, whole, handled);
 }
 
 int td_stats_accumulate_ranges(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,

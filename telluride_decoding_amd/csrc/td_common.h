@@ -442,6 +442,7 @@ struct LagcovPlan {
   bool small = false, few = false, split = false, aligned = false;
   bool narrow = false;           // both operands <= 8 channels: lagcov_narrow_kernel (implies small)
   bool allow_f16 = false;        // set by the caller BEFORE td_lagcov_plan: the reduction divides scales out
+  bool no_chains = false;        // IN: every work item keeps a partial slab of its own (no workgroup walks several)
   bool f16 = false;              // the two-piece float16 form of the split kernel was chosen
   std::vector<int> work_seg;     // the segment each work item belongs to
   // float16 form, set by the caller between plan and launch:

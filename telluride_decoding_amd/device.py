@@ -369,6 +369,21 @@ class LagStats(object):
     return w, b, int(iters.value)
 
   @staticmethod
+  def accumulate_each(stats_list, x, y, file_offsets, input_offset=0, rows_used=None, handle=None):
+    """File f of x / y into stats_list[f] (fresh regression statistics) with ONE targets launch and ONE matrix
+    launch over all the recordings (td_stats_accumulate_each).  False: not a shape of that form, nothing was
+    queued -- accumulate file by file."""
+    h = handle or stats_list[0].h
+    offs, offs_p = _lib.i64_array(file_offsets)
+    used, used_p = (_lib.i64_array(rows_used) if rows_used is not None else (None, None))
+    arr = (ctypes.c_void_p * len(stats_list))(*[s.ptr for s in stats_list])
+    handled = ctypes.c_int(0)
+    h.check(h.lib.td_stats_accumulate_each(h.ptr, arr, _ptr(x), x.stride(0), _ptr(y), y.stride(0), offs_p,
+                                           len(offs) - 1, int(input_offset), used_p, ctypes.byref(handled)))
+    LagStats.last_each_status = int(handled.value)      # (<= 0: which check sent the caller back to the per-file loop)
+    return handled.value > 0
+
+  @staticmethod
   def ridge_solve_loso_terms(total, fold_terms, lambdas, max_iter=40, tol=1e-12, handle=None):
     """The same sweep with every fold given as total + a few signed terms (td_ridge_solve_loso_terms):
     fold_terms[f] = [(LagStats, +1 or -1), ...] -- minus the held-out recording, and for a fold whose

@@ -72,6 +72,8 @@ USE_PCG = True
 PCG_TOL = 1e-9
 # the folds of the sweep solver as signed terms of the total's statistics (False: a sum of 31 statistics per fold)
 USE_TERMS = True
+# the per-recording statistics of a one-rank sweep by ONE accumulate over all the recordings (False: a call per file)
+USE_BATCHED_STATS = True
 # How the last sweep of this process was solved: {'solver': 'pcg' | 'direct', 'iterations': n}
 LAST_SWEEP = {}
 SOLVE_WORKSPACE_BYTES = 6 << 30
@@ -168,8 +170,19 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     st.accumulate(x, None, y, [0, lengths[i]], input_offset=off, rows_used=[rows])
     return st
 
-  # 1. per-file statistics (every zipped frame) of this rank's files
-  per_file = {i: file_stats(i, zipped[i]) for i in plan.files_of(rank)}
+  # 1. per-file statistics (every zipped frame) of this rank's files: one call over all the recordings when this
+  #    rank holds them in one array and the device layer has the batched form, else a call per file
+  mine = plan.files_of(rank)
+  per_file = None
+  if (whole is not None and USE_BATCHED_STATS and hasattr(dev.LagStats, 'accumulate_each') and
+      mine == list(range(n_files)) and all(z > 0 for z in zipped)):
+    x_all, _, y_all, offs_all = whole
+    batch_stats = [new_stats() for _ in mine]
+    if dev.LagStats.accumulate_each(batch_stats, x_all, y_all, offs_all, input_offset=off, rows_used=zipped,
+                                    handle=h):
+      per_file = dict(zip(mine, batch_stats))
+  if per_file is None:
+    per_file = {i: file_stats(i, zipped[i]) for i in mine}
   # 2. make every file's statistics available on every rank: one all-reduce of
   #    [file][packed] with each rank filling only its own rows.
   proto = next(iter(per_file.values())) if per_file else new_stats()
