@@ -66,10 +66,12 @@ def parse_regularization_values(mode_string):
 # The preconditioned-CG solve of the whole sweep (td_ridge_solve_loso); False = always the direct
 # batched Cholesky.
 USE_PCG = True
-# relative residual |b - A w| <= PCG_TOL |b| of every (fold, lambda) system of the sweep solver: the weights leave
-# as float32 (2^-24 = 6e-8); measured at C5: 4 iterations instead of the 6 of 1e-12, the held-out correlations 4e-11
-# from the direct solve's
-PCG_TOL = 1e-9
+# relative residual |b - A w| <= PCG_TOL |b| of every (fold, lambda) system of the sweep solver.  The preconditioned
+# systems have a condition number of ~1.07 (a fold differs from the total by 1 / folds): the ERROR falls ~60 x per
+# iteration from the 3 % of the preconditioned right-hand side -- 2e-9 of the weights after 4 iterations, which is
+# what 1e-8 asks for at C5 (tools: 1e-12 -> 6 iterations, 1e-10 -> 5, 1e-8 -> 4, 1e-6 -> 3); the weights leave as
+# float32 (6e-8), the held-out correlations are 4.5e-11 from the direct solve's
+PCG_TOL = 1e-8
 # the folds of the sweep solver as signed terms of the total's statistics (False: a sum of 31 statistics per fold)
 USE_TERMS = True
 # the per-recording statistics of a one-rank sweep by ONE accumulate over all the recordings (False: a call per file)

@@ -1768,3 +1768,75 @@ def test_loso_folds_as_terms_of_the_total(dev):
     regression.USE_TERMS, regression.USE_PCG = True, True
   np.testing.assert_allclose(runs['terms'], runs['sums'], rtol=0, atol=1e-7)
   np.testing.assert_allclose(runs['terms'], runs['direct'], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize('lens,c,pre,post,d,off', [
+    ((5000, 7000, 3000), 64, 0, 31, 1, 0),
+    ((900, 1500, 777, 130), 64, 0, 7, 1, -3),
+    ((900, 1500, 777), 64, 2, 3, 2, 2),
+    ((2500, 2600), 63, 0, 15, 1, 0),              # (virtual-image shapes -- rows that are not whole 16-byte granules,
+    ((900, 1500, 777), 48, 1, 3, 1, 0),           #  <= 32 channels...: the call declines, nothing queued)
+])
+def test_accumulate_each_matches_per_file_calls(dev, lens, c, pre, post, d, off):
+  """td_stats_accumulate_each (round 6): the per-recording statistics of a leave-one-out sweep from ONE targets
+  launch and ONE matrix launch over all the recordings + a finalize launch each, against one td_stats_accumulate
+  per recording -- frame counts exact, moments to 3e-7 (the float16 kernel's channel scales come from the maxima
+  over all the recordings of the call), then each object keeps accumulating like any other."""
+  rng = np.random.default_rng(11)
+  h = dev.default_handle()
+  n = sum(lens)
+  x = h.to_device((rng.standard_normal((n, c)) * np.logspace(-1, 2, c)).astype(np.float32))
+  y = h.to_device(rng.standard_normal((n, d)).astype(np.float32))
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  used = [l - abs(off) - 7 for l in lens]
+  one = []
+  for f in range(len(lens)):
+    st = dev.LagStats(c, pre, post, d=d)
+    st.accumulate(x[offs[f]:offs[f + 1]], None, y[offs[f]:offs[f + 1]], [0, lens[f]], input_offset=off, rows_used=[used[f]])
+    one.append(st)
+  each = [dev.LagStats(c, pre, post, d=d) for _ in lens]
+  handled = dev.LagStats.accumulate_each(each, x, y, offs, input_offset=off, rows_used=used)
+  if c != 64:
+    assert not handled and all(st.counts() == (0, 0) for st in each)
+    return
+  assert handled
+  for a, b in zip(one, each):
+    assert a.counts() == b.counts()
+    ma, mb = a.moments(), b.moments()
+    for k in ('xtx', 'xty'):
+      pa, pb = ma[k].cpu().numpy(), mb[k].cpu().numpy()
+      assert np.max(np.abs(pa - pb)) <= 3e-7 * np.max(np.abs(pa)), k
+  # the objects are ordinary statistics afterwards: the sum of all of them solves like one call over the files
+  whole = dev.LagStats(c, pre, post, d=d)
+  whole.accumulate(x, None, y, offs, input_offset=off, rows_used=used)
+  total = each[0].like().combine(each)
+  w0, b0 = whole.ridge_solve([0.1])
+  w1, b1 = total.ridge_solve([0.1])
+  assert np.max(np.abs((w0 - w1).cpu().numpy())) <= 2e-6 * np.max(np.abs(w0.cpu().numpy()))
+  # a second call on statistics that hold data is declined
+  assert not dev.LagStats.accumulate_each(each, x, y, offs, input_offset=off, rows_used=used)
+
+
+def test_c2_weights_at_full_size_match_the_oracle(dev):
+  """BASELINE config C2 at FULL size -- 64 ch x 1e6 samples (10 recordings x 100 000 frames), 32 lags, minibatches
+  of 1000, lambda = 0.1, bench.py's synthetic data -- through the model class, against golden G15: the oracle's
+  float64 restatement of the reference's minibatch loop over the materialised lag matrix (brain_model.py:422-481),
+  8.4 TFLOP of float64 products computed once in the build container (tests/golden/make_c2_full.py).
+  |gpu - ref64| < 1e-5 of the largest weight, strict."""
+  from telluride_decoding_amd import brain_data, brain_model, synth
+  g = golden('g15_c2_full')
+  trials = synth.make_trials(2, 10, 100000, 64)
+  # the regenerated data are the fixture's (a seeded NumPy generator and NumPy's FFT)
+  np.testing.assert_allclose(trials[0][0][:4, :4], g['eeg_head'], rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(trials[0][1][:4], g['env_head'], rtol=1e-6)
+  assert abs(sum(float(t[0].astype(np.float64).sum()) for t in trials) - float(g['eeg_sum'])) < 1e-3 * (1 + abs(float(g['eeg_sum'])))
+  files = [(eeg, env, env[:, 0:1].astype(np.float32), att) for eeg, env, att in trials]
+  ds = brain_data.Dataset(files, 1000, pre_context=0, post_context=31)
+  model = brain_model.BrainModelLinearRegression(ds, regularization_lambda=0.1)
+  model.fit(ds)
+  w64, b64 = g['w'], g['b'].reshape(-1)
+  scale = float(np.max(np.abs(w64)))
+  d_w = float(np.max(np.abs(model.w_estimate.astype(np.float64) - w64))) / scale
+  d_b = float(np.max(np.abs(model.b_estimate.astype(np.float64) - b64))) / max(scale, float(np.max(np.abs(b64))))
+  parity_log.record('ridge_c2_full_1e6', gpu_ref64=d_w, bias_gpu_ref64=d_b)
+  assert d_w < 1e-5 and d_b < 1e-5, (d_w, d_b)

@@ -21,7 +21,7 @@ def wrap(obj, name, label):
     out = orig(*a, **k)
     torch.cuda.synchronize(); marks.append((label, time.perf_counter() - t0))
     return out
-  setattr(obj, name, staticmethod(timed) if isinstance(obj, type) and name == 'ridge_solve_loso' else timed)
+  setattr(obj, name, staticmethod(timed) if isinstance(obj, type) and name in ('ridge_solve_loso', 'ridge_solve_loso_terms', 'accumulate_each') else timed)
 acc = {}
 def wrap_sum(cls, name, label):
   orig = getattr(cls, name)
@@ -34,6 +34,8 @@ def wrap_sum(cls, name, label):
 for name in ('__init__', 'accumulate', 'combine', 'like'):
   wrap_sum(dev.LagStats, name, name)
 wrap(dev.LagStats, 'ridge_solve_loso', 'solve')
+wrap(dev.LagStats, 'ridge_solve_loso_terms', 'solve (terms)')
+wrap(dev.LagStats, 'accumulate_each', 'accumulate_each')
 if hasattr(dev, 'side_handles'):
   pass
 wrap(dev, 'predict_fir_per_file', 'evaluate: fir')
