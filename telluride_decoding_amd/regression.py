@@ -309,40 +309,87 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   # all, sends the REST of the sweep to (2).
   n_done = 0
 
-  def fold_terms(f):
-    """Fold f's training statistics as the total's plus signed terms: minus the held-out recording; when
-    batching drops a remainder from the end of the training stream, minus the last training recordings and
-    plus the same accumulated without the frames that fall off (fold_statistics says the same as a sum)."""
-    terms = [(stats[f], -1.0)]
+  def fold_coefficients(f):
+    """Fold f's training statistics as signed coefficients of statistics objects, relative to the sum of ALL
+    recordings: -1 for the held-out recording; when batching drops a remainder from the end of the training
+    stream, -1 for the last training recordings and +1 for the same accumulated without the frames that fall off
+    (fold_statistics says the same as a sum).  Keys: ('file', g) / ('cut', g, frames dropped)."""
+    coef = {('file', f): -1.0}
     members = [g for g in range(n_files) if g != f]
     rem = (total_zipped - zipped[f]) % bsz
     g = len(members) - 1
     while rem > 0 and g >= 0:
       last = members[g]
       cut = min(rem, zipped[last])
-      key = (last, cut)
-      if key not in truncated:
-        truncated[key] = file_stats(last, zipped[last] - cut)
-      terms += [(stats[last], -1.0), (truncated[key], +1.0)]
+      coef[('file', last)] = coef.get(('file', last), 0.0) - 1.0
+      coef[('cut', last, cut)] = coef.get(('cut', last, cut), 0.0) + 1.0
       rem -= cut
       g -= 1
-    return terms
+    return coef
+
+  def stats_of(key):
+    if key[0] == 'file':
+      return stats[key[1]]
+    if key[1:] not in truncated:
+      truncated[key[1:]] = file_stats(key[1], zipped[key[1]] - key[2])
+    return truncated[key[1:]]
+
+  def sweep_base(folds):
+    """The statistics the solver treats as its total, and every fold's terms against it.  Most folds of a sweep
+    over recordings of one length drop the SAME tail (the last recording's remainder): with that tail taken out
+    of the base once -- base = every recording, the last one truncated -- such a fold is the base minus its
+    held-out recording, ONE term (three against the plain total: minus held-out, minus last, plus truncated last)."""
+    coefs = {f: fold_coefficients(f) for f in folds}
+    tails = {}
+    for f, cf in coefs.items():
+      tail = tuple(sorted((k, v) for k, v in cf.items() if k != ('file', f)))
+      tails[tail] = tails.get(tail, 0) + 1
+    common = max(tails, key=lambda t: tails[t]) if tails else ()
+    base_coef = dict(common) if common and 2 * tails[common] > len(folds) else {}
+    terms = {}
+    for f, cf in coefs.items():
+      rel = dict(cf)
+      for k, v in base_coef.items():
+        rel[k] = rel.get(k, 0.0) - v
+      out = []
+      for k, v in rel.items():
+        if v not in (0.0, 1.0, -1.0):
+          return None, None           # (a recording that enters twice: the plain route)
+        if v:
+          out.append((stats_of(k), v))
+      terms[f] = out
+    if any(len(t) > 4 for t in terms.values()):
+      if not base_coef:
+        return None, None
+      return sweep_base_plain(folds)
+    members = list(stats)
+    for k, v in base_coef.items():
+      if k[0] == 'file' and v == -1.0:
+        members[k[1]] = None
+    members = [m for m in members if m is not None] + [stats_of(k) for k, v in base_coef.items() if k[0] == 'cut']
+    return proto.like().combine(members), terms
+
+  def sweep_base_plain(folds):
+    terms = {f: [(stats_of(k), v) for k, v in fold_coefficients(f).items()] for f in folds}
+    if any(len(t) > 4 for t in terms.values()):
+      return None, None
+    return proto.like().combine(stats), terms
 
   # (the CG solver carries at most 8 outputs per system; wider targets take the direct solves)
   if hasattr(dev.LagStats, 'ridge_solve_loso') and my_folds and USE_PCG and d <= 8:
     per_call = _pcg_chunk(len(my_folds), n_lam, proto.k1 + 1, d)
-    total = proto.like().combine(stats)
-    # the folds as signed terms of the total (no fold's statistics are summed: td_ridge_solve_loso_terms) when
-    # the device layer has it and every fold is the total minus a few recordings; else a sum per fold
+    # the folds as signed terms of a base total (no fold's statistics are summed: td_ridge_solve_loso_terms) when
+    # the device layer has it and every fold is the base plus / minus at most four statistics; else a sum per fold
     by_terms = hasattr(dev.LagStats, 'ridge_solve_loso_terms') and USE_TERMS
+    total, all_terms = sweep_base(my_folds) if by_terms else (None, None)
+    if total is None:
+      by_terms = False
+      total = proto.like().combine(stats)
     trains_all = [] if by_terms else [proto.like() for _ in range(per_call)]
     iters_max = 0
     while n_done < len(my_folds):
       folds = my_folds[n_done:n_done + per_call]
-      terms = [fold_terms(f) for f in folds] if by_terms else None
-      if by_terms and max(len(t) for t in terms) > 4:
-        by_terms, terms = False, None
-        trains_all = [proto.like() for _ in range(per_call)]
+      terms = [all_terms[f] for f in folds] if by_terms else None
       if not by_terms:
         for train, f in zip(trains_all, folds):
           fold_statistics(f, train)
