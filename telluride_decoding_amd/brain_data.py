@@ -235,11 +235,22 @@ class Dataset(object):
     box = self._cache_box
     if len(box) < 2:
       box.append({})
-    key = (id(handle), int(i))
-    if key not in box[1]:
+    # (keyed by the recording; the entry remembers the handle OBJECT it was uploaded for -- an id() can come back
+    #  with a new handle on another stream or device once the old one is collected -- and a different handle
+    #  replaces the entry, like device_arrays does)
+    entry = box[1].get(int(i))
+    if entry is None or entry[0] is not handle:
       f = self.files[i]
-      box[1][key] = (handle.to_device(f[0]), handle.to_device(f[2]))
-    return box[1][key]
+      entry = (handle, handle.to_device(f[0]), handle.to_device(f[2]))
+      box[1][int(i)] = entry
+    return entry[1], entry[2]
+
+  def release_device(self):
+    """Drops the dataset's device copies (device_arrays / device_file): the recordings leave HBM when their
+    tensors' last users do."""
+    self._device_cache = None
+    if len(self._cache_box) > 1:
+      self._cache_box[1].clear()
 
   def attention_host(self):
     """Attention labels of the zipped, batched stream (never shifted)."""

@@ -1467,15 +1467,20 @@ int accumulate_fused(td_handle* h, td_stats* s, const float* x_dev, int64_t ldx,
     blocks += 2 * num_files;
   }
   if (deferred) {
+    // A finalize that would read or zero the HANDLE's channel table cannot wait for another stream (the next call
+    // of this one overwrites the table): it is queued here, in the call, like an undeferred one -- the counters
+    // above already describe a finished call either way.
+    bool can_wait = !fp.zero_tab;
     for (int r = 0; r < fp.n_red; ++r)
-      TD_REQUIRE(h, !fp.red[r].scale_a || fp.red[r].scale_a == s->dscale ||
-                        (s->chan_tab && fp.red[r].scale_a == s->chan_tab + kChanShards * 128),
-                 "accumulate_fused: a deferred finalize would read the handle's channel table");
-    TD_REQUIRE(h, !fp.zero_tab, "accumulate_fused: a deferred finalize would zero the handle's channel table");
-    s->pend_params.assign(reinterpret_cast<const char*>(&fp), reinterpret_cast<const char*>(&fp) + sizeof(fp));
-    s->pend_blocks = blocks;
-    s->pending = true;
-    return TD_OK;
+      if (fp.red[r].scale_a && fp.red[r].scale_a != s->dscale &&
+          !(s->chan_tab && fp.red[r].scale_a == s->chan_tab + kChanShards * 128))
+        can_wait = false;
+    if (can_wait) {
+      s->pend_params.assign(reinterpret_cast<const char*>(&fp), reinterpret_cast<const char*>(&fp) + sizeof(fp));
+      s->pend_blocks = blocks;
+      s->pending = true;
+      return TD_OK;
+    }
   }
 #ifndef TD_ABL_NOFINALIZE     // timing ablation (wrong statistics): what the finalize launch costs the accumulate stream
   hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)blocks), dim3(kFinThreads), 0, h->stream, fp);

@@ -77,7 +77,11 @@ class Handle(object):
     self.check(self.lib.td_set_solver(self.ptr, self.SOLVERS[mode]))
 
   def set_option(self, name, value):
-    """td_set_option: 'cca_whitening' (0 automatic / 1 eigen route), 'cg_limit_ticks' (< 0 default)."""
+    """td_set_option: 'cca_whitening' (0 automatic / 1 eigen route), 'cg_limit_ticks' (< 0 default),
+    'narrow16' (1 default: <= 16 channels x <= 16 lags on the one-kernel streaming accumulate; 0: the tiled
+    kernels) and 'async_cg' (1: ridge_solve_async may run conjugate gradients on the compact statistics; its
+    flag can then be 2 = the solver gave up, W and b are NOT usable -- solve again with ridge_solve, as
+    pipeline.FitPipeline does; 0 default: flags 0 / 1 only)."""
     self.check(self.lib.td_set_option(self.ptr, name.encode(), int(value)))
 
   def last_solve_info(self):
@@ -316,7 +320,9 @@ class LagStats(object):
   def ridge_solve_async(self, lambdas, handle=None):
     """ridge_solve without waiting for the device: returns (W, b, flag) where flag() reads the
     singular-system flag (1 = some system was not positive definite) from the handle's pinned
-    host ring -- call it only after waiting for an event recorded behind this call."""
+    host ring -- call it only after waiting for an event recorded behind this call.  On a handle with
+    set_option('async_cg', 1) the flag can also be 2: the conjugate-gradient solver gave up and W / b hold
+    nothing usable -- repeat the solve with ridge_solve (any non-zero flag is NOT "singular" then)."""
     h = handle or self.h
     lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
     w = h.empty((len(lam), self.k1, self.d), 'float32')

@@ -170,6 +170,7 @@ class FitPipeline(object):
     self.ev_tgt = [torch.cuda.Event() for _ in range(buffers)]
     self.ev_solved = [None] * buffers
     self._generation = [0] * buffers     # submits that have used a buffer (guards the flag-2 re-solve)
+    self._last_solve_ev = None           # behind the last queued solve (orders the persistent CG launches)
     self.pending = None          # (buffer index, lambdas) of the fit whose solve is not queued yet
     self._results = []           # queued solves: (w, b, flag reader, event)
     self.count = 0
@@ -204,12 +205,19 @@ class FitPipeline(object):
         self.allreduce(self.stats[buf], h_solve)
       # (the singular-system flag follows the solve into the handle's pinned host ring)
       if self.solves is None or self.solves(index):
+        # (the one-launch conjugate-gradient solver is a persistent grid that needs its workgroups resident
+        #  together: two of them launched at once on the solve streams' shared CU mask can each get half a grid
+        #  and spin until the abort clock -- the solve of fit i starts behind the solve of fit i - 1)
+        if self.cg_solves and self._last_solve_ev is not None and len(self.s_solves) > 1:
+          s_solve.wait_event(self._last_solve_ev)
         w, b, flag = self.stats[buf].ridge_solve_async(lambdas, handle=h_solve)
       else:
         w = b = flag = None
       ev = torch.cuda.Event()
       ev.record(s_solve)
       self.ev_solved[buf] = ev
+      if w is not None:
+        self._last_solve_ev = ev
     self._results.append((w, b, flag, ev, (buf, lambdas, index, self._generation[buf])))
 
   def _pop(self):
