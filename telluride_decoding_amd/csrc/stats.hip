@@ -373,9 +373,8 @@ __device__ __forceinline__ void fin_gram(const GramReduceJob& jb, int block, dou
   }
 }
 
-__global__ __launch_bounds__(kFinThreads) void stats_finalize_kernel(FinalizeParams p) {
-  __shared__ double part[4 * kFinThreads];
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void stats_finalize_body(const FinalizeParams& p, const int b, double* part) {
+  const int tid = threadIdx.x;
   if (b == 0 && tid == 0 && p.n_dst) *p.n_dst = p.n_value;
   if (b == 0 && p.zero_tab)
     for (int i = tid; i < kChanTab; i += kFinThreads) p.zero_tab[i] = 0u;
@@ -476,6 +475,31 @@ __global__ __launch_bounds__(kFinThreads) void stats_finalize_kernel(FinalizePar
       dst[idx] = (own && u >= 0 && u < jw.valid) ? src[(jw.row0 + u) * ld + col] : 0.f;
     }
   }
+}
+
+__global__ __launch_bounds__(kFinThreads) void stats_finalize_kernel(FinalizeParams p) {
+  __shared__ double part[4 * kFinThreads];
+  stats_finalize_body(p, blockIdx.x, part);
+}
+
+// Several finalize launches in one (td_stats_accumulate_each: one parameter block per recording): workgroup b
+// belongs to the block whose range [first[i], first[i + 1]) holds it.
+__global__ __launch_bounds__(kFinThreads) void stats_finalize_multi_kernel(const FinalizeParams* __restrict__ params,
+                                                                          const int* __restrict__ first, int n) {
+  __shared__ double part[4 * kFinThreads];
+  __shared__ __attribute__((aligned(16))) int sp_raw[(sizeof(FinalizeParams) + sizeof(int) - 1) / sizeof(int)];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  // (the block through LDS: every thread reads its fields from there, not from a per-thread copy)
+  const int words = (int)(sizeof(FinalizeParams) / sizeof(int));
+  const int* src = reinterpret_cast<const int*>(params + lo);
+  for (int i = threadIdx.x; i < words; i += kFinThreads) sp_raw[i] = src[i];
+  __syncthreads();
+  stats_finalize_body(*reinterpret_cast<const FinalizeParams*>(sp_raw), b - first[lo], part);
 }
 
 // Expansion in two phases (both fill the chip, neither depends on the number of
@@ -1529,8 +1553,11 @@ int accumulate_each(td_handle* h, td_stats* const* each, const float* x_dev, int
   *handled = 1;
   for (int f = 0; f < num_files; ++f) TD_TRY(ensure_window_capacity(h, each[f], 1));
   const size_t main_bytes = mp.scratch_bytes;
+  // (behind the kernels' scratch: the recordings' finalize parameter blocks and their first workgroups)
+  const size_t kern_bytes = td_round_up(main_bytes + tp.scratch_bytes, 256);
+  const size_t pb = td_round_up(sizeof(FinalizeParams) * (size_t)num_files, 256);
   void* scratch = nullptr;
-  TD_TRY(td_scratch(h, main_bytes + tp.scratch_bytes, &scratch));
+  TD_TRY(td_scratch(h, kern_bytes + pb + sizeof(int) * ((size_t)num_files + 1), &scratch));
   char* base = reinterpret_cast<char*>(scratch);
   const void* jobs_dev = nullptr;
   TD_TRY(td_table_upload(h, j1.data(), sizeof(WinJob) * num_files, &jobs_dev));
@@ -1552,6 +1579,9 @@ int accumulate_each(td_handle* h, td_stats* const* each, const float* x_dev, int
   for (int i = (int)mp.works.size() - 1; i >= 0; --i) w0[mp.work_seg[i]] = i;
   for (int f = num_files - 1; f >= 0; --f) if (w0[f] > w0[f + 1]) w0[f] = w0[f + 1];
   const size_t slab = (size_t)job.e_pad * job.ca_pad * job.cb_pad;
+  // the recordings' finalize launches as ONE (34 launches of ~8 us each were a quarter of the call at C5)
+  std::vector<FinalizeParams> all_fp((size_t)num_files);
+  std::vector<int> first_block((size_t)num_files + 1, 0);
   for (int f = 0; f < num_files; ++f) {
     td_stats* s = each[f];
     FinalizeParams fp;
@@ -1599,10 +1629,20 @@ int accumulate_each(td_handle* h, td_stats* const* each, const float* x_dev, int
     blocks += 2;
     fp.n_dst = s->g + s->off_n; fp.n_value = (double)frames[f];
     if (zero_next && f == num_files - 1) fp.zero_tab = h->chan_max + kChanTab * (h->chan_phase & 1);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)blocks), dim3(kFinThreads), 0, h->stream, fp);
+    all_fp[f] = fp;
+    first_block[f + 1] = first_block[f] + blocks;
     s->n_files = 1; s->frames = frames[f]; s->fresh_main = false; s->fresh_tgt = false;
     s->tab_ready = false;
     if (!whole[f]) s->whole_files = false;
+  }
+  {
+    static_assert(sizeof(FinalizeParams) % sizeof(int) == 0, "FinalizeParams is copied word by word");
+    void* blk = base + kern_bytes;
+    TD_TRY(td_upload_async(h, all_fp.data(), sizeof(FinalizeParams) * (size_t)num_files, blk));
+    TD_TRY(td_upload_async(h, first_block.data(), sizeof(int) * ((size_t)num_files + 1), reinterpret_cast<char*>(blk) + pb));
+    hipLaunchKernelGGL(stats_finalize_multi_kernel, dim3((unsigned)first_block[num_files]), dim3(kFinThreads), 0, h->stream,
+                       reinterpret_cast<const FinalizeParams*>(blk),
+                       reinterpret_cast<const int*>(reinterpret_cast<char*>(blk) + pb), num_files);
   }
   TD_HIP(h, hipGetLastError());
   return TD_OK;
