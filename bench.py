@@ -494,13 +494,20 @@ def loso_leg(eeg, env):
   t0 = time.perf_counter()
   res = regression.jackknife_over_regularizations(ds, lams)
   first = time.perf_counter() - t0
+  # (one collection in front of the sweeps and none between them, like the decode leg: a collection walks the
+  #  process's objects for ~20 ms and the sweep that follows it runs its host side on cold caches -- 10.4 ms against
+  #  9.7 for the same sweep called back to back, tools/time_c5.py; a collection INSIDE a sweep can free a device arena)
   best = None
-  for _ in range(3):
-    gc.collect()
-    t0 = time.perf_counter()
-    res = regression.jackknife_over_regularizations(ds, lams)
-    dt = time.perf_counter() - t0
-    best = dt if best is None else min(best, dt)
+  gc.collect()
+  gc.disable()
+  try:
+    for _ in range(4):
+      t0 = time.perf_counter()
+      res = regression.jackknife_over_regularizations(ds, lams)
+      dt = time.perf_counter() - t0
+      best = dt if best is None else min(best, dt)
+  finally:
+    gc.enable()
   # the same with the upload inside the timed region (pageable host arrays, as the
   # reference's callers hold them)
   ds._device_cache = None
@@ -516,7 +523,7 @@ def loso_leg(eeg, env):
       'solver': dict(regression.LAST_SWEEP,
                      what='pcg = td_ridge_solve_loso (one Cholesky factor per lambda of the total '
                           'covariance preconditions CG on every fold); direct = batched Cholesky'),
-      'inputs': 'resident in HBM (best of 3 sweeps)',
+      'inputs': 'resident in HBM (best of 4 back-to-back sweeps, the statistics objects pooled by the dataset)',
       'seconds_with_upload': with_upload, 'seconds_first_sweep': first,
       'upload': 'host->device copy of the recordings (264 MB, pageable) inside the timed region',
   }

@@ -245,12 +245,26 @@ class Dataset(object):
       box[1][int(i)] = entry
     return entry[1], entry[2]
 
+  def stats_pool(self, handle, layout):
+    """Statistics objects a sweep over this dataset has handed back (regression.jackknife_over_regularizations: 35
+    of them per C5 sweep -- created and destroyed every sweep their 100 allocations and frees were 0.8 of its
+    10.9 ms): a list to pop from and append to, per handle object and layout.  The objects keep device memory
+    (0.5 MB of sums + 2 MB of boundary windows each at C2) until release_device()."""
+    box = self._cache_box
+    while len(box) < 3:
+      box.append({})
+    entry = box[2].get(layout)
+    if entry is None or entry[0] is not handle:
+      entry = (handle, [])
+      box[2][layout] = entry
+    return entry[1]
+
   def release_device(self):
-    """Drops the dataset's device copies (device_arrays / device_file): the recordings leave HBM when their
-    tensors' last users do."""
+    """Drops the dataset's device copies (device_arrays / device_file) and its pooled statistics objects: the
+    recordings leave HBM when their tensors' last users do."""
     self._device_cache = None
-    if len(self._cache_box) > 1:
-      self._cache_box[1].clear()
+    for part in self._cache_box[1:]:
+      part.clear()
 
   def attention_host(self):
     """Attention labels of the zipped, batched stream (never shifted)."""

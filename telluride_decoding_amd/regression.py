@@ -76,6 +76,8 @@ PCG_TOL = 1e-8
 USE_TERMS = True
 # the per-recording statistics of a one-rank sweep by ONE accumulate over all the recordings (False: a call per file)
 USE_BATCHED_STATS = True
+# statistics objects are reused from sweep to sweep over a dataset (Dataset.stats_pool)
+USE_STATS_POOL = True
 # How the last sweep of this process was solved: {'solver': 'pcg' | 'direct', 'iterations': n}
 LAST_SWEEP = {}
 SOLVE_WORKSPACE_BYTES = 6 << 30
@@ -163,8 +165,20 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
         uploaded[i] = (h.to_device(f[0]), h.to_device(f[2]))
     return uploaded[i]
 
+  # statistics objects come from (and go back to) a pool the dataset keeps: a sweep needs ~35 of them
+  layout = (dataset.c1, dataset.pre, dataset.post, dataset.d)
+  pool = (dataset.stats_pool(h, layout) if hasattr(dataset, 'stats_pool') and hasattr(dev.LagStats, 'reset')
+          and USE_STATS_POOL else None)
+  borrowed = []
+
   def new_stats():
-    return dev.LagStats(dataset.c1, dataset.pre, dataset.post, 0, 0, 0, dataset.d, handle=h)
+    if pool:
+      st = pool.pop()
+      st.reset()
+    else:
+      st = dev.LagStats(dataset.c1, dataset.pre, dataset.post, 0, 0, 0, dataset.d, handle=h)
+    borrowed.append(st)
+    return st
 
   def file_stats(i, rows):
     st = new_stats()
@@ -200,7 +214,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     if i in per_file and world_size == 1:
       stats.append(per_file[i])
       continue
-    st = proto.like()
+    st = new_stats()
     st.unpack(table[i].contiguous(), 1, zipped[i])
     stats.append(st)
   # 3-4. folds of this rank
@@ -367,13 +381,13 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
       if k[0] == 'file' and v == -1.0:
         members[k[1]] = None
     members = [m for m in members if m is not None] + [stats_of(k) for k, v in base_coef.items() if k[0] == 'cut']
-    return proto.like().combine(members), terms
+    return new_stats().combine(members), terms
 
   def sweep_base_plain(folds):
     terms = {f: [(stats_of(k), v) for k, v in fold_coefficients(f).items()] for f in folds}
     if any(len(t) > 4 for t in terms.values()):
       return None, None
-    return proto.like().combine(stats), terms
+    return new_stats().combine(stats), terms
 
   # (the CG solver carries at most 8 outputs per system; wider targets take the direct solves)
   if hasattr(dev.LagStats, 'ridge_solve_loso') and my_folds and USE_PCG and d <= 8:
@@ -384,8 +398,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     total, all_terms = sweep_base(my_folds) if by_terms else (None, None)
     if total is None:
       by_terms = False
-      total = proto.like().combine(stats)
-    trains_all = [] if by_terms else [proto.like() for _ in range(per_call)]
+      total = new_stats().combine(stats)
+    trains_all = [] if by_terms else [new_stats() for _ in range(per_call)]
     iters_max = 0
     while n_done < len(my_folds):
       folds = my_folds[n_done:n_done + per_call]
@@ -420,7 +434,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   # that the handle keeps (grow-only), so ~160 systems of n = 2049 are 5.7 GB, but the same
   # count at 64 ch x 64 lags would be 23 GB.
   chunk = _fold_chunk(len(my_folds), n_lam, proto.k1 + 1)
-  trains = [] if done else [proto.like() for _ in range(chunk)]
+  trains = [] if done else [new_stats() for _ in range(chunk)]
   if not n_done:
     LAST_SWEEP.update(solver='direct', iterations=0)
   c0 = n_done
@@ -462,6 +476,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
   for li, lam in enumerate(lambdas):
     results[lam] = (float(run_mean[li]), float(run_std[li]))
   results['all_runs'] = all_folds.T
+  if pool is not None:
+    pool.extend(borrowed)         # (everything queued on them has been waited for: the scores came to the host)
   return results
 
 
