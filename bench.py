@@ -491,9 +491,21 @@ def loso_leg(eeg, env):
   lams = list(np.logspace(-6, 3, 20))
   # first sweep: uploads the recordings (the dataset keeps its device copy) and grows the
   # workspaces; then sweeps with the inputs resident in HBM, like the headline measurement
-  t0 = time.perf_counter()
-  res = regression.jackknife_over_regularizations(ds, lams)
-  first = time.perf_counter() - t0
+  # (no garbage collection inside the first sweep either: a full collection is ~20-40 ms of this process's objects
+  #  and falls where the allocation counters happen to trip -- tools/prof_c5_cold.py caught one inside the sweep)
+  import torch
+  from telluride_decoding_amd import device as _dev
+  gc.collect()
+  gc.disable()
+  try:
+    t0 = time.perf_counter()
+    ds.device_arrays(_dev.default_handle())            # (the 264 MB of pageable host arrays: most of a first sweep)
+    torch.cuda.synchronize()
+    first_upload = time.perf_counter() - t0
+    res = regression.jackknife_over_regularizations(ds, lams)
+    first = time.perf_counter() - t0
+  finally:
+    gc.enable()
   # (one collection in front of the sweeps and none between them, like the decode leg: a collection walks the
   #  process's objects for ~20 ms and the sweep that follows it runs its host side on cold caches -- 10.4 ms against
   #  9.7 for the same sweep called back to back, tools/time_c5.py; a collection INSIDE a sweep can free a device arena)
@@ -525,6 +537,9 @@ def loso_leg(eeg, env):
                           'covariance preconditions CG on every fold); direct = batched Cholesky'),
       'inputs': 'resident in HBM (best of 4 back-to-back sweeps, the statistics objects pooled by the dataset)',
       'seconds_with_upload': with_upload, 'seconds_first_sweep': first,
+      'first_sweep_parts': {'upload_s': first_upload, 'sweep_s': first - first_upload,
+                            'what': 'the first sweep of the process = host->device copy of the recordings (pageable) + the sweep '
+                                    'itself with cold workspaces, tables and code paths'},
       'upload': 'host->device copy of the recordings (264 MB, pageable) inside the timed region',
   }
 

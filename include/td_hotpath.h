@@ -353,11 +353,13 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
  * drops a remainder (brain_data.py:369-370) minus the last training recording's and plus the same recording
  * accumulated without its tail.  The statistics are linear in the recordings, so no fold's training
  * statistics are ever summed and the dense moments of ALL folds come from the total's (expanded once, for the
- * preconditioner) in one launch.  term_begin [n_folds + 1]; everything else as td_ridge_solve_loso. */
+ * preconditioner) in one launch.  term_begin [n_folds + 1].  w_k_major = 1: w_dev is [n_folds][k1][n_lambda][d] --
+ * a fold's models as the output columns of ONE filter, the layout td_predict_fir_per_file takes for the held-out
+ * evaluation (regression.py:197-214) -- instead of [n_folds][n_lambda][k1][d]; everything else as td_ridge_solve_loso. */
 int td_ridge_solve_loso_terms(td_handle* h, td_stats* total, td_stats* const* terms, const int* term_begin,
                               const double* signs, int n_folds, const double* lambdas_host, int n_lambda,
-                              int max_iter, double tol, float* w_dev, float* b_dev, int* status_host,
-                              int* iterations_host);
+                              int max_iter, double tol, int w_k_major, float* w_dev, float* b_dev,
+                              int* status_host, int* iterations_host);
 
 /* Generic SPD solve used by the above and by the shrinkage branch
  * (brain_model.py:456-477): a_dev [batch, n, n] float64 (destroyed),
@@ -466,6 +468,13 @@ int td_window_count(const int64_t* trial_offsets_host, int num_trials, int width
 int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev,
                    int64_t ldb, int cols, const int64_t* trial_offsets_host,
                    int num_trials, int width, int hop, double* out_dev);
+/* The same with b holding b_cols <= cols columns, column j of a paired with column j % b_cols of b: the
+ * predictions of several models (regression.jackknife_one_model: the lambdas of a sweep as output columns)
+ * against ONE truth, without a tiled copy of the truth.  b_cols divides cols; windows and hops that share a
+ * block of >= 32 frames (else TD_ERR_INVALID: tile b and call td_window_sums). */
+int td_window_sums_cycled(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev,
+                          int64_t ldb, int cols, int b_cols, const int64_t* trial_offsets_host,
+                          int num_trials, int width, int hop, double* out_dev);
 
 /* Per-window scores from the five sums.
  *   mode 0: global-statistics correlation mean over the window of

@@ -94,7 +94,7 @@ SIGNATURES = {
     'td_ridge_solve_multi': [_vp, _c.POINTER(_vp), _i, _pd, _i, _vp, _vp, _vp],
     'td_ridge_solve_loso': [_vp, _vp, _c.POINTER(_vp), _i, _pd, _i, _i, _d, _vp, _vp, _c.POINTER(_i),
                             _c.POINTER(_i)],
-    'td_ridge_solve_loso_terms': [_vp, _vp, _c.POINTER(_vp), _c.POINTER(_i), _pd, _i, _pd, _i, _i, _d, _vp, _vp,
+    'td_ridge_solve_loso_terms': [_vp, _vp, _c.POINTER(_vp), _c.POINTER(_i), _pd, _i, _pd, _i, _i, _d, _i, _vp, _vp,
                                   _c.POINTER(_i), _c.POINTER(_i)],
     'td_spd_solve': [_vp, _vp, _vp, _i, _i, _i],
     'td_general_solve': [_vp, _vp, _vp, _i, _i],
@@ -108,6 +108,7 @@ SIGNATURES = {
     'td_jacobi_svd': [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _c.POINTER(_i)],
     'td_window_count': [_pi64, _i, _i, _i, _pi64, _pi64],
     'td_window_sums': [_vp, _vp, _i64, _vp, _i64, _i, _pi64, _i, _i, _i, _vp],
+    'td_window_sums_cycled': [_vp, _vp, _i64, _vp, _i64, _i, _i, _pi64, _i, _i, _i, _vp],
     'td_window_scores': [_vp, _vp, _i64, _i, _i, _i, _i, _pd, _pd, _pd, _vp],
     'td_window_pearson': [_vp, _vp, _i64, _i, _i, _i, _vp],
     'td_frame_scores': [_vp, _vp, _i64, _vp, _i64, _i, _i64, _i, _pd, _pd, _pd, _pd, _d,

@@ -222,10 +222,23 @@ class Dataset(object):
   def device_arrays(self, handle):
     """(x, x2, y, attention) device tensors of the concatenated files + offsets."""
     if self._device_cache is None or self._device_cache[0] is not handle:
-      x = handle.to_device(np.concatenate([f[0] for f in self.files]))
-      x2 = handle.to_device(np.concatenate([f[1] for f in self.files]))
-      y = handle.to_device(np.concatenate([f[2] for f in self.files]))
       offs = np.concatenate(([0], np.cumsum(self.file_lengths()))).astype(np.int64)
+      if hasattr(handle, 'empty') and hasattr(handle, 'device'):
+        # every recording straight into its rows of ONE device tensor: no concatenated host copy first (264 MB of
+        # memcpy at C5: 25 of the 35 ms this upload took)
+        import torch
+        def upload(col):
+          width = self.files[0][col].shape[1]
+          out = handle.empty((int(offs[-1]), width), 'float32')
+          for i, f in enumerate(self.files):
+            if offs[i + 1] > offs[i]:
+              out[int(offs[i]):int(offs[i + 1])].copy_(torch.from_numpy(np.ascontiguousarray(f[col], np.float32)))
+          return out
+        x, x2, y = upload(0), upload(1), upload(2)
+      else:
+        x = handle.to_device(np.concatenate([f[0] for f in self.files]))
+        x2 = handle.to_device(np.concatenate([f[1] for f in self.files]))
+        y = handle.to_device(np.concatenate([f[2] for f in self.files]))
       self._device_cache = (handle, x, x2, y, offs)
     return self._device_cache[1:]
 

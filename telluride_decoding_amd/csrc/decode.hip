@@ -653,7 +653,7 @@ __global__ __launch_bounds__(kThreads) void block_sums_kernel(
 // 290 us for 1e6 rows).  One wave per block, its row phases summed through LDS in a fixed order.
 __global__ __launch_bounds__(kThreads) void block_sums_cols_kernel(
     const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
-    int cols, const FileDesc* __restrict__ trials, int n_trials, long long n_blocks,
+    int cols, int b_cols, const FileDesc* __restrict__ trials, int n_trials, long long n_blocks,
     int g, double* __restrict__ out) {
   __shared__ double part[kThreads / 64][64][5];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -663,6 +663,7 @@ __global__ __launch_bounds__(kThreads) void block_sums_cols_kernel(
   const long long r0 = tr.row0 + (blk - tr.first) * g;
   const int per = 64 / cols;                            // rows per wave step (cols <= 64)
   const int col = lane % cols, rs = lane / cols;
+  const int bc = col % b_cols;                          // (b may have fewer columns: cycled, like block_sums_kernel)
   double s[5] = {0, 0, 0, 0, 0};
   if (rs < per) {
     int r = rs;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void block_sums_cols_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         av[q] = a[(r0 + r + q * per) * lda + col];
-        bv[q] = b[(r0 + r + q * per) * ldb + col];
+        bv[q] = b[(r0 + r + q * per) * ldb + bc];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(kThreads) void block_sums_cols_kernel(
       }
     }
     for (; r < g; r += per) {
-      const double x = (double)a[(r0 + r) * lda + col], y = (double)b[(r0 + r) * ldb + col];
+      const double x = (double)a[(r0 + r) * lda + col], y = (double)b[(r0 + r) * ldb + bc];
       s[0] += x; s[1] += y; s[2] += x * x; s[3] += y * y; s[4] += x * y;
     }
   }
@@ -3047,10 +3048,20 @@ int td_window_count(const int64_t* trial_offsets_host, int num_trials, int width
 int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev, int64_t ldb,
                    int cols, const int64_t* trial_offsets_host, int num_trials, int width, int hop,
                    double* out_dev) {
+  return td_window_sums_cycled(h, a_dev, lda, b_dev, ldb, cols, cols, trial_offsets_host, num_trials, width, hop,
+                               out_dev);
+}
+
+int td_window_sums_cycled(td_handle* h, const float* a_dev, int64_t lda, const float* b_dev, int64_t ldb,
+                          int cols, int b_cols, const int64_t* trial_offsets_host, int num_trials, int width,
+                          int hop, double* out_dev) {
   if (!h || !a_dev || !b_dev || !trial_offsets_host || !out_dev)
     return td_fail(h, TD_ERR_INVALID, "td_window_sums: NULL argument");
   TD_REQUIRE(h, cols > 0 && width > 0 && hop > 0, "td_window_sums: bad sizes");
+  TD_REQUIRE(h, b_cols > 0 && b_cols <= cols && cols % b_cols == 0, "td_window_sums_cycled: b_cols must divide cols");
   const int g = window_block_size(width, hop);
+  TD_REQUIRE(h, b_cols == cols || g > 0,
+             "td_window_sums_cycled: windows without a common block of >= 32 frames take b with all its columns");
   if (g > 0) {
     // shared frames are read once: block partials, then windows from blocks
     std::vector<FileDesc> blk_tab, win_tab;
@@ -3068,13 +3079,13 @@ int td_window_sums(td_handle* h, const float* a_dev, int64_t lda, const float* b
     TD_TRY(td_upload_async(h, win_tab.data(), sizeof(FileDesc) * num_trials, d_win));
     if (cols >= 8 && cols <= 64)
       hipLaunchKernelGGL(block_sums_cols_kernel, dim3((unsigned)td_ceil_div(n_blocks, kThreads / 64)), dim3(kThreads), 0,
-                         h->stream, a_dev, (long long)lda, b_dev, (long long)ldb, cols, d_blk, num_trials,
+                         h->stream, a_dev, (long long)lda, b_dev, (long long)ldb, cols, b_cols, d_blk, num_trials,
                          (long long)n_blocks, g, bsums);
     else
     hipLaunchKernelGGL(block_sums_kernel,
                        dim3((unsigned)td_ceil_div(n_blocks, kThreads / kBlockLanes), (unsigned)(cols < 64 ? cols : 64)),
                        dim3(kThreads), 0, h->stream, a_dev, (long long)lda, b_dev, (long long)ldb,
-                       cols, cols, d_blk, num_trials, (long long)n_blocks, g, bsums);
+                       cols, b_cols, d_blk, num_trials, (long long)n_blocks, g, bsums);
     const long long outs = (long long)n_win * cols * 5;
     if (width / g > 64)
       hipLaunchKernelGGL(window_from_blocks_wide_kernel, dim3((unsigned)td_ceil_div(outs, 4)),

@@ -1477,8 +1477,10 @@ __global__ void loso_rhs_kernel(const double* __restrict__ xty, const double* __
 }
 
 // w [fold][lambda][k1][d], bias [fold][lambda][d] (float32) from the solution rows
+// (k_major: w [fold][k1][lambda][d] -- the models of a fold as the OUTPUT COLUMNS of one filter, what
+//  td_predict_fir_per_file takes)
 __global__ void loso_emit_kernel(const double* __restrict__ x, int k1, int d, int np, int folds,
-                                 int n_lambda, float* __restrict__ w, float* __restrict__ bias) {
+                                 int n_lambda, float* __restrict__ w, float* __restrict__ bias, int k_major) {
   const long long total = (long long)folds * n_lambda * (k1 + 1) * d;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -1488,7 +1490,7 @@ __global__ void loso_emit_kernel(const double* __restrict__ x, int k1, int d, in
     const int f = (int)(i / ((long long)d * (k1 + 1) * n_lambda));
     const float v = (float)x[(((long long)lam * d + q) * folds + f) * np + r];
     const long long sys = (long long)f * n_lambda + lam;
-    if (r < k1) w[((size_t)sys * k1 + r) * d + q] = v;
+    if (r < k1) w[k_major ? (((size_t)f * k1 + r) * n_lambda + lam) * d + q : ((size_t)sys * k1 + r) * d + q] = v;
     else bias[(size_t)sys * d + q] = v;
   }
 }
@@ -1911,7 +1913,8 @@ int td_ridge_solve_async(td_handle* h, td_stats* s, const double* lambdas_host, 
 static int ridge_solve_loso_impl(td_handle* h, td_stats* total, td_stats* const* folds, td_stats* const* terms,
                                  const int* term_begin, const double* signs, int n_folds,
                                  const double* lambdas_host, int n_lambda, int max_iter, double tol,
-                                 float* w_dev, float* b_dev, int* status_host, int* iterations_host) {
+                                 float* w_dev, float* b_dev, int* status_host, int* iterations_host,
+                                 int w_k_major) {
   if (!h || !total || (!folds && !(terms && term_begin && signs)) || !lambdas_host || !w_dev || !b_dev || !status_host)
     return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_loso: NULL argument");
   TD_REQUIRE(h, n_folds > 0 && n_lambda > 0 && max_iter > 0 && tol > 0.0, "td_ridge_solve_loso: bad sizes");
@@ -2082,7 +2085,7 @@ static int ridge_solve_loso_impl(td_handle* h, td_stats* total, td_stats* const*
     if (it < max_iter) TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
   }
   hipLaunchKernelGGL(loso_emit_kernel, dim3(1024), dim3(256), 0, h->stream, X, k1, d, np, n_folds, n_lambda,
-                     w_dev, b_dev);
+                     w_dev, b_dev, w_k_major);
   TD_HIP(h, hipGetLastError());
   *status_host = flag == 2 ? 2 : flag ? 1 : 0;      // 0 converged, 1 not converged in max_iter, 2 not positive definite
   if (iterations_host) *iterations_host = it;
@@ -2094,16 +2097,16 @@ int td_ridge_solve_loso(td_handle* h, td_stats* total, td_stats* const* folds, i
                         float* w_dev, float* b_dev, int* status_host, int* iterations_host) {
   if (!folds) return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_loso: NULL argument");
   return ridge_solve_loso_impl(h, total, folds, nullptr, nullptr, nullptr, n_folds, lambdas_host, n_lambda, max_iter,
-                               tol, w_dev, b_dev, status_host, iterations_host);
+                               tol, w_dev, b_dev, status_host, iterations_host, 0);
 }
 
 int td_ridge_solve_loso_terms(td_handle* h, td_stats* total, td_stats* const* terms, const int* term_begin,
                               const double* signs, int n_folds, const double* lambdas_host, int n_lambda,
-                              int max_iter, double tol, float* w_dev, float* b_dev, int* status_host,
-                              int* iterations_host) {
+                              int max_iter, double tol, int w_k_major, float* w_dev, float* b_dev,
+                              int* status_host, int* iterations_host) {
   if (!terms || !term_begin || !signs) return td_fail(h, TD_ERR_INVALID, "td_ridge_solve_loso_terms: NULL argument");
   return ridge_solve_loso_impl(h, total, nullptr, terms, term_begin, signs, n_folds, lambdas_host, n_lambda, max_iter,
-                               tol, w_dev, b_dev, status_host, iterations_host);
+                               tol, w_dev, b_dev, status_host, iterations_host, w_k_major ? 1 : 0);
 }
 
 }  // extern "C"

@@ -390,16 +390,17 @@ class LagStats(object):
     return handled.value > 0
 
   @staticmethod
-  def ridge_solve_loso_terms(total, fold_terms, lambdas, max_iter=40, tol=1e-12, handle=None):
+  def ridge_solve_loso_terms(total, fold_terms, lambdas, max_iter=40, tol=1e-12, handle=None, k_major=False):
     """The same sweep with every fold given as total + a few signed terms (td_ridge_solve_loso_terms):
     fold_terms[f] = [(LagStats, +1 or -1), ...] -- minus the held-out recording, and for a fold whose
     minibatch stream drops a remainder minus the last training recording plus its truncated twin.  No fold
     statistics are summed; the folds' dense moments come from the total's in one launch.  Returns as
-    ridge_solve_loso."""
+    ridge_solve_loso; k_major: W comes as [n_folds, k1, n_lambda * d] (a fold's models as the output columns of one
+    filter: what predict_fir_per_file takes)."""
     h = handle or total.h
     lam, lam_p = _lib.f64_array(np.atleast_1d(lambdas))
     n_folds = len(fold_terms)
-    w = h.empty((n_folds, len(lam), total.k1, total.d), 'float32')
+    w = h.empty((n_folds, total.k1, len(lam) * total.d) if k_major else (n_folds, len(lam), total.k1, total.d), 'float32')
     b = h.empty((n_folds, len(lam), total.d), 'float32')
     flat = [t for terms in fold_terms for t in terms]
     arr = (ctypes.c_void_p * max(1, len(flat)))(*[s.ptr for s, _ in flat])
@@ -409,7 +410,7 @@ class LagStats(object):
     h.check(h.lib.td_ridge_solve_loso_terms(
         h.ptr, total.ptr, arr, begin.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
         signs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n_folds, lam_p, len(lam), int(max_iter), float(tol),
-        _ptr(w), _ptr(b), ctypes.byref(status), ctypes.byref(iters)))
+        1 if k_major else 0, _ptr(w), _ptr(b), ctypes.byref(status), ctypes.byref(iters)))
     LagStats.last_loso_status = {0: 'converged', 1: 'not converged', 2: 'preconditioner not positive definite'}.get(
         status.value, 'status %d' % status.value)
     if status.value:
@@ -587,13 +588,22 @@ def shrinkage_moment(x, file_offsets, pre, post, batch_rows, input_offset=0, row
   return float(out.cpu()[0])
 
 
+WINDOW_SUMS_CYCLED = True      # window_sums takes a `b` with fewer columns than `a` (td_window_sums_cycled)
+
+
 def window_sums(a, b, trial_offsets, width, hop, handle=None):
-  """Five float64 sums per window and column: [n_windows, cols, 5]."""
+  """Five float64 sums per window and column: [n_windows, cols, 5].  b may hold fewer columns than a (a
+  divisor of a's): column j of a is then paired with column j % b.shape[1] of b (td_window_sums_cycled: several
+  models' predictions against one truth, no tiled copy of the truth)."""
   h = handle or default_handle()
-  cols = int(a.shape[1])
+  cols, b_cols = int(a.shape[1]), int(b.shape[1])
   _, total = window_layout(trial_offsets, width, hop)
   out = h.zeros((total, cols, 5), 'float64')
   offs, offs_p = _lib.i64_array(trial_offsets)
+  if b_cols != cols:
+    h.check(h.lib.td_window_sums_cycled(h.ptr, _ptr(a), a.stride(0), _ptr(b), b.stride(0), cols, b_cols, offs_p,
+                                        len(offs) - 1, int(width), int(hop), _ptr(out)))
+    return out
   h.check(h.lib.td_window_sums(h.ptr, _ptr(a), a.stride(0), _ptr(b), b.stride(0), cols, offs_p,
                                len(offs) - 1, int(width), int(hop), _ptr(out)))
   return out

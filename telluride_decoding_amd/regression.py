@@ -223,6 +223,8 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     raise ValueError('folds must name files of the dataset (0..%d), not %s' % (n_files - 1, folds))
   my_folds = distributed.split_round_robin(fold_list, rank, world_size)
   n_lam, d = len(lambdas), dataset.d
+  # (the cycled window sums need windows that are whole blocks of >= 32 frames: a divisor of the batch size in [32, 4096])
+  window_block_ok = any(bsz % dv == 0 for dv in range(32, min(bsz, 4096) + 1))
   scores = []
   truncated = {}            # (file, frames dropped from its end) -> statistics
   # The solves are queued without waiting for their singular-system flags (the host would
@@ -264,27 +266,37 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
     """y [rows, d] -> [rows, Lambda * d], the truth under every lambda's columns (a strided copy)."""
     return y.unsqueeze(1).expand(-1, n_lam, -1).reshape(y.shape[0], n_lam * d).contiguous()
 
-  def evaluate(f, w, b):
-    """Held-out scores of fold f for its n_lam weight sets w [n_lam, K, d], b [n_lam, d]."""
+  def paired_sums(truth, pred, offsets):
+    """The five window sums of every prediction column against ITS truth column (column j of pred belongs to
+    output j % d).  Pearson's r and its zero rule are symmetric in the two arrays, so the predictions go in as `a`
+    and the d truth columns as a cycled `b` (td_window_sums_cycled: no [rows, Lambda * d] copy of the truth --
+    80 MB at C5, and a torch copy kernel whose first launch cost the first sweep of a process 35 ms); device
+    layers without the cycled form get the tiled truth."""
+    if getattr(dev, 'WINDOW_SUMS_CYCLED', False) and window_block_ok:
+      return dev.window_sums(pred, truth if truth.is_contiguous() else truth.contiguous(), offsets, bsz, bsz,
+                             handle=h)
+    return dev.window_sums(tile_columns(truth), pred, offsets, bsz, bsz, handle=h)
+
+  def evaluate(f, w, b, k_major=False):
+    """Held-out scores of fold f for its n_lam weight sets w [n_lam, K, d] (k_major: [K, n_lam * d]), b [n_lam, d]."""
     u = held_used[f]
     if u == 0:
       scores.append((None, [0]))
       return
-    k = int(w.shape[1])
-    w_all = w.permute(1, 0, 2).reshape(k, n_lam * d).contiguous()
+    w_all = w if k_major else w.permute(1, 0, 2).reshape(int(w.shape[1]), n_lam * d).contiguous()
     xf, yf = file_arrays(f)
     pred = dev.predict_fir(xf, [0, int(xf.shape[0])], w_all, b.reshape(-1).contiguous(),
                            dataset.pre, dataset.post, handle=h, input_offset=off)
     # columns = (lambda, output); the truth repeats per lambda.  pearson_correlation_first =
     # output 0 of each model, with the zero rule taken over that model's d outputs
     p_all = pred[:u] if pred.shape[0] != u else pred
-    y_all = tile_columns(yf[dy:dy + u])
-    sums = dev.window_sums(y_all, p_all, [0, u], bsz, bsz, handle=h)
+    sums = paired_sums(yf[dy:dy + u], p_all, [0, u])
     r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)   # [minibatches, Lambda * d]
     scores.append((r[:, ::d], [u // bsz]))
 
-  def evaluate_folds(folds, w_all, b_all):
-    """evaluate() for the folds of one solver call, w_all [folds, n_lam, K, d].  A run of
+  def evaluate_folds(folds, w_all, b_all, k_major=False):
+    """evaluate() for the folds of one solver call, w_all [folds, n_lam, K, d] (k_major: [folds, K, n_lam * d], the
+    layout the prediction takes: no permuting copy).  A run of
     consecutive recordings of a single-rank sweep without input offset is ONE prediction launch
     with every recording under its own models (td_predict_fir_per_file), one window-sums and
     one scores launch (32 + 32 + 32 launches of ~120 workgroups at C5: 2 of the sweep's 19 ms);
@@ -295,20 +307,17 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
                all(held_used[f] > 0 for f in folds))
     if not batched:
       for fi, f in enumerate(folds):
-        evaluate(f, w_all[fi], b_all[fi])
+        evaluate(f, w_all[fi], b_all[fi], k_major)
       return
-    import torch
     x_all, _, y_all, offs = whole
     r0, r1 = int(offs[folds[0]]), int(offs[folds[-1] + 1])
     sub = [int(offs[f]) - r0 for f in folds] + [r1 - r0]
-    k = int(w_all.shape[2])
-    w_f = w_all.permute(0, 2, 1, 3).reshape(len(folds), k, n_lam * d).contiguous()
-    b_f = b_all.reshape(len(folds), n_lam * d).contiguous()
+    w_f = w_all if k_major else w_all.permute(0, 2, 1, 3).reshape(len(folds), int(w_all.shape[2]), n_lam * d).contiguous()
+    b_f = b_all.reshape(len(folds), n_lam * d)
     pred = dev.predict_fir_per_file(x_all[r0:r1], sub, w_f, b_f, dataset.pre, dataset.post, handle=h)
-    truth = tile_columns(y_all[r0:r1])
     # minibatches = the full windows of every recording (no offset: a recording's zipped stream
     # is the recording), each model scored on its own (groups of d columns)
-    sums = dev.window_sums(truth, pred, sub, bsz, bsz, handle=h)
+    sums = paired_sums(y_all[r0:r1], pred, sub)
     r = dev.window_scores(sums, bsz, mode=1, handle=h, group=d)[:, ::d]    # [minibatches, Lambda]
     scores.append((r, [held_used[f] // bsz for f in folds]))
 
@@ -409,7 +418,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
           fold_statistics(f, train)
       try:
         if by_terms:
-          out = dev.LagStats.ridge_solve_loso_terms(total, terms, lambdas, tol=PCG_TOL, handle=h)
+          out = dev.LagStats.ridge_solve_loso_terms(total, terms, lambdas, tol=PCG_TOL, handle=h, k_major=True)
         else:
           out = dev.LagStats.ridge_solve_loso(total, trains_all[:len(folds)], lambdas, tol=PCG_TOL, handle=h)
       except MemoryError:
@@ -419,7 +428,7 @@ def jackknife_over_regularizations(dataset, regularization_list=None, rank=0, wo
         break
       w_all_folds, b_all_folds, iters = out
       iters_max = max(iters_max, int(iters))
-      evaluate_folds(folds, w_all_folds, b_all_folds)
+      evaluate_folds(folds, w_all_folds, b_all_folds, k_major=by_terms)
       n_done += len(folds)
     if n_done:
       LAST_SWEEP.update(solver='pcg' if n_done == len(my_folds) else 'pcg+direct', iterations=iters_max,

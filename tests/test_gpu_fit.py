@@ -1749,6 +1749,12 @@ def test_loso_folds_as_terms_of_the_total(dev):
   out = dev.LagStats.ridge_solve_loso_terms(total, terms, lambdas, tol=1e-12, handle=h)
   assert out is not None, dev.LagStats.last_loso_status
   w, b, iters = out
+  # ... and with a fold's models as the output columns of one filter (what td_predict_fir_per_file takes)
+  w_km, b_km, _ = dev.LagStats.ridge_solve_loso_terms(total, terms, lambdas, tol=1e-12, handle=h, k_major=True)
+  assert tuple(w_km.shape) == (len(terms), c * (pre + 1 + post), len(lambdas) * d)
+  np.testing.assert_array_equal(w_km.cpu().numpy(),
+                                w.permute(0, 2, 1, 3).reshape(len(terms), -1, len(lambdas) * d).cpu().numpy())
+  np.testing.assert_array_equal(b_km.cpu().numpy(), b.cpu().numpy())
   w_ref, b_ref, flag = dev.LagStats.ridge_solve_multi(sums, lambdas, handle=h, wait=False)
   w, b, w_ref, b_ref = (t.cpu().numpy().astype(np.float64) for t in (w, b, w_ref, b_ref))
   assert flag() == 0 and 1 <= iters <= 40
