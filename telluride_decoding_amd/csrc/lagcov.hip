@@ -2341,6 +2341,10 @@ __global__ __launch_bounds__(kThreads) void lagcov_wave_kernel(LagParams p, doub
 constexpr int kTgtPrefetch = 16;     // steps (row pairs) of x in flight per wave
 constexpr int kTgtBody = 16;         // steps per flush (= the prefetch ring: static slots)
 constexpr int kTgtStrip = 4 * kWaveStrip;   // rows of one WORKGROUP's strip
+#ifndef TD_TGT_STRIP_MIN
+#define TD_TGT_STRIP_MIN 512
+#endif
+constexpr int kTgtStripMin = TD_TGT_STRIP_MIN;   // ... and the shortest the planner cuts (a short call: more, shorter strips)
 
 // Geometry of a wave's share of a strip, the same in both kernels.
 struct TgtStrip {
@@ -3822,7 +3826,7 @@ int td_lagcov_targets_plan(td_handle* h, const float* y, int64_t ldy, int d, con
   for (const LagSeg& sg : segs) total += sg.u_end > sg.u_begin ? sg.u_end - sg.u_begin : 0;
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
   long long t_strip = td_round_up(td_ceil_div(total > 0 ? total : 1, 4 * cus), 32);
-  t_strip = t_strip < 512 ? 512 : (t_strip > kTgtStrip ? kTgtStrip : t_strip);
+  t_strip = t_strip < kTgtStripMin ? kTgtStripMin : (t_strip > kTgtStrip ? kTgtStrip : t_strip);
   // strips of the column-sum kernel (one WAVE each): <= kWaveStrip rows, shorter when the call is
   // short, down to 128 (a strip streams 31 .. 62 rows more than it sums) -- 200k rows in strips of
   // 512 were 391 waves on 1024 SIMDs: 52 us for a 55 MB read

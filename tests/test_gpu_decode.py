@@ -981,3 +981,39 @@ def test_decode_fused_at_full_c4_size(dev, c):
                     max_score_err=worst)
   assert checked == len(subset) * per_trial and flips == 0
   assert worst <= 1e-5 * np.max(np.abs(scores))
+
+
+@pytest.mark.parametrize('cols,b_cols,width,hop', [(20, 1, 1000, 1000), (12, 2, 200, 100), (6, 3, 96, 32), (40, 1, 500, 250)])
+def test_window_sums_against_a_cycled_truth(dev, cols, b_cols, width, hop):
+  """td_window_sums_cycled (round 6): column j of `a` paired with column j % b_cols of `b` -- several models'
+  predictions against ONE truth (regression.py:197-214, the lambdas of a sweep as output columns) -- equals
+  td_window_sums against the tiled copy of b, bit for bit (the same kernels, the same order of additions)."""
+  import torch
+  h = dev.default_handle()
+  torch.manual_seed(cols)
+  lens = [3100, 1250, 2077]
+  offs = np.concatenate(([0], np.cumsum(lens)))
+  a = torch.randn(sum(lens), cols, device='cuda')
+  b = torch.randn(sum(lens), b_cols, device='cuda')
+  tiled = b.repeat(1, cols // b_cols).contiguous()
+  want = dev.window_sums(a, tiled, offs, width, hop, handle=h)
+  got = dev.window_sums(a, b, offs, width, hop, handle=h)
+  assert got.shape == want.shape and got.shape[0] > 0
+  assert torch.equal(got, want)
+  # float64 reference of one window
+  k = int(got.shape[0]) // 2
+  wo, _ = dev.window_layout(offs, width, hop)
+  t = max(i for i in range(len(lens)) if wo[i] <= k)
+  r0 = int(offs[t]) + (k - int(wo[t])) * hop
+  aa = a[r0:r0 + width].double().cpu().numpy(); bb = tiled[r0:r0 + width].double().cpu().numpy()
+  ref = np.stack([aa.sum(0), bb.sum(0), (aa * aa).sum(0), (bb * bb).sum(0), (aa * bb).sum(0)], axis=1)
+  np.testing.assert_allclose(got[k].cpu().numpy(), ref, rtol=1e-12, atol=1e-9)
+
+
+def test_window_sums_cycled_needs_a_common_block(dev):
+  """Windows without a common block of >= 32 frames: the cycled form is refused (ValueError), the caller tiles."""
+  import torch
+  h = dev.default_handle()
+  a = torch.randn(500, 4, device='cuda'); b = torch.randn(500, 1, device='cuda')
+  with pytest.raises(ValueError):
+    dev.window_sums(a, b, [0, 500], 10, 5, handle=h)

@@ -1774,6 +1774,14 @@ def test_loso_folds_as_terms_of_the_total(dev):
     regression.USE_TERMS, regression.USE_PCG = True, True
   np.testing.assert_allclose(runs['terms'], runs['sums'], rtol=0, atol=1e-7)
   np.testing.assert_allclose(runs['terms'], runs['direct'], rtol=0, atol=2e-6)
+  # the statistics objects went back to the dataset's pool, and a sweep on reused objects is the same sweep
+  pooled = len(ds.stats_pool(h, (c, pre, post, d)))
+  assert pooled >= len(files) + 1
+  again = regression.jackknife_over_regularizations(ds, lambdas)['all_runs']
+  np.testing.assert_array_equal(again, runs['terms'])
+  assert len(ds.stats_pool(h, (c, pre, post, d))) == pooled
+  ds.release_device()
+  assert len(ds.stats_pool(h, (c, pre, post, d))) == 0
 
 
 @pytest.mark.parametrize('lens,c,pre,post,d,off', [
