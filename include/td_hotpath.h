@@ -179,7 +179,10 @@ int td_stats_accumulate_parts(td_handle* h, td_stats* s, const float* x_dev, int
  * regression.py:151-242, refits on all files but one: every recording's statistics are needed on their own):
  * the files of x / y as in td_stats_accumulate, but file f is summed into each[f] -- freshly created or reset
  * regression statistics of one layout -- by ONE targets launch and ONE matrix launch over all the recordings
- * and a finalize launch per recording.  *handled = 0: a shape this form does not take (<= 32 or > 64
+ * and ONE finalize launch over all of them.  (The float16 matrix kernel scales a channel by its largest magnitude
+ * over ALL the recordings of the call: a recording whose amplitude is below 2^-9 of the largest one's loses low
+ * bits of its second piece -- 3 bits at a ratio of 1e-6; accumulate such recordings on their own.)
+ * *handled = 0: a shape this form does not take (<= 32 or > 64
  * channels, statistics that already hold data); nothing was queued, call td_stats_accumulate per file. */
 int td_stats_accumulate_each(td_handle* h, td_stats* const* each, const float* x_dev, int64_t ldx,
                              const float* y_dev, int64_t ldy, const int64_t* file_offsets_host, int num_files,
