@@ -616,10 +616,14 @@ __device__ __forceinline__ void tgt_tile(const unsigned* __restrict__ ap, const 
 // channel is a source channel of x read `shift` rows later) and its waves run the tasks of its
 // group's table instead of the fixed (tile pair, lag quad) of their wave number; the sums leave as
 // blocks of four lags [4][32][32] where the task says.  <= 32 channels and 65..128 channels.
-template <bool kVec4, int kBfRowDw, bool kF16, bool kTgt, bool kVirt = false>
+//
+// kKs (virtual images with <= 4 tasks: <= 16 channels): the waves kq = 0 .. kparts - 1 share a task, each runs
+// 8 / kparts of a tile's k-steps as one MFMA chain; their slab sums meet in LDS at the end (a fixed tree).
+template <bool kVec4, int kBfRowDw, bool kF16, bool kTgt, bool kVirt = false, bool kKs = false>
 __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   static_assert(kF16 || !kTgt, "targets ride along in the float16 form only");
   static_assert(!kVirt || (kF16 && !kTgt), "virtual images: the plain float16 form");
+  static_assert(!kKs || kVirt, "shared tasks: virtual images");
 #ifndef TD_F16_CHAIN
 #define TD_F16_CHAIN 8
 #endif
@@ -650,14 +654,20 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   bool active = true, a_ext = false;
   const VirtImage* img = nullptr;
   VirtSeg vs = {0, 0, 0};
+  int kparts = 1, kq = 0;                              // (kKs) the task's sharers and this wave's place
   if constexpr (kVirt) {
     const VirtGroup* vg = p.vgroups + group;
     const VirtTask tk = vg->task[wave];
     img = p.vimgs + vg->image;
     mt = tk.mt; nt = tk.nt; lag_off = tk.lag0; out_lag = tk.out_lag;
     active = out_lag >= 0; a_ext = tk.a_ext != 0;
+    if constexpr (kKs) {
+      kparts = __builtin_amdgcn_readfirstlane((int)tk.kparts);
+      kq = __builtin_amdgcn_readfirstlane((int)tk.kq);
+    }
     vs = p.vsegs[id];
   }
+  const int ksn = 8 / kparts, ks0 = kq * ksn;          // this wave's k-steps of a whole tile
 
   f32x16 total[4];                                     // [lag], the slab's sums
 #pragma unroll
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     const long long hi = v_any_role1 && vs.seg_end < w.a_valid ? vs.seg_end : w.a_valid;
     return ut + v_min_shift >= lo && ut + kBfRows + v_max_shift <= hi;
   };
-  auto prefetch = [&](long long ut) {
+  auto prefetch_to = [&](long long ut, float4 (&pfr)[6]) {
 #ifdef TD_ABL_NOSTAGE
     return;
 #endif
@@ -785,17 +795,17 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
         if (kVec4) {
           const int off = (4 * rg + v_sh(0)) * ld + (v_src(0) < 0 ? 0 : v_src(0));
 #pragma unroll
-          for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const float4*>(base + s * ld + off);
+          for (int s = 0; s < 4; ++s) pfr[s] = *reinterpret_cast<const float4*>(base + s * ld + off);
           if (has_tail) {
             const float* tb = base + kBfTile * ld;
             const int toff = off - 2 * rg * ld;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) pf[4 + s] = *reinterpret_cast<const float4*>(tb + s * ld + toff);
+            for (int s = 0; s < 2; ++s) pfr[4 + s] = *reinterpret_cast<const float4*>(tb + s * ld + toff);
           }
         } else {
           // lane = channel: a load instruction is (a contiguous run of) one row
           const int off = (2 * wave + v_sh(0)) * ld + (v_src(0) < 0 ? 0 : v_src(0));
-          float* pv = reinterpret_cast<float*>(&pf[0]);
+          float* pv = reinterpret_cast<float*>(&pfr[0]);
 #pragma unroll
           for (int j = 0; j < kVPairs; ++j) {
             pv[2 * j] = (base + 16 * j * ld)[off];
@@ -816,18 +826,18 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int rc = max(rlo, min(4 * rg + s + sh, rhi));
-          pf[s] = *reinterpret_cast<const float4*>(base + rc * ld + src);
+          pfr[s] = *reinterpret_cast<const float4*>(base + rc * ld + src);
         }
         if (has_tail) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const int rc = max(rlo, min(kBfTile + 2 * rg + s + sh, rhi));
-            pf[4 + s] = *reinterpret_cast<const float4*>(base + rc * ld + src);
+            pfr[4 + s] = *reinterpret_cast<const float4*>(base + rc * ld + src);
           }
         }
       } else {
         const int src = v_src(0) < 0 ? 0 : v_src(0), sh = v_sh(0);
-        float* pv = reinterpret_cast<float*>(&pf[0]);
+        float* pv = reinterpret_cast<float*>(&pfr[0]);
 #pragma unroll
         for (int j = 0; j < 2 * kVPairs; ++j) {
           const int r = 16 * (j >> 1) + 2 * wave + (j & 1);
@@ -842,29 +852,30 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
       const int ld = (int)p.lda;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        pf[s] = *reinterpret_cast<const float4*>(base + (4 * rg + s) * ld);
+        pfr[s] = *reinterpret_cast<const float4*>(base + (4 * rg + s) * ld);
       if (has_tail) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-          pf[4 + s] = *reinterpret_cast<const float4*>(base + (kBfTile + 2 * rg + s) * ld);
+          pfr[4 + s] = *reinterpret_cast<const float4*>(base + (kBfTile + 2 * rg + s) * ld);
       }
       return;
     }
     const RowWindow rw = row_window(p.a, p.lda, w.a_row0, ut, w.a_valid, 0, p.ca);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) pf[s] = load_row4_raw<kVec4>(rw, 4 * rg + s, c4);
+    for (int s = 0; s < 4; ++s) pfr[s] = load_row4_raw<kVec4>(rw, 4 * rg + s, c4);
     if (has_tail) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) pf[4 + s] = load_row4_raw<kVec4>(rw, kBfTile + 2 * rg + s, c4);
+      for (int s = 0; s < 2; ++s) pfr[4 + s] = load_row4_raw<kVec4>(rw, kBfTile + 2 * rg + s, c4);
     }
   };
-  auto store = [&](long long ut, unsigned* buf) {
+  auto prefetch = [&](long long ut) { prefetch_to(ut, pf); };
+  auto store_from = [&](long long ut, unsigned* buf, const float4 (&pfr)[6]) {
 #ifdef TD_ABL_NOSTAGE    // timing ablation: no staging at all (with prefetch below)
     return;
 #endif
     if constexpr (kVirt && !kVec4) {
       // lane = channel: the pairs of rows this wave fetched, two samples a dword
-      const float* pv = reinterpret_cast<const float*>(&pf[0]);
+      const float* pv = reinterpret_cast<const float*>(&pfr[0]);
       unsigned* dst = buf + lane * kBfRowDw + wave;
       if (vinside(ut)) {
 #pragma unroll
@@ -892,7 +903,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     }
     float4 v[6];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) v[s] = pf[s];
+    for (int s = 0; s < 6; ++s) v[s] = pfr[s];
     if constexpr (kVirt) {
       if (!vinside(ut))
 #pragma unroll
@@ -917,10 +928,10 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     if (!interior(ut)) {
       const RowWindow rw = row_window(p.a, p.lda, w.a_row0, ut, w.a_valid, 0, p.ca);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) v[s] = mask_row4(rw, 4 * rg + s, true, c4, pf[s]);
+      for (int s = 0; s < 4; ++s) v[s] = mask_row4(rw, 4 * rg + s, true, c4, pfr[s]);
       if (has_tail) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) v[4 + s] = mask_row4(rw, kBfTile + 2 * rg + s, true, c4, pf[4 + s]);
+        for (int s = 0; s < 2; ++s) v[4 + s] = mask_row4(rw, kBfTile + 2 * rg + s, true, c4, pfr[4 + s]);
       }
     }
 #pragma unroll
@@ -966,6 +977,7 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
       }
     }
   };
+  auto store = [&](long long ut, unsigned* buf) { store_from(ut, buf, pf); };
 
   const int lj = lane & 31, lg = lane >> 5;
   const int a_off = (mt * 32 + lj) * kBfRowDw + 4 * lg;
@@ -990,6 +1002,60 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
     __syncthreads();                                   // every wave is done with the last tile
     w = p.works[id];
     if constexpr (kVirt) vs = p.vsegs[id];
+  }
+  if constexpr (kKs) {
+    // Shared tasks: a wave's matrix work of a tile is short (8 / kparts k-steps), so the rows of a tile are
+    // fetched TWO tiles ahead (two register sets, the loop unrolled by two) -- one tile ahead the load latency
+    // was most of a tile's 3.3 us.
+    const long long u_stop = vs.u_end_ext;
+    float4 pf2[6];
+    prefetch_to(w.u_begin, pf);
+    store_from(w.u_begin, buf0, pf);
+    if (w.u_begin + kBfTile < u_stop) prefetch_to(w.u_begin + kBfTile, pf);
+    __syncthreads();
+    // tile at ut in `cur`; pfa holds the rows of the next tile, pfb takes those of the one after
+    auto ks_tile = [&](long long ut, const unsigned* cur, unsigned* nxt, float4 (&pfa)[6], float4 (&pfb)[6]) {
+      const bool more = ut + kBfTile < u_stop;
+      if (ut + 2 * kBfTile < u_stop) prefetch_to(ut + 2 * kBfTile, pfb);
+      long long left = (a_ext ? u_stop : w.u_end) - ut;
+      if (!active) left = 0;
+      const unsigned* ap = cur + a_off;
+      const unsigned* bp = cur + b_off;
+      if (left >= kBfTile) {
+        bf_kstep<true, kBfPieceDw, kF16>(ap + 8 * ks0, bp + 8 * ks0, nullptr, acc);
+        for (int s = ks0 + 1; s < ks0 + ksn; ++s)
+          bf_kstep<false, kBfPieceDw, kF16>(ap + 8 * s, bp + 8 * s, nullptr, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) total[r] += acc[r];
+      } else if (left > 16 * ks0) {
+        // the last, cut tile of a slab: A stops at nk
+        const int nk = (int)left;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[r][k] = 0.f;
+        const int t_hi = min(nk, 16 * (ks0 + ksn));
+        for (int t0 = 16 * ks0; t0 < t_hi; t0 += 16) {
+          const int cnt = nk - t0 - 8 * lg;            // may be <= 0 or >= 8
+          unsigned mask[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            mask[d] = cnt >= 2 * d + 2 ? 0xffffffffu : cnt == 2 * d + 1 ? 0x0000ffffu : 0u;
+          bf_kstep<false, kBfPieceDw, kF16>(ap + (t0 >> 1), bp + (t0 >> 1), mask, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) total[r] += acc[r];
+      }
+      if (more) {
+        store_from(ut + kBfTile, nxt, pfa);
+        __syncthreads();
+      }
+    };
+    for (long long ut = w.u_begin; ut < u_stop; ut += 2 * kBfTile) {
+      ks_tile(ut, buf0, buf1, pf, pf2);
+      if (ut + kBfTile < u_stop) ks_tile(ut + kBfTile, buf1, buf0, pf2, pf);
+    }
+    continue;
   }
   prefetch(w.u_begin);
   prefetch_y(w.u_begin);
@@ -1071,6 +1137,31 @@ __global__ __launch_bounds__(kBfThreads) void lagcov_split_kernel(LagParams p) {
   }   // work items of this workgroup
 
   // Epilogue: the wave's 32 x 32 block of its four lags in the workgroup's partial slab.
+  if constexpr (kKs) {
+    // the sharers of a task: (kq, kq + step) pairs through LDS, step = kparts / 2 .. 1 (wave = task * kparts + kq;
+    // at most four writers a round: 16 KB each)
+    float* const red = reinterpret_cast<float*>(ldsu);
+    const int task = wave / kparts;
+    for (int step = kparts >> 1; step >= 1; step >>= 1) {
+      __syncthreads();                                 // the tile buffers / the last round's sums are read
+      if (kq >= step && kq < 2 * step) {
+        float* dst = red + (size_t)(task * step + kq - step) * 4096 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) dst[(r * 16 + k) * 64] = total[r][k];
+      }
+      __syncthreads();
+      if (kq < step) {
+        const float* src = red + (size_t)(task * step + kq) * 4096 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) total[r][k] += src[(r * 16 + k) * 64];
+      }
+    }
+    active = active && kq == 0;
+  }
   if constexpr (kVirt) {
     if (active) {
       float* slab = p.partial + (size_t)part * p.slab_elems;
@@ -3230,8 +3321,8 @@ void virt_put(VirtImage& im, int tile, int col0, int ch0, int w, int shift, int 
 }
 VirtTask virt_task(int mt, int nt, bool a_ext, int lag0, int out_lag) {
   VirtTask t;
-  t.mt = (signed char)mt; t.nt = (signed char)nt; t.a_ext = a_ext ? 1 : 0; t.pad = 0;
-  t.lag0 = (short)lag0; t.pad2 = 0; t.out_lag = out_lag;
+  t.mt = (signed char)mt; t.nt = (signed char)nt; t.a_ext = a_ext ? 1 : 0; t.kparts = 1;
+  t.lag0 = (short)lag0; t.kq = 0; t.out_lag = out_lag;
   return t;
 }
 VirtPair virt_pair(int slot0, int E, int da, int db, int nsa, int nsb, int wa, int wb, int col_a, int col_b) {
@@ -3279,7 +3370,7 @@ void virt_add(std::vector<VirtTask>* tasks, int mt, int nt, bool a_ext, int E, i
 
 int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const std::vector<LagSeg>& segs,
                         int l, VirtPlan* plan) {
-  plan->ok = false;
+  plan->ok = false; plan->ksplit = false;
   plan->c = c; plan->l = l;
   if (h->acc_mode != TD_ACC_F16X2 || l < 1 || l > 64) return TD_OK;
   // (33 .. 64 channels: the plain kernel keeps whole aligned 64-channel rows -- its tile path has no
@@ -3313,6 +3404,26 @@ int td_lagcov_virt_plan(td_handle* h, const float* x, int64_t ldx, int c, const 
     plan->map.pair[0][0] = virt_pair(0, E, E, E * nsa, nsa, nsb, w, w, 0, 0);
     std::vector<VirtTask> tasks;
     virt_add(&tasks, 0, 1, nsa > 1, E, 0);
+    // <= 4 tasks (<= 16 channels at 32 lags: two): the eight waves share them, each wave takes a run of the
+    // tile's eight k-steps -- with two busy waves a tile cost 3.3 us, the matrix work of both 1.3
+    static const bool no_ks = td_dev_env("TD_VIRT_NO_KSPLIT") != nullptr;     // development: A/B runs
+    if (tasks.size() <= 4 && !no_ks) {
+      const int kparts = tasks.size() == 1 ? 8 : tasks.size() == 2 ? 4 : 2;
+      std::vector<VirtTask> shared;
+      for (const VirtTask& t : tasks)
+        for (int kq = 0; kq < kparts; ++kq) {
+          VirtTask s = t;
+          s.kparts = (signed char)kparts; s.kq = (short)kq;
+          shared.push_back(s);
+        }
+      while (shared.size() < 8) {
+        VirtTask idle = virt_task(0, 0, false, 0, -1);
+        idle.kparts = (signed char)kparts;
+        shared.push_back(idle);
+      }
+      tasks.swap(shared);
+      plan->ksplit = true;
+    }
     virt_groups(&plan->groups, 0, tasks);
     next_slot = E;
     ext = E * (nsa - 1);
@@ -3516,19 +3627,22 @@ int td_lagcov_virt_launch(td_handle* h, VirtPlan* plan, const float* x, int64_t 
   p.slab_elems = plan->slab_elems;
   p.chan_max = tab;
   if (!h->lds_opt_virt) {
-#define TD_VOPT(V, R)                                                                                   \
-    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_split_kernel<V, R, true, false, true>), \
+#define TD_VOPT(V, R, K)                                                                                \
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lagcov_split_kernel<V, R, true, false, true, K>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)BfGeom<R, 2>::kLdsBytes))
-    TD_VOPT(true, 83); TD_VOPT(false, 83); TD_VOPT(true, 99); TD_VOPT(false, 99);
+    TD_VOPT(true, 83, false); TD_VOPT(false, 83, false); TD_VOPT(true, 99, false); TD_VOPT(false, 99, false);
+    TD_VOPT(true, 83, true); TD_VOPT(false, 83, true); TD_VOPT(true, 99, true); TD_VOPT(false, 99, true);
 #undef TD_VOPT
     h->lds_opt_virt = true;
   }
   TD_TRY(td_profile_mark(h, true, (double)plan->total));
-#define TD_VLAUNCH(V, R)                                                                                \
-  hipLaunchKernelGGL((lagcov_split_kernel<V, R, true, false, true>), dim3((unsigned)plan->grid),        \
+#define TD_VLAUNCH(V, R, K)                                                                             \
+  hipLaunchKernelGGL((lagcov_split_kernel<V, R, true, false, true, K>), dim3((unsigned)plan->grid),     \
                      dim3(kBfThreads), (BfGeom<R, 2>::kLdsBytes), h->stream, p)
-  if (plan->rowdw == 83) { if (plan->vec4) TD_VLAUNCH(true, 83); else TD_VLAUNCH(false, 83); }
-  else                   { if (plan->vec4) TD_VLAUNCH(true, 99); else TD_VLAUNCH(false, 99); }
+#define TD_VLAUNCH_K(V, R) do { if (plan->ksplit) TD_VLAUNCH(V, R, true); else TD_VLAUNCH(V, R, false); } while (0)
+  if (plan->rowdw == 83) { if (plan->vec4) TD_VLAUNCH_K(true, 83); else TD_VLAUNCH_K(false, 83); }
+  else                   { if (plan->vec4) TD_VLAUNCH_K(true, 99); else TD_VLAUNCH_K(false, 99); }
+#undef TD_VLAUNCH_K
 #undef TD_VLAUNCH
   TD_TRY(td_profile_mark(h, false, 0.0));
   TD_HIP(h, hipGetLastError());

@@ -367,9 +367,9 @@ struct VirtImage {
 struct VirtTask {
   signed char mt, nt;    // A / B tile of the image (0 or 1)
   signed char a_ext;     // the A tile holds role-1 copies: run over the extended range
-  signed char pad;
-  short lag0;            // first of the task's four lags (even)
-  short pad2;
+  signed char kparts;    // 1, or 2 / 4 / 8: the waves kq = 0 .. kparts - 1 share the task, each takes 8 / kparts
+  short lag0;            // first of the task's four lags (even)       // of a tile's k-steps (the same for a whole group)
+  short kq;
   int out_lag;           // slab entry of lag0 (units of 32 x 32 floats), -1: the wave idles
 };
 struct VirtGroup {
@@ -476,6 +476,7 @@ struct VirtPlan {
   bool ok = false;
   int c = 0, l = 0, rowdw = 83, n_part = 0, ext = 0;
   bool vec4 = false;
+  bool ksplit = false;           // every group's waves share their tasks' k-steps (VirtTask::kparts > 1)
   std::vector<VirtImage> images;
   std::vector<VirtGroup> groups;
   VirtMap map;
