@@ -301,6 +301,8 @@ int td_set_solver(td_handle* h, int mode);
  *   "cca_whitening"   0 (default) td_cca_solve whitens the large side by its Cholesky factor when the
  *                     inertia certificate allows; 1 = always the eigen-decomposition the reference calls
  *                     (cca.py:345-360);
+ *   "cca_fused"       1 (default): td_cca_solve runs the dense stage of a small problem (K1 <= 64, K2 <= 16,
+ *                     K2 <= K1) as ONE launch of one workgroup; 0: the chain of launches (A/B runs);
  *   "cg_limit_ticks"  the conjugate-gradient kernel's wait limit per launch in 10 ns ticks (< 0: the
  *                     default, 20 ms; 0: every workgroup gives up at its first empty poll -- the abort /
  *                     drain / Cholesky-fallback route, for tests).
@@ -436,7 +438,8 @@ int td_cca_transform(td_handle* h, const float* x_dev, int64_t ldx, int c1, int 
  *   info_host (may be NULL, else int[4]) receives the Jacobi sweep counts {eig xx, eig yy, svd}
  *   and in [3] which sides were whitened by a Cholesky factor instead of the eigen-decomposition
  *   (any whitening gives the same canonical directions when no eigenvalue is dropped): bit 0 the
- *   x side, bit 1 the other side (17 .. 64 columns).
+ *   x side, bit 1 the other side (17 .. 64 columns); bit 2: the whole stage ran as ONE launch (K1 <= 64,
+ *   K2 <= 16, K2 <= K1 and a Cholesky factor exists; td_set_option "cca_fused").
  * Singular vectors are defined up to a joint sign of (rot_x[:, i], rot_y[:, i]). */
 int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization, double eps_eig,
                  int dim, float* rot_x_dev, float* rot_y_dev, float* mean_x_dev, float* mean_y_dev,

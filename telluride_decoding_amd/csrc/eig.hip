@@ -31,19 +31,19 @@
 #include <cstdlib>
 
 #include "td_common.h"
+#include "td_tile64.h"
 
 int td_stats_dims(const td_stats* s, int* k1, int* k2, int64_t* frames);
+int td_stats_cca_direct(td_handle* h, td_stats* s, const double** xx, const double** yy, const double** xy,
+                        const double** sum1, const double** sum2, int* ok);
 
 namespace {
 
-constexpr int NB = 64;
-constexpr int LS = NB + 2;    // LDS row stride in doubles
+using namespace td_tile64;    // NB = 64, LS = NB + 2 (LDS row stride in doubles), f64x4, factor_inv_tile
 constexpr int HB = 32;        // block-Jacobi block width (a pair = one 64x64 sub-problem)
 constexpr double kRotTol = 1e-15;
 constexpr int kMaxOuterSweeps = 40;
 constexpr int kMaxInnerSweeps = 1;
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // acc += As . Bs^T (64x64x64) on the float64 matrix cores; wave w owns the 32x32 quadrant
 // (w >> 1, w & 1).  Operand lane map: A[i = lane & 15][k = lane >> 4]; C/D: col = lane & 15,
@@ -152,8 +152,13 @@ int gemm(td_handle* h, const double* a, int lda, bool ta, const double* b, int l
 __device__ __forceinline__ void rr_pair(int players, int round, int k, int* p, int* q) {
   const int m = players - 1;
   int a, b;
+  // (round < m and 0 < k < m: one conditional subtraction each -- an integer division is ~40 instructions, and the
+  //  one-wave solver below asks for four pairs per round)
   if (k == 0) { a = round; b = m; }
-  else { a = (round + k) % m; b = (round + m - k) % m; }
+  else {
+    a = round + k; a = a >= m ? a - m : a;
+    b = round + m - k; b = b >= m ? b - m : b;
+  }
   *p = a < b ? a : b;
   *q = a < b ? b : a;
 }
@@ -917,6 +922,394 @@ __global__ void transpose_kernel(const double* __restrict__ src, int rows, int c
   }
 }
 
+// ---- the dense stage of a SMALL CCA in one launch ----------------------------------------------------
+// C3 (64 EEG channels against 8 envelope bands, no context): the dense stage below is a chain of ~26 dependent
+// launches and a host round trip for the factorisation's verdict -- 0.22 ms of launch latency around three
+// single-workgroup kernels (64 x 64 Cholesky 19 us, 8 x 8 Jacobi 38, 8 x 64 SVD 55), most of a 0.34 ms fit.
+// With k1 <= 64 and k2 <= 16 everything fits the LDS of ONE workgroup: covariances, the Cholesky factor of
+// cov_xx + reg I with its inverse (factor_inv_tile: substitutions become triangular products), the Jacobi
+// eigen-decomposition of the small side, T, its one-sided Jacobi SVD, both rotations.  Same arithmetic
+// and the same decisions as the chain (the inertia certificate, the pivot tolerance, the rotation
+// threshold); a matrix without a factor leaves status = 1 and the chain below decides.
+struct CcaSmallParams {
+  const double* xtx; int ld1;       // [k1][ld1]: sum x x^T
+  const double* x2tx2;              // [k2][k2]
+  const double* xtx2;               // [k1][k2]
+  const double* sum1;               // [k1] column sums
+  const double* sum2;               // [k2]
+  int k1, k2, dim;
+  double inv_d, inv_f, reg, eps;
+  int certificate;                  // 1: cov_xx + (reg - eps) I must have a factor too (td_cca_solve, proof 2)
+  int max_sweeps;
+  float *rot_x, *rot_y, *mean_x, *mean_y, *e;
+  int* status;                      // [0] = 0: done, 1: no factor (always written)
+};
+constexpr int kCsLd = 17;           // row stride of the <= 16 x 16 matrices
+
+// The rotation of jacobi_rotation from two reciprocal square roots and no division (the parameters are the serial
+// path of every round of the one-wave solver below): with h = hypot(d, b), c^2 = (1 + |d| / h) / 2 and
+// s = sign(d) b / (2 h c) -- the same small-angle root, c^2 + s^2 = 1 to rounding.
+__device__ __forceinline__ bool jacobi_rotation_rs(double app, double aqq, double apq, double* c, double* s) {
+  *c = 1.0; *s = 0.0;
+  const double mag2 = apq * apq;
+  if (!(mag2 > 1e-290 && mag2 > (kRotTol * kRotTol) * fabs(app * aqq))) return false;
+  const double d = aqq - app, b = 2.0 * apq;
+  const double rh = fast_rsqrt(d * d + b * b);
+  const double x2 = 0.5 + 0.5 * fabs(d) * rh;
+  const double r2 = fast_rsqrt(x2);
+  *c = x2 * r2;
+  *s = (d >= 0.0 ? 0.5 : -0.5) * b * rh * r2;
+  return true;
+}
+
+// Cyclic Jacobi of a symmetric n x n matrix (n <= 16, LDS, stride kCsLd) by ONE wave: round-robin pairs as
+// jacobi64_kernel's direct mode.  Lane (ki, kj) owns the 2 x 2 block of S <- R^T S R of the pairs ki, kj --
+// its four entries are requested first; the diagonal lanes (ki == kj) then take their pair's rotation from
+// theirs and hand (c, s) round by lane shuffles -- and two (row, pair) items of J <- J R.  Two LDS round trips
+// and one rotation per round, no workgroup barrier.  S ends as the diagonal, J as the eigenvectors (columns).
+__device__ __forceinline__ void jacobi_wave16(double* S, double* J, int n, int max_sweeps, int lane) {
+  const int players = n + (n & 1) < 2 ? 2 : n + (n & 1);
+  const int npairs = players / 2;
+  const bool blk = lane < npairs * npairs;
+  const int ki = blk ? lane / npairs : 0, kj = blk ? lane % npairs : 0;
+  // J items: (row, pair) = lane and lane + 64 of players * npairs
+  const int it1 = lane + 64;
+  const bool j0 = lane < players * npairs, j1 = it1 < players * npairs;
+  const int row0 = j0 ? lane / npairs : 0, kc0 = j0 ? lane % npairs : 0;
+  const int row1 = j1 ? it1 / npairs : 0, kc1 = j1 ? it1 % npairs : 0;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    int any = 0;
+    for (int round = 0; round < players - 1; ++round) {
+      int pi, qi, pj, qj, p0, q0, p1, q1;
+      rr_pair(players, round, ki, &pi, &qi);
+      rr_pair(players, round, kj, &pj, &qj);
+      rr_pair(players, round, kc0, &p0, &q0);
+      rr_pair(players, round, kc1, &p1, &q1);
+      const double a00 = S[pi * kCsLd + pj], a01 = S[pi * kCsLd + qj];
+      const double a10 = S[qi * kCsLd + pj], a11 = S[qi * kCsLd + qj];
+      const double jp0 = J[row0 * kCsLd + p0], jq0 = J[row0 * kCsLd + q0];
+      const double jp1 = J[row1 * kCsLd + p1], jq1 = J[row1 * kCsLd + q1];
+      double c = 1.0, sn = 0.0;
+      bool rotated = false;
+      if (blk && ki == kj) rotated = jacobi_rotation_rs(a00, a11, a01, &c, &sn);
+      if (!__any(rotated)) continue;                   // (wave-uniform)
+      any = 1;
+      const int di = ki * npairs + ki, dj = kj * npairs + kj;
+      const double ci = __shfl(c, di, 64), si = __shfl(sn, di, 64);
+      const double cj = __shfl(c, dj, 64), sj = __shfl(sn, dj, 64);
+      const int d0 = kc0 * npairs + kc0, d1 = kc1 * npairs + kc1;
+      const double c0 = __shfl(c, d0, 64), s0 = __shfl(sn, d0, 64);
+      const double c1 = __shfl(c, d1, 64), s1 = __shfl(sn, d1, 64);
+      if (blk) {
+        // columns: [x_p x_q] <- [c x_p - s x_q, s x_p + c x_q]; rows the same with (ci, si)
+        const double b00 = cj * a00 - sj * a01, b01 = sj * a00 + cj * a01;
+        const double b10 = cj * a10 - sj * a11, b11 = sj * a10 + cj * a11;
+        S[pi * kCsLd + pj] = ci * b00 - si * b10;
+        S[pi * kCsLd + qj] = ci * b01 - si * b11;
+        S[qi * kCsLd + pj] = si * b00 + ci * b10;
+        S[qi * kCsLd + qj] = si * b01 + ci * b11;
+      }
+      if (j0) {
+        J[row0 * kCsLd + p0] = c0 * jp0 - s0 * jq0;
+        J[row0 * kCsLd + q0] = s0 * jp0 + c0 * jq0;
+      }
+      if (j1) {
+        J[row1 * kCsLd + p1] = c1 * jp1 - s1 * jq1;
+        J[row1 * kCsLd + q1] = s1 * jp1 + c1 * jq1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (!any) break;
+  }
+}
+constexpr int kCsGs = 65;           // ... of the SVD's vectors (length <= 64)
+constexpr size_t kCcaSmallDoubles = 2 * NB * LS + kFactorScratch + 4 * 16 * LS + 6 * 16 * kCsLd + 16 * kCsGs + 16 + 256;
+
+__global__ __launch_bounds__(256) void cca_small_kernel(CcaSmallParams P) {
+  extern __shared__ double sm[];
+  double* at = sm;                       // cov_xx -> L
+  double* wt = at + NB * LS;             // L^-1
+  double* sc = wt + NB * LS;
+  double* yt = sc + kFactorScratch;      // [k2][LS]: (L^-1 cov_xy)^T rows
+  double* un = yt + 16 * LS;             // [16][LS]: cov_xy^T rows, later the unit vectors of the x side
+  double* s2 = un + 16 * LS;             // [16][kCsLd] cov_yy + reg I -> diagonal
+  double* j2 = s2 + 16 * kCsLd;          // eigenvectors -> W = V f(lambda)
+  double* k22 = j2 + 16 * kCsLd;         // W W^T
+  double* vs = k22 + 16 * kCsLd;         // rotations of the SVD
+  double* vn = vs + 16 * kCsLd;          // its leading rows
+  double* gg = vn + 16 * kCsLd;          // T^T T -> its eigenvalues
+  double* y16a = gg + 16 * kCsLd;        // [16][LS]: cov_yy + reg I, identity-padded -> its Cholesky factor
+  double* y16w = y16a + 16 * LS;         // ... and the factor's inverse
+  double* gs = y16w + 16 * LS;           // [k2][kCsGs]: T^T rows
+  double* norms = gs + 16 * kCsGs;       // [16]
+  double* red = norms + 16;              // [256]
+  __shared__ int flag, nrot, ychol;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k1 = P.k1, k2 = P.k2, dim = P.dim;
+  const double* sum1 = P.sum1;
+#ifdef TD_CCA_STAMPS      // development: where the launch's time goes (100 MHz ticks behind the status word)
+#define TD_STAMP(i) do { if (tid == 0) reinterpret_cast<long long*>(P.status + 16)[i] = wall_clock64(); } while (0)
+#else
+#define TD_STAMP(i) do { } while (0)
+#endif
+  TD_STAMP(0);
+  if (tid < k1) P.mean_x[tid] = (float)(sum1[tid] * P.inv_f);
+  if (tid < k2) P.mean_y[tid] = (float)(P.sum2[tid] * P.inv_f);
+  if (tid == 0) flag = 0;
+  // cov_xx + (reg + shift) I, identity-padded on its own scale, and the pivot tolerance (diag_tol_kernel)
+  auto factor = [&](double shift) -> bool {
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      double v = 0.0;
+      if (r < k1 && c < k1)
+        v = P.xtx[(size_t)r * P.ld1 + c] * P.inv_d - (sum1[r] * P.inv_f) * (sum1[c] * P.inv_f) +
+            (r == c ? P.reg + shift : 0.0);
+      at[r * LS + c] = v;
+    }
+    __syncthreads();
+    red[tid] = tid < k1 ? fabs(at[tid * LS + tid]) : 0.0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
+      __syncthreads();
+    }
+    const double top = red[0];
+    const double tol = 64.0 * k1 * 2.220446049250313e-16 * top;
+    if (tid >= k1 && tid < NB) at[tid * LS + tid] = top > 0.0 ? top : 1.0;
+    __syncthreads();
+    factor_inv_tile(at, wt, sc, tid, &flag, tol);
+    return flag == 0;
+  };
+  if (P.certificate && !factor(-P.eps)) { if (tid == 0) P.status[0] = 1; return; }
+  if (!factor(0.0)) { if (tid == 0) P.status[0] = 1; return; }
+  TD_STAMP(1);
+  // ---- cov_xy^T as rows, cov_yy + reg I and the identity
+  for (int idx = tid; idx < k2 * NB; idx += 256) {
+    const int q = idx >> 6, m = idx & 63;
+    un[q * LS + m] = m < k1 ? P.xtx2[(size_t)m * k2 + q] * P.inv_d - (sum1[m] * P.inv_f) * (P.sum2[q] * P.inv_f) : 0.0;
+  }
+  for (int idx = tid; idx < 16 * 16; idx += 256) {
+    const int r = idx >> 4, c = idx & 15;
+    double v = 0.0;
+    if (r < k2 && c < k2)
+      v = P.x2tx2[(size_t)r * k2 + c] * P.inv_d - (P.sum2[r] * P.inv_f) * (P.sum2[c] * P.inv_f) + (r == c ? P.reg : 0.0);
+    s2[r * kCsLd + c] = v;
+    j2[r * kCsLd + c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // ---- wave 0: the whitening W_y of the small side (W_y C_yy W_y^T = I) -- the inverse of its Cholesky factor
+  //      when nothing can be dropped (the two proofs of td_cca_solve, as for the x side), else the reference's
+  //      symmetric V f(lambda) V^T from the Jacobi eigen-decomposition (eigenvalues <= eps dropped);
+  //      waves 1-3: (L^-1 cov_xy)^T as rows, yt[q][i] = sum_{m <= i} Linv[i][m] cov_xy[m][q]
+  if (wave == 0) {
+    double top = lane < k2 ? fabs(s2[lane * kCsLd + lane]) : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) top = fmax(top, __shfl_xor(top, off, 64));
+    bool ok = true;
+    for (int pass = P.certificate ? 0 : 1; pass < 2 && ok; ++pass) {
+      const double shift = pass == 0 ? -P.eps : 0.0;
+      const double top_s = fabs(top + shift) > 0.0 ? fabs(top + shift) : 1.0;     // (the scale of the padding only)
+      for (int idx = lane; idx < 16 * 16; idx += 64) {
+        const int r = idx >> 4, c = idx & 15;
+        y16a[r * LS + c] = (r < k2 && c < k2) ? s2[r * kCsLd + c] + (r == c ? shift : 0.0) : (r == c ? top_s : 0.0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double pmin = factor_inv_16(y16a, y16w, sc, lane);
+      ok = pmin > 64.0 * k2 * 2.220446049250313e-16 * top_s;
+    }
+    if (ok) {
+      for (int idx = lane; idx < 16 * 16; idx += 64) k22[(idx >> 4) * kCsLd + (idx & 15)] = y16w[(idx >> 4) * LS + (idx & 15)];
+    } else {
+      jacobi_wave16(s2, j2, k2, P.max_sweeps, lane);
+    }
+    if (lane == 0) ychol = ok ? 1 : 0;
+  } else {
+    for (int idx = tid - 64; idx < k2 * NB; idx += 192) {
+      const int q = idx >> 6, i = idx & 63;
+      // (Linv is lower triangular with exact zeros above: the whole row, four chains, no ragged trip counts)
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int m = 0; m < NB; m += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += wt[i * LS + m + u] * un[q * LS + m + u];
+      yt[q * LS + i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+  }
+  __syncthreads();
+  TD_STAMP(2);
+  if (!ychol) {
+    // W = V f(lambda), f = lambda^-1/4 above eps, else 0 (cca.py:345-352); K22 = W W^T
+    if (tid < k2 * k2) {
+      const int r = tid / k2, c = tid % k2;
+      const double lam = s2[c * kCsLd + c];
+      vs[r * kCsLd + c] = lam > P.eps ? j2[r * kCsLd + c] / sqrt(sqrt(lam)) : 0.0;
+    }
+    __syncthreads();
+    if (tid < k2 * k2) {
+      const int r = tid / k2, c = tid % k2;
+      double acc = 0.0;
+      for (int m = 0; m < k2; ++m) acc += vs[r * kCsLd + m] * vs[c * kCsLd + m];
+      k22[r * kCsLd + c] = acc;
+    }
+    __syncthreads();
+  }
+  // ---- T^T [k2][k1] = K22 (L^-1 cov_xy)^T: the vectors whose SVD is wanted
+  for (int idx = tid; idx < k2 * NB; idx += 256) {
+    const int q = idx >> 6, i = idx & 63;
+    if (i < k1) {
+      double acc = 0.0;
+      for (int m = 0; m < k2; ++m) acc += k22[q * kCsLd + m] * yt[m * LS + i];
+      gs[q * kCsGs + i] = acc;
+    }
+  }
+  if (tid < 16 * 16) vs[(tid >> 4) * kCsLd + (tid & 15)] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+  __syncthreads();
+  const int k = k2, m = k1, kp = k + (k & 1);
+  TD_STAMP(3);
+  // ---- the SVD through the k x k Gram matrix G = T^T T (jacobi_svd's route for long vectors): its eigenvalues
+  // are the squared singular values, its eigenvectors the rotation side, the other side follows as
+  // combinations of the rows.  The squaring costs relative accuracy ~eps (s_1 / s_i)^2 on the small ones: taken
+  // when the dim-th eigenvalue is above 1e-8 of the first (2e-8 at worst, float32 outputs), else the one-sided
+  // rounds below.
+  bool gram_ok = false;
+  if (k > 1 && m >= 4 * k) {
+    if (tid < 16 * 16) {
+      const int r = tid >> 4, c = tid & 15;
+      double acc = 0.0;
+      if (r < k && c < k) {
+#pragma unroll 8
+        for (int t = 0; t < m; ++t) acc += gs[r * kCsGs + t] * gs[c * kCsGs + t];
+      }
+      gg[r * kCsLd + c] = acc;
+    }
+    __syncthreads();
+    if (wave == 0) jacobi_wave16(gg, vs, k, P.max_sweeps, lane);
+    __syncthreads();
+    // lane i: eigenvalue i and its place in descending order (ties: lower index first)
+    const double li = lane < k ? gg[lane * kCsLd + lane] : 0.0;
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const double lj = gg[j * kCsLd + j];
+      rank += (lj > li || (lj == li && j < lane)) ? 1 : 0;
+    }
+    const unsigned long long first = __ballot(lane < k && rank == 0), last = __ballot(lane < k && rank == dim - 1);
+    const double top = __shfl(li, __ffsll((long long)first) - 1, 64), low = __shfl(li, __ffsll((long long)last) - 1, 64);
+    gram_ok = top > 0.0 && low > 1e-8 * top;
+    TD_STAMP(4);
+    if (gram_ok) {
+      for (int want = wave; want < dim; want += 4) {
+        const int pick = __ffsll((long long)__ballot(lane < k && rank == want)) - 1;
+        const double lam = __shfl(li, pick, 64);
+        const double sv = lam > 0.0 ? sqrt(lam) : 0.0;
+        const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
+        if (lane == 0) P.e[want] = (float)sv;
+        double acc = 0.0;
+        if (lane < m)
+          for (int t = 0; t < k; ++t) acc += vs[t * kCsLd + pick] * gs[t * kCsGs + lane];
+        un[want * LS + lane] = acc * inv;
+        if (lane < k) vn[want * kCsLd + lane] = vs[lane * kCsLd + pick];
+      }
+    }
+  }
+  if (!gram_ok) {
+    // ---- one-sided Jacobi (svd_small_kernel): a wave per pair, rotations accumulated in vs
+    __syncthreads();
+    if (tid < 16 * 16) vs[(tid >> 4) * kCsLd + (tid & 15)] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < P.max_sweeps && k > 1; ++sweep) {
+      __syncthreads();
+      if (tid == 0) nrot = 0;
+      for (int round = 0; round < kp - 1; ++round) {
+        __syncthreads();
+        for (int pair = wave; pair < kp / 2; pair += 4) {
+          int i, j;
+          rr_pair(kp, round, pair, &i, &j);
+          if (j >= k) continue;
+          double* gi = gs + (size_t)i * kCsGs;
+          double* gj = gs + (size_t)j * kCsGs;
+          double al = 0.0, be = 0.0, ga = 0.0;
+          for (int t = lane; t < m; t += 64) {
+            const double x = gi[t], y = gj[t];
+            al += x * x; be += y * y; ga += x * y;
+          }
+          al = wave_sum64(al); be = wave_sum64(be); ga = wave_sum64(ga);
+          const double mag = fabs(ga);
+          if (!(mag > 1e-290 && mag > kRotTol * sqrt(al * be))) continue;
+          const double tau = (be - al) / (2.0 * ga);
+          const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double c = 1.0 / sqrt(1.0 + tt * tt), sv = tt * c;
+          for (int t = lane; t < m; t += 64) {
+            const double x = gi[t], y = gj[t];
+            gi[t] = c * x - sv * y;
+            gj[t] = sv * x + c * y;
+          }
+          double* vi = vs + (size_t)i * kCsLd;
+          double* vj = vs + (size_t)j * kCsLd;
+          for (int t = lane; t < k; t += 64) {
+            const double x = vi[t], y = vj[t];
+            vi[t] = c * x - sv * y;
+            vj[t] = sv * x + c * y;
+          }
+          if (lane == 0) atomicAdd(&nrot, 1);
+        }
+      }
+      __syncthreads();
+      const int done = nrot;
+      if (done == 0) break;
+    }
+    __syncthreads();
+    for (int i = wave; i < k; i += 4) {
+      double al = 0.0;
+      for (int t = lane; t < m; t += 64) al += gs[(size_t)i * kCsGs + t] * gs[(size_t)i * kCsGs + t];
+      al = wave_sum64(al);
+      if (lane == 0) norms[i] = sqrt(al);
+    }
+    __syncthreads();
+    // the dim largest singular values, descending (ties: lower index first), with their unit vectors
+    for (int want = wave; want < dim; want += 4) {
+      int pick = 0;
+      for (int i = 0; i < k; ++i) {
+        const double si = norms[i];
+        int rank = 0;
+        for (int j = 0; j < k; ++j) rank += (norms[j] > si || (norms[j] == si && j < i)) ? 1 : 0;
+        if (rank == want) pick = i;
+      }
+      const double sv = norms[pick];
+      const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
+      if (lane == 0) P.e[want] = (float)sv;
+      un[want * LS + lane] = lane < m ? gs[(size_t)pick * kCsGs + lane] * inv : 0.0;
+      if (lane < k) vn[want * kCsLd + lane] = vs[(size_t)pick * kCsLd + lane];
+    }
+  }
+  __syncthreads();
+  TD_STAMP(5);
+  // ---- rot_x [k1][dim] = L^-T u, rot_y [k2][dim] = K22 v
+  for (int idx = tid; idx < dim * NB; idx += 256) {
+    const int d = idx >> 6, i = idx & 63;
+    if (i < k1) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};          // (rows above i of column i of Linv are exact zeros)
+#pragma unroll 4
+      for (int mm = 0; mm < NB; mm += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += wt[(mm + u) * LS + i] * un[d * LS + mm + u];
+      P.rot_x[(size_t)i * dim + d] = (float)((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    }
+  }
+  for (int idx = tid; idx < dim * k2; idx += 256) {
+    const int d = idx / k2, j = idx % k2;
+    double acc = 0.0;
+    for (int mm = 0; mm < k2; ++mm) acc += vn[d * kCsLd + mm] * k22[mm * kCsLd + j];
+    P.rot_y[(size_t)j * dim + d] = (float)acc;
+  }
+  if (tid == 0) P.status[0] = 0;
+  TD_STAMP(6);
+#undef TD_STAMP
+}
+
 struct Carver {
   char* p;
   explicit Carver(void* base) : p(reinterpret_cast<char*>(base)) {}
@@ -1023,8 +1416,58 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   void* base = nullptr;
   TD_TRY(td_workspace(h, carve(nullptr), &base));
   carve(base);
-  TD_TRY(td_stats_moments(h, s, w.xtx, nullptr, w.x2tx2, w.xtx2, w.sum2));
   const double inv_d = 1.0 / denom, inv_f = 1.0 / (double)frames;
+  // (td_set_option(h, "cca_whitening", 1): always the reference's eigen route)
+  const bool force_eig = h->cca_whitening == 1;
+  const bool psd_proof = regularization > 2.0 * eps_eig && denom <= (double)frames;   // (see below)
+  const bool one_launch = k1 <= NB && k2 <= 16 && cols && !force_eig && h->cca_fused;
+  // the dense moments: where the statistics keep them (no context: td_stats_cca_direct) or expanded
+  const double *m_xx = nullptr, *m_yy = nullptr, *m_xy = nullptr, *m_s1 = nullptr, *m_s2 = nullptr;
+  int direct = 0, ld_xx = (int)n1;
+  if (one_launch) TD_TRY(td_stats_cca_direct(h, s, &m_xx, &m_yy, &m_xy, &m_s1, &m_s2, &direct));
+  if (direct) ld_xx = k1;
+  bool have_moments = false;
+  if (!direct) {
+    TD_TRY(td_stats_moments(h, s, w.xtx, nullptr, w.x2tx2, w.xtx2, w.sum2));
+    have_moments = true;
+    m_xx = w.xtx; m_yy = w.x2tx2; m_xy = w.xtx2; m_s1 = w.xtx + (size_t)k1 * n1; m_s2 = w.sum2;
+  }
+  if (one_launch) {
+    // the whole dense stage in one launch (cca_small_kernel); status 1 = no Cholesky factor: the chain decides
+    if (!h->lds_opt_cca) {
+      TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&cca_small_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(double) * kCcaSmallDoubles)));
+      h->lds_opt_cca = true;
+    }
+    CcaSmallParams P;
+    P.xtx = m_xx; P.ld1 = ld_xx; P.x2tx2 = m_yy; P.xtx2 = m_xy; P.sum1 = m_s1; P.sum2 = m_s2;
+    P.k1 = k1; P.k2 = k2; P.dim = dim;
+    P.inv_d = inv_d; P.inv_f = inv_f; P.reg = regularization; P.eps = eps_eig;
+    P.certificate = psd_proof ? 0 : 1;
+    P.max_sweeps = kMaxOuterSweeps;
+    P.rot_x = rot_x_dev; P.rot_y = rot_y_dev; P.mean_x = mean_x_dev; P.mean_y = mean_y_dev; P.e = e_dev;
+    P.status = h->dev_flag;
+    hipLaunchKernelGGL(cca_small_kernel, dim3(1), dim3(256), sizeof(double) * kCcaSmallDoubles, h->stream, P);
+    TD_HIP(h, hipGetLastError());
+    int status = 0;
+    TD_HIP(h, hipMemcpyAsync(&status, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    TD_HIP(h, hipStreamSynchronize(h->stream));
+#ifdef TD_CCA_STAMPS
+    {
+      long long st[7];
+      hipMemcpy(st, h->dev_flag + 16, sizeof(st), hipMemcpyDeviceToHost);
+      fprintf(stderr, "cca_small_kernel (us): factor %.1f  eig yy | forward %.1f  K22, T %.1f  gram + eig %.1f  extract / rounds %.1f  rotations %.1f\n",
+              (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0, (st[4] - st[3]) / 100.0,
+              (st[5] - st[4]) / 100.0, (st[6] - st[5]) / 100.0);
+    }
+#endif
+    if (status == 0) {
+      if (info_host) { info_host[0] = info_host[1] = info_host[2] = 0; info_host[3] = 1 | 4; }   // bit 2: one launch
+      return TD_OK;
+    }
+  }
+  if (!have_moments) TD_TRY(td_stats_moments(h, s, w.xtx, nullptr, w.x2tx2, w.xtx2, w.sum2));
   const double* sum1 = w.xtx + (size_t)k1 * n1;        // the ones row of sum_xtx = column sums
   hipLaunchKernelGGL(cov_kernel, dim3(grid_for((long long)k1 * k1)), dim3(256), 0, h->stream, w.xtx,
                      (int)n1, k1, k1, sum1, sum1, inv_d, inv_f, regularization, w.cxx);
@@ -1057,10 +1500,7 @@ int td_cca_solve(td_handle* h, td_stats* s, double denom, double regularization,
   // (every pivot above the rounding tolerance of td_chol_factor) the reference's filter keeps
   // every eigenvalue.  One extra factorisation (4 ms at K1 = 2553) instead of the Jacobi
   // eigen-decomposition (0.2-0.3 s) -- which still decides whenever the certificate fails.
-  // (td_set_option(h, "cca_whitening", 1): always the reference's eigen route)
-  const bool force_eig = h->cca_whitening == 1;
   bool use_chol = k2 <= 64 && cols && !force_eig;
-  const bool psd_proof = regularization > 2.0 * eps_eig && denom <= (double)frames;
   if (use_chol) {
     // right-hand sides as rows: cov_xy^T [k2][k1] (m1 is free until T is formed)
     hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long long)k1 * k2)), dim3(256), 0, h->stream,

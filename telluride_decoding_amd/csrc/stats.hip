@@ -1016,6 +1016,21 @@ int td_stats_compact(const td_stats* s, StatsCompact* out) {
 }
 
 // Used by eig.hip.
+// Two views without context (one lag each): the compact sums ARE the dense moments -- sum x x^T [c1][c1],
+// sum x2 x2^T [c2][c2], sum x x2^T [c1][c2] and the two column sums -- so td_cca_solve's one-launch dense stage
+// reads them where they lie (td_stats_moments would copy them with three launches and two copies).
+// *ok = 0: statistics with context (or no second view).
+int td_stats_cca_direct(td_handle* h, td_stats* s, const double** xx, const double** yy, const double** xy,
+                        const double** sum1, const double** sum2, int* ok) {
+  *ok = 0;
+  if (!s->c2 || s->l1 != 1 || s->l2 != 1) return TD_OK;
+  TD_TRY(stats_materialize(h, s));
+  *xx = s->g + s->off_fxx; *yy = s->g + s->off_fyy; *xy = s->g + s->off_gxy;
+  *sum1 = s->g + s->off_gxo; *sum2 = s->g + s->off_gyo;
+  *ok = 1;
+  return TD_OK;
+}
+
 int td_stats_dims(const td_stats* s, int* k1, int* k2, int64_t* frames) {
   *k1 = s->k1;
   *k2 = s->k2;

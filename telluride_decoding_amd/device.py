@@ -433,6 +433,7 @@ class LagStats(object):
                                _ptr(mean_y), _ptr(e), info))
     self.last_cca_route = 'cholesky' if info[3] & 1 else 'eigen'     # whitening of the x side
     self.last_cca_route_y = 'cholesky' if info[3] & 2 else 'eigen'   # ... of the other side
+    self.last_cca_fused = bool(info[3] & 4)                           # the one-launch dense stage (K1 <= 64, K2 <= 16)
     return rot_x, rot_y, mean_x, mean_y, e, tuple(info[:3])
 
   def __del__(self):

@@ -302,3 +302,58 @@ def test_uneven_batches_denominator_takes_the_eigen_route(dev):
   # with the usual denominator (frames - 1) the same statistics take the shortcut
   st.cca_solve(n - 1, reg, dim)
   assert st.last_cca_route == 'cholesky'
+
+
+@pytest.mark.parametrize('c1,c2,dim,reg', [
+    (64, 8, 5, 0.1),        # C3
+    (64, 8, 8, 0.0),        # reg = 0: the inertia certificate runs inside the launch
+    (64, 16, 16, 0.05),     # the widest second view the launch takes
+    (33, 7, 7, 0.1),        # odd K2: one idle player in both Jacobi orderings; K1 < 64: identity padding
+    (12, 1, 1, 0.1),        # one column: no rotations at all
+    (10, 10, 4, 0.2),       # K1 = K2
+    (48, 3, 2, 1e-3),
+])
+def test_one_launch_dense_stage_agrees_with_the_chain(dev, c1, c2, dim, reg):
+  """K1 <= 64, K2 <= 16: td_cca_solve runs the dense stage as one launch (cca_small_kernel); with
+  td_set_option('cca_fused', 0) the chain of launches computes the same thing."""
+  rng = np.random.default_rng(1000 + c1 * 17 + c2)
+  h = dev.default_handle()
+  n = 9000
+  src = rng.standard_normal((n, 3)).astype(np.float32)
+  x = (src @ rng.standard_normal((3, c1)) + rng.standard_normal((n, c1)) + 2.0).astype(np.float32)
+  x2 = (src @ rng.standard_normal((3, c2)) + 0.5 * rng.standard_normal((n, c2)) - 1.0).astype(np.float32)
+  st = dev.LagStats(c1, 0, 0, c2, 0, 0)
+  st.accumulate(h.to_device(x), h.to_device(x2), None, [0, n])
+  ra, rb, mx, my, e, _ = st.cca_solve(n - 1, reg, dim)
+  assert st.last_cca_fused and st.last_cca_route == 'cholesky'
+  h.set_option('cca_fused', 0)
+  try:
+    ra2, rb2, mx2, my2, e2, _ = st.cca_solve(n - 1, reg, dim)
+    assert not st.last_cca_fused
+  finally:
+    h.set_option('cca_fused', 1)
+  np.testing.assert_allclose(e.cpu().numpy(), e2.cpu().numpy(), rtol=1e-6, atol=1e-7)
+  np.testing.assert_array_equal(mx.cpu().numpy(), mx2.cpu().numpy())
+  np.testing.assert_array_equal(my.cpu().numpy(), my2.cpu().numpy())
+  we = e2.cpu().numpy().astype(np.float64)
+  gap = np.min(np.abs(np.diff(np.concatenate((we, [0.0]))))) if dim > 1 else 1.0
+  tol = 2e-6 / max(gap, 1e-3)
+  a, b = _aligned(ra.cpu().numpy().astype(np.float64), rb.cpu().numpy().astype(np.float64),
+                  ra2.cpu().numpy().astype(np.float64), rb2.cpu().numpy().astype(np.float64))
+  np.testing.assert_allclose(a, ra2.cpu().numpy(), atol=tol * np.max(np.abs(a)))
+  np.testing.assert_allclose(b, rb2.cpu().numpy(), atol=tol * np.max(np.abs(b)))
+
+
+def test_one_launch_dense_stage_hands_a_rank_deficient_covariance_to_the_chain(dev):
+  """No Cholesky factor (an exactly collinear channel, reg = 0): the launch reports it and the chain's
+  eigen route -- which drops the zero eigenvalue as the reference does -- decides."""
+  rng = np.random.default_rng(5)
+  h = dev.default_handle()
+  n, c1, c2 = 5000, 20, 4
+  x = rng.standard_normal((n, c1)).astype(np.float32)
+  x[:, -1] = x[:, 0]
+  x2 = (x[:, :c2] + rng.standard_normal((n, c2))).astype(np.float32)
+  st = dev.LagStats(c1, 0, 0, c2, 0, 0)
+  st.accumulate(h.to_device(x), h.to_device(x2), None, [0, n])
+  st.cca_solve(n - 1, 0.0, 3)
+  assert not st.last_cca_fused and st.last_cca_route == 'eigen'
