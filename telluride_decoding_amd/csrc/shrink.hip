@@ -290,93 +290,309 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const double* __restri
 // A negative Ledoit-Wolf shrinkage -- the reference's own golden case has one, its beta_ is the
 // difference of a normalised and an unnormalised moment (:458-462) -- makes
 // (1 - s) cov_x + s mu I indefinite, which the ridge path's Cholesky rightly refuses.  The
-// reference solves with LU; so does this branch: right-looking LU with partial pivoting in
-// float64, one column per pair of launches.  Launch-bound and O(n^3) memory traffic: a rare,
-// small-n branch, not the fit() path.
+// reference solves with LU; so does this branch: right-looking LU with partial pivoting in float64.
+// Round 6: blocked.  One column per pair of launches with a rank-1 update of the whole trailing matrix
+// was 4100 launches and n^3 / 3 x 16 bytes of traffic (60 ms at n = 2049).  Now, per panel of 32 columns:
+//   lu_gather_kernel  the panel as a matrix of its own (rows 256 bytes apart);
+//   lu_panel_kernel   ONE workgroup factors it there (pivot search, the swap inside the panel, multipliers, the
+//                     rank-1 updates of the panel's own columns) and returns its top block to the matrix;
+//   lu_apply_kernel   a thread per column right of the panel and per right-hand side: the panel's 32 row swaps
+//                     as one permutation, then the forward substitution with the unit-lower L11
+//                     (U12 = L11^-1 A12; the right-hand sides ride along as further columns);
+//   lu_gemm_kernel    A22 -= L21 U12 (64 x 64 output tiles, K = 32), once more for the right-hand sides;
+// and a blocked, row-oriented back substitution in one launch: 28 ms at n = 2049, of which the 65 panel launches
+// are 21 -- one compute unit streams a tall panel 32 times at ~60 GB/s whatever the access pattern (in place or
+// gathered, 4 .. 16 loads in flight, shuffles or v_readlane: all measured, all 0.6 ms for the first panel); the
+// next step would be a panel of 16 columns held in the registers of its workgroup.  A rare branch (fit() never
+// takes it): float64 VALU, no MFMA.
+constexpr int kLuNb = 32;
+constexpr int kLuPanelThreads = 1024;
+#ifndef TD_LU_INFLIGHT
+#define TD_LU_INFLIGHT 8
+#endif
 
-// column j: pivot search over rows >= j, row swap (matrix and right-hand sides), multipliers
-__global__ __launch_bounds__(256) void lu_pivot_kernel(double* __restrict__ a, double* __restrict__ b,
-                                                       int n, int nrhs, int j, int* __restrict__ flag) {
-  __shared__ double best_v[256];
-  __shared__ int best_i[256];
-  double bv = -1.0;
-  int bi = j;
-  for (int i = j + threadIdx.x; i < n; i += 256) {
-    const double v = fabs(a[(size_t)i * n + j]);
-    if (v > bv) { bv = v; bi = i; }
-  }
-  best_v[threadIdx.x] = bv; best_i[threadIdx.x] = bi;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) {
-      const double ov = best_v[threadIdx.x + off];
-      const int oi = best_i[threadIdx.x + off];
-      // ties go to the smaller row index, as LAPACK's idamax does
-      if (ov > best_v[threadIdx.x] || (ov == best_v[threadIdx.x] && oi < best_i[threadIdx.x])) {
-        best_v[threadIdx.x] = ov; best_i[threadIdx.x] = oi;
+// The panel as a matrix of its own, pm [m = n - j0][32] (rows 256 bytes apart): the rows of `a` are n * 8 bytes
+// apart -- 16 KB at n = 2049, every row of a column panel in the same few memory channels, and a panel factored
+// in place ran at 27 GB/s (0.6 ms).  Columns >= w of the last panel are zero.
+__global__ __launch_bounds__(256) void lu_gather_kernel(const double* __restrict__ a, int n, int j0, int w,
+                                                        double* __restrict__ pm, const int* __restrict__ flag) {
+  if (*flag) return;
+  const int r = blockIdx.x * 8 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+  if (r < n - j0) pm[(size_t)r * kLuNb + c] = c < w ? a[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+}
+
+__device__ __forceinline__ double lane_f64(double v, int l) {    // l wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// Lane = (row of a pair, column of the panel): a wave instruction moves two whole 256-byte panel rows.  The pivot
+// candidates of column jj + 1 are picked up while column jj's update has the values in registers: one pass over
+// the panel per column.  Afterwards the top w rows (U11 above, L11 below the diagonal) go back into `a`; the
+// multipliers below them stay in pm for the trailing update -- nothing reads the columns left of a later panel.
+__global__ __launch_bounds__(kLuPanelThreads) void lu_panel_kernel(double* __restrict__ a, double* __restrict__ pm,
+                                                                   int n, int j0, int w, int* __restrict__ piv_out,
+                                                                   int* __restrict__ flag) {
+  constexpr int kWaves = kLuPanelThreads / 64;
+  __shared__ double cand_v[kWaves];
+  __shared__ int cand_i[kWaves];
+  __shared__ double urow[kLuNb];
+  __shared__ int piv_s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int m = n - j0;                                // rows of the panel (local row r = global row j0 + r)
+  if (*flag) return;
+  // the wave's candidate for the pivot of column jc among its rows: lanes (half, jc) hold (bv, bi)
+  auto publish = [&](double bv, int bi, int jc) {
+    const double ov = __shfl(bv, 32 | jc, 64);
+    const int oi = __shfl(bi, 32 | jc, 64);
+    if (lane == jc) {
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      cand_v[wave] = bv; cand_i[wave] = bi;
+    }
+  };
+  {
+    // candidates of the first column
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    for (int r = 2 * wave + half; r < m; r += 2 * kWaves) {
+      if (col == 0) {
+        const double v = fabs(pm[(size_t)r * kLuNb]);
+        if (v > bv) { bv = v; bi = r; }
       }
+    }
+    publish(bv, bi, 0);
+  }
+  __syncthreads();
+  for (int jj = 0; jj < w; ++jj) {
+    if (tid == 0) {
+      double bv = cand_v[0];
+      int bi = cand_i[0];
+      for (int k = 1; k < kWaves; ++k) {
+        // ties go to the smaller row index, as LAPACK's idamax does
+        if (cand_v[k] > bv || (cand_v[k] == bv && cand_i[k] < bi)) { bv = cand_v[k]; bi = cand_i[k]; }
+      }
+      if (!(bv > 0.0)) { *flag = 1; bi = -1; }          // zero (or NaN) column: singular
+      else piv_out[j0 + jj] = j0 + bi;
+      piv_s = bi;
     }
     __syncthreads();
-  }
-  const int piv = best_i[0];
-  if (!(best_v[0] > 0.0)) {           // zero (or NaN) column: singular
-    if (threadIdx.x == 0) *flag = 1;
-    return;
-  }
-  if (piv != j) {
-    for (int k = threadIdx.x; k < n; k += 256) {
-      const double t = a[(size_t)j * n + k];
-      a[(size_t)j * n + k] = a[(size_t)piv * n + k];
-      a[(size_t)piv * n + k] = t;
+    const int piv = piv_s;
+    if (piv < 0) return;
+    if (tid < kLuNb) {
+      // the swap inside the panel, and the pivot row for everybody
+      const double top = pm[(size_t)piv * kLuNb + tid];
+      if (piv != jj) {
+        pm[(size_t)piv * kLuNb + tid] = pm[(size_t)jj * kLuNb + tid];
+        pm[(size_t)jj * kLuNb + tid] = top;
+      }
+      urow[tid] = top;
     }
-    for (int k = threadIdx.x; k < nrhs; k += 256) {
-      const double t = b[(size_t)j * nrhs + k];
-      b[(size_t)j * nrhs + k] = b[(size_t)piv * nrhs + k];
-      b[(size_t)piv * nrhs + k] = t;
+    __syncthreads();
+    const double inv = 1.0 / urow[jj];
+    const double u = urow[col];
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    // (32 row pairs per trip -- 1024 rows of the panel: a store may alias the next load for all the compiler knows,
+    //  so the loads of a trip are issued by hand before its stores; a column step is a handful of L2 round trips)
+    constexpr int kInFlight = TD_LU_INFLIGHT;
+    double* const pcol = pm + col;
+    for (int r0 = jj + 1 + 2 * wave; r0 < m; r0 += 2 * kWaves * kInFlight) {
+      double v[kInFlight];
+#pragma unroll
+      for (int k = 0; k < kInFlight; ++k) {
+        const int r = r0 + 2 * kWaves * k + half;
+        v[k] = r < m ? pcol[(unsigned)r * kLuNb] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < kInFlight; ++k) {
+        const int r = r0 + 2 * kWaves * k + half;
+        const bool ok = r < m;
+        // (the multiplier sits in lane (half, jj): two v_readlane pairs -- as a lane shuffle it is two LDS-crossbar
+        //  operations per row pair and wave, and sixteen waves of them were the whole kernel: 18 us per column)
+        const double l = (half ? lane_f64(v[k], 32 + jj) : lane_f64(v[k], jj)) * inv;
+        const double nv = col == jj ? l : v[k] - l * u;
+        if (ok && col >= jj) pcol[(unsigned)r * kLuNb] = nv;
+        if (ok && col == jj + 1) {
+          const double mg = fabs(nv);
+          if (mg > bv) { bv = mg; bi = r; }
+        }
+      }
+    }
+    if (jj + 1 < w) publish(bv, bi, jj + 1);
+    __syncthreads();
+  }
+  {
+    const int r = tid >> 5, c = tid & 31;              // 1024 threads = 32 x 32
+    if (r < w && c < w) a[(size_t)(j0 + r) * n + j0 + c] = pm[(size_t)r * kLuNb + c];
+  }
+}
+
+// A thread per column right of the panel, c in [j0 + w, n), and per right-hand side: the panel's swaps, then
+// x <- L11^-1 x.  (The columns left of the panel hold the multipliers of earlier panels, which the right-hand sides
+// have already taken -- the forward substitution rides along -- so nobody reads them again: they are not swapped.)
+// The 32 swaps in sequence are a chain of 64 dependent loads per column; their net effect is a permutation of
+// <= 64 rows (the panel's and the pivots' below it), worked out once per workgroup on row NUMBERS (an index
+// array in LDS takes the swaps, the rows that moved are collected): slot s ends with what row src[s] held, so a
+// column is <= 64 independent loads, then its stores.
+__global__ __launch_bounds__(256) void lu_apply_kernel(double* __restrict__ a, double* __restrict__ b, int n, int nrhs,
+                                                       int j0, int w, const int* __restrict__ piv,
+                                                       const int* __restrict__ flag) {
+  extern __shared__ double xs_lds[];                   // [32][256] the panel rows' values of this workgroup's columns
+  int* const at_row = reinterpret_cast<int*>(xs_lds + kLuNb * 256);   // [n - j0]: whose content local row r ends up with
+  __shared__ double l11[kLuNb][kLuNb + 1];
+  __shared__ int slot_row[2 * kLuNb], slot_src[2 * kLuNb];   // slots 0 .. w-1: the panel's rows; then the outside pivots
+  __shared__ int n_slots;
+  if (*flag) return;
+  const int m = n - j0;
+  for (int idx = threadIdx.x; idx < kLuNb * kLuNb; idx += 256) {
+    const int r = idx / kLuNb, c = idx % kLuNb;
+    l11[r][c] = (r < w && c < r) ? a[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+  }
+  for (int r = threadIdx.x; r < m; r += 256) at_row[r] = r;
+  if (threadIdx.x == 0) n_slots = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int jj = 0; jj < w; ++jj) {
+      const int p = piv[j0 + jj] - j0;
+      const int t = at_row[jj]; at_row[jj] = at_row[p]; at_row[p] = t;
     }
   }
   __syncthreads();
-  const double inv = 1.0 / a[(size_t)j * n + j];
-  for (int i = j + 1 + threadIdx.x; i < n; i += 256) a[(size_t)i * n + j] *= inv;
-}
-
-// trailing update a[i][k] -= l[i] a[j][k] for i, k > j, and the same on the right-hand sides
-// (forward substitution on the fly)
-__global__ __launch_bounds__(256) void lu_update_kernel(double* __restrict__ a, double* __restrict__ b,
-                                                        int n, int nrhs, int j,
-                                                        const int* __restrict__ flag) {
-  if (*flag) return;
-  const int cols = n - j - 1 + nrhs;                 // trailing columns, then the rhs columns
-  const int k = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int i0 = j + 1 + blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
-  if (k >= cols) return;
-  const bool is_rhs = k >= n - j - 1;
-  const int kk = is_rhs ? k - (n - j - 1) : j + 1 + k;
-  const double u = is_rhs ? b[(size_t)j * nrhs + kk] : a[(size_t)j * n + kk];
-#pragma unroll 4
-  for (int i = i0; i < i0 + 16 && i < n; ++i) {
-    const double l = a[(size_t)i * n + j];
-    if (is_rhs) b[(size_t)i * nrhs + kk] -= l * u;
-    else a[(size_t)i * n + kk] -= l * u;
+  for (int r = threadIdx.x; r < m; r += 256) {
+    if (r < w) { slot_row[r] = j0 + r; slot_src[r] = j0 + at_row[r]; }
+    else if (at_row[r] != r) {
+      const int k = atomicAdd(&n_slots, 1);
+      slot_row[k] = j0 + r; slot_src[k] = j0 + at_row[r];
+    }
   }
+  __syncthreads();
+  const int ns = n_slots;
+  const int outside = n - j0 - w;                     // matrix columns right of the panel
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= outside + nrhs) return;
+  const bool is_rhs = t >= outside;
+  double* base = is_rhs ? b + (t - outside) : a + (j0 + w + t);
+  const size_t ld = is_rhs ? (size_t)nrhs : (size_t)n;
+  // every load of the column in front of its first store (the slots' rows overlap); the panel rows' values go
+  // through LDS (a register array of 32 + 32 doubles under the unrolled substitution spilled 600 registers)
+  double* const xs = xs_lds + threadIdx.x;             // xs[k * 256]
+  double ext[kLuNb];
+#pragma unroll
+  for (int k = 0; k < kLuNb; ++k) {
+    xs[k * 256] = k < w ? base[(size_t)slot_src[k] * ld] : 0.0;
+    ext[k] = w + k < ns ? base[(size_t)slot_src[w + k] * ld] : 0.0;
+  }
+  for (int jj = 1; jj < w; ++jj) {
+    double acc = xs[jj * 256];
+    for (int kk = 0; kk < jj; ++kk) acc -= l11[jj][kk] * xs[kk * 256];
+    xs[jj * 256] = acc;
+  }
+#pragma unroll
+  for (int k = 0; k < kLuNb; ++k)
+    if (w + k < ns) base[(size_t)slot_row[w + k] * ld] = ext[k];
+  for (int k = 0; k < w; ++k) base[(size_t)(j0 + k) * ld] = xs[k * 256];
 }
 
-// back substitution U x = y, one workgroup, rows from the bottom up
-__global__ __launch_bounds__(256) void lu_back_kernel(const double* __restrict__ a, double* __restrict__ b,
-                                                      int n, int nrhs, const int* __restrict__ flag) {
-  __shared__ double red[256];
+// C[i][c] -= sum_kk L[i][kk] U[kk][c]: L = lp[i * 32 + kk] (the panel's rows below its top block, i < m),
+// U = u[kk * ldu + c], C = cm[(r0 + i) * ldc + c] (c < nc); 64 x 64 tiles, a thread 4 x 4 outputs.
+__global__ __launch_bounds__(256) void lu_gemm_kernel(const double* __restrict__ lp, int w, int r0, int m,
+                                                      const double* __restrict__ u, size_t ldu,
+                                                      double* __restrict__ cm, size_t ldc, int nc,
+                                                      const int* __restrict__ flag) {
+  __shared__ double ls[64][kLuNb + 1];
+  __shared__ double us[kLuNb][64 + 1];
   if (*flag) return;
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int idx = tid; idx < 64 * kLuNb; idx += 256) {
+    const int r = idx / kLuNb, kk = idx % kLuNb;
+    ls[r][kk] = (i0 + r < m && kk < w) ? lp[(size_t)(i0 + r) * kLuNb + kk] : 0.0;
+  }
+  for (int idx = tid; idx < kLuNb * 64; idx += 256) {
+    const int kk = idx / 64, c = idx % 64;
+    us[kk][c] = (kk < w && c0 + c < nc) ? u[(size_t)kk * ldu + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int tr = (tid >> 4) * 4, tc = (tid & 15) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
+#pragma unroll 8
+  for (int kk = 0; kk < kLuNb; ++kk) {
+    double lv[4], uv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { lv[p] = ls[tr + p][kk]; uv[p] = us[kk][tc + p]; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[p][q] += lv[p] * uv[q];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + tr + p, c = c0 + tc + q;
+      if (i < m && c < nc) cm[(size_t)(r0 + i) * ldc + c] -= acc[p][q];
+    }
+}
+
+// back substitution U x = y in blocks of 32 rows from the bottom up, one workgroup, row-oriented (the rows of U are
+// contiguous; a column block of it has its rows 16 KB apart -- the same memory channels, see lu_gather_kernel):
+// the block's rows first lose the unknowns already found -- a wave per two rows, lanes along the row, the
+// products summed by shuffles -- then wave 0 solves the diagonal block (lane = row, the finished unknown handed
+// round through LDS).  The unknowns live in LDS (n <= 8190).
+__global__ __launch_bounds__(kLuPanelThreads) void lu_back_kernel(const double* __restrict__ a, double* __restrict__ b,
+                                                                  int n, int nrhs, const int* __restrict__ flag) {
+  constexpr int kWaves = kLuPanelThreads / 64;
+  extern __shared__ double xs[];                       // [n]
+  __shared__ double ub[kLuNb][kLuNb + 1];
+  __shared__ double yb[kLuNb], rdiag[kLuNb];
+  if (*flag) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int q = 0; q < nrhs; ++q) {
-    for (int i = n - 1; i >= 0; --i) {
-      double acc = 0.0;
-      for (int k = i + 1 + threadIdx.x; k < n; k += 256) acc += a[(size_t)i * n + k] * b[(size_t)k * nrhs + q];
-      red[threadIdx.x] = acc;
-      __syncthreads();
-      for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
+    for (int k0 = ((n - 1) / kLuNb) * kLuNb; k0 >= 0; k0 -= kLuNb) {
+      const int w = n - k0 < kLuNb ? n - k0 : kLuNb;
+      {
+        const int r = tid >> 5, c = tid & 31;          // 1024 threads = the 32 x 32 block
+        ub[r][c] = (r < w && c < w) ? a[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
       }
-      if (threadIdx.x == 0) b[(size_t)i * nrhs + q] = (b[(size_t)i * nrhs + q] - red[0]) / a[(size_t)i * n + i];
+      // rows k0 + 2 wave, + 1: y - sum_{k >= k0 + 32} U[row][k] x[k]
+      for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * wave + rr;
+        double sum = 0.0;
+        if (r < w) {
+          const double* row = a + (size_t)(k0 + r) * n;
+          for (int k = k0 + kLuNb + lane; k < n; k += 64) sum += row[k] * xs[k];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) yb[r] = r < w ? b[(size_t)(k0 + r) * nrhs + q] - sum : 0.0;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        if (tid < kLuNb) rdiag[tid] = 1.0 / ub[tid][tid];
+        double y = tid < kLuNb ? yb[tid] : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int mm = kLuNb - 1; mm >= 0; --mm) {
+          if (tid == mm) yb[mm] = y * rdiag[mm];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (tid < mm) y -= ub[tid][mm] * yb[mm];
+        }
+      }
+      __syncthreads();
+      if (tid < w) {
+        xs[k0 + tid] = yb[tid];
+        b[(size_t)(k0 + tid) * nrhs + q] = yb[tid];
+      }
       __syncthreads();
     }
   }
@@ -464,17 +680,44 @@ extern "C" int td_shrinkage_moment(td_handle* h, const float* x_dev, int64_t ldx
 extern "C" int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs) {
   if (!h) return td_fail(h, TD_ERR_INVALID, "td_general_solve: NULL handle");
   TD_REQUIRE(h, a_dev && rhs_dev && n > 0 && nrhs > 0, "td_general_solve: bad argument");
-  TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
-  for (int j = 0; j < n; ++j) {
-    hipLaunchKernelGGL(lu_pivot_kernel, dim3(1), dim3(256), 0, h->stream, a_dev, rhs_dev, n, nrhs,
-                       j, h->dev_flag);
-    const int rows = n - j - 1, cols = rows + nrhs;
-    if (rows > 0)
-      hipLaunchKernelGGL(lu_update_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
-                         h->stream, a_dev, rhs_dev, n, nrhs, j, h->dev_flag);
+  TD_REQUIRE(h, n <= 8190, "td_general_solve: at most 8190 unknowns (n = %d)", n);
+  void* ws = nullptr;
+  const size_t piv_bytes = td_round_up(sizeof(int) * (size_t)n, 256);
+  TD_TRY(td_workspace(h, piv_bytes + sizeof(double) * (size_t)n * kLuNb, &ws));
+  int* piv = reinterpret_cast<int*>(ws);
+  double* pm = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + piv_bytes);
+  static bool lds_opt = false;
+  if (!lds_opt) {
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_back_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double)));
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_apply_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(double) * kLuNb * 256 + sizeof(int) * 8192)));
+    lds_opt = true;
   }
-  hipLaunchKernelGGL(lu_back_kernel, dim3(1), dim3(256), 0, h->stream, a_dev, rhs_dev, n, nrhs,
-                     h->dev_flag);
+  TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
+  for (int j0 = 0; j0 < n; j0 += kLuNb) {
+    const int w = n - j0 < kLuNb ? n - j0 : kLuNb;
+    hipLaunchKernelGGL(lu_gather_kernel, dim3((unsigned)td_ceil_div(n - j0, 8)), dim3(256), 0, h->stream, a_dev, n,
+                       j0, w, pm, h->dev_flag);
+    hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kLuPanelThreads), 0, h->stream, a_dev, pm, n, j0, w, piv,
+                       h->dev_flag);
+    hipLaunchKernelGGL(lu_apply_kernel, dim3((unsigned)td_ceil_div(n - j0 - w + nrhs, 256)), dim3(256),
+                       sizeof(double) * kLuNb * 256 + sizeof(int) * (size_t)(n - j0), h->stream, a_dev, rhs_dev, n,
+                       nrhs, j0, w, piv, h->dev_flag);
+    const int r0 = j0 + w, m = n - r0;
+    if (m > 0) {
+      const double* lp = pm + (size_t)w * kLuNb;
+      hipLaunchKernelGGL(lu_gemm_kernel, dim3((unsigned)td_ceil_div(m, 64), (unsigned)td_ceil_div(m, 64)), dim3(256),
+                         0, h->stream, lp, w, r0, m, a_dev + (size_t)j0 * n + r0, (size_t)n, a_dev + r0, (size_t)n,
+                         m, h->dev_flag);
+      hipLaunchKernelGGL(lu_gemm_kernel, dim3((unsigned)td_ceil_div(nrhs, 64), (unsigned)td_ceil_div(m, 64)),
+                         dim3(256), 0, h->stream, lp, w, r0, m, rhs_dev + (size_t)j0 * nrhs, (size_t)nrhs, rhs_dev,
+                         (size_t)nrhs, nrhs, h->dev_flag);
+    }
+  }
+  hipLaunchKernelGGL(lu_back_kernel, dim3(1), dim3(kLuPanelThreads), sizeof(double) * (size_t)n, h->stream, a_dev,
+                     rhs_dev, n, nrhs, h->dev_flag);
   TD_HIP(h, hipGetLastError());
   int flag = 0;
   TD_HIP(h, hipMemcpyAsync(&flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
