@@ -18,7 +18,7 @@ def counter(path, kernel, name):
 
 out = {}
 for key, kernel, algo, note in (
-    ('lagcov', 'lagcov_split_kernel<true, 83, true, false, false>', 256000000,
+    ('lagcov', 'lagcov_split_kernel<true, 83, true, false, false, false>', 256000000,
      'reads the 256 MB of input (the four lag-group workgroups of a time slab share one XCD L2); '
      'writes 33 MB = 64 float32 partial slabs of 512 KB (one workgroup per CU and lag group walks '
      'three <= 8192-sample slabs and leaves one partial slab), summed in float64 by '
