@@ -502,8 +502,15 @@ def loso_leg(eeg, env):
     ds.device_arrays(_dev.default_handle())            # (the 264 MB of pageable host arrays: most of a first sweep)
     torch.cuda.synchronize()
     first_upload = time.perf_counter() - t0
+    prof = None
+    if os.environ.get('TD_BENCH_PROFILE_FIRST_SWEEP'):     # development: where a slow first sweep goes (stderr)
+      import cProfile
+      prof = cProfile.Profile(); prof.enable()
     res = regression.jackknife_over_regularizations(ds, lams)
     first = time.perf_counter() - t0
+    if prof is not None:
+      import pstats
+      prof.disable(); pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(14)
   finally:
     gc.enable()
   # (one collection in front of the sweeps and none between them, like the decode leg: a collection walks the
@@ -539,7 +546,9 @@ def loso_leg(eeg, env):
       'seconds_with_upload': with_upload, 'seconds_first_sweep': first,
       'first_sweep_parts': {'upload_s': first_upload, 'sweep_s': first - first_upload,
                             'what': 'the first sweep of the process = host->device copy of the recordings (pageable) + the sweep '
-                                    'itself with cold workspaces, tables and code paths'},
+                                    'itself with cold tables and code paths; the 1.9 GB workspace arena it needs was reserved '
+                                    'when the default handle was created (device.DEFAULT_WORKSPACE_BYTES: a hipMalloc of that '
+                                    'size is ~55 ms -- grown on demand it lands in this sweep: 0.06-0.08 s measured)'},
       'upload': 'host->device copy of the recordings (264 MB, pageable) inside the timed region',
   }
 

@@ -303,6 +303,9 @@ int td_set_solver(td_handle* h, int mode);
  *                     (cca.py:345-360);
  *   "cca_fused"       1 (default): td_cca_solve runs the dense stage of a small problem (K1 <= 64, K2 <= 16,
  *                     K2 <= K1) as ONE launch of one workgroup; 0: the chain of launches (A/B runs);
+ *   "reserve_workspace"  value = bytes: the handle's workspace arena (dense moments, factors, the folds of a
+ *                     leave-one-out sweep: 1.9 GB at C5) is grown to that size NOW -- a hipMalloc of 2 GB takes
+ *                     ~55 ms and otherwise lands in the first call that needs it.  The arena never shrinks;
  *   "cg_limit_ticks"  the conjugate-gradient kernel's wait limit per launch in 10 ns ticks (< 0: the
  *                     default, 20 ms; 0: every workgroup gives up at its first empty poll -- the abort /
  *                     drain / Cholesky-fallback route, for tests).

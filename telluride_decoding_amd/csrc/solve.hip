@@ -1615,6 +1615,12 @@ int td_set_option(td_handle* h, const char* name, int64_t value) {
   } else if (!strcmp(name, "cca_fused")) {
     TD_REQUIRE(h, value == 0 || value == 1, "td_set_option: cca_fused is 0 or 1");
     h->cca_fused = (int)value;
+  } else if (!strcmp(name, "reserve_workspace")) {
+    // grows the handle's workspace arena to `value` bytes now (hipMalloc of a few GB is tens of ms; left to
+    // the first call that needs it, it lands in that call)
+    TD_REQUIRE(h, value >= 0, "td_set_option: reserve_workspace takes a byte count");
+    void* unused = nullptr;
+    if (value > 0) TD_TRY(td_workspace(h, (size_t)value, &unused));
   } else if (!strcmp(name, "cg_limit_ticks")) {
     h->cg_limit_ticks = value;
   } else if (!strcmp(name, "narrow16")) {
