@@ -686,14 +686,13 @@ extern "C" int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, in
   TD_TRY(td_workspace(h, piv_bytes + sizeof(double) * (size_t)n * kLuNb, &ws));
   int* piv = reinterpret_cast<int*>(ws);
   double* pm = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + piv_bytes);
-  static bool lds_opt = false;
-  if (!lds_opt) {
+  if (!h->lds_opt_lu) {
     TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_back_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double)));
     TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_apply_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(double) * kLuNb * 256 + sizeof(int) * 8192)));
-    lds_opt = true;
+    h->lds_opt_lu = true;
   }
   TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
   for (int j0 = 0; j0 < n; j0 += kLuNb) {

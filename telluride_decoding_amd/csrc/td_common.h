@@ -97,7 +97,7 @@ struct td_handle {
   // "cg_limit_ticks" (< 0: the default wait limit of the conjugate-gradient kernel's polls)
   int cca_whitening = 0;
   int cca_fused = 1;            // "cca_fused": k1 <= 64, k2 <= 16 take the one-launch dense stage (0: the chain of launches)
-  bool lds_opt_cca = false;
+  bool lds_opt_cca = false, lds_opt_lu = false;
   long long cg_limit_ticks = -1;
   int async_cg = 0;             // "async_cg": td_ridge_solve_async may use the compact-statistics CG (flag 2 = gave up)
   int narrow16 = 1;             // "narrow16": <= 16 channels take the one-kernel streaming accumulate (0: the tiled kernels)
