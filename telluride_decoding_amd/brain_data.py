@@ -122,8 +122,16 @@ class Dataset(object):
     off = abs(self.input_offset)
     return [max(n - off, 0) for n in self.file_lengths()]
 
+  def _shape_key(self):
+    # what rows_used() / attention_host() depend on (the files of a dataset are fixed when it is built)
+    return (self.batch_size, self.input_offset, self.max_batches, len(self.files))
+
   def rows_used(self):
-    """Per-file rows that survive batch(drop_remainder=True) (and take())."""
+    """Per-file rows that survive batch(drop_remainder=True) (and take()).  (Memoised: a decoder's train() asks
+    six times per call, 200 recordings each -- a third of its 1.6 ms at the C4 size.)"""
+    memo = getattr(self, '_rows_used_memo', None)
+    if memo is not None and memo[0] == self._shape_key():
+      return list(memo[1])
     z = self.zipped_lengths()
     total = sum(z)
     keep = (total // self.batch_size) * self.batch_size
@@ -134,6 +142,7 @@ class Dataset(object):
       u = min(n, keep)
       used.append(u)
       keep -= u
+    self._rows_used_memo = (self._shape_key(), tuple(used))
     return used
 
   def num_batches(self):
@@ -280,9 +289,15 @@ class Dataset(object):
       part.clear()
 
   def attention_host(self):
-    """Attention labels of the zipped, batched stream (never shifted)."""
+    """Attention labels of the zipped, batched stream (never shifted).  (Memoised, read-only.)"""
+    memo = getattr(self, '_attention_memo', None)
+    if memo is not None and memo[0] == self._shape_key():
+      return memo[1]
     used = self.rows_used()
-    return np.concatenate([f[3][:u] for f, u in zip(self.files, used)])
+    att = np.concatenate([f[3][:u] for f, u in zip(self.files, used)])
+    att.flags.writeable = False
+    self._attention_memo = (self._shape_key(), att)
+    return att
 
 
 class BrainData(object):

@@ -176,13 +176,18 @@ class Decoder(object):
     """Adds a [frames, dims] block to the running statistics; the five sums come
     from the window-sums kernel (one window = the block), the scalar update of
     means and power (reference :306-310) is host bookkeeping in float64."""
+    rows, sums = self._correlator_sums_device(x, y)
+    if rows:
+      self._add_sums(rows, sums.cpu().numpy()[0])
+
+  def _correlator_sums_device(self, x, y):
+    """(frames, the block's five sums as a device tensor [1, cols, 5]) -- queued, not waited for."""
     h = device.default_handle()
     xd, yd = brain_model._as_2d_device(h, x), brain_model._as_2d_device(h, y)
     rows = int(xd.shape[0])
     if rows == 0:
-      return
-    s = device.window_sums(xd, yd, [0, rows], rows, rows, handle=h).cpu().numpy()[0]
-    self._add_sums(rows, s)
+      return 0, None
+    return rows, device.window_sums(xd, yd, [0, rows], rows, rows, handle=h)
 
   def _stat_vectors(self, cols):
     vec = lambda v: np.broadcast_to(np.asarray(v, np.float64).reshape(-1), (cols,)).copy()
@@ -239,9 +244,11 @@ class Decoder(object):
         raise TypeError('Must feed training routine %s with a tf.data.Dataset not a %s.' %
                         (name, type(data)))
     decoded = [self._decode_dataset(data) for data in (data0, data1)]
-    for streams in decoded:
-      if streams is not None:
-        self.add_data_correlator(streams[0], streams[1])
+    # (both datasets' sums are queued before the first is waited for: one round trip to the device, not two)
+    queued = [self._correlator_sums_device(streams[0], streams[1]) for streams in decoded if streams is not None]
+    for rows, sums in queued:
+      if rows:
+        self._add_sums(rows, sums.cpu().numpy()[0])
     if window_size <= 1 and all(s is not None and int(s[0].shape[0]) > 0 for s in decoded):
       # Frame-level training data (the default): the per-frame correlations stay on the device, the
       # LDA takes its class moments there (scaled_lda._class_moments_device: the accumulate
