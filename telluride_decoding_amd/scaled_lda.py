@@ -57,6 +57,16 @@ def _class_moments_of(labels, members):
   # instruction (every product exact to 2^-24, float64 slab sums), whatever accumulate mode the fits of
   # this handle use -- the float16 two-piece form scales a column by its largest magnitude, and
   # per-frame correlation products are heavy-tailed.
+  if dims == 1:
+    # One column (the per-frame correlation of a one-output decoder: infer_decoder.train's LDA): count, sum and
+    # sum of squares are the window-sums kernel's float64 sums over one window = the whole class -- 29 us per
+    # class where the Gram route's four launches take 257 for a 4.8 MB column.
+    queued = [device.window_sums(rows, rows, [0, int(rows.shape[0])], int(rows.shape[0]), int(rows.shape[0]), handle=h)
+              for rows in members]
+    for rows, q in zip(members, queued):                # (every class queued before the first wait)
+      s = q.cpu().numpy()[0, 0]                         # {sum x, sum y, sum x^2, sum y^2, sum xy}, y = x
+      moments.append(np.array([[s[2], s[0]], [s[0], float(rows.shape[0])]]))
+    return _moments_to_scatter(labels, moments, dims)
   mode = h.accumulate_mode
   h.set_accumulate_mode('f32')
   try:
@@ -68,6 +78,11 @@ def _class_moments_of(labels, members):
     moments = [m.cpu().numpy() for m in stats]          # (every class queued before the first wait)
   finally:
     h.set_accumulate_mode(mode)
+  return _moments_to_scatter(labels, moments, dims)
+
+
+def _moments_to_scatter(labels, moments, dims):
+  """moments[i] = [[X^T X, sum], [sum^T, n]] of class i -> (labels, means, within, between, per_class)."""
   total = sum(m[dims, dims] for m in moments)
   grand_mean = sum(m[dims, :dims] for m in moments) / total
   within = np.zeros((dims, dims))
