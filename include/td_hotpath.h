@@ -391,6 +391,19 @@ int td_shrinkage_moment(td_handle* h, const float* x_dev, int64_t ldx, int c, in
                         const int64_t* file_offsets_host, int num_files, int input_offset,
                         const int64_t* rows_used_host, int64_t batch_rows, double* result_dev);
 
+/* The shrinkage algebra of brain_model.py:449-476 on the device.  s_dev [n rows, row stride ld]: float64 moment
+ * sums (td_stats_moments: with use_offset n = K + 1 includes the ones row and column), sum_row_dev [n]: the column-sum
+ * row of the moments (the ones row), frames: rows summed.  With zc = S - m^T m, m = sum_row / frames ("sum minus mean
+ * outer", sic, :450): out_host[0] = trace(zc), out_host[1] = sum(zc^2) -- from which mu = trace / n,
+ * delta = (sum(zc^2) - 2 mu trace + n mu^2) / n and beta_ (:457-462) are scalars.  Synchronous. */
+int td_shrinkage_terms(td_handle* h, const double* s_dev, int64_t ld, int n, const double* sum_row_dev, double frames,
+                       double* out_host);
+/* out = scale * S + diag * I (:463-465 with scale = (1 - shrinkage) / frames, diag = shrinkage * mu; a ridge with
+ * scale = 1 / frames, diag = lambda): out64_dev [n, n] float64 for the solver and / or out32_dev [n, n] float32 (what
+ * the reference returns as cov_x); either may be NULL.  Queued on the handle's stream. */
+int td_shrunk_covariance(td_handle* h, const double* s_dev, int64_t ld, int n, double scale, double diag,
+                         double* out64_dev, float* out32_dev);
+
 /* ------------------------------------------------------------------ A3' / A4 forward
  * Linear model forward X.W + b on the lagged view of x, never materialised
  * (Keras Dense in brain_model.py:335-341, 376).  out_dev [rows, d] float32. */

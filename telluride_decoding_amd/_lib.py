@@ -99,6 +99,8 @@ SIGNATURES = {
     'td_spd_solve': [_vp, _vp, _vp, _i, _i, _i],
     'td_general_solve': [_vp, _vp, _vp, _i, _i],
     'td_shrinkage_moment': [_vp, _vp, _i64, _i, _i, _i, _pi64, _i, _i, _pi64, _i64, _vp],
+    'td_shrinkage_terms': [_vp, _vp, _i64, _i, _vp, _c.c_double, _pd],
+    'td_shrunk_covariance': [_vp, _vp, _i64, _i, _c.c_double, _c.c_double, _vp, _vp],
     'td_predict_fir': [_vp, _vp, _i64, _pi64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64],
     'td_predict_fir_per_file': [_vp, _vp, _i64, _pi64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64],
     'td_cca_transform': [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i, _i, _pi64, _i, _i,

@@ -205,45 +205,37 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
       # host at C2 -- 27 of the 30 ms of a fit through the model class
       return w_np, b_np.reshape(1, -1), None, None, lamb
     m = st.moments()
-    cov_x = m['xtx'].cpu().numpy() / frames
-    cov_x[np.diag_indices(k + 1)] += lamb
-    return (w_np, b_np.reshape(1, -1), cov_x.astype(np.float32),
+    _, cov32 = device.shrunk_covariance(m['xtx'], k + 1, 1.0 / frames, lamb, want64=False, handle=h)
+    return (w_np, b_np.reshape(1, -1), cov32.cpu().numpy(),
             (m['xty'].cpu().numpy() / frames).astype(np.float32), lamb)
-  # Remaining (rare) branches: the dense float64 moments come from the device, the O(n^2)
-  # shrinkage algebra of brain_model.py:447-476 is host NumPy, the solve is td_spd_solve /
-  # td_general_solve on the device.
+  # Remaining (rare) branches: the dense float64 moments stay on the device -- the O(n^2) reductions and the
+  # scaling of the shrinkage algebra (brain_model.py:447-476) are two device passes over them
+  # (td_shrinkage_terms / td_shrunk_covariance; on the host they were 20 ms of NumPy on 33 MB arrays at C2), the
+  # scalars are host arithmetic, the solve is td_spd_solve / td_general_solve.
   m = st.moments()
   n = k + 1 if use_offset else k
-  xtx_full = m['xtx'].cpu().numpy()
-  xtx = np.ascontiguousarray(xtx_full[:n, :n])
-  xty = np.ascontiguousarray(m['xty'].cpu().numpy()[:n])
-  cov_x = xtx / frames
-  cov_xy = xty / frames
+  xtx_d = m['xtx']                                   # [k + 1, k + 1] float64, the ones row / column last
+  cov_xy_d = (m['xty'][:n] / frames).contiguous()    # [n, d]: plumbing
   if use_ridge:
-    cov_x[np.diag_indices(n)] += lamb
     shrinkage = lamb
+    a, cov32 = device.shrunk_covariance(xtx_d, n, 1.0 / frames, lamb, handle=h)
   else:
-    # Blankertz shrinkage, brain_model.py:449-476.  sum_x is the column-sum row of the moments
-    # (with use_offset it includes the ones column's own sum, the frame count).
-    mean_x = (xtx_full[k:k + 1, :n] / frames)
-    cov_x_zc = xtx - mean_x.T @ mean_x            # sum minus mean outer (sic, :450)
-    mu = float(np.trace(cov_x_zc) / n)
+    # Blankertz shrinkage, brain_model.py:449-476.  mean_x is the column-sum row of the moments / frames (with
+    # use_offset it includes the ones column's own sum, the frame count); cov_x_zc = sum minus mean outer (sic, :450)
+    trace, sq = device.shrinkage_terms(xtx_d, n, k, frames, handle=h)
+    mu = trace / n
     if ledoit_wolf:                               # :457-465
-      delta_ = cov_x_zc.copy()
-      delta_[np.diag_indices(n)] -= mu
-      delta = float((delta_ ** 2).sum()) / n
-      beta_ = 1. / (n * frames) * (x2_moment / frames - float((cov_x_zc ** 2).sum()))
+      delta = (sq - 2.0 * mu * trace + n * mu * mu) / n      # sum((zc - mu I)^2) / n
+      beta_ = 1. / (n * frames) * (x2_moment / frames - sq)
       shrinkage = min(beta_, delta) / delta
     else:
       shrinkage = lamb
-    cov_x = (1 - shrinkage) * cov_x
-    cov_x[np.diag_indices(n)] += shrinkage * mu
-  a = h.to_device(cov_x, np.float64)
-  rhs = h.to_device(cov_xy, np.float64)
+    a, cov32 = device.shrunk_covariance(xtx_d, n, (1 - shrinkage) / frames, shrinkage * mu, handle=h)
+  rhs = cov_xy_d.clone()
   if ledoit_wolf:
     # (1 - s) cov + s mu I is positive definite for 0 <= s <= 1: the blocked Cholesky (2.5 ms at C2).  A negative
     # estimated shrinkage (the reference's golden case has one; so has white-ish data at C2: -1e-6) can make
-    # the matrix indefinite: LU like np.linalg.solve (:477) -- one column per launch, 60 ms at C2
+    # the matrix indefinite: LU like np.linalg.solve (:477) -- blocked, 28 ms at C2
     if 0.0 <= shrinkage <= 1.0:
       try:
         rhs = device.spd_solve(a, rhs, handle=h)
@@ -254,8 +246,8 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
   else:
     rhs = device.spd_solve(a, rhs, handle=h)
   sol = rhs.cpu().numpy().astype(np.float32)
-  cov_x_np = cov_x.astype(np.float32)
-  cov_xy_np = cov_xy.astype(np.float32)
+  cov_x_np = cov32.cpu().numpy()
+  cov_xy_np = cov_xy_d.cpu().numpy().astype(np.float32)
   if use_offset:
     return sol[:-1], sol[-1:], cov_x_np, cov_xy_np, shrinkage
   return sol, np.zeros((1,)), cov_x_np, cov_xy_np, shrinkage

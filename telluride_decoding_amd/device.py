@@ -598,6 +598,27 @@ def shrinkage_moment(x, file_offsets, pre, post, batch_rows, input_offset=0, row
   return float(out.cpu()[0])
 
 
+def shrinkage_terms(moments, n, sum_row, frames, handle=None):
+  """(trace(zc), sum(zc^2)) of zc = S - m^T m for the [n, n] corner of the float64 device matrix `moments` (row
+  stride = its own), m = row `sum_row` of it / frames: the two reductions of the reference's shrinkage algebra
+  (brain_model.py:449-462), td_shrinkage_terms."""
+  h = handle or default_handle()
+  out = (ctypes.c_double * 2)()
+  row = moments[int(sum_row)]
+  h.check(h.lib.td_shrinkage_terms(h.ptr, _ptr(moments), moments.stride(0), int(n), _ptr(row), float(frames), out))
+  return float(out[0]), float(out[1])
+
+
+def shrunk_covariance(moments, n, scale, diag, want64=True, want32=True, handle=None):
+  """scale * moments[:n, :n] + diag * I as a float64 and / or a float32 device tensor (td_shrunk_covariance)."""
+  h = handle or default_handle()
+  o64 = h.empty((int(n), int(n)), 'float64') if want64 else None
+  o32 = h.empty((int(n), int(n)), 'float32') if want32 else None
+  h.check(h.lib.td_shrunk_covariance(h.ptr, _ptr(moments), moments.stride(0), int(n), float(scale), float(diag),
+                                     _ptr(o64), _ptr(o32)))
+  return o64, o32
+
+
 WINDOW_SUMS_CYCLED = True      # window_sums takes a `b` with fewer columns than `a` (td_window_sums_cycled)
 
 
