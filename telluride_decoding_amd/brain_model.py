@@ -235,7 +235,7 @@ def calculate_linear_regressor_parameters_from_dataset(dataset, lamb=0.1, use_of
   if ledoit_wolf:
     # (1 - s) cov + s mu I is positive definite for 0 <= s <= 1: the blocked Cholesky (2.5 ms at C2).  A negative
     # estimated shrinkage (the reference's golden case has one; so has white-ish data at C2: -1e-6) can make
-    # the matrix indefinite: LU like np.linalg.solve (:477) -- blocked, 28 ms at C2
+    # the matrix indefinite: LU like np.linalg.solve (:477) -- blocked, 12 ms at C2
     if 0.0 <= shrinkage <= 1.0:
       try:
         rhs = device.spd_solve(a, rhs, handle=h)

@@ -13,6 +13,7 @@
 // Three small kernels, all HBM/L2-streaming (the lag window of consecutive rows overlaps, the
 // caches absorb the re-reads); nothing here is on the ridge path that fit() takes.
 #include <algorithm>
+#include <type_traits>
 
 #include "td_common.h"
 
@@ -336,21 +337,25 @@ __global__ __launch_bounds__(256) void shrunk_cov_kernel(const double* __restric
 // (1 - s) cov_x + s mu I indefinite, which the ridge path's Cholesky rightly refuses.  The
 // reference solves with LU; so does this branch: right-looking LU with partial pivoting in float64.
 // Round 6: blocked.  One column per pair of launches with a rank-1 update of the whole trailing matrix
-// was 4100 launches and n^3 / 3 x 16 bytes of traffic (60 ms at n = 2049).  Now, per panel of 32 columns:
-//   lu_gather_kernel  the panel as a matrix of its own (rows 256 bytes apart);
-//   lu_panel_kernel   ONE workgroup factors it there (pivot search, the swap inside the panel, multipliers, the
-//                     rank-1 updates of the panel's own columns) and returns its top block to the matrix;
-//   lu_apply_kernel   a thread per column right of the panel and per right-hand side: the panel's 32 row swaps
+// was 4100 launches and n^3 / 3 x 16 bytes of traffic (60 ms at n = 2049).  Now, per panel of NB columns:
+//   lu_gather_kernel  the panel as a matrix of its own (rows NB x 8 bytes apart);
+//   lu_panel_*        ONE workgroup factors it (pivot search, the swap inside the panel, multipliers, the rank-1
+//                     updates of the panel's own columns) and returns its top block to the matrix:
+//                     lu_panel_reg_kernel (NB = 16, up to 3072 rows) holds the panel in registers -- ~2-4 us per
+//                     column; lu_panel_kernel (NB = 32, any height) streams it through the L2 32 times -- 18 us per
+//                     column at 2049 rows whatever the access pattern (in place or gathered, 4 .. 16 loads in
+//                     flight, shuffles or v_readlane: all measured), one compute unit moving 1 MB per column;
+//   lu_apply_kernel   a thread per column right of the panel and per right-hand side: the panel's row swaps
 //                     as one permutation, then the forward substitution with the unit-lower L11
 //                     (U12 = L11^-1 A12; the right-hand sides ride along as further columns);
-//   lu_gemm_kernel    A22 -= L21 U12 (64 x 64 output tiles, K = 32), once more for the right-hand sides;
-// and a blocked, row-oriented back substitution in one launch: 28 ms at n = 2049, of which the 65 panel launches
-// are 21 -- one compute unit streams a tall panel 32 times at ~60 GB/s whatever the access pattern (in place or
-// gathered, 4 .. 16 loads in flight, shuffles or v_readlane: all measured, all 0.6 ms for the first panel); the
-// next step would be a panel of 16 columns held in the registers of its workgroup.  A rare branch (fit() never
-// takes it): float64 VALU, no MFMA.
-constexpr int kLuNb = 32;
+//   lu_gemm_kernel    A22 -= L21 U12 (64 x 64 output tiles, K = NB), once more for the right-hand sides;
+// and a blocked, row-oriented back substitution in one launch: 12 ms at n = 2049 (28 with the streamed panel).
+// A rare branch (fit() never takes it): float64 VALU, no MFMA.
+constexpr int kLuNb = 32;             // panel width of the global-memory panel kernel (systems of more than 3072 unknowns)
+constexpr int kLuNbReg = 16;          // ... of the register-resident one
+constexpr int kLuBack = 32;           // rows per block of the back substitution
 constexpr int kLuPanelThreads = 1024;
+constexpr int kLuRegThreads = 512, kLuRegMaxRows = 6;
 #ifndef TD_LU_INFLIGHT
 #define TD_LU_INFLIGHT 8
 #endif
@@ -358,11 +363,12 @@ constexpr int kLuPanelThreads = 1024;
 // The panel as a matrix of its own, pm [m = n - j0][32] (rows 256 bytes apart): the rows of `a` are n * 8 bytes
 // apart -- 16 KB at n = 2049, every row of a column panel in the same few memory channels, and a panel factored
 // in place ran at 27 GB/s (0.6 ms).  Columns >= w of the last panel are zero.
+template <int NB>
 __global__ __launch_bounds__(256) void lu_gather_kernel(const double* __restrict__ a, int n, int j0, int w,
                                                         double* __restrict__ pm, const int* __restrict__ flag) {
   if (*flag) return;
-  const int r = blockIdx.x * 8 + (threadIdx.x >> 5), c = threadIdx.x & 31;
-  if (r < n - j0) pm[(size_t)r * kLuNb + c] = c < w ? a[(size_t)(j0 + r) * n + j0 + c] : 0.0;
+  const int r = blockIdx.x * (256 / NB) + (int)threadIdx.x / NB, c = (int)threadIdx.x % NB;
+  if (r < n - j0) pm[(size_t)r * NB + c] = c < w ? a[(size_t)(j0 + r) * n + j0 + c] : 0.0;
 }
 
 __device__ __forceinline__ double lane_f64(double v, int l) {    // l wave-uniform
@@ -473,6 +479,127 @@ __global__ __launch_bounds__(kLuPanelThreads) void lu_panel_kernel(double* __res
   }
 }
 
+// The panel in REGISTERS: 16 columns, thread t of 512 holds the local rows t, t + 512, .. (R <= 6 of them: up to
+// 3072 rows) -- 32 R registers.  A column step is then a pivot search over registers (wave shuffles, eight
+// candidates through LDS), the exchange of two rows through LDS and 16 - jj multiply-adds per row: no memory
+// traffic at all between the load and the store of the panel, ~2 us per column where the streamed panel takes
+// 18 (one compute unit moving 1 MB per column).
+template <int R>
+__global__ __launch_bounds__(kLuRegThreads) void lu_panel_reg_kernel(double* __restrict__ a, double* __restrict__ pm,
+                                                                     int n, int j0, int w, int* __restrict__ piv_out,
+                                                                     int* __restrict__ flag) {
+  constexpr int NB = kLuNbReg, kWaves = kLuRegThreads / 64;
+  __shared__ double cand_v[kWaves];
+  __shared__ int cand_i[kWaves];
+  __shared__ double rowp[NB], rowj[NB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = n - j0;
+  if (*flag) return;
+  double x[R][NB];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int r = tid + kLuRegThreads * k;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[k][c] = r < m ? pm[(size_t)r * NB + c] : 0.0;
+  }
+  // (a column step per call of a generic lambda with the column as a TYPE: as a loop the sixteen steps are "too large
+  //  to unroll" from four rows per thread on, and the rows' registers turn into scratch memory)
+  bool singular = false;
+  auto step = [&](auto jj_tag) {
+    constexpr int jj = decltype(jj_tag)::value;
+    if (jj < w && !singular) {                           // (uniform: the last panel may be narrower)
+      // the largest magnitude of column jj among the rows >= jj (ties: the smaller row, as LAPACK's idamax)
+      double bv = -1.0;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int r = tid + kLuRegThreads * k;
+        const double v = fabs(x[k][jj]);
+        if (r >= jj && r < m && v > bv) { bv = v; bi = r; }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (lane == 0) { cand_v[wave] = bv; cand_i[wave] = bi; }
+      __syncthreads();
+      bv = cand_v[0]; bi = cand_i[0];
+#pragma unroll
+      for (int k = 1; k < kWaves; ++k)
+        if (cand_v[k] > bv || (cand_v[k] == bv && cand_i[k] < bi)) { bv = cand_v[k]; bi = cand_i[k]; }
+      if (!(bv > 0.0)) {                                 // zero (or NaN) column: singular
+        if (tid == 0) *flag = 1;
+        singular = true;
+        return;
+      }
+      const int piv = bi;
+      if (tid == 0) piv_out[j0 + jj] = j0 + piv;
+      // rows jj and piv change places (their owners: thread jj's first row, thread piv % 512's row piv / 512)
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int r = tid + kLuRegThreads * k;
+        if (r == piv) {
+#pragma unroll
+          for (int c = 0; c < NB; ++c) rowp[c] = x[k][c];
+        }
+        if (r == jj) {
+#pragma unroll
+          for (int c = 0; c < NB; ++c) rowj[c] = x[k][c];
+        }
+      }
+      __syncthreads();
+      if (piv != jj) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const int r = tid + kLuRegThreads * k;
+          if (r == piv) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[k][c] = rowj[c];
+          }
+          if (r == jj) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[k][c] = rowp[c];
+          }
+        }
+      }
+      const double inv = 1.0 / rowp[jj];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int r = tid + kLuRegThreads * k;
+        if (r > jj && r < m) {
+          const double l = x[k][jj] * inv;
+          x[k][jj] = l;
+#pragma unroll
+          for (int c = jj + 1; c < NB; ++c) x[k][c] -= l * rowp[c];
+        }
+      }
+    }
+  };
+#define TD_STEP(J) step(std::integral_constant<int, J>())
+  TD_STEP(0); TD_STEP(1); TD_STEP(2); TD_STEP(3); TD_STEP(4); TD_STEP(5); TD_STEP(6); TD_STEP(7);
+  TD_STEP(8); TD_STEP(9); TD_STEP(10); TD_STEP(11); TD_STEP(12); TD_STEP(13); TD_STEP(14); TD_STEP(15);
+#undef TD_STEP
+  static_assert(NB == 16, "sixteen column steps");
+  if (singular) return;
+  // the multipliers stay in pm for the trailing update, the top block (U11 above, L11 below the diagonal) returns
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int r = tid + kLuRegThreads * k;
+    if (r < m) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) pm[(size_t)r * NB + c] = x[k][c];
+      if (r < w) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c < w) a[(size_t)(j0 + r) * n + j0 + c] = x[k][c];
+      }
+    }
+  }
+}
+
 // A thread per column right of the panel, c in [j0 + w, n), and per right-hand side: the panel's swaps, then
 // x <- L11^-1 x.  (The columns left of the panel hold the multipliers of earlier panels, which the right-hand sides
 // have already taken -- the forward substitution rides along -- so nobody reads them again: they are not swapped.)
@@ -480,18 +607,19 @@ __global__ __launch_bounds__(kLuPanelThreads) void lu_panel_kernel(double* __res
 // <= 64 rows (the panel's and the pivots' below it), worked out once per workgroup on row NUMBERS (an index
 // array in LDS takes the swaps, the rows that moved are collected): slot s ends with what row src[s] held, so a
 // column is <= 64 independent loads, then its stores.
+template <int NB>
 __global__ __launch_bounds__(256) void lu_apply_kernel(double* __restrict__ a, double* __restrict__ b, int n, int nrhs,
                                                        int j0, int w, const int* __restrict__ piv,
                                                        const int* __restrict__ flag) {
   extern __shared__ double xs_lds[];                   // [32][256] the panel rows' values of this workgroup's columns
-  int* const at_row = reinterpret_cast<int*>(xs_lds + kLuNb * 256);   // [n - j0]: whose content local row r ends up with
-  __shared__ double l11[kLuNb][kLuNb + 1];
-  __shared__ int slot_row[2 * kLuNb], slot_src[2 * kLuNb];   // slots 0 .. w-1: the panel's rows; then the outside pivots
+  int* const at_row = reinterpret_cast<int*>(xs_lds + NB * 256);   // [n - j0]: whose content local row r ends up with
+  __shared__ double l11[NB][NB + 1];
+  __shared__ int slot_row[2 * NB], slot_src[2 * NB];   // slots 0 .. w-1: the panel's rows; then the outside pivots
   __shared__ int n_slots;
   if (*flag) return;
   const int m = n - j0;
-  for (int idx = threadIdx.x; idx < kLuNb * kLuNb; idx += 256) {
-    const int r = idx / kLuNb, c = idx % kLuNb;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+    const int r = idx / NB, c = idx % NB;
     l11[r][c] = (r < w && c < r) ? a[(size_t)(j0 + r) * n + j0 + c] : 0.0;
   }
   for (int r = threadIdx.x; r < m; r += 256) at_row[r] = r;
@@ -522,9 +650,9 @@ __global__ __launch_bounds__(256) void lu_apply_kernel(double* __restrict__ a, d
   // every load of the column in front of its first store (the slots' rows overlap); the panel rows' values go
   // through LDS (a register array of 32 + 32 doubles under the unrolled substitution spilled 600 registers)
   double* const xs = xs_lds + threadIdx.x;             // xs[k * 256]
-  double ext[kLuNb];
+  double ext[NB];
 #pragma unroll
-  for (int k = 0; k < kLuNb; ++k) {
+  for (int k = 0; k < NB; ++k) {
     xs[k * 256] = k < w ? base[(size_t)slot_src[k] * ld] : 0.0;
     ext[k] = w + k < ns ? base[(size_t)slot_src[w + k] * ld] : 0.0;
   }
@@ -534,27 +662,28 @@ __global__ __launch_bounds__(256) void lu_apply_kernel(double* __restrict__ a, d
     xs[jj * 256] = acc;
   }
 #pragma unroll
-  for (int k = 0; k < kLuNb; ++k)
+  for (int k = 0; k < NB; ++k)
     if (w + k < ns) base[(size_t)slot_row[w + k] * ld] = ext[k];
   for (int k = 0; k < w; ++k) base[(size_t)(j0 + k) * ld] = xs[k * 256];
 }
 
 // C[i][c] -= sum_kk L[i][kk] U[kk][c]: L = lp[i * 32 + kk] (the panel's rows below its top block, i < m),
 // U = u[kk * ldu + c], C = cm[(r0 + i) * ldc + c] (c < nc); 64 x 64 tiles, a thread 4 x 4 outputs.
+template <int NB>
 __global__ __launch_bounds__(256) void lu_gemm_kernel(const double* __restrict__ lp, int w, int r0, int m,
                                                       const double* __restrict__ u, size_t ldu,
                                                       double* __restrict__ cm, size_t ldc, int nc,
                                                       const int* __restrict__ flag) {
-  __shared__ double ls[64][kLuNb + 1];
-  __shared__ double us[kLuNb][64 + 1];
+  __shared__ double ls[64][NB + 1];
+  __shared__ double us[NB][64 + 1];
   if (*flag) return;
   const int tid = threadIdx.x;
   const int i0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  for (int idx = tid; idx < 64 * kLuNb; idx += 256) {
-    const int r = idx / kLuNb, kk = idx % kLuNb;
-    ls[r][kk] = (i0 + r < m && kk < w) ? lp[(size_t)(i0 + r) * kLuNb + kk] : 0.0;
+  for (int idx = tid; idx < 64 * NB; idx += 256) {
+    const int r = idx / NB, kk = idx % NB;
+    ls[r][kk] = (i0 + r < m && kk < w) ? lp[(size_t)(i0 + r) * NB + kk] : 0.0;
   }
-  for (int idx = tid; idx < kLuNb * 64; idx += 256) {
+  for (int idx = tid; idx < NB * 64; idx += 256) {
     const int kk = idx / 64, c = idx % 64;
     us[kk][c] = (kk < w && c0 + c < nc) ? u[(size_t)kk * ldu + c0 + c] : 0.0;
   }
@@ -566,7 +695,7 @@ __global__ __launch_bounds__(256) void lu_gemm_kernel(const double* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
 #pragma unroll 8
-  for (int kk = 0; kk < kLuNb; ++kk) {
+  for (int kk = 0; kk < NB; ++kk) {
     double lv[4], uv[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) { lv[p] = ls[tr + p][kk]; uv[p] = us[kk][tc + p]; }
@@ -593,14 +722,14 @@ __global__ __launch_bounds__(kLuPanelThreads) void lu_back_kernel(const double* 
                                                                   int n, int nrhs, const int* __restrict__ flag) {
   constexpr int kWaves = kLuPanelThreads / 64;
   extern __shared__ double xs[];                       // [n]
-  __shared__ double ub[kLuNb][kLuNb + 1];
-  __shared__ double yb[kLuNb], rdiag[kLuNb];
+  __shared__ double ub[kLuBack][kLuBack + 1];
+  __shared__ double yb[kLuBack], rdiag[kLuBack];
   if (*flag) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int q = 0; q < nrhs; ++q) {
-    for (int k0 = ((n - 1) / kLuNb) * kLuNb; k0 >= 0; k0 -= kLuNb) {
-      const int w = n - k0 < kLuNb ? n - k0 : kLuNb;
+    for (int k0 = ((n - 1) / kLuBack) * kLuBack; k0 >= 0; k0 -= kLuBack) {
+      const int w = n - k0 < kLuBack ? n - k0 : kLuBack;
       {
         const int r = tid >> 5, c = tid & 31;          // 1024 threads = the 32 x 32 block
         ub[r][c] = (r < w && c < w) ? a[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
@@ -611,7 +740,7 @@ __global__ __launch_bounds__(kLuPanelThreads) void lu_back_kernel(const double* 
         double sum = 0.0;
         if (r < w) {
           const double* row = a + (size_t)(k0 + r) * n;
-          for (int k = k0 + kLuNb + lane; k < n; k += 64) sum += row[k] * xs[k];
+          for (int k = k0 + kLuBack + lane; k < n; k += 64) sum += row[k] * xs[k];
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -619,12 +748,12 @@ __global__ __launch_bounds__(kLuPanelThreads) void lu_back_kernel(const double* 
       }
       __syncthreads();
       if (tid < 64) {
-        if (tid < kLuNb) rdiag[tid] = 1.0 / ub[tid][tid];
-        double y = tid < kLuNb ? yb[tid] : 0.0;
+        if (tid < kLuBack) rdiag[tid] = 1.0 / ub[tid][tid];
+        double y = tid < kLuBack ? yb[tid] : 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int mm = kLuNb - 1; mm >= 0; --mm) {
+        for (int mm = kLuBack - 1; mm >= 0; --mm) {
           if (tid == mm) yb[mm] = y * rdiag[mm];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -733,32 +862,56 @@ extern "C" int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, in
   if (!h->lds_opt_lu) {
     TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_back_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double)));
-    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_apply_kernel),
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_apply_kernel<kLuNb>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(double) * kLuNb * 256 + sizeof(int) * 8192)));
+    TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_apply_kernel<kLuNbReg>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(double) * kLuNbReg * 256 + sizeof(int) * 8192)));
     h->lds_opt_lu = true;
   }
   TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));
-  for (int j0 = 0; j0 < n; j0 += kLuNb) {
-    const int w = n - j0 < kLuNb ? n - j0 : kLuNb;
-    hipLaunchKernelGGL(lu_gather_kernel, dim3((unsigned)td_ceil_div(n - j0, 8)), dim3(256), 0, h->stream, a_dev, n,
-                       j0, w, pm, h->dev_flag);
-    hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kLuPanelThreads), 0, h->stream, a_dev, pm, n, j0, w, piv,
-                       h->dev_flag);
-    hipLaunchKernelGGL(lu_apply_kernel, dim3((unsigned)td_ceil_div(n - j0 - w + nrhs, 256)), dim3(256),
-                       sizeof(double) * kLuNb * 256 + sizeof(int) * (size_t)(n - j0), h->stream, a_dev, rhs_dev, n,
-                       nrhs, j0, w, piv, h->dev_flag);
-    const int r0 = j0 + w, m = n - r0;
-    if (m > 0) {
-      const double* lp = pm + (size_t)w * kLuNb;
-      hipLaunchKernelGGL(lu_gemm_kernel, dim3((unsigned)td_ceil_div(m, 64), (unsigned)td_ceil_div(m, 64)), dim3(256),
-                         0, h->stream, lp, w, r0, m, a_dev + (size_t)j0 * n + r0, (size_t)n, a_dev + r0, (size_t)n,
-                         m, h->dev_flag);
-      hipLaunchKernelGGL(lu_gemm_kernel, dim3((unsigned)td_ceil_div(nrhs, 64), (unsigned)td_ceil_div(m, 64)),
-                         dim3(256), 0, h->stream, lp, w, r0, m, rhs_dev + (size_t)j0 * nrhs, (size_t)nrhs, rhs_dev,
-                         (size_t)nrhs, nrhs, h->dev_flag);
+  const bool reg_panel = n <= kLuRegThreads * kLuRegMaxRows;
+  auto panel_steps = [&](auto nb_tag) {
+    constexpr int NB = decltype(nb_tag)::value;
+    for (int j0 = 0; j0 < n; j0 += NB) {
+      const int w = n - j0 < NB ? n - j0 : NB;
+      hipLaunchKernelGGL((lu_gather_kernel<NB>), dim3((unsigned)td_ceil_div(n - j0, 256 / NB)), dim3(256), 0, h->stream,
+                         a_dev, n, j0, w, pm, h->dev_flag);
+      if (NB == kLuNbReg) {
+        const int rows = (int)td_ceil_div(n - j0, kLuRegThreads);
+#define TD_LU_REG(R) hipLaunchKernelGGL((lu_panel_reg_kernel<R>), dim3(1), dim3(kLuRegThreads), 0, h->stream, a_dev, pm, \
+                                        n, j0, w, piv, h->dev_flag)
+        switch (rows) {
+          case 1: TD_LU_REG(1); break;
+          case 2: TD_LU_REG(2); break;
+          case 3: TD_LU_REG(3); break;
+          case 4: TD_LU_REG(4); break;
+          case 5: TD_LU_REG(5); break;
+          default: TD_LU_REG(6); break;
+        }
+#undef TD_LU_REG
+      } else {
+        hipLaunchKernelGGL(lu_panel_kernel, dim3(1), dim3(kLuPanelThreads), 0, h->stream, a_dev, pm, n, j0, w, piv,
+                           h->dev_flag);
+      }
+      hipLaunchKernelGGL((lu_apply_kernel<NB>), dim3((unsigned)td_ceil_div(n - j0 - w + nrhs, 256)), dim3(256),
+                         sizeof(double) * NB * 256 + sizeof(int) * (size_t)(n - j0), h->stream, a_dev, rhs_dev, n,
+                         nrhs, j0, w, piv, h->dev_flag);
+      const int r0 = j0 + w, m = n - r0;
+      if (m > 0) {
+        const double* lp = pm + (size_t)w * NB;
+        hipLaunchKernelGGL((lu_gemm_kernel<NB>), dim3((unsigned)td_ceil_div(m, 64), (unsigned)td_ceil_div(m, 64)),
+                           dim3(256), 0, h->stream, lp, w, r0, m, a_dev + (size_t)j0 * n + r0, (size_t)n, a_dev + r0,
+                           (size_t)n, m, h->dev_flag);
+        hipLaunchKernelGGL((lu_gemm_kernel<NB>), dim3((unsigned)td_ceil_div(nrhs, 64), (unsigned)td_ceil_div(m, 64)),
+                           dim3(256), 0, h->stream, lp, w, r0, m, rhs_dev + (size_t)j0 * nrhs, (size_t)nrhs, rhs_dev,
+                           (size_t)nrhs, nrhs, h->dev_flag);
+      }
     }
-  }
+  };
+  if (reg_panel) panel_steps(std::integral_constant<int, kLuNbReg>());
+  else panel_steps(std::integral_constant<int, kLuNb>());
   hipLaunchKernelGGL(lu_back_kernel, dim3(1), dim3(kLuPanelThreads), sizeof(double) * (size_t)n, h->stream, a_dev,
                      rhs_dev, n, nrhs, h->dev_flag);
   TD_HIP(h, hipGetLastError());
