@@ -92,9 +92,8 @@ def calculate_cca_parameters_from_dataset(dataset, dim, regularization=0.1,
     raise ValueError('No minibatches in dataset, can\'t compute CCA model.')
   # u[:, 0:dim] of the reference slices to what exists
   dim_eff = max(1, min(int(dim), st.k1, st.k2))
-  rot_x, rot_y, mean_x, mean_y, e, _ = st.cca_solve(num_mini_batches * n_row - 1, regularization,
-                                                    dim_eff, eps_eig, handle=h)
-  return tuple(t.cpu().numpy() for t in (rot_x, rot_y, mean_x, mean_y, e))
+  st.cca_solve(num_mini_batches * n_row - 1, regularization, dim_eff, eps_eig, handle=h)
+  return st.cca_results_host()
 
 
 class BrainCcaLayer(object):

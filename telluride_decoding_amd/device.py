@@ -431,11 +431,16 @@ class LagStats(object):
     device tensors (rot_x [k1, dim], rot_y [k2, dim], mean_x [1, k1], mean_y [1, k2], e [dim])
     and the Jacobi sweep counts (eig xx, eig yy, svd)."""
     h = handle or self.h
-    rot_x = h.empty((self.k1, dim), 'float32')
-    rot_y = h.empty((self.k2, dim), 'float32')
-    mean_x = h.empty((1, self.k1), 'float32')
-    mean_y = h.empty((1, self.k2), 'float32')
-    e = h.empty((dim,), 'float32')
+    # (one buffer, five views: a caller that wants the results on the host copies it once -- cca_results_host)
+    k1, k2, dim = self.k1, self.k2, int(dim)
+    buf = h.empty(((k1 + k2) * dim + k1 + k2 + dim,), 'float32')
+    o = [0, k1 * dim, (k1 + k2) * dim, (k1 + k2) * dim + k1, (k1 + k2) * dim + k1 + k2]
+    rot_x = buf[o[0]:o[1]].view(k1, dim)
+    rot_y = buf[o[1]:o[2]].view(k2, dim)
+    mean_x = buf[o[2]:o[3]].view(1, k1)
+    mean_y = buf[o[3]:o[4]].view(1, k2)
+    e = buf[o[4]:]
+    self._cca_buf = (buf, o, k1, k2, dim)
     info = (ctypes.c_int * 4)()
     h.check(h.lib.td_cca_solve(h.ptr, self.ptr, float(denom), float(regularization),
                                float(eps_eig), int(dim), _ptr(rot_x), _ptr(rot_y), _ptr(mean_x),
@@ -444,6 +449,13 @@ class LagStats(object):
     self.last_cca_route_y = 'cholesky' if info[3] & 2 else 'eigen'   # ... of the other side
     self.last_cca_fused = bool(info[3] & 4)                           # the one-launch dense stage (K1 <= 64, K2 <= 16)
     return rot_x, rot_y, mean_x, mean_y, e, tuple(info[:3])
+
+  def cca_results_host(self):
+    """The last cca_solve's five results as float32 NumPy arrays from ONE device-to-host copy."""
+    buf, o, k1, k2, dim = self._cca_buf
+    a = buf.cpu().numpy()
+    return (a[o[0]:o[1]].reshape(k1, dim), a[o[1]:o[2]].reshape(k2, dim), a[o[2]:o[3]].reshape(1, k1),
+            a[o[3]:o[4]].reshape(1, k2), a[o[4]:].copy())
 
   def __del__(self):
     try:
