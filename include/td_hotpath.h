@@ -377,7 +377,7 @@ int td_spd_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs, 
 /* General square solve (np.linalg.solve, brain_model.py:477) for the one branch whose matrix
  * may be indefinite: a negative Ledoit-Wolf shrinkage.  Float64 LU with partial pivoting on
  * the device; a_dev [n, n] is destroyed, rhs_dev [n, nrhs] is overwritten with the solution.
- * TD_ERR_SINGULAR on a zero pivot column. */
+ * TD_ERR_SINGULAR on a zero pivot column.  n <= 16320 (as the Cholesky solves). */
 int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs);
 
 /* Ledoit-Wolf moment of the automatic-shrinkage branch (lamb == -1, use_ridge False):

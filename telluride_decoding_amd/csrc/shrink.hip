@@ -354,6 +354,8 @@ __global__ __launch_bounds__(256) void shrunk_cov_kernel(const double* __restric
 constexpr int kLuNb = 32;             // panel width of the global-memory panel kernel (systems of more than 3072 unknowns)
 constexpr int kLuNbReg = 16;          // ... of the register-resident one
 constexpr int kLuBack = 32;           // rows per block of the back substitution
+constexpr int kLuMaxN = 16320;        // the back substitution keeps the unknowns in LDS (128 KB), the swaps' index array too:
+                                      // the limit of the blocked Cholesky (solve.hip)
 constexpr int kLuPanelThreads = 1024;
 constexpr int kLuRegThreads = 512, kLuRegMaxRows = 6;
 #ifndef TD_LU_INFLIGHT
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(256) void lu_gemm_kernel(const double* __restrict__
 // contiguous; a column block of it has its rows 16 KB apart -- the same memory channels, see lu_gather_kernel):
 // the block's rows first lose the unknowns already found -- a wave per two rows, lanes along the row, the
 // products summed by shuffles -- then wave 0 solves the diagonal block (lane = row, the finished unknown handed
-// round through LDS).  The unknowns live in LDS (n <= 8190).
+// round through LDS).  The unknowns live in LDS (n <= kLuMaxN).
 __global__ __launch_bounds__(kLuPanelThreads) void lu_back_kernel(const double* __restrict__ a, double* __restrict__ b,
                                                                   int n, int nrhs, const int* __restrict__ flag) {
   constexpr int kWaves = kLuPanelThreads / 64;
@@ -853,7 +855,7 @@ extern "C" int td_shrinkage_moment(td_handle* h, const float* x_dev, int64_t ldx
 extern "C" int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, int n, int nrhs) {
   if (!h) return td_fail(h, TD_ERR_INVALID, "td_general_solve: NULL handle");
   TD_REQUIRE(h, a_dev && rhs_dev && n > 0 && nrhs > 0, "td_general_solve: bad argument");
-  TD_REQUIRE(h, n <= 8190, "td_general_solve: at most 8190 unknowns (n = %d)", n);
+  TD_REQUIRE(h, n <= kLuMaxN, "td_general_solve: at most %d unknowns (n = %d)", kLuMaxN, n);
   void* ws = nullptr;
   const size_t piv_bytes = td_round_up(sizeof(int) * (size_t)n, 256);
   TD_TRY(td_workspace(h, piv_bytes + sizeof(double) * (size_t)n * kLuNb, &ws));
@@ -861,13 +863,13 @@ extern "C" int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, in
   double* pm = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + piv_bytes);
   if (!h->lds_opt_lu) {
     TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_back_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * (int)sizeof(double)));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLuMaxN * (int)sizeof(double)));
     TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_apply_kernel<kLuNb>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(sizeof(double) * kLuNb * 256 + sizeof(int) * 8192)));
+                                  (int)(sizeof(double) * kLuNb * 256 + sizeof(int) * kLuMaxN)));
     TD_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lu_apply_kernel<kLuNbReg>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(sizeof(double) * kLuNbReg * 256 + sizeof(int) * 8192)));
+                                  (int)(sizeof(double) * kLuNbReg * 256 + sizeof(int) * kLuMaxN)));
     h->lds_opt_lu = true;
   }
   TD_HIP(h, hipMemsetAsync(h->dev_flag, 0, sizeof(int), h->stream));

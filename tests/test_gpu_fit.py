@@ -1111,22 +1111,27 @@ def test_ledoit_wolf_regression_matches_reference_golden(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,nrhs', [(1, 1), (5, 2), (15, 1), (16, 2), (17, 1), (31, 1), (32, 2), (33, 1), (70, 1), (300, 3),
-                                    (513, 1), (1030, 2), (1600, 1), (2049, 1), (2600, 1), (3100, 2)])
+                                    (513, 1), (1030, 2), (1600, 1), (2049, 1), (2600, 1), (3100, 2), (8200, 1)])
 def test_general_solve_indefinite_and_singular(dev, n, nrhs):
   """td_general_solve = np.linalg.solve (brain_model.py:477) for the branch whose matrix can be
   indefinite; a singular matrix raises like NumPy does.  (Sizes on both sides of the panel widths 16 / 32, one to six
-  rows per thread of the register-resident panel -- 513 .. 2600 --, and 3100: the streamed panel of larger systems.)"""
+  rows per thread of the register-resident panel -- 513 .. 2600 --, 3100: the streamed panel of larger systems, and
+  8200: beyond the 64 KB of dynamic LDS a kernel has by default.)"""
   import torch
   rng = np.random.default_rng(n)
-  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
-  eig = np.linspace(-3.0, 5.0, n) if n > 1 else np.array([-2.0])
-  a = (q * eig) @ q.T + 1e-3 * rng.standard_normal((n, n))      # indefinite, not symmetric
+  if n <= 4000:
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    eig = np.linspace(-3.0, 5.0, n) if n > 1 else np.array([-2.0])
+    a = (q * eig) @ q.T + 1e-3 * rng.standard_normal((n, n))      # indefinite, not symmetric
+  else:
+    a = rng.standard_normal((n, n))                               # (no QR of a matrix that size: seconds of host time)
+    a = a + a.T + 1e-3 * rng.standard_normal((n, n))
   b = rng.standard_normal((n, nrhs))
   h = dev.default_handle()
   got = dev.general_solve(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), handle=h)
   want = np.linalg.solve(a, b)
   np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-9 * max(1, n // 100), atol=1e-10 * max(1, n // 100))
-  if n > 1:
+  if 1 < n <= 4000:
     a[:, 1] = 0.0                                  # an exactly zero pivot column
     with pytest.raises(np.linalg.LinAlgError, match='Singular matrix'):
       np.linalg.solve(a, b)
