@@ -2415,6 +2415,38 @@ __global__ __launch_bounds__(kThreads) void lagcov_wave_kernel(LagParams p, doub
   }
 }
 
+// Column sums alone (no targets) of a NARROW stream, cb <= 32: lagcov_wave_kernel<32, 0> gives a lane to a channel
+// and a load instruction to a row -- 4 useful bytes per instruction for one channel, 74 us for a 4 MB signal.
+// Here a lane is (row of a group, channel): 64 / cbp rows per instruction (cbp = cb rounded up to a power of two),
+// float64 sums, the rows of a group met by shuffles.  Same work items, same output slots.
+__global__ __launch_bounds__(kThreads) void colsum_rows_kernel(LagParams p, double* __restrict__ csum, int cbp) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long wi = blockIdx.x * (long long)(kThreads / 64) + wave;
+  if (wi >= p.n_work) return;
+  const LagWork w = p.works[wi];
+  const int per = 64 / cbp, c = lane % cbp, rs = lane / cbp;
+  const bool ch_ok = c < p.cb;
+  // the rows [u_begin, u_end) that exist
+  const long long lo = w.u_begin > 0 ? w.u_begin : 0, hi = w.u_end < w.b_valid ? w.u_end : w.b_valid;
+  const float* base = p.b + w.b_row0 * p.ldb + (ch_ok ? c : 0);
+  double cs = 0.0;
+  constexpr int kInFlight = 8;
+  for (long long u0 = lo + rs; u0 < hi; u0 += (long long)per * kInFlight) {
+    float v[kInFlight];
+#pragma unroll
+    for (int k = 0; k < kInFlight; ++k) {
+      const long long u = u0 + (long long)per * k;
+      v[k] = u < hi ? base[u * p.ldb] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < kInFlight; ++k) cs += (double)v[k];
+  }
+  for (int off = cbp; off < 64; off <<= 1) cs += __shfl_xor(cs, off, 64);
+  // (slot of channel c; the other lanes of the item's 64 slots hold zero)
+  csum[(size_t)wi * p.cb_pad + lane] = (lane < cbp && ch_ok) ? cs : 0.0;
+}
+
 // The same moments on the matrix cores (one target column, at most 32 lags).  As a product,
 // G[m][j] = sum_v A[m][v] B[v][j] with A[m][v] = y[v - e_min - m] (a Toeplitz matrix of the
 // strip's targets, zero outside [u_begin, u_end)) and B[v][j] = x~[v][j]: M = lag, K = time,
@@ -3988,8 +4020,14 @@ int td_lagcov_targets_launch(td_handle* h, TargetsPlan* plan, void* scratch, dou
   if (d == 0) {
     double* ysum = reinterpret_cast<double*>(base + plan->cs_bytes + plan->part_bytes);
     const unsigned blocks = (unsigned)td_ceil_div((int64_t)n_work * p.n_cbt, kThreads / 64);
-    hipLaunchKernelGGL((lagcov_wave_kernel<32, 0>), dim3(blocks), dim3(kThreads), 0, h->stream, p,
-                       nullptr, csum, ysum);
+    if (cb <= 32) {
+      int cbp = 1;
+      while (cbp < cb) cbp <<= 1;
+      hipLaunchKernelGGL(colsum_rows_kernel, dim3(blocks), dim3(kThreads), 0, h->stream, p, csum, cbp);
+    } else {
+      hipLaunchKernelGGL((lagcov_wave_kernel<32, 0>), dim3(blocks), dim3(kThreads), 0, h->stream, p,
+                         nullptr, csum, ysum);
+    }
   } else {
     const float* y = p.a;
     const bool vec2 = (p.ldb % 2 == 0) && (cb % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.b) & 7) == 0);
