@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void lu_gemm_kernel(const double* __restrict__
     }
 }
 
-// back substitution U x = y in blocks of 32 rows from the bottom up, one workgroup, row-oriented (the rows of U are
+// back substitution U x = y in blocks of 32 rows from the bottom up, one workgroup per right-hand side, row-oriented (the rows of U are
 // contiguous; a column block of it has its rows 16 KB apart -- the same memory channels, see lu_gather_kernel):
 // the block's rows first lose the unknowns already found -- a wave per two rows, lanes along the row, the
 // products summed by shuffles -- then wave 0 solves the diagonal block (lane = row, the finished unknown handed
@@ -729,7 +729,8 @@ __global__ __launch_bounds__(kLuPanelThreads) void lu_back_kernel(const double* 
   if (*flag) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int q = 0; q < nrhs; ++q) {
+  {
+    const int q = blockIdx.x;                          // a workgroup per right-hand side
     for (int k0 = ((n - 1) / kLuBack) * kLuBack; k0 >= 0; k0 -= kLuBack) {
       const int w = n - k0 < kLuBack ? n - k0 : kLuBack;
       {
@@ -914,8 +915,8 @@ extern "C" int td_general_solve(td_handle* h, double* a_dev, double* rhs_dev, in
   };
   if (reg_panel) panel_steps(std::integral_constant<int, kLuNbReg>());
   else panel_steps(std::integral_constant<int, kLuNb>());
-  hipLaunchKernelGGL(lu_back_kernel, dim3(1), dim3(kLuPanelThreads), sizeof(double) * (size_t)n, h->stream, a_dev,
-                     rhs_dev, n, nrhs, h->dev_flag);
+  hipLaunchKernelGGL(lu_back_kernel, dim3((unsigned)nrhs), dim3(kLuPanelThreads), sizeof(double) * (size_t)n, h->stream,
+                     a_dev, rhs_dev, n, nrhs, h->dev_flag);
   TD_HIP(h, hipGetLastError());
   int flag = 0;
   TD_HIP(h, hipMemcpyAsync(&flag, h->dev_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));

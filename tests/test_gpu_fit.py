@@ -1111,7 +1111,7 @@ def test_ledoit_wolf_regression_matches_reference_golden(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,nrhs', [(1, 1), (5, 2), (15, 1), (16, 2), (17, 1), (31, 1), (32, 2), (33, 1), (70, 1), (300, 3),
-                                    (513, 1), (1030, 2), (1600, 1), (2049, 1), (2600, 1), (3100, 2), (8200, 1)])
+                                    (300, 70), (513, 1), (1030, 2), (1600, 1), (2049, 1), (2600, 1), (3100, 2), (8200, 1)])
 def test_general_solve_indefinite_and_singular(dev, n, nrhs):
   """td_general_solve = np.linalg.solve (brain_model.py:477) for the branch whose matrix can be
   indefinite; a singular matrix raises like NumPy does.  (Sizes on both sides of the panel widths 16 / 32, one to six
